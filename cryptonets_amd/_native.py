@@ -1,0 +1,318 @@
+"""ctypes binding of libcnhip.so (C ABI declared in include/cnhip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is present, the
+operations raise.  The oracle under oracle/ is never imported from this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "lib", "libcnhip.so")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("cn_api.hip", "cn_tables.cpp")]
+HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("cn_kernels.hip.h", "cn_internal.h")] + [
+    os.path.join(_ROOT, "include", "cnhip.h")]
+
+U64P = C.POINTER(C.c_uint64)
+I32P = C.POINTER(C.c_int32)
+U32P = C.POINTER(C.c_uint32)
+
+
+class CnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libcnhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CnStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "Multiplication", "PlainMultiplication", "Addition", "PlainAddition", "Subtraction", "PlainSubtraction",
+        "Rotation", "AddMany", "AddManyItemCount", "Relinarization",
+        "ntt_forward_limbs", "ntt_inverse_limbs", "kernel_launches")]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    deps = SOURCES + HEADERS
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
+           *SOURCES, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+# every exported symbol of include/cnhip.h: name -> (restype, argtypes)
+_H = C.c_uint64
+_CTX = C.c_void_p
+_u32 = C.c_uint32
+SIGNATURES = {
+    "cn_version": (C.c_int, []),
+    "cn_last_error": (C.c_char_p, []),
+    "cn_device_count": (C.c_int, []),
+    "cn_ctx_create": (C.c_int, [_u32, U64P, _u32, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(_CTX)]),
+    "cn_ctx_destroy": (C.c_int, [_CTX]),
+    "cn_sync": (C.c_int, [_CTX]),
+    "cn_default_coeff_modulus": (C.c_int, [_u32, U64P]),
+    "cn_key_words": (C.c_size_t, [_CTX, C.c_int]),
+    "cn_set_relin_key": (C.c_int, [_CTX, C.c_void_p, C.c_size_t, C.c_int]),
+    "cn_set_galois_key": (C.c_int, [_CTX, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
+    "cn_has_galois_key": (C.c_int, [_CTX, C.c_uint64]),
+    "cn_galois_elt_from_step": (C.c_uint64, [_CTX, C.c_int]),
+    "cn_ct_alloc": (C.c_int, [_CTX, _u32, _u32, C.POINTER(_H)]),
+    "cn_pt_alloc": (C.c_int, [_CTX, _u32, C.POINTER(_H)]),
+    "cn_free": (C.c_int, [_CTX, _H]),
+    "cn_ct_upload": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
+    "cn_ct_download": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
+    "cn_pt_upload": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
+    "cn_copy": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_device_ptr": (C.c_int, [_CTX, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "cn_live_handles": (C.c_int, [_CTX]),
+    "cn_add": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
+    "cn_sub": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
+    "cn_negate": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_add_many": (C.c_int, [_CTX, _H, U32P, _u32, _H, _u32]),
+    "cn_add_plain": (C.c_int, [_CTX, _H, _u32, _H, _u32, C.c_int, _H, _u32, _u32]),
+    "cn_mul_plain": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32, _H, _u32, _u32]),
+    "cn_mul_scalar": (C.c_int, [_CTX, _H, _u32, U64P, _u32, _H, _u32, _u32]),
+    "cn_scalar_gemm": (C.c_int, [_CTX, _H, I32P, U64P, _u32, _u32, _H, I32P, _H, _u32]),
+    "cn_multiply": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
+    "cn_relinearize": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_mul_relin": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32, _u32, _H, _u32, _u32]),
+    "cn_apply_galois": (C.c_int, [_CTX, _H, _u32, C.c_uint64, _H, _u32, _u32]),
+    "cn_rotate_rows": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _u32]),
+    "cn_rotate_columns": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_ntt_forward": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
+    "cn_ntt_inverse": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
+    "cn_ct_ntt": (C.c_int, [_CTX, _H, _u32, _u32, C.c_int]),
+    "cn_ntt_time": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "cn_stream": (C.c_void_p, [_CTX]),
+    "cn_event_time_begin": (C.c_int, [_CTX]),
+    "cn_event_time_end": (C.c_int, [_CTX, C.POINTER(C.c_float)]),
+    "cn_stats_get": (C.c_int, [_CTX, C.POINTER(CnStats), C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libcnhip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "cryptonets_amd: %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the ABI and the header diverge
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "expected contiguous uint64 array"
+    return a.ctypes.data_as(U64P)
+
+
+def default_coeff_modulus(n):
+    buf = (C.c_uint64 * 16)()
+    cnt = lib().cn_default_coeff_modulus(n, buf)
+    if cnt <= 0:
+        raise ValueError("no default coefficient modulus for n=%d" % n)
+    return [int(buf[i]) for i in range(cnt)]
+
+
+class Context:
+    """One BFV evaluation context resident on one MI355X (HBM tables, keys, buffers, stream)."""
+
+    def __init__(self, n, t, q=None, dbc=10, gdbc=20, device=0):
+        self.L = lib()
+        if q is None:
+            q = default_coeff_modulus(n)
+        self.n, self.t, self.q, self.k = int(n), int(t), [int(x) for x in q], len(q)
+        self.dbc, self.gdbc, self.device = dbc, gdbc, device
+        self.ctw = 2 * self.k * self.n
+        qa = (C.c_uint64 * self.k)(*self.q)
+        h = _CTX()
+        self._h = None
+        self._chk(self.L.cn_ctx_create(self.n, qa, self.k, self.t, dbc, gdbc, device, C.byref(h)))
+        self._h = h
+
+    def _chk(self, rc):
+        if rc:
+            raise CnError(rc, self.L.cn_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            self.L.cn_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- keys
+    def key_words(self, galois=False):
+        return int(self.L.cn_key_words(self._h, int(galois)))
+
+    def set_relin_key(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._chk(self.L.cn_set_relin_key(self._h, w.ctypes.data, w.size, 0))
+
+    def set_relin_key_device(self, dev_ptr, words):
+        self._chk(self.L.cn_set_relin_key(self._h, dev_ptr, words, 1))
+
+    def set_galois_key(self, elt, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._chk(self.L.cn_set_galois_key(self._h, elt, w.ctypes.data, w.size, 0))
+
+    def set_galois_key_device(self, elt, dev_ptr, words):
+        self._chk(self.L.cn_set_galois_key(self._h, elt, dev_ptr, words, 1))
+
+    def has_galois_key(self, elt):
+        return bool(self.L.cn_has_galois_key(self._h, elt))
+
+    def galois_elt_from_step(self, steps):
+        return int(self.L.cn_galois_elt_from_step(self._h, steps))
+
+    # ---- buffers
+    def ct_alloc(self, count, size=2):
+        h = _H()
+        self._chk(self.L.cn_ct_alloc(self._h, count, size, C.byref(h)))
+        return h.value
+
+    def pt_alloc(self, count):
+        h = _H()
+        self._chk(self.L.cn_pt_alloc(self._h, count, C.byref(h)))
+        return h.value
+
+    def free(self, h):
+        self._chk(self.L.cn_free(self._h, h))
+
+    def ct_upload(self, h, first, data):
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        count = d.shape[0] if d.ndim > 1 else 1
+        self._chk(self.L.cn_ct_upload(self._h, h, first, count, _p64(d)))
+
+    def ct_download(self, h, first, count, size=2):
+        out = np.empty((count, size * self.k * self.n), dtype=np.uint64)
+        self._chk(self.L.cn_ct_download(self._h, h, first, count, _p64(out)))
+        return out
+
+    def pt_upload(self, h, first, data):
+        d = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, self.n)
+        self._chk(self.L.cn_pt_upload(self._h, h, first, d.shape[0], _p64(d)))
+
+    def copy(self, src, sfirst, dst, dfirst, count):
+        self._chk(self.L.cn_copy(self._h, src, sfirst, dst, dfirst, count))
+
+    def device_ptr(self, h):
+        p, b = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.cn_device_ptr(self._h, h, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def live_handles(self):
+        return self.L.cn_live_handles(self._h)
+
+    def sync(self):
+        self._chk(self.L.cn_sync(self._h))
+
+    # ---- evaluator
+    def add(self, a, ai, b, bi, out, oi, count=1):
+        self._chk(self.L.cn_add(self._h, a, ai, b, bi, out, oi, count))
+
+    def sub(self, a, ai, b, bi, out, oi, count=1):
+        self._chk(self.L.cn_sub(self._h, a, ai, b, bi, out, oi, count))
+
+    def negate(self, a, ai, out, oi, count=1):
+        self._chk(self.L.cn_negate(self._h, a, ai, out, oi, count))
+
+    def add_many(self, src, idx, out, oi):
+        ia = np.ascontiguousarray(idx, dtype=np.uint32)
+        self._chk(self.L.cn_add_many(self._h, src, ia.ctypes.data_as(U32P), ia.size, out, oi))
+
+    def add_plain(self, a, ai, pt, pi, out, oi, count=1, subtract=False):
+        self._chk(self.L.cn_add_plain(self._h, a, ai, pt, pi, int(subtract), out, oi, count))
+
+    def mul_plain(self, a, ai, pt, pi, out, oi, count=1, pt_stride=1):
+        self._chk(self.L.cn_mul_plain(self._h, a, ai, pt, pi, pt_stride, out, oi, count))
+
+    def mul_scalar(self, a, ai, scalars, out, oi, count=1, broadcast=False):
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1)
+        self._chk(self.L.cn_mul_scalar(self._h, a, ai, _p64(s), 0 if broadcast else 1, out, oi, count))
+
+    def scalar_gemm(self, src, W, out, oi, idx=None, bias_pt=0, bias_idx=None):
+        W = np.ascontiguousarray(W, dtype=np.uint64)
+        O, K = W.shape
+        ip = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            assert idx.shape == (O, K)
+            ip = idx.ctypes.data_as(I32P)
+        bp = None
+        if bias_pt:
+            bias_idx = np.ascontiguousarray(bias_idx, dtype=np.int32)
+            assert bias_idx.shape == (O,)
+            bp = bias_idx.ctypes.data_as(I32P)
+        self._chk(self.L.cn_scalar_gemm(self._h, src, ip, _p64(W), O, K, bias_pt, bp, out, oi))
+
+    def multiply(self, a, ai, b, bi, out3, oi, count=1):
+        self._chk(self.L.cn_multiply(self._h, a, ai, b, bi, out3, oi, count))
+
+    def relinearize(self, in3, ii, out, oi, count=1):
+        self._chk(self.L.cn_relinearize(self._h, in3, ii, out, oi, count))
+
+    def mul_relin(self, a, ai, b, bi, out, oi, count=1, a_stride=1, b_stride=1):
+        self._chk(self.L.cn_mul_relin(self._h, a, ai, a_stride, b, bi, b_stride, out, oi, count))
+
+    def apply_galois(self, src, ii, elt, out, oi, count=1):
+        self._chk(self.L.cn_apply_galois(self._h, src, ii, elt, out, oi, count))
+
+    def rotate_rows(self, src, ii, steps, out, oi, count=1):
+        self._chk(self.L.cn_rotate_rows(self._h, src, ii, steps, out, oi, count))
+
+    def rotate_columns(self, src, ii, out, oi, count=1):
+        self._chk(self.L.cn_rotate_columns(self._h, src, ii, out, oi, count))
+
+    # ---- raw transforms / timing / stats
+    def ct_ntt(self, h, first, count, inverse=False):
+        self._chk(self.L.cn_ct_ntt(self._h, h, first, count, int(inverse)))
+
+    def ntt_forward(self, dev_ptr, limbs, base=0):
+        self._chk(self.L.cn_ntt_forward(self._h, dev_ptr, limbs, base))
+
+    def ntt_inverse(self, dev_ptr, limbs, base=0):
+        self._chk(self.L.cn_ntt_inverse(self._h, dev_ptr, limbs, base))
+
+    def ntt_time(self, dev_ptr, limbs, base=0, inverse=False, iters=10):
+        ms = C.c_float()
+        self._chk(self.L.cn_ntt_time(self._h, dev_ptr, limbs, base, int(inverse), iters, C.byref(ms)))
+        return ms.value
+
+    def stream(self):
+        return self.L.cn_stream(self._h)
+
+    def time_begin(self):
+        self._chk(self.L.cn_event_time_begin(self._h))
+
+    def time_end(self):
+        ms = C.c_float()
+        self._chk(self.L.cn_event_time_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def stats(self, reset=False):
+        s = CnStats()
+        self._chk(self.L.cn_stats_get(self._h, C.byref(s), int(reset)))
+        return {n: int(getattr(s, n)) for n, _ in CnStats._fields_}

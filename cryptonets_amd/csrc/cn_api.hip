@@ -1,0 +1,639 @@
+// libcnhip.so host runtime: contexts, device buffers, launch logic behind the C ABI of include/cnhip.h.
+// The compute path is HIP-only: there is no CPU fallback; every entry point fails with CN_ERR_NODEV /
+// CN_ERR_HIP when no gfx950 device is usable.
+#include "../../include/cnhip.h"
+#include "cn_kernels.hip.h"
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(CN_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+#define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct Buffer {
+    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array
+    uint32_t count, size;     // size = polys per ciphertext
+    uint64_t *d;
+    size_t item_words;
+    std::vector<uint8_t> pt_zero;   // per plaintext: all coefficients zero?
+};
+struct KsKey { uint64_t *d; bool owned; };
+
+struct cn_ctx {
+    int device;
+    hipStream_t stream;
+    DevConsts hc;             // host copy
+    DevConsts *dc;            // device copy
+    uint64_t *tw;
+    std::mutex mu;
+    std::unordered_map<cn_handle, Buffer> bufs;
+    cn_handle next_handle = 1;
+    KsKey rlk{nullptr, false};
+    std::map<uint64_t, KsKey> gk;
+    char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
+    cn_stats st{};
+    hipEvent_t ev0, ev1;
+    uint32_t bs, chunks;      // element-wise geometry
+    size_t ctw2;              // words of a size-2 ciphertext
+};
+
+// ---------------------------------------------------------------- helpers
+static int use(cn_ctx *c) { HIPCHK(hipSetDevice(c->device)); return 0; }
+
+static int ensure_scratch(cn_ctx *c, size_t bytes) {
+    c->soff = 0;
+    if (bytes <= c->scap) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->scratch) HIPCHK(hipFree(c->scratch));
+    c->scratch = nullptr; c->scap = 0;
+    size_t want = bytes + (bytes >> 3) + (1 << 20);
+    HIPCHK(hipMalloc((void **)&c->scratch, want));
+    c->scap = want;
+    return 0;
+}
+static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+template <class T> static T *salloc(cn_ctx *c, size_t count) {
+    size_t b = al(count * sizeof(T));
+    if (c->soff + b > c->scap) return nullptr;
+    T *p = (T *)(c->scratch + c->soff); c->soff += b; return p;
+}
+template <class T> static int upload_tmp(cn_ctx *c, const T *host, size_t count, T **dev) {
+    *dev = salloc<T>(c, count);
+    if (!*dev) return fail(CN_ERR_HIP, "internal: scratch exhausted");
+    HIPCHK(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+static Buffer *getbuf(cn_ctx *c, cn_handle h, int kind) {
+    auto it = c->bufs.find(h);
+    if (it == c->bufs.end() || it->second.kind != kind) return nullptr;
+    return &it->second;
+}
+static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t stride = 1) {
+    if (!count) return 1;
+    uint64_t last = (uint64_t)first + (uint64_t)(count - 1) * stride;
+    return last < b->count;
+}
+#define GETCT(var, h, sz) Buffer *var = getbuf(ctx, h, 0); if (!var) return fail(CN_ERR_ARG, "invalid ciphertext handle " #h); \
+    if ((sz) && var->size != (uint32_t)(sz)) return fail(CN_ERR_ARG, "ciphertext size mismatch for " #h)
+#define GETPT(var, h) Buffer *var = getbuf(ctx, h, 1); if (!var) return fail(CN_ERR_ARG, "invalid plaintext handle " #h)
+#define LOCK std::lock_guard<std::mutex> lk_(ctx->mu); CHECK(use(ctx))
+
+static void launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }
+
+static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
+    if (!limbs) return 0;
+    uint32_t n = c->hc.n, nt = std::min<uint32_t>(512, n / 2);
+    hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+    HIPCHK(hipGetLastError());
+    launch_count(c);
+    if (inverse) c->st.ntt_inverse_limbs += limbs; else c->st.ntt_forward_limbs += limbs;
+    return 0;
+}
+
+// ---------------------------------------------------------------- misc API
+extern "C" int cn_version(void) { return 100; }
+extern "C" const char *cn_last_error(void) { return g_err; }
+extern "C" int cn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int cn_default_coeff_modulus(uint32_t n, uint64_t *q) { return cn_default_coeff_modulus_impl(n, q); }
+
+template <int EPT> static int set_ks_attr(size_t bytes) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc, int device, cn_ctx **out) {
+    if (!out || !q) return fail(CN_ERR_ARG, "null argument");
+    int ndev = cn_device_count();
+    if (ndev <= 0) return fail(CN_ERR_NODEV, "no HIP device available (libcnhip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(CN_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+    if (n > 16384) return fail(CN_ERR_ARG, "poly modulus degree %u too large for the LDS-resident NTT (max 16384)", n);
+    std::vector<uint64_t> tw((size_t)(2 * k + 1) * 4 * n);
+    cn_ctx *c = new cn_ctx();
+    char err[256];
+    if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
+    c->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipMalloc((void **)&c->tw, tw.size() * 8));
+    HIPCHK(hipMemcpy(c->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    c->hc.tw = c->tw;
+    HIPCHK(hipMalloc((void **)&c->dc, sizeof(DevConsts)));
+    HIPCHK(hipMemcpy(c->dc, &c->hc, sizeof(DevConsts), hipMemcpyHostToDevice));
+    c->bs = std::min<uint32_t>(256, n); c->chunks = n / c->bs;
+    c->ctw2 = (size_t)2 * k * n;
+    const char *env = getenv("CN_SCRATCH_GB");
+    c->smax = (size_t)(env ? atof(env) : 24.0) * (1ull << 30);
+    size_t lds = (size_t)n * 8;
+    if (lds > 48 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
+    }
+    *out = c;
+    return 0;
+}
+extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->bufs) (void)hipFree(kv.second.d);
+    if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
+    for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
+    (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->dc);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
+extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ? ctx->hc.gk_tot : ctx->hc.rl_tot) * ctx->ctw2; }
+
+static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count, size_t expect, int is_dev) {
+    if (!words || count != expect) return fail(CN_ERR_ARG, "key has %zu words, expected %zu", count, expect);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (slot.owned && slot.d) HIPCHK(hipFree(slot.d));
+    slot = {nullptr, false};
+    if (is_dev) { slot.d = (uint64_t *)words; slot.owned = false; return 0; }
+    HIPCHK(hipMalloc((void **)&slot.d, count * 8));
+    slot.owned = true;
+    HIPCHK(hipMemcpy(slot.d, words, count * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_dev) {
+    LOCK; return set_key(ctx, ctx->rlk, words, count, cn_key_words(ctx, 0), is_dev);
+}
+extern "C" int cn_set_galois_key(cn_ctx *ctx, uint64_t elt, const uint64_t *words, size_t count, int is_dev) {
+    LOCK;
+    if (!(elt & 1) || elt >= 2ull * ctx->hc.n) return fail(CN_ERR_ARG, "invalid Galois element");
+    return set_key(ctx, ctx->gk[elt], words, count, cn_key_words(ctx, 1), is_dev);
+}
+extern "C" int cn_has_galois_key(cn_ctx *ctx, uint64_t elt) { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
+extern "C" uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps) {
+    uint64_t n = ctx->hc.n, m = 2 * n;
+    if (steps == 0) return m - 1;
+    uint64_t pos = (uint64_t)std::abs((long)steps);
+    if (pos >= n / 2) return 0;
+    uint64_t s = steps < 0 ? n / 2 - pos : pos, e = 1;
+    while (s--) e = (e * 3) & (m - 1);
+    return e;
+}
+
+// ---------------------------------------------------------------- buffers
+static int alloc_buf(cn_ctx *ctx, int kind, uint32_t count, uint32_t size, cn_handle *out) {
+    if (!out || !count) return fail(CN_ERR_ARG, "bad allocation request");
+    Buffer b; b.kind = kind; b.count = count; b.size = size;
+    b.item_words = kind == 0 ? (size_t)size * ctx->hc.k * ctx->hc.n : ctx->hc.n;
+    HIPCHK(hipMalloc((void **)&b.d, b.item_words * 8 * count));
+    if (kind == 1) b.pt_zero.assign(count, 1);
+    cn_handle h = ctx->next_handle++;
+    ctx->bufs[h] = std::move(b);
+    *out = h;
+    return 0;
+}
+extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) {
+    LOCK; if (size < 2 || size > 3) return fail(CN_ERR_ARG, "ciphertext size must be 2 or 3"); return alloc_buf(ctx, 0, count, size, out);
+}
+extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { LOCK; return alloc_buf(ctx, 1, count, 1, out); }
+extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
+    LOCK;
+    auto it = ctx->bufs.find(h);
+    if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(it->second.d));
+    ctx->bufs.erase(it);
+    return 0;
+}
+extern "C" int cn_live_handles(cn_ctx *ctx) { std::lock_guard<std::mutex> lk(ctx->mu); return (int)ctx->bufs.size(); }
+extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
+    LOCK; GETCT(b, h, 0);
+    if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
+    HIPCHK(hipMemcpyAsync(b->d + first * b->item_words, host, count * b->item_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) {
+    LOCK; GETCT(b, h, 0);
+    if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
+    HIPCHK(hipMemcpyAsync(host, b->d + first * b->item_words, count * b->item_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
+    LOCK; GETPT(b, h);
+    if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
+    const uint32_t n = ctx->hc.n; const uint64_t t = ctx->hc.t.q;
+    for (uint32_t p = 0; p < count; p++) {
+        uint8_t z = 1;
+        for (uint32_t i = 0; i < n; i++) { uint64_t v = host[(size_t)p * n + i]; if (v >= t) return fail(CN_ERR_ARG, "plaintext coefficient >= plain modulus"); if (v) z = 0; }
+        b->pt_zero[first + p] = z;
+    }
+    HIPCHK(hipMemcpyAsync(b->d + (size_t)first * n, host, (size_t)count * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) {
+    LOCK;
+    auto is = ctx->bufs.find(src), id = ctx->bufs.find(dst);
+    if (is == ctx->bufs.end() || id == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
+    Buffer *s = &is->second, *d = &id->second;
+    if (s->kind != d->kind || s->item_words != d->item_words) return fail(CN_ERR_ARG, "copy between different buffer shapes");
+    if (!range_ok(s, sfirst, count) || !range_ok(d, dfirst, count)) return fail(CN_ERR_ARG, "index out of range");
+    HIPCHK(hipMemcpyAsync(d->d + dfirst * d->item_words, s->d + sfirst * s->item_words, count * s->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (s->kind == 1) for (uint32_t i = 0; i < count; i++) d->pt_zero[dfirst + i] = s->pt_zero[sfirst + i];
+    return 0;
+}
+extern "C" int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->bufs.find(h);
+    if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
+    if (ptr) *ptr = it->second.d;
+    if (bytes) *bytes = it->second.item_words * 8 * it->second.count;
+    return 0;
+}
+
+// ---------------------------------------------------------------- linear ops
+static int addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op) {
+    GETCT(A, a, 0); GETCT(O, out, A->size);
+    Buffer *B = A;
+    if (op != 2) { B = getbuf(ctx, b, 0); if (!B || B->size != A->size) return fail(CN_ERR_ARG, "operand sizes do not match"); }
+    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || (op != 2 && !range_ok(B, bi, count))) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    uint32_t limbs = count * A->size * ctx->hc.k;
+    hipLaunchKernelGGL(k_addsub, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, A->d + ai * A->item_words,
+                       B->d + (op != 2 ? bi : ai) * B->item_words, O->d + oi * O->item_words, ctx->dc, ctx->chunks, op);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    return 0;
+}
+extern "C" int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 0)); ctx->st.Addition += count; return 0;
+}
+extern "C" int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 1)); ctx->st.Subtraction += count; return 0;
+}
+extern "C" int cn_negate(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; return addsub(ctx, a, ai, a, ai, out, oi, count, 2);
+}
+extern "C" int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint32_t n_idx, cn_handle out, uint32_t oi) {
+    LOCK; GETCT(I, in, 0); GETCT(O, out, I->size);
+    if (!n_idx || !idx) return fail(CN_ERR_ARG, "AddMany of an empty list");
+    for (uint32_t i = 0; i < n_idx; i++) if (idx[i] >= I->count) return fail(CN_ERR_ARG, "index out of range");
+    if (oi >= O->count) return fail(CN_ERR_ARG, "index out of range");
+    CHECK(ensure_scratch(ctx, al(n_idx * 4)));
+    uint32_t *didx; CHECK(upload_tmp(ctx, idx, n_idx, &didx));
+    uint32_t limbs = I->size * ctx->hc.k;
+    hipLaunchKernelGGL(k_add_many, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, n_idx, I->item_words,
+                       O->d + oi * O->item_words, ctx->dc, ctx->chunks);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    ctx->st.AddMany += 1; ctx->st.AddManyItemCount += n_idx;
+    return 0;
+}
+extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    uint32_t limbs = count * A->size * ctx->hc.k;
+    hipLaunchKernelGGL(k_add_plain, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, A->d + ai * A->item_words,
+                       P->d + (size_t)pi * ctx->hc.n, ctx->hc.n, O->d + oi * O->item_words, ctx->dc, ctx->chunks, A->size, subtract);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    if (subtract) ctx->st.PlainSubtraction += count; else ctx->st.PlainAddition += count;
+    return 0;
+}
+extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pstride, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
+    for (uint32_t c = 0; c < npt; c++) if (P->pt_zero[pi + c * pstride]) return fail(CN_ERR_ZERO, "plain cannot be zero");
+    CHECK(ensure_scratch(ctx, al((size_t)npt * k * n * 8)));
+    uint64_t *lift = salloc<uint64_t>(ctx, (size_t)npt * k * n);
+    // lift every referenced plaintext into the k limbs, NTT it
+    for (uint32_t c = 0; c < npt; c++) {
+        hipLaunchKernelGGL(k_lift_plain, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, P->d + (size_t)(pi + c * pstride) * n,
+                           lift + (size_t)c * k * n, ctx->dc, ctx->chunks);
+    }
+    HIPCHK(hipGetLastError()); launch_count(ctx, npt);
+    CHECK(run_ntt(ctx, lift, npt * k, 0, k, 0));
+    uint64_t *o = O->d + oi * O->item_words;
+    if (o != A->d + ai * A->item_words) HIPCHK(hipMemcpyAsync(o, A->d + ai * A->item_words, count * A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    uint32_t limbs = count * A->size * k;
+    CHECK(run_ntt(ctx, o, limbs, 0, k, 0));
+    hipLaunchKernelGGL(k_dyadic_pt, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, o, lift, pstride ? 1u : 0u, ctx->dc, ctx->chunks, A->size);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    CHECK(run_ntt(ctx, o, limbs, 0, k, 1));
+    ctx->st.PlainMultiplication += count;
+    return 0;
+}
+static uint64_t lift_scalar(const DevConsts &hc, uint64_t w, uint32_t j) { return w >= hc.t_half ? w + hc.lift_inc[j] : w; }
+extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars, uint32_t sstride, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size);
+    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !scalars) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    const uint32_t k = ctx->hc.k, ns = sstride ? count : 1;
+    std::vector<uint64_t> sc((size_t)ns * k);
+    for (uint32_t c = 0; c < ns; c++) {
+        uint64_t w = scalars[(size_t)c * sstride];
+        if (w >= ctx->hc.t.q) return fail(CN_ERR_ARG, "scalar >= plain modulus");
+        if (!w) return fail(CN_ERR_ZERO, "plain cannot be zero");
+        for (uint32_t j = 0; j < k; j++) sc[(size_t)c * k + j] = lift_scalar(ctx->hc, w, j);
+    }
+    CHECK(ensure_scratch(ctx, al(sc.size() * 8)));
+    uint64_t *dsc; CHECK(upload_tmp(ctx, sc.data(), sc.size(), &dsc));
+    uint32_t limbs = count * A->size * k;
+    hipLaunchKernelGGL(k_mul_scalar, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, A->d + ai * A->item_words, dsc, sstride ? 1u : 0u,
+                       O->d + oi * O->item_words, ctx->dc, ctx->chunks, A->size);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    ctx->st.PlainMultiplication += count;
+    return 0;
+}
+
+// HOT LOOP A
+template <int MT>
+static void launch_gemm(cn_ctx *ctx, const uint64_t *in, const int32_t *idx, const uint64_t *Wl, const int32_t *oidx, const uint64_t *bias,
+                        const int32_t *bidx, uint64_t *out, uint32_t G, uint32_t M, uint32_t K, uint32_t lazy) {
+    uint32_t mtiles = (M + MT - 1) / MT;
+    size_t blocks = (size_t)ctx->chunks * 2 * ctx->hc.k * mtiles * G;
+    hipLaunchKernelGGL(k_scalar_gemm<MT>, dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, in, idx, Wl, oidx, bias, bidx, out, ctx->dc,
+                       ctx->chunks, G, M, K, mtiles, lazy);
+}
+extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
+                              const int32_t *bias_idx, cn_handle out, uint32_t oi) {
+    LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
+    if (!O || !K || !W) return fail(CN_ERR_ARG, "empty scalar GEMM");
+    if (!range_ok(OB, oi, O)) return fail(CN_ERR_ARG, "output index out of range");
+    if (I == OB) return fail(CN_ERR_ARG, "scalar GEMM cannot run in place");
+    Buffer *BP = nullptr;
+    if (bias_pt) { BP = getbuf(ctx, bias_pt, 1); if (!BP || !bias_idx) return fail(CN_ERR_ARG, "invalid bias plaintext handle"); }
+    const uint32_t k = ctx->hc.k; const uint64_t t = ctx->hc.t.q;
+    // validate + default gather (identity) + reference semantics: zero weights are skipped, all-zero row is an error
+    std::vector<int32_t> gidx((size_t)O * K);
+    for (uint32_t o = 0; o < O; o++) {
+        bool any = false;
+        for (uint32_t kk = 0; kk < K; kk++) {
+            int32_t id = idx ? idx[(size_t)o * K + kk] : (int32_t)kk;
+            uint64_t w = W[(size_t)o * K + kk];
+            if (w >= t) return fail(CN_ERR_ARG, "weight >= plain modulus");
+            if (id >= (int32_t)I->count) return fail(CN_ERR_ARG, "input index out of range");
+            if (id >= 0 && w) any = true;
+            gidx[(size_t)o * K + kk] = id;
+        }
+        if (!any) return fail(CN_ERR_ARG, "output %u has no non-zero term (AddMany of nothing)", o);
+        if (BP && (bias_idx[o] < 0 || (uint32_t)bias_idx[o] >= BP->count)) return fail(CN_ERR_ARG, "bias index out of range");
+    }
+    // group outputs that gather the same inputs (PoolLayer: every map of one corner shares its patch)
+    std::map<std::vector<int32_t>, std::vector<uint32_t>> groups;
+    for (uint32_t o = 0; o < O; o++) groups[std::vector<int32_t>(gidx.begin() + (size_t)o * K, gidx.begin() + (size_t)(o + 1) * K)].push_back(o);
+    uint32_t G = (uint32_t)groups.size(), M = (uint32_t)groups.begin()->second.size();
+    bool uniform = true;
+    for (auto &g : groups) if (g.second.size() != M) uniform = false;
+    std::vector<int32_t> hidx, hoidx, hbidx; std::vector<uint64_t> hW;
+    if (!uniform) { G = O; M = 1; }
+    hidx.resize((size_t)G * K); hoidx.resize((size_t)G * M); hbidx.assign((size_t)G * M, 0); hW.resize((size_t)k * G * M * K);
+    auto fill = [&](uint32_t g, uint32_t m, uint32_t o) {
+        hoidx[(size_t)g * M + m] = (int32_t)(oi + o);
+        if (BP) hbidx[(size_t)g * M + m] = bias_idx[o];
+        for (uint32_t j = 0; j < k; j++) for (uint32_t kk = 0; kk < K; kk++) {
+            uint64_t w = W[(size_t)o * K + kk];
+            hW[(((size_t)j * G + g) * M + m) * K + kk] = w ? lift_scalar(ctx->hc, w, j) : 0;
+        }
+    };
+    if (uniform) {
+        uint32_t g = 0;
+        for (auto &kv : groups) { memcpy(&hidx[(size_t)g * K], kv.first.data(), K * 4); for (uint32_t m = 0; m < M; m++) fill(g, m, kv.second[m]); g++; }
+    } else {
+        for (uint32_t o = 0; o < O; o++) { memcpy(&hidx[(size_t)o * K], &gidx[(size_t)o * K], K * 4); fill(o, 0, o); }
+    }
+    CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hW.size() * 8)));
+    int32_t *didx, *doidx, *dbidx; uint64_t *dW;
+    CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));
+    CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hW.data(), hW.size(), &dW));
+    // lazy-reduction interval: K' products of two values < q_max fit in 128 bits
+    uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+    int bits = 64 - __builtin_clzll(qmax);
+    uint32_t lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
+    const uint64_t *bias = BP ? BP->d : nullptr;
+    if (M >= 8) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+    else if (M >= 3) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+    else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    for (size_t x = 0; x < (size_t)O * K; x++) if (W[x] && gidx[x] >= 0) { ctx->st.PlainMultiplication++; ctx->st.Addition++; }
+    ctx->st.Addition -= O;
+    if (BP) ctx->st.PlainAddition += O;
+    return 0;
+}
+
+// ---------------------------------------------------------------- BEHZ multiply / key switching
+template <int K> static void launch_extend(cn_ctx *c, const uint64_t *src, uint32_t stride, uint64_t *aq, uint64_t *ab, uint32_t cnt) {
+    hipLaunchKernelGGL(k_behz_extend<K>, dim3(cnt * 2 * c->chunks), dim3(c->bs), 0, c->stream, src, stride, aq, ab, c->dc, c->chunks);
+}
+template <int K> static void launch_floor(cn_ctx *c, const uint64_t *dq, const uint64_t *db, uint64_t *out, uint32_t cnt) {
+    hipLaunchKernelGGL(k_behz_floor<K>, dim3(cnt * 3 * c->chunks), dim3(c->bs), 0, c->stream, dq, db, out, c->dc, c->chunks);
+}
+#define DISPATCH_K(fn, ...) switch (ctx->hc.k) { \
+    case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; \
+    case 4: fn<4>(__VA_ARGS__); break; case 5: fn<5>(__VA_ARGS__); break; case 6: fn<6>(__VA_ARGS__); break; \
+    case 7: fn<7>(__VA_ARGS__); break; case 8: fn<8>(__VA_ARGS__); break; case 9: fn<9>(__VA_ARGS__); break; \
+    default: return fail(CN_ERR_ARG, "ciphertext multiply supports at most 9 coefficient moduli"); }
+
+static size_t mul_scratch_per_ct(cn_ctx *c, bool square) {
+    size_t n = c->hc.n, k = c->hc.k, kb = c->hc.kb;
+    size_t w = (square ? 1 : 2) * 2 * (k + kb) * n + 3 * (k + kb) * n;
+    return al(w * 8) + 1024;
+}
+// a, b: pointers to first operand ciphertext (size 2); out3: [cnt][3][k][N]; scratch must be ensured by caller
+static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const uint64_t *b, uint32_t bstride, uint64_t *out3, uint32_t cnt) {
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k, kb = ctx->hc.kb;
+    const bool square = (a == b && astride == bstride);
+    uint64_t *aq = salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n), *ab = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n);
+    uint64_t *bq = aq, *bb = ab;
+    if (!square) { bq = salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n); bb = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n); }
+    uint64_t *dq = salloc<uint64_t>(ctx, (size_t)cnt * 3 * k * n), *db = salloc<uint64_t>(ctx, (size_t)cnt * 3 * kb * n);
+    if (!aq || !ab || !bq || !bb || !dq || !db) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply");
+    DISPATCH_K(launch_extend, ctx, a, astride, aq, ab, cnt);
+    if (!square) { DISPATCH_K(launch_extend, ctx, b, bstride, bq, bb, cnt); }
+    HIPCHK(hipGetLastError()); launch_count(ctx, square ? 1 : 2);
+    CHECK(run_ntt(ctx, aq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, ab, cnt * 2 * kb, k, kb, 0));
+    if (!square) { CHECK(run_ntt(ctx, bq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, bb, cnt * 2 * kb, k, kb, 0)); }
+    hipLaunchKernelGGL(k_tensor, dim3(cnt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, aq, bq, dq, ctx->dc, ctx->chunks, k, 0u);
+    hipLaunchKernelGGL(k_tensor, dim3(cnt * kb * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ab, bb, db, ctx->dc, ctx->chunks, kb, k);
+    HIPCHK(hipGetLastError()); launch_count(ctx, 2);
+    CHECK(run_ntt(ctx, dq, cnt * 3 * k, 0, k, 1)); CHECK(run_ntt(ctx, db, cnt * 3 * kb, k, kb, 1));
+    DISPATCH_K(launch_floor, ctx, dq, db, out3, cnt);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    ctx->st.Multiplication += cnt;
+    return 0;
+}
+template <int EPT>
+static void launch_ks(cn_ctx *c, uint32_t nt, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
+                      const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
+    hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, target, tstride, add0, add1, astride, key, out, c->dc, galois);
+}
+static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
+                        const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
+    uint32_t n = ctx->hc.n, nt = std::min<uint32_t>(1024, n), ept = n / nt;
+    switch (ept) {
+        case 1: launch_ks<1>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 2: launch_ks<2>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 4: launch_ks<4>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 8: launch_ks<8>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
+    }
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    uint32_t tot = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
+    ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot * ctx->hc.k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * ctx->hc.k;
+    return 0;
+}
+static uint32_t chunk_for(cn_ctx *ctx, size_t per_ct, uint32_t count) {
+    size_t c = std::max<size_t>(1, ctx->smax / per_ct);
+    return (uint32_t)std::min<size_t>(c, count);
+}
+
+extern "C" int cn_multiply(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out3, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out3, 3);
+    if (!range_ok(A, ai, count) || !range_ok(B, bi, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    const uint64_t *pa = A->d + ai * A->item_words, *pb = B->d + bi * B->item_words;
+    size_t per = mul_scratch_per_ct(ctx, pa == pb);
+    uint32_t ch = chunk_for(ctx, per, count);
+    for (uint32_t s = 0; s < count; s += ch) {
+        uint32_t c = std::min(ch, count - s);
+        CHECK(ensure_scratch(ctx, per * c + 4096));
+        CHECK(do_multiply(ctx, pa + s * A->item_words, 1, pb + s * B->item_words, 1, O->d + (oi + s) * O->item_words, c));
+    }
+    return 0;
+}
+extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in3, 3); GETCT(O, out, 2);
+    if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!ctx->rlk.d) return fail(CN_ERR_NOKEY, "relinearization keys not set");
+    if (!count) return 0;
+    const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
+    const uint64_t *p = I->d + ii * I->item_words;
+    CHECK(do_keyswitch(ctx, p + 2 * kn, 3 * kn, p, p + kn, 3 * kn, ctx->rlk.d, O->d + oi * O->item_words, count, 0));
+    ctx->st.Relinarization += count;
+    return 0;
+}
+extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out,
+                            uint32_t oi, uint32_t count) {
+    LOCK; GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out, 2);
+    if (!range_ok(A, ai, astride ? count : 1, astride ? astride : 1) || !range_ok(B, bi, bstride ? count : 1, bstride ? bstride : 1) || !range_ok(O, oi, count))
+        return fail(CN_ERR_ARG, "index out of range");
+    if (!ctx->rlk.d) return fail(CN_ERR_NOKEY, "relinearization keys not set");
+    if (!count) return 0;
+    const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
+    const uint64_t *pa = A->d + ai * A->item_words, *pb = B->d + bi * B->item_words;
+    const bool square = (pa == pb && astride == bstride);
+    size_t per = mul_scratch_per_ct(ctx, square) + al(3 * kn * 8);
+    uint32_t ch = chunk_for(ctx, per, count);
+    for (uint32_t s = 0; s < count; s += ch) {
+        uint32_t c = std::min(ch, count - s);
+        CHECK(ensure_scratch(ctx, per * c + 8192));
+        uint64_t *t3 = salloc<uint64_t>(ctx, (size_t)c * 3 * kn);
+        CHECK(do_multiply(ctx, pa + (size_t)s * astride * A->item_words, astride, pb + (size_t)s * bstride * B->item_words, bstride, t3, c));
+        CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk.d, O->d + (oi + s) * O->item_words, c, 0));
+    }
+    ctx->st.Relinarization += count;
+    return 0;
+}
+
+// ---------------------------------------------------------------- rotations
+// in/out device pointers to size-2 ciphertext arrays; tmp holds count size-2 ciphertexts
+static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *out, uint64_t *tmp, uint32_t count) {
+    auto it = ctx->gk.find(elt);
+    if (it == ctx->gk.end() || !it->second.d) return fail(CN_ERR_NOKEY, "Galois key not present");
+    const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
+    uint32_t limbs = count * 2 * ctx->hc.k;
+    hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second.d, out, count, 1));
+    ctx->st.Rotation += count;
+    return 0;
+}
+extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t elt, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(O, out, 2);
+    if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+    uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
+    return do_galois(ctx, I->d + ii * I->item_words, elt, O->d + oi * O->item_words, tmp, count);
+}
+// Evaluator::rotate_internal: direct key if present, otherwise non-adjacent-form decomposition
+static int rotate_rec(cn_ctx *ctx, uint64_t *cur, int steps, uint64_t *tmp, uint32_t count) {
+    if (steps == 0) return 0;
+    uint64_t elt = cn_galois_elt_from_step(ctx, steps);
+    if (!elt) return fail(CN_ERR_ARG, "step count too large");
+    auto it = ctx->gk.find(elt);
+    if (it != ctx->gk.end() && it->second.d) return do_galois(ctx, cur, elt, cur, tmp, count);
+    std::vector<int> naf;
+    bool sign = steps < 0; int v = std::abs(steps);
+    for (int i = 0; v; i++) { int zi = (v & 1) ? 2 - (v & 3) : 0; v = (v - zi) >> 1; if (zi) naf.push_back((sign ? -zi : zi) * (1 << i)); }
+    if (naf.size() == 1) return fail(CN_ERR_NOKEY, "Galois key not present");
+    for (int s : naf) {
+        if ((uint32_t)std::abs(s) == ctx->hc.n / 2) continue;
+        CHECK(rotate_rec(ctx, cur, s, tmp, count));
+    }
+    return 0;
+}
+extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(O, out, 2);
+    if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+    uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
+    uint64_t *o = O->d + oi * O->item_words; const uint64_t *i = I->d + ii * I->item_words;
+    if (o != i) HIPCHK(hipMemcpyAsync(o, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return rotate_rec(ctx, o, steps, tmp, count);
+}
+extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
+    return cn_apply_galois(ctx, in, ii, 2ull * ctx->hc.n - 1, out, oi, count);
+}
+
+// ---------------------------------------------------------------- raw transforms / timing / stats
+static int raw_ntt(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse) {
+    if (base != 0 && base != 1) return fail(CN_ERR_ARG, "base must be 0 (q) or 1 (Bsk)");
+    return run_ntt(ctx, (uint64_t *)p, limbs, base ? ctx->hc.k : 0, base ? ctx->hc.kb : ctx->hc.k, inverse);
+}
+extern "C" int cn_ntt_forward(cn_ctx *ctx, void *p, uint32_t limbs, int base) { LOCK; return raw_ntt(ctx, p, limbs, base, 0); }
+extern "C" int cn_ntt_inverse(cn_ctx *ctx, void *p, uint32_t limbs, int base) { LOCK; return raw_ntt(ctx, p, limbs, base, 1); }
+extern "C" int cn_ct_ntt(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, int inverse) {
+    LOCK; GETCT(B, h, 0);
+    if (!range_ok(B, first, count)) return fail(CN_ERR_ARG, "index out of range");
+    return raw_ntt(ctx, B->d + first * B->item_words, count * B->size * ctx->hc.k, 0, inverse);
+}
+extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse, int iters, float *ms) {
+    LOCK;
+    if (iters < 1 || !ms) return fail(CN_ERR_ARG, "bad arguments");
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; i++) CHECK(raw_ntt(ctx, p, limbs, base, inverse));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    float t = 0; HIPCHK(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+    *ms = t / iters;
+    return 0;
+}
+extern "C" int cn_event_time_begin(cn_ctx *ctx) { LOCK; HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return 0; }
+extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) {
+    LOCK;
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream)); HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+extern "C" int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (out) *out = ctx->st;
+    if (reset) ctx->st = cn_stats{};
+    return 0;
+}

@@ -1,0 +1,37 @@
+// Internal structures shared by the host runtime and the HIP kernels of libcnhip.so.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#define CN_MAXK 12
+
+// modulus with Barrett constant floor(2^128/q) (two words), as SEAL's SmallModulus carries it
+struct DMod { uint64_t q, r0, r1; };
+
+// Everything a kernel needs to know about the BFV context; lives in device memory,
+// passed by pointer (wave-uniform -> scalar loads).
+struct DevConsts {
+    uint32_t n, logn, k, kb;
+    DMod q[CN_MAXK];
+    DMod bsk[CN_MAXK + 1];           // BEHZ base B (k primes) then m_sk
+    DMod t;
+    // twiddles: for modulus m (0..k-1 = q_j, k..k+kb-1 = bsk_j): tw + m*4*n = {w[n], ws[n], iw[n], iws[n]}
+    uint64_t *tw;
+    uint64_t ninv[2 * CN_MAXK + 1], ninvs[2 * CN_MAXK + 1];
+    // plaintext scaling (Encryptor::preencrypt / add_plain) and fast plain lift (multiply_plain)
+    uint64_t t_half, delta[CN_MAXK], rtq[CN_MAXK], lift_inc[CN_MAXK];
+    // BEHZ constants (SEAL util/baseconverter.cpp)
+    uint64_t inv_qhat_q[CN_MAXK], mt_inv_qhat_q[CN_MAXK], qhat_mt[CN_MAXK];
+    uint64_t qhat_bsk[CN_MAXK + 1][CN_MAXK];
+    uint64_t inv_q_mt, q_bsk[CN_MAXK + 1], inv_mt_bsk[CN_MAXK + 1], inv_q_bsk[CN_MAXK + 1];
+    uint64_t inv_bhat_b[CN_MAXK], bhat_q[CN_MAXK][CN_MAXK], bhat_msk[CN_MAXK], inv_B_msk, B_q[CN_MAXK];
+    uint64_t t_q[CN_MAXK], t_bsk[CN_MAXK + 1];
+    // key switching
+    int32_t dbc, gdbc;
+    uint32_t rl_dig[CN_MAXK], gk_dig[CN_MAXK], rl_tot, gk_tot;
+};
+
+// host-side precompute (cn_tables.cpp). tw_host must hold (k+kb)*4*n words.
+int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc,
+                    uint64_t *tw_host, char *err, size_t errlen);
+int cn_default_coeff_modulus_impl(uint32_t n, uint64_t *q);

@@ -1,0 +1,365 @@
+// HIP kernels of libcnhip.so (gfx950 / CDNA4, wave64).  Integer VALU only: all arithmetic is
+// unsigned 64-bit modular arithmetic over RNS residues (no MFMA - nothing here is a float contraction).
+//
+// Data layout in HBM: ciphertext array = [ct][poly][limb][N] u64 (SEAL's per-ciphertext layout,
+// contiguous over the batch), so lane i of a wave touches coefficient i of one limb: every global
+// access below is a fully coalesced 8 B/lane (512 B/wave) stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "cn_internal.h"
+
+typedef unsigned __int128 u128;
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------ modular helpers
+DEV uint64_t bred128(uint64_t x0, uint64_t x1, const DMod &m) {   // Barrett, x = x1:x0 < 2^128
+    uint64_t carry = __umul64hi(x0, m.r0);
+    uint64_t t2lo = x0 * m.r1, t2hi = __umul64hi(x0, m.r1);
+    uint64_t tmp1 = t2lo + carry, tmp3 = t2hi + (tmp1 < carry);
+    uint64_t t3lo = x1 * m.r0, t3hi = __umul64hi(x1, m.r0);
+    uint64_t s = tmp1 + t3lo;
+    carry = t3hi + (s < tmp1);
+    uint64_t qhat = x1 * m.r1 + tmp3 + carry;
+    uint64_t r = x0 - qhat * m.q;
+    return r >= m.q ? r - m.q : r;
+}
+DEV uint64_t bred128(u128 x, const DMod &m) { return bred128((uint64_t)x, (uint64_t)(x >> 64), m); }
+DEV uint64_t mulmod(uint64_t a, uint64_t b, const DMod &m) { return bred128(a * b, __umul64hi(a, b), m); }
+DEV uint64_t addmod(uint64_t a, uint64_t b, uint64_t q) { uint64_t s = a + b; return s >= q ? s - q : s; }
+DEV uint64_t submod(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
+DEV uint64_t negmod(uint64_t a, uint64_t q) { return a ? q - a : 0; }
+// Harvey/Shoup lazy product: y*w mod q in [0,2q) for any 64-bit y, ws = floor(w*2^64/q)
+DEV uint64_t shoup_lazy(uint64_t y, uint64_t w, uint64_t ws, uint64_t q) { return y * w - __umul64hi(ws, y) * q; }
+
+// ------------------------------------------------------------------ in-LDS negacyclic NTT
+// One workgroup owns one limb (N words in LDS). Cooley-Tukey DIT, bit-reversed twiddle table,
+// values kept lazily in [0,4q); output order = SEAL's (bit-reversed evaluations).
+DEV void ntt_fwd_lds(uint64_t *s, const uint64_t *__restrict__ w, const uint64_t *__restrict__ ws, uint64_t q, uint32_t n) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, half = n >> 1;
+    const uint64_t q2 = 2 * q;
+    uint32_t logt = 31 - __clz(half);
+    for (uint32_t m = 1; m < n; m <<= 1, logt--) {
+        const uint32_t t = 1u << logt;
+        for (uint32_t b = tid; b < half; b += nt) {
+            uint32_t i = b >> logt, j = b & (t - 1);
+            uint32_t ia = (i << (logt + 1)) + j, ib = ia + t;
+            uint64_t W = w[m + i], Ws = ws[m + i];
+            uint64_t X = s[ia], Y = s[ib];
+            X -= (X >= q2) ? q2 : 0;
+            uint64_t Q = shoup_lazy(Y, W, Ws, q);
+            s[ia] = X + Q;
+            s[ib] = X + q2 - Q;
+        }
+        __syncthreads();
+    }
+}
+// Gentleman-Sande inverse; input canonical or in [0,2q), output in [0,2q) WITHOUT the 1/N factor.
+DEV void ntt_inv_lds(uint64_t *s, const uint64_t *__restrict__ iw, const uint64_t *__restrict__ iws, uint64_t q, uint32_t n) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, half = n >> 1;
+    const uint64_t q2 = 2 * q;
+    uint32_t logt = 0;
+    for (uint32_t m = half; m >= 1; m >>= 1, logt++) {
+        const uint32_t t = 1u << logt;
+        for (uint32_t b = tid; b < half; b += nt) {
+            uint32_t i = b >> logt, j = b & (t - 1);
+            uint32_t ia = (i << (logt + 1)) + j, ib = ia + t;
+            uint64_t W = iw[m + i], Ws = iws[m + i];
+            uint64_t U = s[ia], V = s[ib];
+            uint64_t S = U + V;
+            S -= (S >= q2) ? q2 : 0;
+            s[ia] = S;
+            s[ib] = shoup_lazy(U + q2 - V, W, Ws, q);
+        }
+        __syncthreads();
+    }
+}
+DEV uint64_t canon4(uint64_t v, uint64_t q) { uint64_t q2 = 2 * q; v -= (v >= q2) ? q2 : 0; v -= (v >= q) ? q : 0; return v; }
+
+// tw layout: modulus m -> tw + m*4n : w, ws, iw, iws
+DEV const uint64_t *tw_of(const DevConsts *C, uint32_t mod) { return C->tw + (size_t)mod * 4 * C->n; }
+
+// batched in-place NTT: block b transforms limb b; modulus = base_off + (b % nmod)
+__global__ void __launch_bounds__(1024) k_ntt(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
+    extern __shared__ uint64_t s[];
+    const uint32_t n = C->n, mod = base_off + blockIdx.x % nmod;
+    const uint64_t q = mod < C->k ? C->q[mod].q : C->bsk[mod - C->k].q;
+    uint64_t *x = data + (size_t)blockIdx.x * n;
+    const uint64_t *tw = tw_of(C, mod);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s[i] = x[i];
+    __syncthreads();
+    if (!inverse) {
+        ntt_fwd_lds(s, tw, tw + n, q, n);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) x[i] = canon4(s[i], q);
+    } else {
+        ntt_inv_lds(s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, n);
+        const uint64_t ni = C->ninv[mod], nis = C->ninvs[mod];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { uint64_t v = shoup_lazy(s[i], ni, nis, q); x[i] = v >= q ? v - q : v; }
+    }
+}
+
+// ------------------------------------------------------------------ element-wise kernels
+// grid.x = limbs * chunks ; limb index is block-uniform so moduli come from scalar loads.
+struct Geo { uint32_t chunks, bs; };
+DEV void decode(uint32_t chunks, uint32_t &limb, uint32_t &i) { limb = blockIdx.x / chunks; i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; }
+
+// op: 0 add, 1 sub, 2 negate(a).  a,b,out point at ciphertext arrays with `polys` polys each.
+__global__ void k_addsub(const uint64_t *a, const uint64_t *b, uint64_t *out, const DevConsts *__restrict__ C, uint32_t chunks, int op) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint64_t q = C->q[limb % C->k].q; size_t o = (size_t)limb * C->n + i;
+    uint64_t x = a[o];
+    out[o] = op == 0 ? addmod(x, b[o], q) : (op == 1 ? submod(x, b[o], q) : negmod(x, q));
+}
+// out = sum_i in[idx[i]] ; limbs = polys*k of ONE ciphertext
+__global__ void k_add_many(const uint64_t *in, const uint32_t *__restrict__ idx, uint32_t n_idx, size_t ct_words, uint64_t *out,
+                           const DevConsts *__restrict__ C, uint32_t chunks) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint64_t q = C->q[limb % C->k].q; size_t o = (size_t)limb * C->n + i;
+    uint64_t acc = 0;
+    for (uint32_t t = 0; t < n_idx; t++) acc = addmod(acc, in[(size_t)idx[t] * ct_words + o], q);
+    out[o] = acc;
+}
+DEV uint64_t scale_plain(const DevConsts *C, uint64_t m, uint32_t j) {       // Delta*m (+ r_t(q) in the upper half) mod q_j
+    u128 p = (u128)C->delta[j] * m;
+    if (m >= C->t_half) p += C->rtq[j];
+    return bred128(p, C->q[j]);
+}
+// a: [count][polys][k][N]; pt: [..][N]; grid over count*polys*k limbs
+__global__ void k_add_plain(const uint64_t *a, const uint64_t *pt, uint32_t pt_stride_words, uint64_t *out, const DevConsts *__restrict__ C,
+                            uint32_t chunks, uint32_t polys, int subtract) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, j = limb % k, p = (limb / k) % polys, ct = limb / (k * polys);
+    size_t o = (size_t)limb * C->n + i;
+    uint64_t x = a[o];
+    if (p == 0) {
+        uint64_t s = scale_plain(C, pt[(size_t)ct * pt_stride_words + i], j), q = C->q[j].q;
+        x = subtract ? submod(x, s, q) : addmod(x, s, q);
+    }
+    out[o] = x;
+}
+// lifted[pi][j][i] = fast plain lift of pt[pi][i] into q_j (multiply_plain)
+__global__ void k_lift_plain(const uint64_t *pt, uint64_t *lifted, const DevConsts *__restrict__ C, uint32_t chunks) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, j = limb % k, pi = limb / k;
+    uint64_t m = pt[(size_t)pi * C->n + i];
+    lifted[(size_t)limb * C->n + i] = m >= C->t_half ? m + C->lift_inc[j] : m;
+}
+// x[ct][p][j][i] *= ptn[(ct*pstride)][j][i]   (both in NTT form)
+__global__ void k_dyadic_pt(uint64_t *x, const uint64_t *ptn, uint32_t pstride, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t polys) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, j = limb % k, ct = limb / (k * polys);
+    size_t o = (size_t)limb * C->n + i;
+    x[o] = mulmod(x[o], ptn[((size_t)ct * pstride * k + j) * C->n + i], C->q[j]);
+}
+// out[ct] = a[ct] * lifted scalar sc[ct*sstride*k + j]   (constant-plaintext multiply_plain)
+__global__ void k_mul_scalar(const uint64_t *a, const uint64_t *__restrict__ sc, uint32_t sstride, uint64_t *out, const DevConsts *__restrict__ C,
+                             uint32_t chunks, uint32_t polys) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, j = limb % k, ct = limb / (k * polys);
+    size_t o = (size_t)limb * C->n + i;
+    out[o] = mulmod(a[o], sc[(size_t)ct * sstride * k + j], C->q[j]);
+}
+
+// ------------------------------------------------------------------ HOT LOOP A: scalar GEMM
+// Group g gathers K input ciphertexts idx[g][:] once and produces M outputs (register tile MT):
+//   out[out_idx[g][m]] = sum_k Wl[j][g][m][k] * in[idx[g][k]]  (+ scaled bias)   per limb j, coefficient i.
+// Products accumulate lazily in 128 bits; one Barrett reduction per `lazy` terms.
+template <int MT>
+__global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const uint64_t *__restrict__ Wl,
+                                                     const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
+                                                     uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy) {
+    const uint32_t n = C->n, k = C->k, limbs = 2 * k;
+    uint32_t bx = blockIdx.x;
+    const uint32_t chunk = bx % chunks; bx /= chunks;
+    const uint32_t limb = bx % limbs; bx /= limbs;
+    const uint32_t mt = bx % mtiles, g = bx / mtiles;
+    const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
+    const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
+    const DMod qm = C->q[j];
+    u128 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0;
+    const int32_t *gi = idx + (size_t)g * K;
+    const uint64_t *gw = Wl + (((size_t)j * G + g) * M + (size_t)mt * MT) * K;
+    const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
+    uint32_t since = 0;
+    for (uint32_t kk = 0; kk < K; kk++) {
+        const int32_t id = gi[kk];
+        if (id < 0) continue;
+        const uint64_t x = in[(size_t)id * ctw + e];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            if ((uint32_t)m < mcnt) acc[m] += (u128)x * gw[(size_t)m * K + kk];
+        if (++since == lazy) {
+            since = 0;
+#pragma unroll
+            for (int m = 0; m < MT; m++) acc[m] = bred128(acc[m], qm);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        if ((uint32_t)m < mcnt) {
+            const uint32_t o = g * M + mt * MT + m;
+            uint64_t r = bred128(acc[m], qm);
+            if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
+            out[(size_t)out_idx[o] * ctw + e] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ HOT LOOP B: BEHZ multiply
+// Step 0/1 (fastbconv_mtilde + mont_rq): q -> Bsk, removing q-overflows via m~ = 2^32.
+// src ciphertext c = srcbase + (first + c*stride)*ctw ; writes the q copy (for the q-side NTT) and Bsk.
+template <int K>
+__global__ void __launch_bounds__(256) k_behz_extend(const uint64_t *__restrict__ src, uint32_t stride, uint64_t *__restrict__ aq, uint64_t *__restrict__ ab,
+                                                     const DevConsts *__restrict__ C, uint32_t chunks) {
+    const uint32_t n = C->n;
+    const uint32_t cp = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;   // cp = ct*2 + poly
+    const uint32_t ct = cp >> 1, p = cp & 1;
+    const uint64_t *x = src + ((size_t)ct * stride * 2 + p) * K * n + i;
+    uint64_t *oq = aq + (size_t)cp * K * n + i, *ob = ab + (size_t)cp * (K + 1) * n + i;
+    uint64_t y[K], mt = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        uint64_t v = x[(size_t)j * n];
+        oq[(size_t)j * n] = v;
+        y[j] = mulmod(v, C->mt_inv_qhat_q[j], C->q[j]);
+        mt += y[j] * C->qhat_mt[j];
+    }
+    mt &= 0xffffffffull;
+    const uint64_t r = (0 - mt * C->inv_q_mt) & 0xffffffffull;      // r = -x q^{-1} mod m~
+#pragma unroll
+    for (int b = 0; b <= K; b++) {
+        const DMod bm = C->bsk[b];
+        u128 acc = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) acc += (u128)y[j] * C->qhat_bsk[b][j];
+        uint64_t xb = bred128(acc, bm);
+        uint64_t rr = r >= 0x80000000ull ? r + bm.q - 0x100000000ull : r;           // centred r
+        uint64_t v = bred128((u128)C->q_bsk[b] * rr + xb, bm);
+        ob[(size_t)b * n] = mulmod(v, C->inv_mt_bsk[b], bm);
+    }
+}
+// Step 2: tensor product in NTT form; A,B: [cnt][2][L][N], D: [cnt][3][L][N]; L limbs with moduli base_off..
+__global__ void k_tensor(const uint64_t *__restrict__ A, const uint64_t *__restrict__ B, uint64_t *__restrict__ D, const DevConsts *__restrict__ C,
+                         uint32_t chunks, uint32_t L, uint32_t base_off) {
+    uint32_t limb, i; decode(chunks, limb, i);                       // limb = ct*L + l
+    const uint32_t n = C->n, l = limb % L, ct = limb / L, mod = base_off + l;
+    const DMod m = mod < C->k ? C->q[mod] : C->bsk[mod - C->k];
+    const size_t Ln = (size_t)L * n, a = (size_t)ct * 2 * Ln + (size_t)l * n + i, d = (size_t)ct * 3 * Ln + (size_t)l * n + i;
+    uint64_t a0 = A[a], a1 = A[a + Ln], b0 = B[a], b1 = B[a + Ln];
+    D[d] = mulmod(a0, b0, m);
+    D[d + Ln] = addmod(mulmod(a0, b1, m), mulmod(a1, b0, m), m.q);
+    D[d + 2 * Ln] = mulmod(a1, b1, m);
+}
+// Steps 3/4 (x t, fast_floor: q u Bsk -> Bsk, fastbconv_sk: Bsk -> q) per coefficient.
+template <int K>
+__global__ void __launch_bounds__(256) k_behz_floor(const uint64_t *__restrict__ dq, const uint64_t *__restrict__ db, uint64_t *__restrict__ out,
+                                                    const DevConsts *__restrict__ C, uint32_t chunks) {
+    const uint32_t n = C->n;
+    const uint32_t cp = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;   // cp = ct*3 + poly
+    const uint64_t *xq = dq + (size_t)cp * K * n + i, *xb = db + (size_t)cp * (K + 1) * n + i;
+    uint64_t *o = out + (size_t)cp * K * n + i;
+    uint64_t y[K], f[K + 1], z[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) y[j] = mulmod(mulmod(xq[(size_t)j * n], C->t_q[j], C->q[j]), C->inv_qhat_q[j], C->q[j]);
+#pragma unroll
+    for (int b = 0; b <= K; b++) {
+        const DMod bm = C->bsk[b];
+        u128 acc = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) acc += (u128)y[j] * C->qhat_bsk[b][j];
+        uint64_t conv = bred128(acc, bm);
+        uint64_t xt = mulmod(xb[(size_t)b * n], C->t_bsk[b], bm);
+        f[b] = mulmod(xt + (bm.q - conv), C->inv_q_bsk[b], bm);
+    }
+    const DMod sk = C->bsk[K];
+    u128 acc = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) { z[j] = mulmod(f[j], C->inv_bhat_b[j], C->bsk[j]); acc += (u128)z[j] * C->bhat_msk[j]; }
+    const uint64_t alpha = mulmod(bred128(acc, sk) + (sk.q - f[K]), C->inv_B_msk, sk);
+    const bool neg = alpha > (sk.q >> 1);
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const DMod qm = C->q[j];
+        u128 a2 = 0;
+#pragma unroll
+        for (int l = 0; l < K; l++) a2 += (u128)z[l] * C->bhat_q[j][l];
+        uint64_t conv = bred128(a2, qm);
+        o[(size_t)j * n] = neg ? bred128((u128)C->B_q[j] * (sk.q - alpha) + conv, qm) : bred128((u128)(qm.q - C->B_q[j]) * alpha + conv, qm);
+    }
+}
+
+// ------------------------------------------------------------------ key switching (relinearize / Galois)
+// Fused per (ciphertext, output limb j): for every (source limb l, digit d): extract the base-2^dbc digit of
+// target[l], NTT it under q_j in LDS, multiply-accumulate with the key pair K[(l,d)][0/1][j] (NTT form) in
+// registers; finally INTT both accumulators and add them to add0/add1.  The digit polynomials never touch HBM.
+// block = NT threads, EPT = N/NT accumulators per thread per output poly.
+template <int EPT>
+__global__ void __launch_bounds__(1024) k_keyswitch(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
+                                                    const uint64_t *__restrict__ add1, size_t add_stride, const uint64_t *__restrict__ key,
+                                                    uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois) {
+    extern __shared__ uint64_t s[];
+    const uint32_t n = C->n, k = C->k, nt = blockDim.x, tid = threadIdx.x;
+    const uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const uint64_t *tw = tw_of(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    uint64_t acc0[EPT], acc1[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) { acc0[e] = 0; acc1[e] = 0; }
+    const uint64_t *kp = key;
+    for (uint32_t l = 0; l < k; l++) {
+        const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+            const int sh = dbc * (int)d;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                uint64_t v = (src[tid + e * nt] >> sh) & mask;
+                if (mask >= q) v = v >= q ? bred128(v, 0, qm) : v;
+                s[tid + e * nt] = v;
+            }
+            __syncthreads();
+            ntt_fwd_lds(s, tw, tw + n, q, n);
+            const uint64_t *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                uint64_t x = canon4(s[tid + e * nt], q);
+                acc0[e] = addmod(acc0[e], mulmod(x, k0[tid + e * nt], qm), q);
+                acc1[e] = addmod(acc1[e], mulmod(x, k1[tid + e * nt], qm), q);
+            }
+            __syncthreads();
+        }
+    }
+    const uint64_t ni = C->ninv[j], nis = C->ninvs[j];
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) s[tid + e * nt] = p ? acc1[e] : acc0[e];
+        __syncthreads();
+        ntt_inv_lds(s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, n);
+        const uint64_t *ad = p ? add1 : add0;
+        uint64_t *o = out + ((size_t)ct * 2 + p) * kn + (size_t)j * n;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            uint64_t v = shoup_lazy(s[tid + e * nt], ni, nis, q);
+            v = v >= q ? v - q : v;
+            if (ad) v = addmod(v, ad[(size_t)ct * add_stride + (size_t)j * n + tid + e * nt], q);
+            o[tid + e * nt] = v;
+        }
+        __syncthreads();
+    }
+}
+// Galois automorphism x -> x^elt on coefficient-form limbs: dst[(i*elt) mod N] = +-src[i]
+__global__ void k_galois(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, const DevConsts *__restrict__ C, uint32_t chunks, uint64_t elt) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t n = C->n;
+    const uint64_t q = C->q[limb % C->k].q;
+    const uint64_t raw = (uint64_t)i * elt;
+    const uint32_t idx = (uint32_t)(raw & (n - 1));
+    uint64_t v = src[(size_t)limb * n + i];
+    dst[(size_t)limb * n + idx] = ((raw >> C->logn) & 1) ? negmod(v, q) : v;
+}

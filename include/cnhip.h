@@ -1,0 +1,147 @@
+/*
+ * cnhip.h -- C ABI of libcnhip.so: the MI355X-native BFV evaluator that replaces the
+ * SEAL 3.2 native calls issued by microsoft/CryptoNets' AtomicSealBfvEncryptedVector.
+ *
+ * Boundary being replaced: the managed->native P/Invoke layer inside SEALNet.dll
+ * (NuGet Microsoft.Research.SEALNet 3.2.0, `HE Wrapper/packages.config:6`), reached only
+ * from `HE Wrapper/AtomicSealBfvVector.cs` through `epenv.evaluator.*`.  Each entry point
+ * below cites the reference call sites (file:line under /root/reference) it serves.
+ *
+ * Conventions:
+ *  - plain C, opaque context pointer + 64-bit buffer handles, no C++/torch types;
+ *  - every function returns 0 on success, <0 on error; cn_last_error() returns a
+ *    thread-local message (the reference throws .NET exceptions at the same points);
+ *  - all functions are thread-safe (one mutex per context: the reference calls from
+ *    Defaults.ThreadCount threads, `HE Wrapper/Utils.cs:46-88`);
+ *  - work is enqueued on the context's HIP stream; results are ordered; host reads
+ *    (cn_ct_download) synchronise; cn_sync() waits for everything;
+ *  - BATCHED BY CONSTRUCTION: a buffer handle is an ARRAY of ciphertexts (or dense
+ *    plaintexts); every op takes (handle, first index, count), so one layer is a handful
+ *    of launches instead of 10^5 P/Invokes.  count==1 is the per-ciphertext SEAL call.
+ *  - ciphertext layout = SEAL's: [poly][limb][N] u64 canonical residues, coefficient
+ *    form; plaintext = N u64 coefficients mod t; keys = NTT form (bit-reversed order):
+ *    key-switch key = for limb l, digit d (low->high): [2][k][N], flattened in (l,d) order.
+ */
+#ifndef CNHIP_H
+#define CNHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cn_ctx cn_ctx;
+typedef uint64_t cn_handle;
+
+#define CN_OK 0
+#define CN_ERR_ARG (-1)      /* bad argument / shape mismatch (reference: `throw new Exception(...)`) */
+#define CN_ERR_HIP (-2)      /* HIP runtime failure */
+#define CN_ERR_NOKEY (-3)    /* relin / Galois key missing (SEAL: "Galois key not present") */
+#define CN_ERR_ZERO (-4)     /* multiply_plain by an all-zero plaintext (SEAL: "plain cannot be zero") */
+#define CN_ERR_NODEV (-5)    /* no HIP device available */
+
+int cn_version(void);
+const char *cn_last_error(void);
+int cn_device_count(void);
+
+/* ---- context = AtomicSealBfvEncryptedEnvironment (AtomicSealBfvVector.cs:19-74,140-173):
+ * (n, coeff moduli q[k], plain modulus t, DecompositionBitCount, GaloisDecompositionBitCount). */
+int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc,
+                  int device, cn_ctx **out);
+int cn_ctx_destroy(cn_ctx *ctx);
+int cn_sync(cn_ctx *ctx);
+/* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
+int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
+/* number of u64 words of one key-switch key for this context (relin: which=0, galois: which=1) */
+size_t cn_key_words(cn_ctx *ctx, int which);
+/* keys.RelinKeys(dbc) / keys.GaloisKeys(gdbc) (AtomicSealBfvVector.cs:68-69): upload from host
+ * memory, or adopt a device buffer (e.g. one filled by an RCCL broadcast). */
+int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_device_ptr);
+int cn_set_galois_key(cn_ctx *ctx, uint64_t galois_elt, const uint64_t *words, size_t count, int is_device_ptr);
+int cn_has_galois_key(cn_ctx *ctx, uint64_t galois_elt);
+/* Evaluator/util galois_elt_from_step: steps>0 left, <0 right, 0 = column swap (2N-1) */
+uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps);
+
+/* ---- buffers = arrays of SEAL Ciphertext / Plaintext objects (ctor/Set/Dispose:
+ * AtomicSealBfvVector.cs:373,389-397,413-428) */
+int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out);   /* size = polys per ct (2 or 3) */
+int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out);                  /* dense plaintexts, N coeffs each */
+int cn_free(cn_ctx *ctx, cn_handle h);
+int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host);
+int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host);
+int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host);
+int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count);
+int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes);
+int cn_live_handles(cn_ctx *ctx);                                              /* leak counter */
+
+/* ---- linear ops ---------------------------------------------------------------------- */
+/* Evaluator.Add / Sub / Negate (AtomicSealBfvVector.cs:491,646,671,865,1005,1258) */
+int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count);
+int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count);
+int cn_negate(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count);
+/* Evaluator.AddMany (AtomicSealBfvVector.cs:502,698,708,902): out[oi] = sum_i in[idx[i]] */
+int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint32_t n_idx, cn_handle out, uint32_t oi);
+/* Evaluator.AddPlain / SubPlain (AtomicSealBfvVector.cs:1019,1267), dense plaintexts */
+int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract,
+                 cn_handle out, uint32_t oi, uint32_t count);
+/* Evaluator.MultiplyPlain with a dense (BatchEncoded) plaintext: lift, NTT, dyadic, INTT
+ * (AtomicSealBfvVector.cs:645,670,803,855,942,1455).  pt_stride 0 = same plaintext for all. */
+int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pt_stride,
+                 cn_handle out, uint32_t oi, uint32_t count);
+/* Evaluator.MultiplyPlain with a constant (sparse-format) plaintext `Plaintext(hex)`
+ * (AtomicSealBfvVector.cs:1136,1164,1179 -> :472,482,571,592): scalars[i] in [0,t). */
+int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars, uint32_t scalar_stride,
+                  cn_handle out, uint32_t oi, uint32_t count);
+/* HOT LOOP A: AtomicSealBfvEncryptedVector.DenseMatrixBySparseVectorMultiply for O outputs at
+ * once (AtomicSealBfvVector.cs:434-521 as driven by PoolLayer.ConvolveOnce/Apply,
+ * NeuralNetworks/PoolLayer.cs:113-121,149-229):
+ *   out[oi+o] = sum_k W[o*K+k] * in[idx[o*K+k]]  (+ Delta-scaled dense plaintext bias[bias_idx[o]])
+ * idx<0 = padded tap (skipped, PoolLayer.cs:68-80); W in [0,t), zero weights skipped (:468);
+ * an output whose weights are all zero is an error like SEAL's AddMany of nothing. */
+int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K,
+                   cn_handle bias_pt, const int32_t *bias_idx, cn_handle out, uint32_t oi);
+
+/* ---- non-linear ops ------------------------------------------------------------------ */
+/* Evaluator.Multiply (BEHZ), size2 x size2 -> size3 (AtomicSealBfvVector.cs:461,546,786,839,1457) */
+int cn_multiply(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out3, uint32_t oi, uint32_t count);
+/* Evaluator.Relinearize size3 -> size2 (AtomicSealBfvVector.cs:462,547,787,840) */
+int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count);
+/* HOT LOOP B: Multiply + Relinearize per block (PointwiseMultiply, AtomicSealBfvVector.cs:839-840;
+ * SquareActivation.cs:10-13).  a_stride/b_stride 0 broadcast one operand (PointwiseMultiplySparseDimOne). */
+int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t a_stride, cn_handle b, uint32_t bi, uint32_t b_stride,
+                 cn_handle out, uint32_t oi, uint32_t count);
+
+/* ---- rotations (HOT LOOP C) ----------------------------------------------------------- */
+/* Evaluator.ApplyGalois: automorphism + key switch of c1 */
+int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t galois_elt, cn_handle out, uint32_t oi, uint32_t count);
+/* Evaluator.RotateRows(/Inplace): NAF decomposition when no key exists for the step
+ * (AtomicSealBfvVector.cs:625,631,637,660,864,1420,1458) */
+int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count);
+/* Evaluator.RotateColumns(/Inplace) (AtomicSealBfvVector.cs:709,914,1391) */
+int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count);
+
+/* ---- raw transforms (kernel benchmarks / parity tests of the NTT itself) --------------- */
+/* in-place negacyclic NTT over `limbs` limbs of N words at a device pointer; limb i uses modulus
+ * (i % nmod) of base 0 (coeff moduli q) or base 1 (BEHZ Bsk moduli).  Async on the ctx stream. */
+int cn_ntt_forward(cn_ctx *ctx, void *dev_ptr, uint32_t limbs, int base);
+int cn_ntt_inverse(cn_ctx *ctx, void *dev_ptr, uint32_t limbs, int base);
+int cn_ct_ntt(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, int inverse);   /* same on a ct array */
+/* times `iters` back-to-back launches of the forward NTT kernel with HIP events on the ctx
+ * stream; returns average milliseconds per launch in *ms. */
+int cn_ntt_time(cn_ctx *ctx, void *dev_ptr, uint32_t limbs, int base, int inverse, int iters, float *ms);
+void *cn_stream(cn_ctx *ctx);                       /* hipStream_t of the context */
+int cn_event_time_begin(cn_ctx *ctx);               /* HIP-event stopwatch on the ctx stream */
+int cn_event_time_end(cn_ctx *ctx, float *ms);
+
+/* ---- statistics = OperationsCount (AtomicSealBfvVector.cs:211-294) ---------------------- */
+typedef struct cn_stats {
+    uint64_t Multiplication, PlainMultiplication, Addition, PlainAddition, Subtraction, PlainSubtraction,
+        Rotation, AddMany, AddManyItemCount, Relinarization;   /* reference names */
+    uint64_t ntt_forward_limbs, ntt_inverse_limbs, kernel_launches;
+} cn_stats;
+int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

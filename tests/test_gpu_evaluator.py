@@ -1,0 +1,238 @@
+"""GPU parity: every evaluator entry point of the C ABI vs the CPU oracle, BIT-EXACT (u64 words).
+
+Inputs are fresh BFV encryptions made by the oracle with a seeded RNG; the same words go to both sides.
+Tolerance: none - integer arithmetic, every ciphertext word must match.
+"""
+import numpy as np
+import pytest
+
+from conftest import PARAMS, get_gpu, get_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def enc_batch(o, rng, count):
+    vals = rng.integers(0, o.t, size=(count, o.n), dtype=np.uint64)
+    return vals, np.stack([o.encrypt(o.encode(v)) for v in vals])
+
+
+def up(g, cts, size=2):
+    h = g.ct_alloc(len(cts), size)
+    g.ct_upload(h, 0, cts)
+    return h
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c2", "c3"])
+def test_ntt_roundtrip_and_parity(name, rng):
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    cts = np.stack([rng.integers(0, q, size=o.n, dtype=np.uint64) for _ in range(2) for q in o.q] * 3).reshape(3, -1)
+    h = up(g, cts)
+    g.ct_ntt(h, 0, 3)
+    got = g.ct_download(h, 0, 3)
+    exp = np.stack([np.concatenate([o.ntt_fwd(j % o.k, c.reshape(2 * o.k, o.n)[j]) for j in range(2 * o.k)]) for c in cts])
+    assert np.array_equal(got, exp)
+    g.ct_ntt(h, 0, 3, inverse=True)
+    assert np.array_equal(g.ct_download(h, 0, 3), cts)
+    g.free(h)
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c3"])
+def test_linear_ops(name, rng):
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    vals, cts = enc_batch(o, rng, 4)
+    h = up(g, cts)
+    out = g.ct_alloc(4)
+    g.add(h, 0, h, 2, out, 0, 2)
+    g.sub(h, 0, h, 2, out, 2, 2)
+    got = g.ct_download(out, 0, 4)
+    for i in range(2):
+        assert np.array_equal(got[i], o.add(cts[i], cts[i + 2]))
+        assert np.array_equal(got[2 + i], o.sub(cts[i], cts[i + 2]))
+    g.negate(h, 1, out, 0, 1)
+    assert np.array_equal(g.ct_download(out, 0, 1)[0], o.negate(cts[1]))
+    g.add_many(h, [0, 3, 1, 2], out, 3)
+    exp = o.add(o.add(o.add(cts[0], cts[3]), cts[1]), cts[2])
+    assert np.array_equal(g.ct_download(out, 3, 1)[0], exp)
+    # add_plain / sub_plain with dense plaintexts (upper-half coefficients exercised by uniform values)
+    pv = rng.integers(0, o.t, size=(2, o.n), dtype=np.uint64)
+    plains = np.stack([o.encode(v) for v in pv])
+    ph = g.pt_alloc(2)
+    g.pt_upload(ph, 0, plains)
+    g.add_plain(h, 0, ph, 0, out, 0, 2)
+    g.add_plain(h, 2, ph, 0, out, 2, 2, subtract=True)
+    got = g.ct_download(out, 0, 4)
+    for i in range(2):
+        assert np.array_equal(got[i], o.add_plain(cts[i], plains[i]))
+        assert np.array_equal(got[2 + i], o.add_plain(cts[2 + i], plains[i], subtract=True))
+    for x in (h, out, ph):
+        g.free(x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c2", "c3"])
+def test_multiply_plain_dense_and_scalar(name, rng):
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    vals, cts = enc_batch(o, rng, 3)
+    h, out = up(g, cts), g.ct_alloc(3)
+    plains = rng.integers(0, o.t, size=(3, o.n), dtype=np.uint64)        # dense polynomial plaintexts
+    ph = g.pt_alloc(3)
+    g.pt_upload(ph, 0, plains)
+    g.mul_plain(h, 0, ph, 0, out, 0, 3)
+    got = g.ct_download(out, 0, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], o.multiply_plain(cts[i], plains[i]))
+    g.mul_plain(h, 0, ph, 1, out, 0, 3, pt_stride=0)                      # one plaintext broadcast
+    got = g.ct_download(out, 0, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], o.multiply_plain(cts[i], plains[1]))
+    # constant (sparse-format) plaintexts incl. negative weights t-|w| and the largest residue
+    sc = np.array([3, o.t - 7, o.t - 1], dtype=np.uint64)
+    g.mul_scalar(h, 0, sc, out, 0, 3)
+    got = g.ct_download(out, 0, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], o.multiply_plain(cts[i], sc[i:i + 1]))
+    # all-zero plaintext: SEAL throws "plain cannot be zero" -> CN_ERR_ZERO
+    from cryptonets_amd._native import CnError
+    g.pt_upload(ph, 2, np.zeros(o.n, dtype=np.uint64))
+    with pytest.raises(CnError) as e:
+        g.mul_plain(h, 0, ph, 2, out, 0, 1)
+    assert e.value.code == -4
+    with pytest.raises(CnError):
+        g.mul_scalar(h, 0, np.zeros(1, dtype=np.uint64), out, 0, 1)
+    for x in (h, out, ph):
+        g.free(x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c3"])
+def test_scalar_gemm(name, rng):
+    """HOT LOOP A (DenseMatrixBySparseVectorMultiply) incl. shared patches, padded taps, zero weights, bias."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    n_in, K = 7, 5
+    vals, cts = enc_batch(o, rng, n_in)
+    h = up(g, cts)
+    # conv-like: 3 "corners" with their own gather rows, 4 maps each, map-major output order like PoolLayer
+    corners = np.array([[0, 1, 2, 3, 4], [2, 3, -1, 5, 6], [6, 5, 4, -1, -1]], dtype=np.int32)
+    maps = 4
+    O = maps * len(corners)
+    idx = np.zeros((O, K), dtype=np.int32)
+    W = rng.integers(0, o.t, size=(O, K), dtype=np.uint64)
+    W[1, 2] = 0
+    W[5, :3] = 0
+    W[7] = np.array([1, o.t - 1, 2, o.t - 2, 0], dtype=np.uint64)
+    for m in range(maps):
+        for c in range(len(corners)):
+            idx[m * len(corners) + c] = corners[c]
+    bias_vals = rng.integers(0, o.t, size=maps, dtype=np.uint64)
+    bias_plain = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in bias_vals])
+    bh = g.pt_alloc(maps)
+    g.pt_upload(bh, 0, bias_plain)
+    bias_idx = np.repeat(np.arange(maps, dtype=np.int32), len(corners))
+    out = g.ct_alloc(O + 1)
+    g.scalar_gemm(h, W, out, 1, idx=idx, bias_pt=bh, bias_idx=bias_idx)
+    got = g.ct_download(out, 1, O)
+    exp = o.scalar_gemm(cts, W, idx)
+    exp = o.add_plain_batch(exp, bias_plain[bias_idx])
+    assert np.array_equal(got, exp)
+    # dense layer shape (identity gather, one group), no bias, more outputs than the register tile
+    O2 = 13
+    W2 = rng.integers(0, o.t, size=(O2, n_in), dtype=np.uint64)
+    out2 = g.ct_alloc(O2)
+    g.scalar_gemm(h, W2, out2, 0)
+    assert np.array_equal(g.ct_download(out2, 0, O2), o.scalar_gemm(cts, W2))
+    # an output with no non-zero term is an error (reference: AddMany of an empty list)
+    from cryptonets_amd._native import CnError
+    W2[3] = 0
+    with pytest.raises(CnError):
+        g.scalar_gemm(h, W2, out2, 0)
+    for x in (h, out, out2, bh):
+        g.free(x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c2", "c3"])
+def test_multiply_relinearize(name, rng):
+    """HOT LOOP B: Evaluator.Multiply (BEHZ) and Relinearize, separately and fused, incl. squaring."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    vals, cts = enc_batch(o, rng, 4)
+    h = up(g, cts)
+    out3, out2 = g.ct_alloc(2, 3), g.ct_alloc(4)
+    g.multiply(h, 0, h, 2, out3, 0, 2)
+    got3 = g.ct_download(out3, 0, 2, size=3)
+    exp3 = [o.multiply(cts[i], cts[i + 2]) for i in range(2)]
+    for i in range(2):
+        assert np.array_equal(got3[i], exp3[i])
+    g.relinearize(out3, 0, out2, 0, 2)
+    got2 = g.ct_download(out2, 0, 2)
+    for i in range(2):
+        assert np.array_equal(got2[i], o.relinearize(exp3[i]))
+    # fused multiply+relinearize, squaring path (SquareActivation: m.ElementWiseMultiply(m))
+    g.mul_relin(h, 0, h, 0, out2, 0, 4)
+    got = g.ct_download(out2, 0, 4)
+    exp = o.mul_relin_batch(cts, cts)
+    assert np.array_equal(got, exp)
+    # decrypted slots are the products (sanity that the compared words are a valid ciphertext)
+    dec = o.decode(o.decrypt(got[0]))
+    assert np.array_equal(dec, np.array([(int(a) * int(a)) % o.t for a in vals[0]], dtype=np.uint64))
+    # broadcast one operand (PointwiseMultiplySparseDimOne)
+    g.mul_relin(h, 0, h, 3, out2, 0, 3, b_stride=0)
+    got = g.ct_download(out2, 0, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], o.relinearize(o.multiply(cts[i], cts[3])))
+    for x in (h, out3, out2):
+        g.free(x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c4"])
+def test_rotations(name, rng):
+    """HOT LOOP C: Galois automorphism + key switch, direct keys and NAF-decomposed steps, column swap."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    vals, cts = enc_batch(o, rng, 2)
+    h, out = up(g, cts), g.ct_alloc(2)
+    half = o.n // 2
+    for steps in [1, -1, 2, -4, 3, -3, 169, -169, 7, half - 1, -(half - 1), 1024 - half if half > 1024 else 5]:
+        if abs(steps) >= half or steps == 0:
+            continue
+        g.rotate_rows(h, 0, steps, out, 0, 2)
+        got = g.ct_download(out, 0, 2)
+        for i in range(2):
+            assert np.array_equal(got[i], o.rotate_rows(cts[i], steps)), steps
+    d = o.decode(o.decrypt(got[0]))
+    g.rotate_columns(h, 0, out, 0, 2)
+    got = g.ct_download(out, 0, 2)
+    for i in range(2):
+        assert np.array_equal(got[i], o.rotate_columns(cts[i]))
+    assert np.array_equal(o.decode(o.decrypt(got[1])), np.concatenate([vals[1][half:], vals[1][:half]]))
+    # in-place rotation (RotateRowsInplace)
+    g.rotate_rows(h, 0, -5, h, 0, 1)
+    assert np.array_equal(g.ct_download(h, 0, 1)[0], o.rotate_rows(cts[0], -5))
+    for x in (h, out):
+        g.free(x)
+
+
+def test_c5_shapes_multiply_and_rotate(rng):
+    """N=16384, k=8, dbc=60 (LoLa-CIFAR parameters): one multiply+relinearize and one rotation."""
+    o, g = get_oracle("c5", galois=True), get_gpu("c5", galois=True)
+    vals, cts = enc_batch(o, rng, 2)
+    h, out = up(g, cts), g.ct_alloc(2)
+    g.mul_relin(h, 0, h, 1, out, 0, 1)
+    assert np.array_equal(g.ct_download(out, 0, 1)[0], o.relinearize(o.multiply(cts[0], cts[1])))
+    g.rotate_rows(h, 0, -3, out, 0, 2)
+    got = g.ct_download(out, 0, 2)
+    for i in range(2):
+        assert np.array_equal(got[i], o.rotate_rows(cts[i], -3))
+    for x in (h, out):
+        g.free(x)
+
+
+def test_handle_errors_and_leak_counter():
+    from cryptonets_amd._native import CnError
+    g = get_gpu("tiny", galois=False)
+    base = g.live_handles()
+    h = g.ct_alloc(2)
+    assert g.live_handles() == base + 1
+    with pytest.raises(CnError):
+        g.add(h, 0, h, 1, h, 2, 1)            # index out of range
+    with pytest.raises(CnError):
+        g.rotate_rows(h, 0, 1, h, 0, 1)       # no Galois keys in this context
+    g.free(h)
+    with pytest.raises(CnError):
+        g.free(h)
+    assert g.live_handles() == base
