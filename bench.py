@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""bench.py -- encrypted images/s of CryptoNets-MNIST (N=8192, 5 RNS limbs, 2 plaintext primes) on MI355X.
+
+One step = one 8192-image ciphertext batch through the five evaluated layers (the reference's "Batch-Time"
+window, CryptoNets/CryptoNets.cs:31,74) for BOTH plaintext-prime channels, inputs resident in HBM.
+N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL), every rank evaluates its own
+independent batch (weak scaling, no data-path collective); evaluation keys are broadcast once from rank 0.
+Prints ONE JSON line on rank 0 with `roofline` (the N=8192 NTT kernel, HIP-event timed) and, at N=1,
+`cpu_baseline` (the CPU oracle = port of the reference's SEAL path, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def uniform_ct_words(rng, q, n, count, polys=2):
+    """Uniform RNS residues: the distribution of fresh BFV ciphertext / key words."""
+    out = np.empty((count, polys, len(q), n), dtype=np.uint64)
+    for j, qj in enumerate(q):
+        out[:, :, j, :] = rng.integers(0, qj, size=(count, polys, n), dtype=np.uint64)
+    return out.reshape(count, -1)
+
+
+def cpu_baseline(cores, budget_s=20.0):
+    """Time the CPU oracle (port of the SEAL 3.2 path the reference runs) on a bounded sample of the same
+    workload and extrapolate to one 8192-image batch over both plaintext primes."""
+    from oracle.cno import Oracle
+    from cryptonets_amd import cryptonets_mnist as cm
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    o = Oracle(cm.N, cm.PLAIN_PRIMES[0], dbc=10, gdbc=20)
+    o.keygen(1, galois=False)
+    rng = np.random.default_rng(7)
+    ns = max(8, cores)                                # sample sizes that keep every core busy
+    cts = uniform_ct_words(rng, o.q, o.n, 64)
+    t0 = time.perf_counter(); o.scalar_gemm(cts[:25], rng.integers(1, 1 << 20, size=(4 * ns, 25), dtype=np.uint64)); t_conv = (time.perf_counter() - t0) / (4 * ns)
+    big = np.tile(cts, (14, 1))[:845]
+    t0 = time.perf_counter(); o.scalar_gemm(big, rng.integers(1, 1 << 20, size=(ns, 845), dtype=np.uint64)); t_d3 = (time.perf_counter() - t0) / ns
+    t0 = time.perf_counter(); o.scalar_gemm(big[:100], rng.integers(1, 1 << 20, size=(ns, 100), dtype=np.uint64)); t_d5 = (time.perf_counter() - t0) / ns
+    sq = np.tile(cts, (max(1, (2 * ns + 63) // 64), 1))[:2 * ns]
+    t0 = time.perf_counter(); o.mul_relin_batch(sq, sq); t_sq = (time.perf_counter() - t0) / (2 * ns)
+    per_prime = 845 * t_conv + 945 * t_sq + 100 * t_d3 + 10 * t_d5
+    total = 2 * per_prime
+    return {"value": 8192.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle (C restatement of SEAL 3.2 BFV, OpenMP) timed on %d conv outputs, %d dense-845 outputs, %d dense-100 "
+                      "outputs, %d square+relinearize ciphertexts of the N=8192 k=5 workload, extrapolated to 845/100/10/945 x 2 primes "
+                      "(%.1f s per batch)" % (4 * ns, ns, ns, 2 * ns, total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libcnhip has no CPU path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from cryptonets_amd._native import Context
+    from cryptonets_amd import cryptonets_mnist as cm
+
+    rng = np.random.default_rng(1000 + rank)
+    layers = cm.layer_tables(*cm.synthetic_weights(1))
+    chans, key_tensors = [], []
+    for p in cm.PLAIN_PRIMES:
+        g = Context(cm.N, p, dbc=10, gdbc=20, device=local)
+        # relinearisation keys: rank 0 draws them, RCCL broadcast over xGMI puts them on every GPU
+        words = g.key_words(False)
+        if rank == 0:
+            kw = uniform_ct_words(np.random.default_rng(p % 1000), g.q, g.n, words // g.ctw).reshape(-1)
+            kt = torch.from_numpy(kw.view(np.int64)).cuda()
+        else:
+            kt = torch.empty(words, dtype=torch.int64, device="cuda")
+        if dist is not None:
+            dist.broadcast(kt, src=0)
+        torch.cuda.synchronize()
+        g.set_relin_key_device(kt.data_ptr(), words)
+        key_tensors.append(kt)
+        ch = cm.CryptoNetsChannel(g, layers, cm.constant_plaintext(cm.N))
+        inp = uniform_ct_words(rng, g.q, g.n, 784)
+        for i in range(0, 784, 98):
+            g.ct_upload(ch.h_in, i, inp[i:i + 98])
+        chans.append(ch)
+
+    def step():
+        for ch in chans:
+            ch.forward()
+
+    def sync_all():
+        for ch in chans:
+            ch.g.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: the batched N=8192 RNS NTT, timed with HIP events on the ctx stream
+    g = chans[0].g
+    limbs = 845 * 2 * g.k
+    ptr, _ = g.device_ptr(chans[0].h2)
+    g.ntt_time(ptr, limbs, 0, False, 2)
+    ms = g.ntt_time(ptr, limbs, 0, False, 20)
+    alg_bytes = limbs * g.n * 8 * 2                      # each limb read once + written once (128 KiB per N=8192 limb)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_ntt (forward, %d limbs of N=%d u64)" % (limbs, g.n), "achieved": round(achieved, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "ms_per_launch": round(ms, 4), "bytes_per_launch": alg_bytes}
+
+    if rank == 0:
+        images = 8192 * args.steps * world
+        out = {"metric": "encrypted images/sec (CryptoNets-MNIST, N=8192)", "value": round(images / dt, 1), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
+                                      "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
+                                      "dbc=10; inputs/keys = uniform RNS residues resident in HBM",
+                          "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

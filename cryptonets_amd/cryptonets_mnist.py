@@ -1,0 +1,116 @@
+"""CryptoNets-MNIST (the reference's headline workload) expressed as batched libcnhip calls.
+
+Workload definition follows `CryptoNets/CryptoNets.cs:12-110`: 8192-slot batch, plaintext primes
+{549764251649, 549764284417}, N = 8192, CoeffModulus128(8192) (5 limbs), dbc 10:
+  PoolLayer conv 28x28, 5x5, stride 2, upper pad 1, 5 maps (scale 32; bias = 26th weight of every map)
+  -> SquareActivation -> PoolLayer dense 845->100 (scale 1024, Biases_2) -> SquareActivation
+  -> PoolLayer dense 100->10 (scale 32, Biases_3).
+The timed window is the one the reference's TimingLayers bracket (`CryptoNets.cs:31,74`): after encryption,
+before decryption.  One plaintext prime = one independent CRT channel = one device context
+(`EncryptedSealBfvVector.cs:225-236` fans every op out per prime).
+"""
+import numpy as np
+
+from .convolution import ConvolutionEngine
+
+PLAIN_PRIMES = (549764251649, 549764284417)
+N = 8192
+INPUT_SCALE = 16.0
+NORMALIZATION = 1.0 / 256.0
+WEIGHT_SCALE = 32
+
+
+def _round_scaled(values, scale):
+    """v.Multiply(Scale).PointwiseRound() -> BigInteger (EncryptedSealBfvVector.cs:355-357): double product,
+    round-half-even, exact integer."""
+    return [int(round(float(v) * float(scale))) for v in values]
+
+
+def layer_tables(weights0, weights1, biases2, weights3, biases3):
+    """Integer (scaled, signed) weight / bias tables and gather indices of the three PoolLayers.
+
+    weights0: 130 doubles (5 maps x 26, last of each 26 is the bias), weights1: 84500 (845x100, transposed by
+    CryptoNets.Transpose, CryptoNets.cs:112-123), weights3: 1000 (10x100).  Returns a list of dicts with
+    idx [O,K] int32, W [O,K] python ints, bias [O] python ints, in the reference's output order (map-major)."""
+    layers = []
+    # --- conv (no-bias branch of PoolLayer.Apply, PoolLayer.cs:196-227): kernelSize = 25 + 1
+    eng = ConvolutionEngine([28, 28], [5, 5], [2, 2], Upperpadding=[1, 1], MapCount=[5, 1])
+    ks = 26
+    gather = eng.gather_table()                                   # [169, 25]
+    win = eng.weight_windows(weights0, ks)                        # [5, 25]
+    O = eng.maps * len(eng.Corners)
+    idx = np.zeros((O, gather.shape[1]), dtype=np.int32)
+    W, bias = [], []
+    s_in = INPUT_SCALE
+    for m in range(eng.maps):
+        wrow = _round_scaled(win[m], WEIGHT_SCALE)
+        b = _round_scaled([weights0[(m + 1) * ks - 1]], s_in * WEIGHT_SCALE)[0]
+        for c in range(len(eng.Corners)):
+            idx[m * len(eng.Corners) + c] = gather[c]
+            W.append(wrow)
+            bias.append(b)
+    layers.append(dict(idx=idx, W=W, bias=bias, scale=s_in * WEIGHT_SCALE))
+    s = (s_in * WEIGHT_SCALE) ** 2
+    # --- dense 845 -> 100
+    w1t = np.zeros(len(weights1))
+    for i in range(845):
+        for j in range(100):
+            w1t[i + 845 * j] = weights1[100 * i + j]
+    ws = WEIGHT_SCALE * WEIGHT_SCALE
+    W = [_round_scaled(w1t[m * 845:(m + 1) * 845], ws) for m in range(100)]
+    bias = _round_scaled(biases2, s * ws)
+    layers.append(dict(idx=np.tile(np.arange(845, dtype=np.int32), (100, 1)), W=W, bias=bias, scale=s * ws))
+    s = (s * ws) ** 2
+    # --- dense 100 -> 10
+    W = [_round_scaled(weights3[m * 100:(m + 1) * 100], WEIGHT_SCALE) for m in range(10)]
+    bias = _round_scaled(biases3, s * WEIGHT_SCALE)
+    layers.append(dict(idx=np.tile(np.arange(100, dtype=np.int32), (10, 1)), W=W, bias=bias, scale=s * WEIGHT_SCALE))
+    return layers
+
+
+def synthetic_weights(seed=1):
+    """Random-init weights of the CryptoNets-MNIST architecture (the trained ones live in the reference repo)."""
+    r = np.random.default_rng(seed)
+    return (r.normal(0, 0.4, 130), r.normal(0, 0.05, 84500), r.normal(0, 0.05, 100), r.normal(0, 0.3, 1000), r.normal(0, 0.1, 10))
+
+
+def residues(int_rows, p):
+    return np.array([[x % p for x in row] for row in int_rows], dtype=np.uint64)
+
+
+class CryptoNetsChannel:
+    """One plaintext-prime channel of the network on one GPU: device buffers + the five layer launches."""
+
+    def __init__(self, ctx, layers, encode_constant):
+        """ctx: cryptonets_amd._native.Context for this prime.  encode_constant(value mod t) -> N plaintext
+        coefficients of the dense vector holding `value` in every slot (BatchEncoder of a constant vector is the
+        constant polynomial, so this is [value, 0, 0, ...])."""
+        self.g, p = ctx, ctx.t
+        self.layers = []
+        for L in layers:
+            W = residues(L["W"], p)
+            bias = np.array([b % p for b in L["bias"]], dtype=np.uint64)
+            uniq, inv = np.unique(bias, return_inverse=True)
+            bh = ctx.pt_alloc(len(uniq))
+            ctx.pt_upload(bh, 0, np.stack([encode_constant(int(v)) for v in uniq]))
+            self.layers.append(dict(idx=L["idx"], W=W, bias_pt=bh, bias_idx=inv.astype(np.int32)))
+        self.h_in = ctx.ct_alloc(784)
+        self.h1, self.h2 = ctx.ct_alloc(845), ctx.ct_alloc(845)
+        self.h3, self.h4 = ctx.ct_alloc(100), ctx.ct_alloc(100)
+        self.h5 = ctx.ct_alloc(10)
+
+    def forward(self):
+        g, L = self.g, self.layers
+        g.scalar_gemm(self.h_in, L[0]["W"], self.h1, 0, idx=L[0]["idx"], bias_pt=L[0]["bias_pt"], bias_idx=L[0]["bias_idx"])
+        g.mul_relin(self.h1, 0, self.h1, 0, self.h2, 0, 845)
+        g.scalar_gemm(self.h2, L[1]["W"], self.h3, 0, idx=L[1]["idx"], bias_pt=L[1]["bias_pt"], bias_idx=L[1]["bias_idx"])
+        g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
+        g.scalar_gemm(self.h4, L[2]["W"], self.h5, 0, idx=L[2]["idx"], bias_pt=L[2]["bias_pt"], bias_idx=L[2]["bias_idx"])
+
+
+def constant_plaintext(n):
+    def enc(v):
+        p = np.zeros(n, dtype=np.uint64)
+        p[0] = v
+        return p
+    return enc

@@ -169,8 +169,9 @@ def test_multiply_relinearize(name, rng):
     exp = o.mul_relin_batch(cts, cts)
     assert np.array_equal(got, exp)
     # decrypted slots are the products (sanity that the compared words are a valid ciphertext)
-    dec = o.decode(o.decrypt(got[0]))
-    assert np.array_equal(dec, np.array([(int(a) * int(a)) % o.t for a in vals[0]], dtype=np.uint64))
+    if name != "c2":      # 2 limbs (86-bit q) with a 39-bit t leave no noise budget for a ct x ct product
+        dec = o.decode(o.decrypt(got[0]))
+        assert np.array_equal(dec, np.array([(int(a) * int(a)) % o.t for a in vals[0]], dtype=np.uint64))
     # broadcast one operand (PointwiseMultiplySparseDimOne)
     g.mul_relin(h, 0, h, 3, out2, 0, 3, b_stride=0)
     got = g.ct_download(out2, 0, 3)
