@@ -72,6 +72,9 @@ SIGNATURES = {
     "cn_ct_upload": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_ct_download": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_pt_upload": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
+    "cn_pt_download": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
+    "cn_encode": (C.c_int, [_CTX, U64P, _u32, _H, _u32]),
+    "cn_decode": (C.c_int, [_CTX, _H, _u32, U64P]),
     "cn_copy": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
     "cn_device_ptr": (C.c_int, [_CTX, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cn_live_handles": (C.c_int, [_CTX]),
@@ -214,6 +217,20 @@ class Context:
     def pt_upload(self, h, first, data):
         d = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, self.n)
         self._chk(self.L.cn_pt_upload(self._h, h, first, d.shape[0], _p64(d)))
+
+    def pt_download(self, h, first, count):
+        out = np.empty((count, self.n), dtype=np.uint64)
+        self._chk(self.L.cn_pt_download(self._h, h, first, count, _p64(out)))
+        return out
+
+    def encode(self, values, pt, pi):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        self._chk(self.L.cn_encode(self._h, _p64(v), v.size, pt, pi))
+
+    def decode(self, pt, pi):
+        out = np.empty(self.n, dtype=np.uint64)
+        self._chk(self.L.cn_decode(self._h, pt, pi, _p64(out)))
+        return out
 
     def copy(self, src, sfirst, dst, dfirst, count):
         self._chk(self.L.cn_copy(self._h, src, sfirst, dst, dfirst, count))

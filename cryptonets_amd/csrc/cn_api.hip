@@ -46,6 +46,7 @@ struct cn_ctx {
     cn_stats st{};
     hipEvent_t ev0, ev1;
     uint32_t bs, chunks;      // element-wise geometry
+    std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
     size_t ctw2;              // words of a size-2 ciphertext
 };
 
@@ -119,10 +120,12 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (ndev <= 0) return fail(CN_ERR_NODEV, "no HIP device available (libcnhip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(CN_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
     if (n > 16384) return fail(CN_ERR_ARG, "poly modulus degree %u too large for the LDS-resident NTT (max 16384)", n);
-    std::vector<uint64_t> tw((size_t)(2 * k + 1) * 4 * n);
+    if (k == 0 || k > CN_MAXK) return fail(CN_ERR_ARG, "coeff modulus count out of range");
+    std::vector<uint64_t> tw((size_t)(2 * k + 2) * 4 * n);
     cn_ctx *c = new cn_ctx();
     char err[256];
-    if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
+    c->index_map.assign(n, 0);
+    if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), c->index_map.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
     c->device = device;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -242,6 +245,49 @@ extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t c
     }
     HIPCHK(hipMemcpyAsync(b->d + (size_t)first * n, host, (size_t)count * n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) {
+    LOCK; GETPT(b, h);
+    if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
+    HIPCHK(hipMemcpyAsync(host, b->d + (size_t)first * ctx->hc.n, (size_t)count * ctx->hc.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+// BatchEncoder.Encode: slot values -> plaintext coefficients (scatter by the index map, INTT mod t on the device)
+extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi) {
+    LOCK; GETPT(b, pt);
+    if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
+    const uint32_t n = ctx->hc.n;
+    if (pi >= b->count || nvalues > n || (nvalues && !values)) return fail(CN_ERR_ARG, "bad encode arguments");
+    std::vector<uint64_t> tmp(n, 0);
+    uint8_t zero = 1;
+    for (uint32_t i = 0; i < nvalues; i++) {
+        if (values[i] >= ctx->hc.t.q) return fail(CN_ERR_ARG, "value >= plain modulus");
+        if (values[i]) zero = 0;
+        tmp[ctx->index_map[i]] = values[i];
+    }
+    uint64_t *d = b->d + (size_t)pi * n;
+    HIPCHK(hipMemcpyAsync(d, tmp.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    CHECK(run_ntt(ctx, d, 1, ctx->hc.k + ctx->hc.kb, 1, 1));
+    b->pt_zero[pi] = zero;
+    return 0;
+}
+// BatchEncoder.Decode: plaintext coefficients -> N slot values
+extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values) {
+    LOCK; GETPT(b, pt);
+    if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
+    const uint32_t n = ctx->hc.n;
+    if (pi >= b->count || !values) return fail(CN_ERR_ARG, "bad decode arguments");
+    CHECK(ensure_scratch(ctx, al((size_t)n * 8)));
+    uint64_t *tmp = salloc<uint64_t>(ctx, n);
+    HIPCHK(hipMemcpyAsync(tmp, b->d + (size_t)pi * n, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CHECK(run_ntt(ctx, tmp, 1, ctx->hc.k + ctx->hc.kb, 1, 0));
+    std::vector<uint64_t> host(n);
+    HIPCHK(hipMemcpyAsync(host.data(), tmp, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n; i++) values[i] = host[ctx->index_map[i]];
     return 0;
 }
 extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) {

@@ -15,9 +15,11 @@ struct DevConsts {
     DMod q[CN_MAXK];
     DMod bsk[CN_MAXK + 1];           // BEHZ base B (k primes) then m_sk
     DMod t;
-    // twiddles: for modulus m (0..k-1 = q_j, k..k+kb-1 = bsk_j): tw + m*4*n = {w[n], ws[n], iw[n], iws[n]}
+    // twiddles: for modulus m (0..k-1 = q_j, k..k+kb-1 = bsk_j, k+kb = plain modulus t when batching):
+    // tw + m*4*n = {w[n], ws[n], iw[n], iws[n]}
     uint64_t *tw;
-    uint64_t ninv[2 * CN_MAXK + 1], ninvs[2 * CN_MAXK + 1];
+    uint64_t ninv[2 * CN_MAXK + 2], ninvs[2 * CN_MAXK + 2];
+    uint32_t batching;               // t is prime and == 1 mod 2N: BatchEncoder available
     // plaintext scaling (Encryptor::preencrypt / add_plain) and fast plain lift (multiply_plain)
     uint64_t t_half, delta[CN_MAXK], rtq[CN_MAXK], lift_inc[CN_MAXK];
     // BEHZ constants (SEAL util/baseconverter.cpp)
@@ -31,7 +33,8 @@ struct DevConsts {
     uint32_t rl_dig[CN_MAXK], gk_dig[CN_MAXK], rl_tot, gk_tot;
 };
 
-// host-side precompute (cn_tables.cpp). tw_host must hold (k+kb)*4*n words.
+// host-side precompute (cn_tables.cpp). tw_host must hold (k+kb+1)*4*n words; index_map (n entries) receives the
+// BatchEncoder slot->coefficient map when batching is possible.
 int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc,
-                    uint64_t *tw_host, char *err, size_t errlen);
+                    uint64_t *tw_host, uint32_t *index_map, char *err, size_t errlen);
 int cn_default_coeff_modulus_impl(uint32_t n, uint64_t *q);

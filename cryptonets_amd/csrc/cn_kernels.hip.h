@@ -82,7 +82,7 @@ DEV const uint64_t *tw_of(const DevConsts *C, uint32_t mod) { return C->tw + (si
 __global__ void __launch_bounds__(1024) k_ntt(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
     extern __shared__ uint64_t s[];
     const uint32_t n = C->n, mod = base_off + blockIdx.x % nmod;
-    const uint64_t q = mod < C->k ? C->q[mod].q : C->bsk[mod - C->k].q;
+    const uint64_t q = mod < C->k ? C->q[mod].q : (mod < C->k + C->kb ? C->bsk[mod - C->k].q : C->t.q);
     uint64_t *x = data + (size_t)blockIdx.x * n;
     const uint64_t *tw = tw_of(C, mod);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s[i] = x[i];

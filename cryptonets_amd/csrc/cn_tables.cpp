@@ -99,7 +99,7 @@ int cn_default_coeff_modulus_impl(uint32_t n, uint64_t *q) {
 }
 
 int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc,
-                    uint64_t *tw_host, char *err, size_t errlen) {
+                    uint64_t *tw_host, uint32_t *index_map, char *err, size_t errlen) {
     memset(c, 0, sizeof *c);
     if (k == 0 || k > CN_MAXK) { snprintf(err, errlen, "coeff modulus count %u out of range", k); return -1; }
     if (n < 4 || (n & (n - 1))) { snprintf(err, errlen, "poly modulus degree must be a power of two"); return -1; }
@@ -125,6 +125,19 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         uint64_t mod = m < k ? q[m] : bsk[m - k];
         if (!fill_twiddles(tw_host + (size_t)m * 4 * n, n, c->logn, mod, c->ninv[m], c->ninvs[m])) {
             snprintf(err, errlen, "modulus 0x%llx has no primitive %u-th root of unity", (unsigned long long)mod, 2 * n); return -1;
+        }
+    }
+    // plain modulus tables + BatchEncoder index map (SEAL batchencoder.cpp: generator 3, bit-reversed positions)
+    {
+        const uint32_t m = k + c->kb;
+        c->batching = is_prime_u64(t) && fill_twiddles(tw_host + (size_t)m * 4 * n, n, c->logn, t, c->ninv[m], c->ninvs[m]);
+        if (c->batching && index_map) {
+            uint64_t mm = 2ull * n, pos = 1;
+            for (uint32_t i = 0; i < n / 2; i++) {
+                index_map[i] = brev((uint32_t)((pos - 1) >> 1), c->logn);
+                index_map[n / 2 + i] = brev((uint32_t)((mm - pos - 1) >> 1), c->logn);
+                pos = (pos * 3) & (mm - 1);
+            }
         }
     }
     // Delta = floor(q/t) mod q_j, r_t(q) = q mod t  (multi-precision q)

@@ -1,0 +1,1131 @@
+"""Host-side mirror of the reference's HE wrapper (`HE Wrapper/*.cs`) on top of libcnhip.
+
+Same names, argument meaning and error behaviour as the C# classes so the parity tests read like the reference's
+MSTest suite:
+  AtomicSealBfvEncryptedEnvironment / AtomicSealBfvEncryptedVector   <- AtomicSealBfvVector.cs
+  EncryptedSealBfvEnvironment / EncryptedSealBfvVector               <- EncryptedSealBfvVector.cs (CRT over plaintext primes)
+  EncryptedSealBfvMatrix                                             <- EncryptedSealBfvMatrix.cs
+  EncryptedSealBfvFactory                                            <- IFactory.cs:240-410
+Every `epenv.evaluator.*` call of the reference becomes a (batched) libcnhip call on device-resident ciphertext
+arrays.  What stays on the client in the reference (KeyGenerator, Encryptor, Decryptor - SEAL calls at
+AtomicSealBfvVector.cs:62-74,1042,1211) is behind the small `ClientCrypto` interface: the evaluator never sees a
+secret key.  BatchEncoder (public math) runs on the device (cn_encode / cn_decode).
+"""
+import enum
+import math
+
+import numpy as np
+
+
+class EVectorFormat(enum.Enum):
+    dense = 0
+    sparse = 1
+
+
+class EMatrixFormat(enum.Enum):
+    ColumnMajor = 0
+    RowMajor = 1
+
+
+class ClientCrypto:
+    """The client-side SEAL objects of AtomicSealBfvEncryptedEnvironment.SetKeys (AtomicSealBfvVector.cs:62-74):
+    KeyGenerator / Encryptor / Decryptor for ONE plaintext modulus."""
+
+    def generate_keys(self, with_galois=True):
+        raise NotImplementedError
+
+    def relin_key(self):            # u64 words, layout of include/cnhip.h
+        raise NotImplementedError
+
+    def galois_keys(self):          # dict galois_elt -> u64 words
+        raise NotImplementedError
+
+    def encrypt(self, plain):       # N plaintext coefficients -> size-2 ciphertext words
+        raise NotImplementedError
+
+    def decrypt(self, ct):          # ciphertext words -> N plaintext coefficients
+        raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------------------------ device buffers
+class _Buf:
+    """Ref-counted device array of ciphertexts (kind 'ct') or dense plaintexts (kind 'pt')."""
+
+    def __init__(self, ctx, kind, count, size=2):
+        self.ctx, self.kind, self.count, self.size, self.refs = ctx, kind, count, size, 0
+        self.h = ctx.ct_alloc(count, size) if kind == "ct" else ctx.pt_alloc(count)
+
+    def view(self, first=0, count=None):
+        return _View(self, first, self.count - first if count is None else count)
+
+
+class _View:
+    def __init__(self, buf, first, count):
+        self.buf, self.first, self.count = buf, first, count
+        buf.refs += 1
+        self.live = True
+
+    def release(self):
+        if self.live:
+            self.live = False
+            self.buf.refs -= 1
+            if self.buf.refs == 0 and self.buf.h is not None:
+                self.buf.ctx.free(self.buf.h)
+                self.buf.h = None
+
+    def sub(self, i, count=1):
+        return _View(self.buf, self.first + i, count)
+
+    @property
+    def h(self):
+        return self.buf.h
+
+
+def _gather(ctx, views):
+    """Return (buffer handle, [index per ciphertext], temp view or None) with every ciphertext of `views` in ONE device
+    array: in place when they already share a buffer, otherwise packed into a temporary (device-to-device copies)."""
+    b0 = views[0].buf
+    if all(v.buf is b0 for v in views):
+        return b0.h, [v.first + i for v in views for i in range(v.count)], None
+    total = sum(v.count for v in views)
+    tmp = _Buf(ctx, "ct", total).view()
+    pos, idx = 0, []
+    for v in views:
+        ctx.copy(v.h, v.first, tmp.h, pos, v.count)
+        idx.extend(range(pos, pos + v.count))
+        pos += v.count
+    return tmp.h, idx, tmp
+
+
+# ------------------------------------------------------------------------------------------------ atomic layer
+class AtomicSealBfvEncryptedEnvironment:
+    """One plaintext modulus = one device context + its evaluation keys (AtomicSealBfvVector.cs:19-206)."""
+
+    def __init__(self, ctx, client=None):
+        self.ctx, self.client = ctx, client
+        self.plainmodulusValue = ctx.t
+        self.ParentFactory = None
+
+    @property
+    def SlotCount(self):
+        return self.ctx.n
+
+    @property
+    def PlaintextCapacity(self):
+        return self.ctx.n
+
+    @property
+    def Primes(self):
+        return [self.plainmodulusValue]
+
+    def GenerateEncryptionKeys(self, with_galois=True):
+        """KeyGenerator + SetKeys (AtomicSealBfvVector.cs:62-74,163-173): keys are made by the client, the public
+        evaluation keys are uploaded to HBM."""
+        self.client.generate_keys(with_galois)
+        self.ctx.set_relin_key(self.client.relin_key())
+        if with_galois:
+            for elt, words in self.client.galois_keys().items():
+                self.ctx.set_galois_key(elt, words)
+
+    def encode(self, values):
+        """BatchEncoder.Encode into a fresh device plaintext; returns a pt view."""
+        v = _Buf(self.ctx, "pt", 1).view()
+        self.ctx.encode(np.asarray(values, dtype=np.uint64), v.h, 0)
+        return v
+
+
+class AtomicSealBfvEncryptedVector:
+    """A vector under ONE plaintext modulus: ceil(Dim/N) ciphertexts (dense) or Dim ciphertexts holding one constant
+    polynomial each (sparse) - or the same as plaintexts (AtomicSealBfvVector.cs:303-326)."""
+
+    def __init__(self, v=None, env=None, Scale=1.0, SignedNumbers=True, EncryptData=True, Format=EVectorFormat.dense):
+        self.encData = None          # _View over a ciphertext array
+        self.plainDense = None       # _View over a device plaintext array (dense format)
+        self.plainZero = None        # per dense plaintext: IsZero
+        self.plainSparse = None      # list of ints, one constant polynomial each (sparse format)
+        self.Scale, self.IsSigned, self.Format, self.Dim = Scale, SignedNumbers, Format, 0
+        if v is not None:
+            if EncryptData:
+                self._Encrypt(v, Format, env)
+            else:
+                self._Plain(v, Format, env)
+
+    # -- construction -----------------------------------------------------------------------------------------
+    @classmethod
+    def _new(cls, **kw):
+        r = cls()
+        for k, val in kw.items():
+            setattr(r, k, val)
+        return r
+
+    @classmethod
+    def Copy(cls, v, env):
+        """copy constructor (AtomicSealBfvVector.cs:365-374): deep copy"""
+        r = cls._new(Scale=v.Scale, Dim=v.Dim, IsSigned=v.IsSigned, Format=v.Format)
+        if v.encData is not None:
+            r.encData = _Buf(env.ctx, "ct", v.encData.count).view()
+            env.ctx.copy(v.encData.h, v.encData.first, r.encData.h, 0, v.encData.count)
+        if v.plainDense is not None:
+            r.plainDense = _Buf(env.ctx, "pt", v.plainDense.count).view()
+            env.ctx.copy(v.plainDense.h, v.plainDense.first, r.plainDense.h, 0, v.plainDense.count)
+            r.plainZero = list(v.plainZero)
+        if v.plainSparse is not None:
+            r.plainSparse = list(v.plainSparse)
+        return r
+
+    def _values(self, v, env):
+        """VectorToPlaintext value mapping (AtomicSealBfvVector.cs:1120-1122): round(v*Scale), negatives -> t + x"""
+        t = env.plainmodulusValue
+        a = np.asarray(v)
+        if a.dtype == np.uint64:
+            return [int(x) for x in a]
+        if self.Scale == 0:
+            self.Scale = 1
+        out = []
+        for x in np.rint(np.asarray(v, dtype=np.float64) * self.Scale):
+            x = int(x)
+            out.append(x if (not self.IsSigned or x >= 0) else t + x)
+        return out
+
+    def _to_plaintexts(self, v, env):
+        values = self._values(v, env)
+        t = env.plainmodulusValue
+        for x in values:
+            if not 0 <= x < t:
+                raise Exception("value does not fit the plaintext modulus")
+        self.Dim = len(values)
+        if self.Format == EVectorFormat.dense:
+            slots = env.SlotCount
+            blocks = max(1, -(-len(values) // slots)) if values else 0
+            if blocks == 0:
+                raise Exception("empty vector")
+            pv = _Buf(env.ctx, "pt", blocks).view()
+            zero = []
+            for b in range(blocks):
+                chunk = values[b * slots:(b + 1) * slots]
+                env.ctx.encode(np.array(chunk, dtype=np.uint64), pv.h, b)
+                zero.append(all(c == 0 for c in chunk))
+            return pv, zero, None
+        return None, None, values
+
+    def _Plain(self, v, Format, env):
+        self.Format = Format
+        self.plainDense, self.plainZero, self.plainSparse = self._to_plaintexts(v, env)
+        self.encData = None
+
+    def _Encrypt(self, v, Format, env):
+        """Encrypt (AtomicSealBfvVector.cs:1202-1232): one Encryptor.Encrypt per plaintext, done by the client."""
+        self.Format = Format
+        pv, _, sparse = self._to_plaintexts(v, env)
+        ctx = env.ctx
+        if sparse is None:
+            plains = ctx.pt_download(pv.h, 0, pv.count)
+            pv.release()
+        else:
+            plains = np.zeros((len(sparse), ctx.n), dtype=np.uint64)
+            plains[:, 0] = np.array(sparse, dtype=np.uint64)
+        self.encData = _Buf(ctx, "ct", len(plains)).view()
+        cts = np.stack([env.client.encrypt(p) for p in plains])
+        ctx.ct_upload(self.encData.h, 0, cts)
+
+    # -- properties -------------------------------------------------------------------------------------------
+    @property
+    def IsEncrypted(self):
+        return self.encData is not None
+
+    def _blocks(self):
+        if self.encData is not None:
+            return self.encData.count
+        return self.plainDense.count if self.plainDense is not None else len(self.plainSparse)
+
+    def RegisterDim(self, dim):
+        self.Dim = dim
+
+    def RegisterScale(self, scale):
+        self.Scale = scale
+
+    def Dispose(self):
+        for v in (self.encData, self.plainDense):
+            if v is not None:
+                v.release()
+        self.encData = self.plainDense = self.plainSparse = None
+
+    def _plain_is_zero(self, i):
+        return self.plainZero[i] if self.plainDense is not None else self.plainSparse[i] == 0
+
+    # -- HOT LOOP A -------------------------------------------------------------------------------------------
+    @staticmethod
+    def DenseMatrixBySparseVectorMultiply(denses, sparse, env):
+        """AtomicSealBfvVector.cs:434-521: out_block[i] = sum_k denses[k].block[i] * sparse[k]."""
+        if len(denses) != sparse.Dim:
+            raise Exception("dimensions do not match")
+        if sparse.Format != EVectorFormat.sparse:
+            raise Exception("expecting a sparse vector")
+        if not denses[0].IsEncrypted and not sparse.IsEncrypted:
+            raise Exception("at least one parameter has to be encrypted")
+        if denses[0].IsSigned != sparse.IsSigned:
+            raise Exception("can't mix signed and unsigned messages")
+        ctx = env.ctx
+        l = denses[0]._blocks()
+        K = len(denses)
+        res = _Buf(ctx, "ct", l).view()
+        if denses[0].IsEncrypted and sparse.IsEncrypted:
+            # Multiply + Relinearize per term, then AddMany (:459-465,502)
+            terms = _Buf(ctx, "ct", K * l).view()
+            for k in range(K):
+                ctx.mul_relin(denses[k].encData.h, denses[k].encData.first, sparse.encData.h, sparse.encData.first + k,
+                              terms.h, k * l, l, a_stride=1, b_stride=0)
+            for i in range(l):
+                ctx.add_many(terms.h, [k * l + i for k in range(K)], res.h, i)
+            terms.release()
+        elif denses[0].IsEncrypted:
+            # ct blocks x constant plaintexts: one scalar GEMM with l outputs
+            h, idx, tmp = _gather(ctx, [d.encData for d in denses])
+            W = np.tile(np.array(sparse.plainSparse, dtype=np.uint64), (l, 1))
+            gidx = np.array([[idx[k * l + i] for k in range(K)] for i in range(l)], dtype=np.int32)
+            try:
+                ctx.scalar_gemm(h, W, res.h, 0, idx=gidx)
+            finally:
+                if tmp is not None:
+                    tmp.release()
+        else:
+            # plain dense columns x encrypted sparse entries (:476-485): MultiplyPlain(sparse.enc[k], denses[k].plain[i])
+            terms = _Buf(ctx, "ct", K).view()
+            for i in range(l):
+                used = []
+                for k in range(K):
+                    if denses[k]._plain_is_zero(i):
+                        continue
+                    ctx.mul_plain(sparse.encData.h, sparse.encData.first + k, denses[k].plainDense.h, denses[k].plainDense.first + i,
+                                  terms.h, k, 1)
+                    used.append(k)
+                if not used:
+                    raise Exception("AddMany of an empty list")
+                ctx.add_many(terms.h, used, res.h, i)
+            terms.release()
+        return AtomicSealBfvEncryptedVector._new(Format=EVectorFormat.dense, Scale=denses[0].Scale * sparse.Scale, IsSigned=sparse.IsSigned,
+                                                 encData=res, Dim=denses[0].Dim)
+
+    # -- packing ops (slot movement) ----------------------------------------------------------------------------
+    @staticmethod
+    def _Inteleave(vecs, shift, outputBlockCount, env):
+        """AtomicSealBfvVector.cs:600-722.  vecs: list of single-ciphertext views."""
+        ctx = env.ctx
+        blockSize = env.SlotCount
+        absShift = -shift if shift < 0 else shift
+        if shift < 0 and outputBlockCount > 1:
+            raise Exception("Negative shifts with multiple output blocks are not implemented yet")
+        if absShift > blockSize // 2 and outputBlockCount > 1:
+            raise Exception("Shifts of more than half block size with multiple output blocks are not implemented yet")
+        if absShift * len(vecs) > blockSize * outputBlockCount:
+            raise Exception("not enough room for interleaving")
+        work = _Buf(ctx, "ct", 2 * len(vecs)).view()      # slot 2k: v, slot 2k+1: v2
+        lower = [[] for _ in range(outputBlockCount)]
+        upper = [[] for _ in range(outputBlockCount)]
+        half = blockSize // 2
+
+        def ones_mask(count):
+            return env.encode(np.ones(count, dtype=np.uint64))
+
+        for k, src in enumerate(vecs):
+            thisShift = shift * k
+            if thisShift < 0:
+                thisShift = half + thisShift
+            inBlockShift = thisShift % blockSize
+            startBlock = thisShift // blockSize
+            endBlock = (thisShift + absShift) // blockSize
+            v, v2 = 2 * k, 2 * k + 1
+            ctx.copy(src.h, src.first, work.h, v, 1)
+            if inBlockShift == 0:
+                lower[startBlock].append(v)
+            elif inBlockShift + absShift < half:
+                ctx.rotate_rows(work.h, v, -thisShift, work.h, v, 1)
+                lower[startBlock].append(v)
+            elif inBlockShift >= half:
+                ctx.rotate_rows(work.h, v, -(inBlockShift - half), work.h, v, 1)
+                if startBlock == endBlock:
+                    upper[startBlock].append(v)
+                else:
+                    upperPartSize = inBlockShift + absShift - blockSize
+                    ctx.copy(work.h, v, work.h, v2, 1)
+                    p = ones_mask(upperPartSize)
+                    ctx.mul_plain(work.h, v, p.h, 0, work.h, v, 1)
+                    ctx.sub(work.h, v2, work.h, v, work.h, v2, 1)
+                    p.release()
+                    upper[startBlock].append(v2)
+                    lower[endBlock].append(v)
+            else:
+                ctx.rotate_rows(work.h, v, -inBlockShift, work.h, v, 1)
+                upperPartSize = inBlockShift + absShift - half
+                if upperPartSize > 0:
+                    ctx.copy(work.h, v, work.h, v2, 1)
+                    p = ones_mask(upperPartSize)
+                    ctx.mul_plain(work.h, v, p.h, 0, work.h, v, 1)
+                    ctx.sub(work.h, v2, work.h, v, work.h, v2, 1)
+                    p.release()
+                    upper[startBlock].append(v)
+                    lower[startBlock].append(v2)
+                else:
+                    lower[startBlock].append(v)
+        res = _Buf(ctx, "ct", outputBlockCount).view()
+        tmp = _Buf(ctx, "ct", 1).view()
+        for i in range(outputBlockCount):
+            if not lower[i]:
+                raise Exception("AddMany of an empty list")
+            ctx.add_many(work.h, lower[i], res.h, i)
+            if upper[i]:
+                ctx.add_many(work.h, upper[i], tmp.h, 0)
+                ctx.rotate_columns(tmp.h, 0, tmp.h, 0, 1)
+                ctx.add(res.h, i, tmp.h, 0, res.h, i, 1)
+        tmp.release()
+        work.release()
+        return res
+
+    @staticmethod
+    def Interleave(vecs, shift, env):
+        """AtomicSealBfvVector.cs:729-750"""
+        if vecs[0].Format != EVectorFormat.dense:
+            raise Exception("Expecting dense vector")
+        blockSize = env.SlotCount
+        outputBlocks = 1
+        if shift > 0:
+            outputBlocks = int(math.ceil(vecs[0].Dim * len(vecs) / float(blockSize)))
+        enc = AtomicSealBfvEncryptedVector._Inteleave([v.encData.sub(0) for v in vecs], shift, outputBlocks, env)
+        return AtomicSealBfvEncryptedVector._new(encData=enc, Dim=vecs[0].Dim, Scale=vecs[0].Scale, IsSigned=vecs[0].IsSigned,
+                                                 Format=EVectorFormat.dense)
+
+    @staticmethod
+    def Stack(vecs, env):
+        """AtomicSealBfvVector.cs:756-761"""
+        res = AtomicSealBfvEncryptedVector.Interleave(vecs, int(vecs[0].Dim), env)
+        res.Dim = vecs[0].Dim * len(vecs)
+        return res
+
+    # -- HOT LOOP B -------------------------------------------------------------------------------------------
+    def _PointwiseMultiplySparseDimOne(self, ev, env):
+        """AtomicSealBfvVector.cs:774-810: multiply every block by one constant"""
+        ctx = env.ctx
+        t = AtomicSealBfvEncryptedVector._new(Scale=self.Scale * ev.Scale, Dim=self.Dim, Format=self.Format, IsSigned=self.IsSigned)
+        if self.encData is not None and ev.encData is not None:
+            t.encData = _Buf(ctx, "ct", self.encData.count).view()
+            ctx.mul_relin(ev.encData.h, ev.encData.first, self.encData.h, self.encData.first, t.encData.h, 0, self.encData.count,
+                          a_stride=0, b_stride=1)
+            return t
+        if self.encData is not None:                 # enc blocks x plain constant
+            t.encData = _Buf(ctx, "ct", self.encData.count).view()
+            w = ev.plainSparse[0]
+            if w == 0:
+                raise Exception("plain cannot be zero")
+            ctx.mul_scalar(self.encData.h, self.encData.first, np.array([w], dtype=np.uint64), t.encData.h, 0, self.encData.count, broadcast=True)
+        else:                                        # plain blocks x encrypted constant
+            cnt = self.plainDense.count
+            t.encData = _Buf(ctx, "ct", cnt).view()
+            for i in range(cnt):
+                ctx.mul_plain(ev.encData.h, ev.encData.first, self.plainDense.h, self.plainDense.first + i, t.encData.h, i, 1)
+        return t
+
+    def PointwiseMultiply(self, v, env):
+        """AtomicSealBfvVector.cs:813-860"""
+        ev = v
+        if self.IsSigned != ev.IsSigned:
+            raise Exception("Can't mix signed and unsigned numbers.")
+        if not self.IsEncrypted and not ev.IsEncrypted:
+            raise Exception("multiplying two plaintexts is not implemented")
+        if self.Dim == 1 and self.Format == EVectorFormat.sparse:
+            return ev._PointwiseMultiplySparseDimOne(self, env)
+        if ev.Dim == 1 and ev.Format == EVectorFormat.sparse:
+            return self._PointwiseMultiplySparseDimOne(ev, env)
+        if self.Dim != v.Dim:
+            raise Exception("Dimensions do not match")
+        if self.Format != ev.Format:
+            raise Exception("Format mismatch")
+        ctx = env.ctx
+        t = AtomicSealBfvEncryptedVector._new(Scale=self.Scale * ev.Scale, Dim=self.Dim, Format=self.Format, IsSigned=self.IsSigned)
+        if self.encData is not None and ev.encData is not None:
+            n = ev.encData.count
+            t.encData = _Buf(ctx, "ct", n).view()
+            ctx.mul_relin(ev.encData.h, ev.encData.first, self.encData.h, self.encData.first, t.encData.h, 0, n)
+            return t
+        enc = self.encData if self.encData is not None else ev.encData
+        pl = self if self.encData is None else ev
+        t.encData = _Buf(ctx, "ct", enc.count).view()
+        if pl.plainDense is not None:
+            ctx.mul_plain(enc.h, enc.first, pl.plainDense.h, pl.plainDense.first, t.encData.h, 0, enc.count)
+        else:
+            if any(w == 0 for w in pl.plainSparse):
+                raise Exception("plain cannot be zero")
+            ctx.mul_scalar(enc.h, enc.first, np.array(pl.plainSparse, dtype=np.uint64), t.encData.h, 0, enc.count)
+        return t
+
+    # -- HOT LOOP C -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _RotateRowsAndAdd(ctx, c_h, c_i, steps, agg_h, agg_i, tmp_h, tmp_i):
+        """AtomicSealBfvVector.cs:862-868: agg += RotateRows(c, -steps)"""
+        ctx.rotate_rows(c_h, c_i, -steps, tmp_h, tmp_i, 1)
+        ctx.add(agg_h, agg_i, tmp_h, tmp_i, agg_h, agg_i, 1)
+
+    def SumAllSlots(self, env, length=None, ForceOutputInColumn=None):
+        """AtomicSealBfvVector.cs:877-955 (length None = Int32.MaxValue = full sum)"""
+        INT_MAX = 2 ** 31 - 1
+        if length is None:
+            length = INT_MAX
+        if self.Format != EVectorFormat.dense:
+            raise Exception("Expecting dense vector format")
+        if length != INT_MAX and ForceOutputInColumn is not None:
+            raise Exception("forcing output in a column works only when doing complete sum")
+        if self.encData is None:
+            raise Exception("SumAllSlots can be applied to encrypted data only")
+        if length <= 0:
+            raise Exception("Can't sum over less then one element")
+        if length == 1:
+            return self
+        ctx, slots = env.ctx, env.SlotCount
+        work = _Buf(ctx, "ct", 3).view()           # 0: sum, 1: tmp, 2: sumLong
+        if self.encData.count > 1:
+            ctx.add_many(self.encData.h, [self.encData.first + i for i in range(self.encData.count)], work.h, 2)
+        else:
+            ctx.copy(self.encData.h, self.encData.first, work.h, 2, 1)
+        if length >= slots // 2:
+            ctx.rotate_columns(work.h, 2, work.h, 1, 1)
+            ctx.add(work.h, 2, work.h, 1, work.h, 0, 1)
+            length = slots // 2
+        else:
+            ctx.copy(work.h, 2, work.h, 0, 1)
+        steps = 1
+        while steps < length:
+            self._RotateRowsAndAdd(ctx, work.h, 0, steps, work.h, 0, work.h, 1)
+            steps *= 2
+        if ForceOutputInColumn is not None:
+            col = ForceOutputInColumn
+            mask = np.zeros(col + 1, dtype=np.uint64)
+            mask[col] = 1
+            p = env.encode(mask)
+            ctx.mul_plain(work.h, 0, p.h, 0, work.h, 0, 1)
+            p.release()
+            length = 1
+        res = _Buf(ctx, "ct", 1).view()
+        ctx.copy(work.h, 0, res.h, 0, 1)
+        work.release()
+        return AtomicSealBfvEncryptedVector._new(IsSigned=self.IsSigned, Scale=self.Scale, Dim=1 if length >= slots // 2 else self.Dim, encData=res,
+                                                 Format=EVectorFormat.sparse if length >= slots else EVectorFormat.dense)
+
+    def DotProduct(self, v, env, length=None, ForceOutputInColumn=None):
+        """AtomicSealBfvVector.cs:963-977"""
+        mul = self.PointwiseMultiply(v, env)
+        res = mul.SumAllSlots(env, length, ForceOutputInColumn)
+        if res is not mul:
+            mul.Dispose()
+        return res
+
+    # -- linear ---------------------------------------------------------------------------------------------
+    def Add(self, v, env):
+        """AtomicSealBfvVector.cs:983-1024"""
+        if self.Scale == 0:
+            return v
+        if v.Scale == 0:
+            return self
+        if self.Scale != v.Scale:
+            raise Exception("Scales do not match.")
+        if self.Dim != v.Dim:
+            raise Exception("Dimensions do not match")
+        if self.Format != v.Format:
+            raise Exception("Format mismatch")
+        if self.IsSigned != v.IsSigned:
+            raise Exception("can't mix signed and unsigned numbers.")
+        if not self.IsEncrypted and not v.IsEncrypted:
+            raise Exception("adding two plaintexts is not supported")
+        ctx = env.ctx
+        t = AtomicSealBfvEncryptedVector._new(Scale=self.Scale, Dim=self.Dim, Format=self.Format, IsSigned=self.IsSigned)
+        if self.IsEncrypted and v.IsEncrypted:
+            n = self.encData.count
+            t.encData = _Buf(ctx, "ct", n).view()
+            ctx.add(v.encData.h, v.encData.first, self.encData.h, self.encData.first, t.encData.h, 0, n)
+            return t
+        enc, pl = (self.encData, v) if self.IsEncrypted else (v.encData, self)
+        t.encData = _Buf(ctx, "ct", enc.count).view()
+        pv, tmp = pl._dense_plain_view(env)
+        ctx.add_plain(enc.h, enc.first, pv.h, pv.first, t.encData.h, 0, pv.count)
+        if tmp:
+            pv.release()
+        return t
+
+    def Subtract(self, v, env):
+        """AtomicSealBfvVector.cs:1238-1271"""
+        if v.Scale == 0:
+            return self
+        if self.Scale != v.Scale:
+            raise Exception("Scales do not match.")
+        if self.Dim != v.Dim:
+            raise Exception("Dimensions do not match")
+        if self.Format != v.Format:
+            raise Exception("Format mismatch")
+        if self.IsSigned != v.IsSigned:
+            raise Exception("Can't mix signed and unsigned numbers.")
+        if not self.IsEncrypted:
+            raise Exception("the first argument for subtraction must be encrypted")
+        ctx = env.ctx
+        n = self.encData.count
+        t = AtomicSealBfvEncryptedVector._new(Scale=self.Scale, Dim=self.Dim, Format=self.Format, IsSigned=self.IsSigned)
+        t.encData = _Buf(ctx, "ct", n).view()
+        if v.IsEncrypted:
+            ctx.sub(self.encData.h, self.encData.first, v.encData.h, v.encData.first, t.encData.h, 0, n)
+        else:
+            pv, tmp = v._dense_plain_view(env)
+            ctx.add_plain(self.encData.h, self.encData.first, pv.h, pv.first, t.encData.h, 0, n, subtract=True)
+            if tmp:
+                pv.release()
+        return t
+
+    def _dense_plain_view(self, env):
+        """Plaintexts as device polynomials: dense plaintexts as they are; sparse ones as constant polynomials."""
+        if self.plainDense is not None:
+            return self.plainDense, False
+        pv = _Buf(env.ctx, "pt", len(self.plainSparse)).view()
+        polys = np.zeros((len(self.plainSparse), env.ctx.n), dtype=np.uint64)
+        polys[:, 0] = np.array(self.plainSparse, dtype=np.uint64)
+        env.ctx.pt_upload(pv.h, 0, polys)
+        return pv, True
+
+    # -- decryption (client side) -------------------------------------------------------------------------------
+    def _decrypt_ints(self, env):
+        """Unsigned residues per element, exactly as Decrypt / DecryptFullPrecision read them (AtomicSealBfvVector.cs:1030-1110)."""
+        ctx = env.ctx
+        res = []
+        n_items = self._blocks()
+        if self.encData is not None:
+            cts = ctx.ct_download(self.encData.h, self.encData.first, self.encData.count)
+            plains = np.stack([env.client.decrypt(c) for c in cts])
+        elif self.plainDense is not None:
+            plains = ctx.pt_download(self.plainDense.h, self.plainDense.first, self.plainDense.count)
+        else:
+            plains = None
+        if self.Format == EVectorFormat.dense:
+            tmp = _Buf(ctx, "pt", 1).view()
+            for i in range(n_items):
+                ctx.pt_upload(tmp.h, 0, plains[i])
+                local = ctx.decode(tmp.h, 0)
+                left = int(self.Dim) - len(res)
+                res.extend(int(x) for x in local[:min(left, len(local))])
+            tmp.release()
+        else:
+            for i in range(n_items):
+                res.append(int(plains[i][0]) if plains is not None else int(self.plainSparse[i]))
+        return res
+
+    def DecryptFullPrecision(self, env):
+        t = env.plainmodulusValue
+        return [(v - t) if (self.IsSigned and v * 2 > t) else v for v in self._decrypt_ints(env)]
+
+    def Decrypt(self, env):
+        mod = float(env.plainmodulusValue)
+        t = env.plainmodulusValue
+        return np.array([((float(v) - mod) if (self.IsSigned and v * 2 > t) else float(v)) / self.Scale for v in self._decrypt_ints(env)])
+
+    # -- misc -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def GenerateSparseOfArray(encryptedVector, env):
+        """AtomicSealBfvVector.cs:1347-1359: first block of every vector becomes one entry of a sparse vector"""
+        ctx = env.ctx
+        res = _Buf(ctx, "ct", len(encryptedVector)).view()
+        for i, e in enumerate(encryptedVector):
+            ctx.copy(e.encData.h, e.encData.first, res.h, i, 1)
+        return AtomicSealBfvEncryptedVector._new(Scale=encryptedVector[0].Scale, Dim=len(encryptedVector), Format=EVectorFormat.sparse,
+                                                 IsSigned=encryptedVector[0].IsSigned, encData=res)
+
+    def Duplicate(self, count, env):
+        """AtomicSealBfvVector.cs:1370-1408"""
+        shift = 1
+        while shift < self.Dim:
+            shift *= 2
+        if self.encData is None:
+            raise Exception("Duplicate operates only on encrypted data")
+        if self.Format == EVectorFormat.sparse:
+            raise Exception("Duplicate operates only on dense vectors")
+        slots, ctx = env.SlotCount, env.ctx
+        if shift * count > slots:
+            raise Exception("Packed vector must fit in a single ciphertext")
+        work = _Buf(ctx, "ct", 3).view()            # 0: res, 1: rotator, 2: tmp
+        ctx.copy(self.encData.h, self.encData.first, work.h, 0, 1)
+        ctx.copy(self.encData.h, self.encData.first, work.h, 1, 1)
+        columnRotated = False
+        for i in range(1, int(count)):
+            target = i * shift
+            if target * 2 >= slots:
+                if not columnRotated:
+                    columnRotated = True
+                    ctx.rotate_columns(self.encData.h, self.encData.first, work.h, 1, 1)
+                target -= slots // 2
+            self._RotateRowsAndAdd(ctx, work.h, 1, target, work.h, 0, work.h, 2)
+        res = _Buf(ctx, "ct", 1).view()
+        ctx.copy(work.h, 0, res.h, 0, 1)
+        work.release()
+        return AtomicSealBfvEncryptedVector._new(IsSigned=self.IsSigned, Scale=self.Scale, Dim=count * shift, encData=res, Format=EVectorFormat.dense)
+
+    def Rotate(self, amount, env):
+        """AtomicSealBfvVector.cs:1414-1430"""
+        if self.encData is None:
+            raise Exception("Rotate operates only on encrypted data")
+        if self.Format == EVectorFormat.sparse:
+            raise Exception("Rotate operates only on dense vectors")
+        res = _Buf(env.ctx, "ct", 1).view()
+        env.ctx.rotate_rows(self.encData.h, self.encData.first, amount, res.h, 0, 1)
+        return AtomicSealBfvEncryptedVector._new(IsSigned=self.IsSigned, Scale=self.Scale, Dim=self.Dim, encData=res, Format=EVectorFormat.dense)
+
+    def Permute(self, selections, shifts, outputDim, env):
+        """AtomicSealBfvVector.cs:1436-1475: sum_i rotL(x * sel_i, shifts[i])"""
+        if self.Format != EVectorFormat.dense:
+            raise Exception("Permute works only on dense vectors")
+        if len(selections) != len(shifts):
+            raise Exception("number of selection vectors and number of shifts does not match")
+        if self.encData is None:
+            raise Exception("can permute only encrypted vectors")
+        if self.encData.count > 1:
+            raise Exception("can permute only a single block")
+        ctx = env.ctx
+        work = _Buf(ctx, "ct", 3).view()            # 0: res, 1: t, 2: t3->relin tmp
+        first = -1
+        for i, s in enumerate(selections):
+            if s is None:
+                continue
+            if first < 0:
+                first = i
+            if s.Dim != self.Dim:
+                raise Exception("dimension of selection vector does not match dimension of data vector")
+            if s.Scale != selections[first].Scale:
+                raise Exception("scales of all selection vectors should be the same")
+            if s.plainDense is not None:
+                ctx.mul_plain(self.encData.h, self.encData.first, s.plainDense.h, s.plainDense.first, work.h, 1, 1)
+            else:
+                # the reference multiplies without relinearising here (:1457) and would then fail to rotate a size-3
+                # ciphertext; encrypted selections are therefore relinearised
+                ctx.mul_relin(self.encData.h, self.encData.first, s.encData.h, s.encData.first, work.h, 1, 1)
+            ctx.rotate_rows(work.h, 1, shifts[i], work.h, 1, 1)
+            if i == first:
+                ctx.copy(work.h, 1, work.h, 0, 1)
+            else:
+                ctx.add(work.h, 0, work.h, 1, work.h, 0, 1)
+        if first < 0:
+            raise Exception("permuting with no selected values is illigal")
+        res = _Buf(ctx, "ct", 1).view()
+        ctx.copy(work.h, 0, res.h, 0, 1)
+        work.release()
+        return AtomicSealBfvEncryptedVector._new(IsSigned=self.IsSigned, Scale=self.Scale * selections[first].Scale, Dim=outputDim, encData=res,
+                                                 Format=EVectorFormat.dense)
+
+
+# ------------------------------------------------------------------------------------------------ CRT layer
+class EncryptedSealBfvEnvironment:
+    """All plaintext-prime channels + CRT coefficients (EncryptedSealBfvVector.cs:17-149)."""
+
+    def __init__(self, environments, ParentFactory=None):
+        self.Environments = environments
+        self.ParentFactory = ParentFactory
+        primes = [e.plainmodulusValue for e in environments]
+        self.bigFactor = 1
+        for p in primes:
+            self.bigFactor *= p
+        # PreCompute (:79-90): coef_i = (M/p_i) * ((M/p_i)^-1 mod p_i)
+        self.preComputedCoefficients = [(self.bigFactor // p) * pow((self.bigFactor // p) % p, -1, p) for p in primes]
+
+    @property
+    def Primes(self):
+        return [e.plainmodulusValue for e in self.Environments]
+
+
+class EncryptedSealBfvVector:
+    """Values split over the plaintext primes; every op fans out to eVectors[i] (EncryptedSealBfvVector.cs:150-573)."""
+
+    def __init__(self, v=None, env=None, Scale=1.0, EncryptData=True, Format=EVectorFormat.dense, integers=None):
+        self.eVectors = None
+        self.Scale = Scale
+        self.IsSigned = True
+        if v is not None or integers is not None:
+            if integers is None:
+                w = [int(x) for x in np.rint(np.asarray(v, dtype=np.float64) * Scale)]       # SplitBigNumbers (:352-365)
+            else:
+                w = [int(x) for x in integers]
+            z = [x + env.bigFactor if x < 0 else x for x in w]
+            self.eVectors = [AtomicSealBfvEncryptedVector(np.array([x % e.plainmodulusValue for x in z], dtype=np.uint64), e, Scale=1,
+                                                          SignedNumbers=False, EncryptData=EncryptData, Format=Format) for e in env.Environments]
+
+    @classmethod
+    def _of(cls, vecs, Scale=1.0):
+        r = cls()
+        r.eVectors, r.Scale = vecs, Scale
+        return r
+
+    @classmethod
+    def Copy(cls, v, env):
+        return cls._of([AtomicSealBfvEncryptedVector.Copy(x, e) for x, e in zip(v.eVectors, env.Environments)], v.Scale)
+
+    Dim = property(lambda self: 0 if self.eVectors is None else self.eVectors[0].Dim)
+    IsEncrypted = property(lambda self: False if self.eVectors is None else self.eVectors[0].IsEncrypted)
+    Format = property(lambda self: self.eVectors[0].Format)
+    BlockSize = property(lambda self: None)
+
+    def Dispose(self):
+        if self.eVectors is not None:
+            for v in self.eVectors:
+                if v is not None:
+                    v.Dispose()
+        self.eVectors = None
+
+    def RegisterScale(self, scale):
+        self.Scale = scale
+
+    def RegisterDim(self, dim):
+        for v in self.eVectors:
+            v.RegisterDim(dim)
+
+    def _each(self, fn, env):
+        return [fn(i, e) for i, e in enumerate(env.Environments)]
+
+    @staticmethod
+    def Interleave(vecs, shift, env):
+        return EncryptedSealBfvVector._of([AtomicSealBfvEncryptedVector.Interleave([v.eVectors[i] for v in vecs], shift, e)
+                                           for i, e in enumerate(env.Environments)], vecs[0].Scale)
+
+    @staticmethod
+    def Stack(vecs, env):
+        return EncryptedSealBfvVector._of([AtomicSealBfvEncryptedVector.Stack([v.eVectors[i] for v in vecs], e)
+                                           for i, e in enumerate(env.Environments)], vecs[0].Scale)
+
+    def Add(self, v, env):
+        if self.Scale == 0:
+            return v
+        if v.Scale == 0:
+            return self
+        if self.Scale != v.Scale:
+            raise Exception("Scales do not match.")
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].Add(v.eVectors[i], e), env), self.Scale)
+
+    def Subtract(self, v, env):
+        if v.Scale == 0:
+            return self
+        if self.Scale != v.Scale:
+            raise Exception("Scales do not match.")
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].Subtract(v.eVectors[i], e), env), self.Scale)
+
+    @staticmethod
+    def GenerateSpareOfArray(SparseVectors, env):
+        return EncryptedSealBfvVector._of([AtomicSealBfvEncryptedVector.GenerateSparseOfArray([v.eVectors[i] for v in SparseVectors], e)
+                                           for i, e in enumerate(env.Environments)], SparseVectors[0].Scale)
+
+    @staticmethod
+    def DenseMatrixBySparseVectorMultiply(denses, sparse, env):
+        return EncryptedSealBfvVector._of([AtomicSealBfvEncryptedVector.DenseMatrixBySparseVectorMultiply([d.eVectors[i] for d in denses],
+                                                                                                           sparse.eVectors[i], e)
+                                           for i, e in enumerate(env.Environments)], denses[0].Scale * sparse.Scale)
+
+    def PointwiseMultiply(self, v, env):
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].PointwiseMultiply(v.eVectors[i], e), env), self.Scale * v.Scale)
+
+    def SumAllSlots(self, env, length=None):
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].SumAllSlots(e, length), env), self.Scale)
+
+    def DotProduct(self, v, env, length=None, ForceOutputInColumn=None):
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].DotProduct(v.eVectors[i], e, length, ForceOutputInColumn), env),
+                                          self.Scale * v.Scale)
+
+    def Duplicate(self, count, env):
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].Duplicate(count, e), env), self.Scale)
+
+    def Rotate(self, amount, env):
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].Rotate(amount, e), env), self.Scale)
+
+    def Permute(self, selections, shifts, outputDim, env):
+        I = [i for i, s in enumerate(selections) if s is not None]
+        sel, sh = [selections[i] for i in I], [shifts[i] for i in I]
+        return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].Permute([x.eVectors[i] for x in sel], sh, outputDim, e), env), self.Scale)
+
+    def _join(self, split, env, signed=True):
+        """JoinSplitNumbers (EncryptedSealBfvVector.cs:381-411)"""
+        out = []
+        for j in range(len(split[0])):
+            x = sum(int(split[i][j]) * env.preComputedCoefficients[i] for i in range(len(split))) % env.bigFactor
+            if signed and x * 2 > env.bigFactor:
+                x -= env.bigFactor
+            out.append(x)
+        return out
+
+    def DecryptFullPrecision(self, env):
+        return self._join([v.DecryptFullPrecision(e) for v, e in zip(self.eVectors, env.Environments)], env, self.IsSigned)
+
+    def Decrypt(self, env):
+        ints = self._join([v._decrypt_ints(e) for v, e in zip(self.eVectors, env.Environments)], env)
+        return np.array([float(x) / self.Scale for x in ints])
+
+
+# ------------------------------------------------------------------------------------------------ matrix
+class EncryptedSealBfvMatrix:
+    """Array of CRT vectors, column- or row-major (EncryptedSealBfvMatrix.cs)."""
+
+    def __init__(self, columns=None, env=None, CopyVectors=True, Format=EMatrixFormat.ColumnMajor):
+        self.Format = Format
+        self.DataDisposedExternaly = False
+        self.leVectors = None
+        if columns is not None:
+            if any(c.Dim != columns[0].Dim for c in columns):
+                raise Exception("all columns of a matrix should have the same size")
+            self.leVectors = [EncryptedSealBfvVector.Copy(c, env) for c in columns] if CopyVectors else list(columns)
+
+    RowCount = property(lambda self: len(self.leVectors) if self.Format == EMatrixFormat.RowMajor else self.leVectors[0].Dim)
+    ColumnCount = property(lambda self: len(self.leVectors) if self.Format == EMatrixFormat.ColumnMajor else self.leVectors[0].Dim)
+    Scale = property(lambda self: self.leVectors[0].Scale)
+    IsEncrypted = property(lambda self: all(v.IsEncrypted for v in self.leVectors))
+
+    def Dispose(self):
+        if self.leVectors is not None and not self.DataDisposedExternaly:
+            for v in self.leVectors:
+                if v is not None:
+                    v.Dispose()
+        self.leVectors = None
+
+    def Decrypt(self, env):
+        vecs = [v.Decrypt(env) for v in self.leVectors]
+        return np.stack(vecs, axis=0) if self.Format == EMatrixFormat.RowMajor else np.stack(vecs, axis=1)
+
+    def Mul(self, v, env, ForceDenseFormat=False):
+        """EncryptedSealBfvMatrix.cs:70-121"""
+        if self.Format == EMatrixFormat.ColumnMajor:
+            if ForceDenseFormat:
+                raise Exception("Forcing dense format is available only in RowMajor mode")
+            return EncryptedSealBfvVector.DenseMatrixBySparseVectorMultiply(self.leVectors, v, env)
+        if not ForceDenseFormat:
+            temp = [row.DotProduct(v, env) for row in self.leVectors]
+            res = EncryptedSealBfvVector.GenerateSpareOfArray(temp, env)
+            for t in temp:
+                t.Dispose()
+            return res
+        total = None
+        for colIndex, row in enumerate(self.leVectors):
+            t = row.DotProduct(v, env, ForceOutputInColumn=colIndex)
+            if total is None:
+                total = t
+            else:
+                s = total.Add(t, env)
+                total.Dispose()
+                t.Dispose()
+                total = s
+        total.RegisterDim(len(self.leVectors))
+        if total.Format != EVectorFormat.dense:
+            raise Exception("Internal probloem: expecting the output to be dense")
+        return total
+
+    def _check(self, m):
+        if m.Format != self.Format:
+            raise Exception("Format mismatch")
+        if m.RowCount != self.RowCount:
+            raise Exception("Row count mismatch")
+        if m.ColumnCount != self.ColumnCount:
+            raise Exception("Column count mismatch")
+
+    def Add(self, m, env):
+        self._check(m)
+        r = EncryptedSealBfvMatrix(Format=self.Format)
+        r.leVectors = [a.Add(b, env) for a, b in zip(self.leVectors, m.leVectors)]
+        return r
+
+    def ElementWiseMultiply(self, m, env):
+        """EncryptedSealBfvMatrix.cs:140-154; on the GPU all columns of one prime go through ONE cn_mul_relin launch chain."""
+        self._check(m)
+        r = EncryptedSealBfvMatrix(Format=self.Format)
+        cols = len(self.leVectors)
+        batched = all(a.IsEncrypted and b.IsEncrypted and a.Format == b.Format and a.Dim == b.Dim for a, b in zip(self.leVectors, m.leVectors))
+        if not batched:
+            r.leVectors = [a.PointwiseMultiply(b, env) for a, b in zip(self.leVectors, m.leVectors)]
+            return r
+        out = [[None] * len(env.Environments) for _ in range(cols)]
+        for i, e in enumerate(env.Environments):
+            ctx = e.ctx
+            av = [c.eVectors[i] for c in self.leVectors]
+            bv = [c.eVectors[i] for c in m.leVectors]
+            for x, y in zip(av, bv):
+                if x.IsSigned != y.IsSigned:
+                    raise Exception("Can't mix signed and unsigned numbers.")
+            ha, ia, ta = _gather(ctx, [x.encData for x in av])
+            if m is self:
+                hb, ib, tb = ha, ia, None
+            else:
+                hb, ib, tb = _gather(ctx, [y.encData for y in bv])
+            total = len(ia)
+            res = _Buf(ctx, "ct", total)
+            contiguous = ia == list(range(ia[0], ia[0] + total)) and ib == list(range(ib[0], ib[0] + total))
+            if contiguous:
+                ctx.mul_relin(ha, ia[0], hb, ib[0], res.h, 0, total)
+            else:
+                for j in range(total):
+                    ctx.mul_relin(ha, ia[j], hb, ib[j], res.h, j, 1)
+            pos = 0
+            for c, x in enumerate(av):
+                cnt = x.encData.count
+                out[c][i] = AtomicSealBfvEncryptedVector._new(Scale=x.Scale * bv[c].Scale, Dim=x.Dim, Format=x.Format, IsSigned=x.IsSigned,
+                                                              encData=res.view(pos, cnt))
+                pos += cnt
+            for t in (ta, tb):
+                if t is not None:
+                    t.release()
+        r.leVectors = [EncryptedSealBfvVector._of(out[c], self.leVectors[c].Scale * m.leVectors[c].Scale) for c in range(cols)]
+        return r
+
+    def GetColumn(self, columnNumber):
+        if columnNumber >= len(self.leVectors):
+            raise Exception("Column does not exist")
+        if self.Format != EMatrixFormat.ColumnMajor:
+            raise Exception("Columns can be extracted only from a column major matrix")
+        return self.leVectors[columnNumber]
+
+    def GetRow(self, rowNumber):
+        if rowNumber >= len(self.leVectors):
+            raise Exception("Row does not exist")
+        if self.Format != EMatrixFormat.RowMajor:
+            raise Exception("Rows can be extracted only from a row major matrix")
+        return self.leVectors[rowNumber]
+
+    def SetColumn(self, columnNumber, vector):
+        if columnNumber >= len(self.leVectors):
+            raise Exception("Column does not exist")
+        if self.Format != EMatrixFormat.ColumnMajor:
+            raise Exception("Columns can be set only from a column major matrix")
+        old = self.leVectors[columnNumber]
+        if vector.Dim != old.Dim:
+            raise Exception("dimension of vector does not match the dimension of the vector it is replacing")
+        if vector.Scale != old.Scale:
+            raise Exception("Scale of vector does not match the scale of the vector it is replacing")
+        if vector.IsEncrypted != old.IsEncrypted:
+            raise Exception("can't exchange encrypted and not encrypted vectors")
+        self.leVectors[columnNumber] = vector
+
+    def RegisterScale(self, scale):
+        for v in self.leVectors:
+            v.RegisterScale(scale)
+
+    def ConvertToColumnVector(self, env):
+        return EncryptedSealBfvVector.Stack(self.leVectors, env)
+
+    def Interleave(self, shift, env):
+        if self.Format != EMatrixFormat.ColumnMajor:
+            raise Exception("Expecting ColumnMajor matrix")
+        return EncryptedSealBfvVector.Interleave(self.leVectors, shift, env)
+
+    # ---- batched HOT LOOP A for a whole PoolLayer (PoolLayer.cs:149-229 issues one Mul per output) -----------------
+    def MulManySparse(self, gather, weights, bias, out_scale, env):
+        """out[o] = sum_k weights[o][k] * column[gather[o][k]] + bias[o]  for all outputs in one scalar GEMM per prime.
+        gather: int32 [O,K] (-1 = padded tap), weights: integer rows (scaled, signed), bias: integers or None.
+        Equivalent to O calls of Mul(sparse plain weight window) followed by Add(dense plain bias)."""
+        if self.Format != EMatrixFormat.ColumnMajor:
+            raise Exception("Expecting ColumnMajor matrix")
+        O = len(weights)
+        per_prime = []
+        for i, e in enumerate(env.Environments):
+            ctx, p = e.ctx, e.plainmodulusValue
+            cols = [c.eVectors[i] for c in self.leVectors]
+            if any(c.encData is None or c.encData.count != 1 for c in cols):
+                raise Exception("batched PoolLayer expects single-block encrypted columns")
+            h, idx, tmp = _gather(ctx, [c.encData for c in cols])
+            g = np.asarray(gather, dtype=np.int64)
+            gidx = np.where(g >= 0, np.asarray(idx, dtype=np.int64)[np.maximum(g, 0)], -1).astype(np.int32)
+            W = np.array([[int(x) % p for x in row] for row in weights], dtype=np.uint64)
+            res = _Buf(ctx, "ct", O)
+            bh, bidx = 0, None
+            if bias is not None:
+                bvals = [int(b) % p for b in bias]
+                uniq = sorted(set(bvals))
+                pos = {v: j for j, v in enumerate(uniq)}
+                bp = _Buf(ctx, "pt", len(uniq)).view()
+                polys = np.zeros((len(uniq), ctx.n), dtype=np.uint64)
+                polys[:, 0] = np.array(uniq, dtype=np.uint64)      # Encode(constant vector) = constant polynomial
+                ctx.pt_upload(bp.h, 0, polys)
+                bh, bidx = bp.h, np.array([pos[v] for v in bvals], dtype=np.int32)
+            try:
+                ctx.scalar_gemm(h, W, res.h, 0, idx=gidx, bias_pt=bh, bias_idx=bidx)
+            finally:
+                if tmp is not None:
+                    tmp.release()
+                if bias is not None:
+                    bp.release()
+            per_prime.append(res)
+        dim = self.leVectors[0].Dim
+        vecs = []
+        for o in range(O):
+            atoms = [AtomicSealBfvEncryptedVector._new(Scale=1, Dim=dim, Format=EVectorFormat.dense, IsSigned=False, encData=per_prime[i].view(o, 1))
+                     for i in range(len(env.Environments))]
+            vecs.append(EncryptedSealBfvVector._of(atoms, out_scale))
+        r = EncryptedSealBfvMatrix(Format=EMatrixFormat.ColumnMajor)
+        r.leVectors = vecs
+        return r
+
+
+# ------------------------------------------------------------------------------------------------ factory
+class EncryptedSealBfvFactory:
+    """IFactory.cs:240-410.  `client_factory(t, n, q, dbc, gdbc)` builds the client-side SEAL objects for one plaintext
+    prime; the device contexts are libcnhip contexts (`context_factory` is only overridden by the CPU test harness)."""
+    DefaultDecompositionBitCount = 10
+    DefaultGaloisDecompositionBitCount = 20
+
+    def __init__(self, primes=None, n=4096, DecompositionBitCount=10, GaloisDecompositionBitCount=20, SmallModulusCount=-1,
+                 client_factory=None, context_factory=None, device=0, galois=True):
+        if primes is None:
+            primes = [40961, 65537, 114689, 147457, 188417]
+            n = 4096
+        if context_factory is None:
+            from ._native import Context, default_coeff_modulus
+
+            def context_factory(n_, t_, q_, dbc_, gdbc_):
+                return Context(n_, t_, q=q_, dbc=dbc_, gdbc=gdbc_, device=device)
+            q = default_coeff_modulus(n)
+        else:
+            q = context_factory.default_coeff_modulus(n)
+        if SmallModulusCount > 0:
+            q = q[:SmallModulusCount]
+        envs = []
+        for t in primes:
+            ctx = context_factory(n, t, q, DecompositionBitCount, GaloisDecompositionBitCount)
+            client = client_factory(t, n, q, DecompositionBitCount, GaloisDecompositionBitCount) if client_factory else None
+            e = AtomicSealBfvEncryptedEnvironment(ctx, client)
+            if client is not None:
+                e.GenerateEncryptionKeys(with_galois=galois)
+            envs.append(e)
+        self.referenceEnvironment = EncryptedSealBfvEnvironment(envs, ParentFactory=self)
+
+    def AllocateComputationEnv(self):
+        return self.referenceEnvironment
+
+    def FreeComputationEnv(self, env):
+        pass
+
+    def CopyVector(self, v):
+        return EncryptedSealBfvVector.Copy(v, self.referenceEnvironment)
+
+    def GetPlainVector(self, v, format, scale=None):
+        if scale is None:
+            return EncryptedSealBfvVector(env=self.referenceEnvironment, EncryptData=False, Format=format, integers=v)
+        return EncryptedSealBfvVector(v, self.referenceEnvironment, scale, EncryptData=False, Format=format)
+
+    def GetEncryptedVector(self, v, format, scale=None):
+        if scale is None:
+            return EncryptedSealBfvVector(env=self.referenceEnvironment, EncryptData=True, Format=format, integers=v)
+        return EncryptedSealBfvVector(v, self.referenceEnvironment, scale, EncryptData=True, Format=format)
+
+    def _matrix(self, m, format, scale, encrypt):
+        m = np.asarray(m, dtype=np.float64)
+        rows = m.T if format == EMatrixFormat.ColumnMajor else m
+        vecs = [EncryptedSealBfvVector(r, self.referenceEnvironment, scale, EncryptData=encrypt, Format=EVectorFormat.dense) for r in rows]
+        return EncryptedSealBfvMatrix(vecs, self.referenceEnvironment, CopyVectors=False, Format=format)
+
+    def GetPlainMatrix(self, m, format, scale):
+        return self._matrix(m, format, scale, False)
+
+    def GetEncryptedMatrix(self, m, format, scale):
+        return self._matrix(m, format, scale, True)
+
+    def GetMatrix(self, vectors, format, CopyVectors=True):
+        return EncryptedSealBfvMatrix(list(vectors), self.referenceEnvironment, CopyVectors=CopyVectors, Format=format)
+
+    def GetValueFromString(self, s):
+        f = [int(x) for x in s.split(",")]
+        env = self.referenceEnvironment
+        return sum(c * x for c, x in zip(env.preComputedCoefficients, f)) % env.bigFactor
+
+    def GetStringFromValue(self, value):
+        return ",".join(str(value % e.plainmodulusValue) for e in self.referenceEnvironment.Environments)

@@ -70,6 +70,11 @@ int cn_free(cn_ctx *ctx, cn_handle h);
 int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host);
 int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host);
 int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host);
+int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host);
+/* BatchEncoder.Encode / Decode (AtomicSealBfvVector.cs:644,669,941,1130,1158 / :1050,1093): slot values <-> plaintext
+ * coefficients; the (I)NTT mod t runs on the device.  Requires t prime, t == 1 mod 2N. */
+int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi);
+int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values /* N */);
 int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count);
 int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes);
 int cn_live_handles(cn_ctx *ctx);                                              /* leak counter */

@@ -1,0 +1,173 @@
+"""CPU test harness: the libcnhip `Context` protocol and the `ClientCrypto` interface implemented on the oracle.
+
+Lets the SAME wrapper logic (cryptonets_amd/hewrapper.py) replay the reference's known-answer tests on the CPU
+(pinning the oracle at the decrypted-slot level) and provides the client side (keygen / encrypt / decrypt) for the
+GPU tests.  Lives under tests/: the product never imports it.
+"""
+import numpy as np
+
+from oracle.cno import COEFF_MODULUS_128, Oracle
+
+
+class OracleClient:
+    """ClientCrypto on the oracle (KeyGenerator / Encryptor / Decryptor of one plaintext modulus)."""
+
+    def __init__(self, t, n, q, dbc, gdbc, seed=None, oracle=None):
+        self.o = oracle if oracle is not None else Oracle(n, t, q=q, dbc=dbc, gdbc=gdbc)
+        self.seed = (t % 1000003) if seed is None else seed
+
+    def generate_keys(self, with_galois=True):
+        self.o.keygen(self.seed, galois=with_galois)
+
+    def relin_key(self):
+        return self.o.relin_key()
+
+    def galois_keys(self):
+        return {e: self.o.galois_key(i) for i, e in enumerate(self.o.galois_elts())}
+
+    def encrypt(self, plain):
+        return self.o.encrypt(np.ascontiguousarray(plain, dtype=np.uint64))
+
+    def decrypt(self, ct):
+        return self.o.decrypt(np.ascontiguousarray(ct, dtype=np.uint64))
+
+
+class OracleBackend:
+    """Same method names as cryptonets_amd._native.Context, computing with the oracle on numpy arrays."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+        self.n, self.t, self.q, self.k = oracle.n, oracle.t, list(oracle.q), oracle.k
+        self.ctw = oracle.ctw
+        self.bufs, self.next = {}, 1
+
+    # buffers
+    def ct_alloc(self, count, size=2):
+        h = self.next
+        self.next += 1
+        self.bufs[h] = np.zeros((count, size * self.k * self.n), dtype=np.uint64)
+        return h
+
+    def pt_alloc(self, count):
+        h = self.next
+        self.next += 1
+        self.bufs[h] = np.zeros((count, self.n), dtype=np.uint64)
+        return h
+
+    def free(self, h):
+        del self.bufs[h]
+
+    def live_handles(self):
+        return len(self.bufs)
+
+    def ct_upload(self, h, first, data):
+        d = np.asarray(data, dtype=np.uint64).reshape(-1, self.bufs[h].shape[1])
+        self.bufs[h][first:first + len(d)] = d
+
+    def ct_download(self, h, first, count, size=2):
+        return self.bufs[h][first:first + count].copy()
+
+    def pt_upload(self, h, first, data):
+        d = np.asarray(data, dtype=np.uint64).reshape(-1, self.n)
+        self.bufs[h][first:first + len(d)] = d
+
+    def pt_download(self, h, first, count):
+        return self.bufs[h][first:first + count].copy()
+
+    def encode(self, values, pt, pi):
+        self.bufs[pt][pi] = self.o.encode(np.asarray(values, dtype=np.uint64))
+
+    def decode(self, pt, pi):
+        return self.o.decode(self.bufs[pt][pi])
+
+    def copy(self, src, sfirst, dst, dfirst, count):
+        self.bufs[dst][dfirst:dfirst + count] = self.bufs[src][sfirst:sfirst + count].copy()
+
+    def set_relin_key(self, words):
+        pass            # the oracle context already holds the keys it generated
+
+    def set_galois_key(self, elt, words):
+        pass
+
+    def sync(self):
+        pass
+
+    # evaluator
+    def add(self, a, ai, b, bi, out, oi, count=1):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.add(self.bufs[a][ai + i], self.bufs[b][bi + i])
+
+    def sub(self, a, ai, b, bi, out, oi, count=1):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.sub(self.bufs[a][ai + i], self.bufs[b][bi + i])
+
+    def add_many(self, src, idx, out, oi):
+        acc = self.bufs[src][idx[0]].copy()
+        for i in idx[1:]:
+            acc = self.o.add(acc, self.bufs[src][i])
+        self.bufs[out][oi] = acc
+
+    def add_plain(self, a, ai, pt, pi, out, oi, count=1, subtract=False):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.add_plain(self.bufs[a][ai + i], self.bufs[pt][pi + i], subtract)
+
+    def mul_plain(self, a, ai, pt, pi, out, oi, count=1, pt_stride=1):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.multiply_plain(self.bufs[a][ai + i], self.bufs[pt][pi + i * pt_stride])
+
+    def mul_scalar(self, a, ai, scalars, out, oi, count=1, broadcast=False):
+        s = np.asarray(scalars, dtype=np.uint64).reshape(-1)
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.multiply_plain(self.bufs[a][ai + i], s[0:1] if broadcast else s[i:i + 1])
+
+    def scalar_gemm(self, src, W, out, oi, idx=None, bias_pt=0, bias_idx=None):
+        res = self.o.scalar_gemm(self.bufs[src], W, idx)
+        if bias_pt:
+            res = self.o.add_plain_batch(res, self.bufs[bias_pt][np.asarray(bias_idx)])
+        self.bufs[out][oi:oi + len(res)] = res
+
+    def mul_relin(self, a, ai, b, bi, out, oi, count=1, a_stride=1, b_stride=1):
+        for i in range(count):
+            m3 = self.o.multiply(self.bufs[a][ai + i * a_stride], self.bufs[b][bi + i * b_stride])
+            self.bufs[out][oi + i] = self.o.relinearize(m3)
+
+    def rotate_rows(self, src, ii, steps, out, oi, count=1):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.rotate_rows(self.bufs[src][ii + i], steps)
+
+    def rotate_columns(self, src, ii, out, oi, count=1):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.rotate_columns(self.bufs[src][ii + i])
+
+
+class OracleHarness:
+    """Factories for EncryptedSealBfvFactory(client_factory=..., context_factory=...): backend 'gpu' = libcnhip contexts with
+    oracle-made keys; backend 'cpu' = everything on the oracle."""
+
+    def __init__(self, backend):
+        self.backend = backend
+        self.oracles = {}
+
+    def default_coeff_modulus(self, n):
+        return list(COEFF_MODULUS_128[n])
+
+    def _oracle(self, n, t, q, dbc, gdbc):
+        key = (n, t, tuple(q), dbc, gdbc)
+        if key not in self.oracles:
+            self.oracles[key] = Oracle(n, t, q=q, dbc=dbc, gdbc=gdbc)
+        return self.oracles[key]
+
+    def client_factory(self, t, n, q, dbc, gdbc):
+        return OracleClient(t, n, q, dbc, gdbc, oracle=self._oracle(n, t, q, dbc, gdbc))
+
+    def __call__(self, n, t, q, dbc, gdbc):          # context_factory
+        if self.backend == "cpu":
+            return OracleBackend(self._oracle(n, t, q, dbc, gdbc))
+        from cryptonets_amd._native import Context
+        return Context(n, t, q=q, dbc=dbc, gdbc=gdbc, device=0)
+
+
+def make_factory(backend, primes=None, n=4096, dbc=10, gdbc=20, small_modulus_count=-1, galois=True):
+    from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
+    h = OracleHarness(backend)
+    return EncryptedSealBfvFactory(primes, n, dbc, gdbc, small_modulus_count, client_factory=h.client_factory, context_factory=h, galois=galois)

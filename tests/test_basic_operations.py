@@ -1,0 +1,178 @@
+"""Port of the reference's known-answer tests `HE Wrapper Tests/BasicOperations.cs` (same names, same values, exact
+equality on decrypted doubles, default factory N=4096 / 5 plaintext primes, BasicOperations.cs:29).
+
+Runs the SAME wrapper logic (cryptonets_amd.hewrapper) on two backends:
+  cpu : the oracle behind the Context protocol   -> pins the ORACLE against the reference's golden values (-m "not gpu")
+  gpu : libcnhip on the MI355X (oracle only plays the client: keygen / encrypt / decrypt)      (-m gpu)
+"""
+import numpy as np
+import pytest
+
+from oracle_backend import make_factory
+from cryptonets_amd.hewrapper import EMatrixFormat, EVectorFormat
+
+BACKENDS = [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)]
+_factories = {}
+
+values1 = np.array([-1, 9, 3, 20, 1000, -6945], dtype=float)
+values2 = np.array([8, -22, 5, 4, 254, -12], dtype=float)
+scale = 12.0
+values_m = np.array([[1, -2, 3, -44, 5, 7], [99, 12, -88, 22, 16, 13]], dtype=float)
+
+
+class Fix:
+    def __init__(self, backend):
+        self.Factory = make_factory(backend)
+        f = self.Factory
+        self.env = f.AllocateComputationEnv()
+        self.enc1 = f.GetEncryptedVector(values1, EVectorFormat.dense, scale)
+        self.enc2 = f.GetEncryptedVector(values2, EVectorFormat.dense, scale)
+        self.plain2 = f.GetPlainVector(values2, EVectorFormat.dense, scale)
+        self.mat = f.GetEncryptedMatrix(values_m, EMatrixFormat.ColumnMajor, scale)
+
+
+@pytest.fixture(params=BACKENDS)
+def fx(request):
+    if request.param not in _factories:
+        _factories[request.param] = Fix(request.param)
+    return _factories[request.param]
+
+
+def Compare(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape
+    assert np.array_equal(a, b), (a, b)
+
+
+def test_Decrypt(fx):
+    Compare(values1, fx.enc1.Decrypt(fx.env))
+
+
+def test_DecryptMatrix(fx):
+    Compare(values_m, fx.mat.Decrypt(fx.env))
+
+
+def test_MatrixColumn(fx):
+    Compare(values_m[:, 0], fx.mat.GetColumn(0).Decrypt(fx.env))
+
+
+def test_MatrixVectorMultiplication(fx):
+    enc_sparse = fx.Factory.GetEncryptedVector(values1, EVectorFormat.sparse, scale)
+    Compare(values_m @ values1, fx.mat.Mul(enc_sparse, fx.env).Decrypt(fx.env))
+
+
+def test_MatrixVectorMultiplicationPlain(fx):
+    enc_plain = fx.Factory.GetPlainVector(values1, EVectorFormat.sparse, scale)
+    Compare(values_m @ values1, fx.mat.Mul(enc_plain, fx.env).Decrypt(fx.env))
+
+
+def test_Add(fx):
+    Compare(values1 + values2, fx.enc1.Add(fx.enc2, fx.env).Decrypt(fx.env))
+    Compare(values1 + values2, fx.enc1.Add(fx.plain2, fx.env).Decrypt(fx.env))
+
+
+def test_ElementMultiply(fx):
+    Compare(values1 * values2, fx.enc1.PointwiseMultiply(fx.enc2, fx.env).Decrypt(fx.env))
+    Compare(values1 * values2, fx.enc1.PointwiseMultiply(fx.plain2, fx.env).Decrypt(fx.env))
+
+
+def test_DotProduct(fx):
+    assert fx.enc1.DotProduct(fx.enc2, fx.env).Decrypt(fx.env)[0] == float(values1 @ values2)
+    assert fx.enc1.DotProduct(fx.plain2, fx.env).Decrypt(fx.env)[0] == float(values1 @ values2)
+
+
+def test_Sum(fx):
+    assert fx.enc1.SumAllSlots(fx.env).Decrypt(fx.env)[0] == float(values1.sum())
+
+
+def test_Subtract(fx):
+    Compare(values1 - values2, fx.enc1.Subtract(fx.enc2, fx.env).Decrypt(fx.env))
+    Compare(values1 - values2, fx.enc1.Subtract(fx.plain2, fx.env).Decrypt(fx.env))
+
+
+def test_Meta(fx):
+    assert fx.enc1.IsEncrypted is True
+    assert fx.plain2.IsEncrypted is False
+    assert fx.enc1.Scale == scale
+    enc2 = fx.Factory.CopyVector(fx.enc1)
+    enc2.RegisterScale(20)
+    Compare(values1 * scale / 20, enc2.Decrypt(fx.env))
+
+
+@pytest.mark.parametrize("count", [4096 // 8, 10, 4096 // 8 - 5])
+def test_Duplicate(fx, count):
+    dup = fx.enc1.Duplicate(count, fx.env)
+    assert dup.Dim == count * 8
+    d = dup.Decrypt(fx.env)
+    assert len(d) == count * 8
+    exp = np.zeros(8)
+    exp[:6] = values1
+    assert np.array_equal(d, np.tile(exp, count))
+
+
+def test_PackedDotProduct(fx):
+    res = fx.enc1.DotProduct(fx.enc2, fx.env, length=4).Decrypt(fx.env)
+    assert res[3] == float(values1[:4] @ values2[:4])
+
+
+def test_BigPackedDotProduct(fx):
+    data = np.rint(np.random.default_rng(5).standard_normal(4096) * 10)
+    enc = fx.Factory.GetEncryptedVector(data, EVectorFormat.dense, 1)
+    res = enc.DotProduct(enc, fx.env, length=1024).Decrypt(fx.env)
+    for i in range(4):
+        assert res[1024 * i + 1023] == float((data[i * 1024:(i + 1) * 1024] ** 2).sum())
+
+
+def test_Interleave(fx):
+    data = np.array([[1, 0, 0, 2, 0, 0], [3, 0, 0, 4, 0, 0]], dtype=float).T
+    m = fx.Factory.GetEncryptedMatrix(data, EMatrixFormat.ColumnMajor, 10)
+    Compare([1, 3, 0, 2, 4, 0], m.Interleave(1, fx.env).Decrypt(fx.env))
+
+
+def test_InterleaveReverse(fx):
+    data = np.array([[0, 0, 1, 0, 0, 2], [0, 0, 3, 0, 0, 4], [0, 0, 5, 0, 0, 6]], dtype=float).T
+    m = fx.Factory.GetEncryptedMatrix(data, EMatrixFormat.ColumnMajor, 10)
+    Compare([5, 3, 1, 6, 4, 2], m.Interleave(-1, fx.env).Decrypt(fx.env))
+
+
+def test_Permute(fx):
+    values = np.arange(1, 11, dtype=float)
+    v = fx.Factory.GetEncryptedVector(values, EVectorFormat.dense, 1)
+    S1, S2 = np.zeros(10), np.zeros(10)
+    S1[[1, 4]] = 1.0
+    S2[[3, 6]] = 1.0
+    sel1 = fx.Factory.GetPlainVector(S1, EVectorFormat.dense, 1)
+    sel2 = fx.Factory.GetPlainVector(S2, EVectorFormat.dense, 1)
+    w = v.Permute([sel1, sel2], [1, 2], 5, fx.env)
+    Compare([2, 4, 0, 5, 7], w.Decrypt(fx.env))
+
+
+def test_BigStack(fx):
+    n = 1050
+    v = [fx.Factory.GetEncryptedVector(np.arange(i * n, (i + 1) * n, dtype=float), EVectorFormat.dense, 1) for i in range(4)]
+    m = fx.Factory.GetMatrix(v, EMatrixFormat.ColumnMajor)
+    dec = m.ConvertToColumnVector(fx.env).Decrypt(fx.env)
+    Compare(np.arange(4 * n, dtype=float), dec)
+
+
+def test_GenerateValueFromString(fx):
+    primes = [40961, 65537, 114689, 147457, 188417]
+    expected = [21399, 63588, 101610, 90324, 148561]
+    v = fx.Factory.GetValueFromString(",".join(str(x) for x in expected))
+    for p, e in zip(primes, expected):
+        assert v % p == e
+    assert fx.Factory.GetStringFromValue(v) == ",".join(str(x) for x in expected)
+
+
+def test_error_behaviour_matches_reference(fx):
+    """the reference throws at these points (AtomicSealBfvVector.cs:436-440, 817-828, 987-996)"""
+    f = fx.Factory
+    other = f.GetEncryptedVector(values1[:3], EVectorFormat.dense, scale)
+    with pytest.raises(Exception, match="Dimensions do not match"):
+        fx.enc1.Add(other, fx.env)
+    with pytest.raises(Exception, match="Scales do not match"):
+        fx.enc1.Add(f.GetEncryptedVector(values1, EVectorFormat.dense, 3.0), fx.env)
+    with pytest.raises(Exception, match="multiplying two plaintexts"):
+        fx.plain2.PointwiseMultiply(fx.plain2, fx.env)
+    with pytest.raises(Exception, match="expecting a sparse vector"):
+        fx.mat.Mul(fx.enc1, fx.env)
