@@ -1,0 +1,113 @@
+"""Layer-level known-answer tests ported from `NeuralNetworksTest/LayersTest.cs` (EvenPool :54-82,
+PoolLayerAsSparseToDense :155-185) plus a small end-to-end CNN, on the oracle (CPU) and on libcnhip (GPU)."""
+import numpy as np
+import pytest
+
+from oracle_backend import make_factory
+from cryptonets_amd.hewrapper import EMatrixFormat, EVectorFormat
+from cryptonets_amd.layers import EncryptLayer, FakeLayer, InputLayer, LLDenseLayer, PoolLayer, SquareActivation
+
+BACKENDS = [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)]
+_f = {}
+
+
+def factory(backend, **kw):
+    key = (backend, tuple(sorted(kw.items())))
+    if key not in _f:
+        _f[key] = make_factory(backend, **kw)
+    return _f[key]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_EvenPool(backend):
+    Factory = factory(backend)
+    layer = PoolLayer(Factory=Factory, InputShape=[3, 4, 4], KernelShape=[1, 2, 2], Stride=[1, 2, 2])
+    layer.Prepare()
+    data = np.arange(48, dtype=float).reshape(1, 48)
+    m = Factory.GetEncryptedMatrix(data, EMatrixFormat.ColumnMajor, 1)
+    t = layer.Apply(m)
+    res = t.Decrypt(Factory.AllocateComputationEnv())
+    assert res.shape == (1, 12)
+    assert list(res[0]) == [2.5, 4.5, 10.5, 12.5, 18.5, 20.5, 26.5, 28.5, 34.5, 36.5, 42.5, 44.5]
+    t.Dispose()
+    m.Dispose()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_PoolLayerAsSparseToDense(backend):
+    Factory = factory(backend)
+    vec = Factory.GetEncryptedVector(np.array([1.0, 2.0, 3.0]), EVectorFormat.sparse, 1)
+    m = Factory.GetMatrix([vec], EMatrixFormat.ColumnMajor)
+    layer = LLDenseLayer(Factory=Factory, Weights=[1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 1], Bias=[0] * 6, WeightsScale=1,
+                         InputFormat=EVectorFormat.sparse, Source=FakeLayer())
+    layer.Prepare()
+    res = layer.Apply(m)
+    dec = res.Decrypt(Factory.AllocateComputationEnv())
+    assert dec.shape == (6, 1)
+    assert [dec[i, 0] for i in range(6)] == [1 + (i % 3) for i in range(6)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("force_dense", [False, True])
+def test_LLDenseLayer_dense_input(backend, force_dense):
+    """LoLa dense layer on a packed ciphertext: per-row dense MultiplyPlain + SumAllSlots (rotate-and-add), sparse
+    output or mask-accumulated dense output (EncryptedSealBfvMatrix.cs:79-120)."""
+    Factory = factory(backend)
+    rng = np.random.default_rng(3)
+    x = rng.integers(-5, 6, size=40).astype(float)
+    W = rng.integers(-4, 5, size=(6, 40)).astype(float)
+    b = rng.integers(-9, 10, size=6).astype(float)
+    col = Factory.GetEncryptedVector(x, EVectorFormat.dense, 2.0)
+    m = Factory.GetMatrix([col], EMatrixFormat.ColumnMajor, CopyVectors=False)
+
+    class Src(FakeLayer):
+        def GetOutputScale(self):
+            return 2.0
+    layer = LLDenseLayer(Factory=Factory, Weights=W.reshape(-1), Bias=b, WeightsScale=3.0, ForceDenseFormat=force_dense, Source=Src())
+    res = layer.Apply(m)
+    dec = res.Decrypt(Factory.AllocateComputationEnv())
+    assert np.array_equal(dec[:, 0], W @ x + b)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_small_cnn_end_to_end(backend):
+    """conv (with padding, several maps) -> square -> dense+bias -> square -> dense+bias through the layer classes,
+    checked exactly against integer arithmetic on the scaled inputs/weights."""
+    Factory = factory(backend, primes=(40961, 65537, 114689), n=4096, galois=False)
+    rng = np.random.default_rng(11)
+    samples = 50
+    img = rng.integers(0, 4, size=(samples, 36)).astype(float)                  # 6x6 images
+    w0 = rng.integers(-2, 3, size=2 * 10).astype(float)                         # 2 maps x (3x3 + bias)
+    conv = dict(InputShape=[6, 6], KernelShape=[3, 3], Stride=[2, 2], Upperpadding=[1, 1], MapCount=[2, 1])
+    src = InputLayer(img, Scale=1.0, Factory=Factory)
+    enc = EncryptLayer(Source=src)
+    l1 = PoolLayer(Source=enc, Weights=w0, WeightsScale=1.0, **conv)
+    a1 = SquareActivation(Source=l1)
+    n1 = l1.OutputDimension()
+    w1 = rng.integers(-1, 2, size=4 * n1).astype(float)
+    b1 = rng.integers(-3, 4, size=4).astype(float)
+    l2 = PoolLayer(Source=a1, InputShape=[n1], KernelShape=[n1], Stride=[1000], MapCount=[4], Weights=w1, Bias=b1, WeightsScale=1.0)
+    a2 = SquareActivation(Source=l2)
+    w2 = rng.integers(-1, 2, size=3 * 4).astype(float)
+    b2 = rng.integers(-3, 4, size=3).astype(float)
+    l3 = PoolLayer(Source=a2, InputShape=[4], KernelShape=[4], Stride=[1000], MapCount=[3], Weights=w2, Bias=b2, WeightsScale=1.0)
+    l3.PrepareNetwork()
+    out = l3.GetNext()
+    dec = out.Decrypt(Factory.AllocateComputationEnv())
+    # integer model
+    g = l1.engine.gather_table()
+    x = img.astype(np.int64)
+    y1 = np.zeros((samples, n1), dtype=np.int64)
+    for mi in range(2):
+        for c in range(len(l1.engine.Corners)):
+            acc = np.full(samples, int(w0[(mi + 1) * 10 - 1]), dtype=np.int64)
+            for k, idx in enumerate(g[c]):
+                if idx >= 0:
+                    acc += int(l1.weightWindows[mi][k]) * x[:, idx]
+            y1[:, mi * len(l1.engine.Corners) + c] = acc
+    y1 = y1 ** 2
+    y2 = (y1 @ w1.reshape(4, n1).T.astype(np.int64) + b1.astype(np.int64)) ** 2
+    y3 = y2 @ w2.reshape(3, 4).T.astype(np.int64) + b2.astype(np.int64)
+    assert dec.shape == (samples, 3)
+    assert np.array_equal(dec, y3.astype(float))
+    out.Dispose()
