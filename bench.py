@@ -76,6 +76,7 @@ def main():
 
     from cryptonets_amd._native import Context
     from cryptonets_amd import cryptonets_mnist as cm
+    from cryptonets_amd.distributed import broadcast_words, max_over_ranks
 
     rng = np.random.default_rng(1000 + rank)
     layers = cm.layer_tables(*cm.synthetic_weights(1))
@@ -84,13 +85,8 @@ def main():
         g = Context(cm.N, p, dbc=10, gdbc=20, device=local)
         # relinearisation keys: rank 0 draws them, RCCL broadcast over xGMI puts them on every GPU
         words = g.key_words(False)
-        if rank == 0:
-            kw = uniform_ct_words(np.random.default_rng(p % 1000), g.q, g.n, words // g.ctw).reshape(-1)
-            kt = torch.from_numpy(kw.view(np.int64)).cuda()
-        else:
-            kt = torch.empty(words, dtype=torch.int64, device="cuda")
-        if dist is not None:
-            dist.broadcast(kt, src=0)
+        kw = uniform_ct_words(np.random.default_rng(p % 1000), g.q, g.n, words // g.ctw).reshape(-1) if rank == 0 else None
+        kt = broadcast_words(kw, words, 0, torch.device("cuda", local), dist)
         torch.cuda.synchronize()
         g.set_relin_key_device(kt.data_ptr(), words)
         key_tensors.append(kt)
@@ -119,10 +115,7 @@ def main():
         step()
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, torch.device("cuda", local), dist)
 
     # ---- roofline of the dominant kernel: the batched N=8192 RNS NTT, timed with HIP events on the ctx stream
     g = chans[0].g
