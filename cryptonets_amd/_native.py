@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "lib", "libcnhip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("cn_api.hip", "cn_tables.cpp")]
-HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("cn_kernels.hip.h", "cn_internal.h")] + [
+HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("cn_kernels.hip.h", "cn_ntt_core.hip.h", "cn_internal.h")] + [
     os.path.join(_ROOT, "include", "cnhip.h")]
 
 U64P = C.POINTER(C.c_uint64)

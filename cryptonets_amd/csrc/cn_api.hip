@@ -48,6 +48,7 @@ struct cn_ctx {
     uint32_t bs, chunks;      // element-wise geometry
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
     size_t ctw2;              // words of a size-2 ciphertext
+    bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
 };
 
 // ---------------------------------------------------------------- helpers
@@ -93,10 +94,23 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
 
 static void launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }
 
+template <int L> static void launch_ntt_rr(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
+    hipLaunchKernelGGL(k_ntt_rr<L>, dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+}
 static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
     if (!limbs) return 0;
-    uint32_t n = c->hc.n, nt = std::min<uint32_t>(512, n / 2);
-    hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+    uint32_t n = c->hc.n;
+    switch (c->legacy_ntt ? 0 : c->hc.logn) {
+        case 10: launch_ntt_rr<10>(c, data, limbs, base_off, nmod, inverse); break;
+        case 11: launch_ntt_rr<11>(c, data, limbs, base_off, nmod, inverse); break;
+        case 12: launch_ntt_rr<12>(c, data, limbs, base_off, nmod, inverse); break;
+        case 13: launch_ntt_rr<13>(c, data, limbs, base_off, nmod, inverse); break;
+        case 14: launch_ntt_rr<14>(c, data, limbs, base_off, nmod, inverse); break;
+        default: {
+            uint32_t nt = std::min<uint32_t>(512, n / 2);
+            hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+        }
+    }
     HIPCHK(hipGetLastError());
     launch_count(c);
     if (inverse) c->st.ntt_inverse_limbs += limbs; else c->st.ntt_forward_limbs += limbs;
@@ -139,10 +153,15 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->ctw2 = (size_t)2 * k * n;
     const char *env = getenv("CN_SCRATCH_GB");
     c->smax = (size_t)(env ? atof(env) : 24.0) * (1ull << 30);
-    size_t lds = (size_t)n * 8;
+    c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
+    size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     *out = c;
     return 0;
@@ -526,16 +545,31 @@ static void launch_ks(cn_ctx *c, uint32_t nt, const uint64_t *target, size_t tst
                       const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
     hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, target, tstride, add0, add1, astride, key, out, c->dc, galois);
 }
+template <int L>
+static void launch_ks_rr(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
+                         const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
+    hipLaunchKernelGGL(k_keyswitch_rr<L>, dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, target, tstride, add0, add1,
+                       astride, key, out, c->dc, galois);
+}
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                         const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
     uint32_t n = ctx->hc.n, nt = std::min<uint32_t>(1024, n), ept = n / nt;
-    switch (ept) {
-        case 1: launch_ks<1>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 2: launch_ks<2>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 4: launch_ks<4>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 8: launch_ks<8>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
+    int sel = ctx->legacy_ntt ? 0 : (int)ctx->hc.logn;
+    switch (sel) {
+        case 10: launch_ks_rr<10>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 11: launch_ks_rr<11>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 12: launch_ks_rr<12>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 13: launch_ks_rr<13>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        case 14: launch_ks_rr<14>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+        default:
+            switch (ept) {
+                case 1: launch_ks<1>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+                case 2: launch_ks<2>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+                case 4: launch_ks<4>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+                case 8: launch_ks<8>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+                case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
+                default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
+            }
     }
     HIPCHK(hipGetLastError()); launch_count(ctx);
     uint32_t tot = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "cn_internal.h"
+#include "cn_ntt_core.hip.h"
 
 typedef unsigned __int128 u128;
 #define DEV __device__ __forceinline__
@@ -362,4 +363,112 @@ __global__ void k_galois(const uint64_t *__restrict__ src, uint64_t *__restrict_
     const uint32_t idx = (uint32_t)(raw & (n - 1));
     uint64_t v = src[(size_t)limb * n + i];
     dst[(size_t)limb * n + idx] = ((raw >> C->logn) & 1) ? negmod(v, q) : v;
+}
+
+// ------------------------------------------------------------------ register-radix NTT kernels (N = 2^L, L = 10..14)
+template <int L>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
+    extern __shared__ __align__(16) uint64_t s[];
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, mod = base_off + blockIdx.x % nmod;
+    const uint64_t q = mod < C->k ? C->q[mod].q : (mod < C->k + C->kb ? C->bsk[mod - C->k].q : C->t.q);
+    uint64_t *x = data + (size_t)blockIdx.x * n;
+    const uint64_t *tw = tw_of(C, mod);
+    uint64_t v[16];
+    if (!inverse) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = x[pass_index<L, SA, 0>(tid, r)];
+        ntt_forward_regs<L>(v, s, tw, tw + n, q, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            ulonglong2 o; o.x = canon4(v[r], q); o.y = canon4(v[r + 1], q);
+            *reinterpret_cast<ulonglong2 *>(x + tail_index<L>(tid, r)) = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            ulonglong2 i2 = *reinterpret_cast<const ulonglong2 *>(x + tail_index<L>(tid, r));
+            v[r] = i2.x; v[r + 1] = i2.y;
+        }
+        ntt_inverse_regs<L>(v, s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, tid);
+        const uint64_t ni = C->ninv[mod], nis = C->ninvs[mod];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { uint64_t o = shoup_lazy(v[r], ni, nis, q); x[pass_index<L, SA, 0>(tid, r)] = o >= q ? o - q : o; }
+    }
+}
+
+// Key switching on the register-radix core: block = (ciphertext, output limb j).  For every source limb l the 16
+// coefficients a thread owns are read ONCE; each base-2^dbc digit goes through the forward transform in registers/LDS and is
+// multiply-accumulated with the key pair (16 B/lane coalesced key loads) into canonical 64-bit accumulators; two inverse
+// transforms finish.  The digit polynomials never exist in HBM.
+template <int L>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
+                                                                 const uint64_t *__restrict__ add1, size_t add_stride, const uint64_t *__restrict__ key,
+                                                                 uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois) {
+    extern __shared__ __align__(16) uint64_t s[];
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const uint64_t *tw = tw_of(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    uint64_t acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const uint64_t *kp = key;
+    for (uint32_t l = 0; l < k; l++) {
+        const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+            const int sh = dbc * (int)d;
+            uint64_t v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint64_t t = (src[pass_index<L, SA, 0>(tid, r)] >> sh) & mask;      // L2-resident re-read per digit
+                if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t;
+                v[r] = t;
+            }
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));           // opaque copy of tid: keeps LDS/twiddle address math and twiddle loads inside the
+                                                   // loop (hoisted as loop invariants they cost >150 VGPRs and spill)
+            ntt_forward_regs<L>(v, s, tw, tw + n, q, tl);
+            const uint64_t *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                __builtin_amdgcn_sched_barrier(0);           // bound the key loads in flight (register pressure)
+                const uint32_t pos = tail_index<L>(tid, r);
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(k0 + pos), b = *reinterpret_cast<const ulonglong2 *>(k1 + pos);
+                const uint64_t x0 = canon4(v[r], q), x1 = canon4(v[r + 1], q);
+                acc0[r] = addmod(acc0[r], mulmod(x0, a.x, qm), q); acc0[r + 1] = addmod(acc0[r + 1], mulmod(x1, a.y, qm), q);
+                acc1[r] = addmod(acc1[r], mulmod(x0, b.x, qm), q); acc1[r + 1] = addmod(acc1[r + 1], mulmod(x1, b.y, qm), q);
+            }
+            __syncthreads();                      // LDS of this transform is reused by the next one
+        }
+    }
+    const uint64_t ni = C->ninv[j], nis = C->ninvs[j];
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        uint64_t v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));               // see above: no hoisting / sharing of address math across the two transforms
+        ntt_inverse_regs<L>(v, s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, tl);
+        const uint64_t *ad = p ? add1 : add0;
+        uint64_t *o = out + ((size_t)ct * 2 + p) * kn + (size_t)j * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t e = pass_index<L, SA, 0>(tl, r);
+            uint64_t val = shoup_lazy(v[r], ni, nis, q);
+            val = val >= q ? val - q : val;
+            if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], q);
+            o[e] = val;
+        }
+        __syncthreads();
+    }
 }
