@@ -60,6 +60,7 @@ SIGNATURES = {
     "cn_ctx_create": (C.c_int, [_u32, U64P, _u32, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(_CTX)]),
     "cn_ctx_destroy": (C.c_int, [_CTX]),
     "cn_sync": (C.c_int, [_CTX]),
+    "cn_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_int]),
     "cn_default_coeff_modulus": (C.c_int, [_u32, U64P]),
     "cn_key_words": (C.c_size_t, [_CTX, C.c_int]),
     "cn_set_relin_key": (C.c_int, [_CTX, C.c_void_p, C.c_size_t, C.c_int]),
@@ -154,6 +155,9 @@ class Context:
     def _chk(self, rc):
         if rc:
             raise CnError(rc, self.L.cn_last_error().decode())
+
+    def set_option(self, name, value):
+        self._chk(self.L.cn_set_option(self._h, name.encode(), int(value)))
 
     def close(self):
         if self._h is not None:

@@ -29,7 +29,7 @@ struct Buffer {
     size_t item_words;
     std::vector<uint8_t> pt_zero;   // per plaintext: all coefficients zero?
 };
-struct KsKey { uint64_t *d; bool owned; };
+struct KsKey { uint64_t *d; bool owned; bool f64; };   // f64: words converted to doubles for the FP64 key-switch kernel
 
 struct cn_ctx {
     int device;
@@ -40,7 +40,9 @@ struct cn_ctx {
     std::mutex mu;
     std::unordered_map<cn_handle, Buffer> bufs;
     cn_handle next_handle = 1;
-    KsKey rlk{nullptr, false};
+    KsKey rlk{nullptr, false, false};
+    double *twd = nullptr;
+    bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
     std::map<uint64_t, KsKey> gk;
     char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
     cn_stats st{};
@@ -94,22 +96,29 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
 
 static void launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }
 
-template <int L> static void launch_ntt_rr(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
-    hipLaunchKernelGGL(k_ntt_rr<L>, dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+template <int L, class AR> static void launch_ntt_rr(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
+    hipLaunchKernelGGL((k_ntt_rr<L, AR>), dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+}
+template <class AR> static bool launch_ntt_by_size(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
+    switch (c->hc.logn) {
+        case 10: launch_ntt_rr<10, AR>(c, data, limbs, base_off, nmod, inverse); return true;
+        case 11: launch_ntt_rr<11, AR>(c, data, limbs, base_off, nmod, inverse); return true;
+        case 12: launch_ntt_rr<12, AR>(c, data, limbs, base_off, nmod, inverse); return true;
+        case 13: launch_ntt_rr<13, AR>(c, data, limbs, base_off, nmod, inverse); return true;
+        case 14: launch_ntt_rr<14, AR>(c, data, limbs, base_off, nmod, inverse); return true;
+        default: return false;
+    }
 }
 static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
     if (!limbs) return 0;
     uint32_t n = c->hc.n;
-    switch (c->legacy_ntt ? 0 : c->hc.logn) {
-        case 10: launch_ntt_rr<10>(c, data, limbs, base_off, nmod, inverse); break;
-        case 11: launch_ntt_rr<11>(c, data, limbs, base_off, nmod, inverse); break;
-        case 12: launch_ntt_rr<12>(c, data, limbs, base_off, nmod, inverse); break;
-        case 13: launch_ntt_rr<13>(c, data, limbs, base_off, nmod, inverse); break;
-        case 14: launch_ntt_rr<14>(c, data, limbs, base_off, nmod, inverse); break;
-        default: {
-            uint32_t nt = std::min<uint32_t>(512, n / 2);
-            hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
-        }
+    bool f64 = c->use_f64;
+    for (uint32_t m = base_off; m < base_off + nmod; m++) f64 = f64 && c->hc.f64ok[m];
+    bool done = !c->legacy_ntt && (f64 ? launch_ntt_by_size<ArF64>(c, data, limbs, base_off, nmod, inverse)
+                                       : launch_ntt_by_size<ArU64>(c, data, limbs, base_off, nmod, inverse));
+    if (!done) {
+        uint32_t nt = std::min<uint32_t>(512, n / 2);
+        hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
     }
     HIPCHK(hipGetLastError());
     launch_count(c);
@@ -147,6 +156,14 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     HIPCHK(hipMalloc((void **)&c->tw, tw.size() * 8));
     HIPCHK(hipMemcpy(c->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
     c->hc.tw = c->tw;
+    {
+        std::vector<double> twd((size_t)(2 * k + 2) * 2 * n, 0.0);
+        cn_build_f64_tables(&c->hc, tw.data(), twd.data());
+        HIPCHK(hipMalloc((void **)&c->twd, twd.size() * 8));
+        HIPCHK(hipMemcpy(c->twd, twd.data(), twd.size() * 8, hipMemcpyHostToDevice));
+        c->hc.twd = c->twd;
+        c->use_f64 = !(getenv("CN_NO_F64") && atoi(getenv("CN_NO_F64")));
+    }
     HIPCHK(hipMalloc((void **)&c->dc, sizeof(DevConsts)));
     HIPCHK(hipMemcpy(c->dc, &c->hc, sizeof(DevConsts), hipMemcpyHostToDevice));
     c->bs = std::min<uint32_t>(256, n); c->chunks = n / c->bs;
@@ -158,10 +175,14 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     *out = c;
     return 0;
@@ -173,11 +194,18 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     for (auto &kv : ctx->bufs) (void)hipFree(kv.second.d);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
-    (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->dc);
+    (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
+}
+extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
+    LOCK;
+    if (!name) return fail(CN_ERR_ARG, "null option name");
+    if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
+    if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
+    return fail(CN_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
 extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
@@ -187,11 +215,20 @@ static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count
     if (!words || count != expect) return fail(CN_ERR_ARG, "key has %zu words, expected %zu", count, expect);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (slot.owned && slot.d) HIPCHK(hipFree(slot.d));
-    slot = {nullptr, false};
-    if (is_dev) { slot.d = (uint64_t *)words; slot.owned = false; return 0; }
-    HIPCHK(hipMalloc((void **)&slot.d, count * 8));
-    slot.owned = true;
-    HIPCHK(hipMemcpy(slot.d, words, count * 8, hipMemcpyHostToDevice));
+    slot = {nullptr, false, false};
+    if (is_dev) { slot.d = (uint64_t *)words; slot.owned = false; }
+    else {
+        HIPCHK(hipMalloc((void **)&slot.d, count * 8));
+        slot.owned = true;
+        HIPCHK(hipMemcpy(slot.d, words, count * 8, hipMemcpyHostToDevice));
+    }
+    if (ctx->use_f64 && ctx->hc.q_f64 && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) {
+        // FP64 key-switch kernel reads the key as doubles: convert once, in place (an adopted device buffer is converted too)
+        hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, slot.d, count);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot.f64 = true;
+    }
     return 0;
 }
 extern "C" int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_dev) {
@@ -545,31 +582,47 @@ static void launch_ks(cn_ctx *c, uint32_t nt, const uint64_t *target, size_t tst
                       const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
     hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, target, tstride, add0, add1, astride, key, out, c->dc, galois);
 }
-template <int L>
+template <int L, class AR>
 static void launch_ks_rr(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                         const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
-    hipLaunchKernelGGL(k_keyswitch_rr<L>, dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, target, tstride, add0, add1,
-                       astride, key, out, c->dc, galois);
+                         const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
+    hipLaunchKernelGGL((k_keyswitch_rr<L, AR>), dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, target, tstride, add0,
+                       add1, astride, (const void *)key, out, c->dc, galois, accmax);
+}
+template <class AR>
+static bool launch_ks_by_size(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
+                              const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
+    switch (c->hc.logn) {
+        case 10: launch_ks_rr<10, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 11: launch_ks_rr<11, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 12: launch_ks_rr<12, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 13: launch_ks_rr<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 14: launch_ks_rr<14, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        default: return false;
+    }
 }
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                        const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
+                        const KsKey &key, uint64_t *out, uint32_t cnt, int galois) {
     uint32_t n = ctx->hc.n, nt = std::min<uint32_t>(1024, n), ept = n / nt;
-    int sel = ctx->legacy_ntt ? 0 : (int)ctx->hc.logn;
-    switch (sel) {
-        case 10: launch_ks_rr<10>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 11: launch_ks_rr<11>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 12: launch_ks_rr<12>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 13: launch_ks_rr<13>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        case 14: launch_ks_rr<14>(ctx, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-        default:
-            switch (ept) {
-                case 1: launch_ks<1>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-                case 2: launch_ks<2>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-                case 4: launch_ks<4>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-                case 8: launch_ks<8>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-                case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key, out, cnt, galois); break;
-                default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
-            }
+    bool done = false;
+    if (key.f64) {
+        // lazy FP64 accumulators: |term| <= 2.1 q, keep the sum below 2^52
+        uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+        int bits = 64 - __builtin_clzll(qmax);
+        uint32_t accmax = bits >= 50 ? 1u : (1u << std::min(10, 50 - bits));
+        done = launch_ks_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
+        if (!done) return fail(CN_ERR_ARG, "internal: FP64 key without FP64 kernel");
+    } else if (!ctx->legacy_ntt) {
+        done = launch_ks_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu);
+    }
+    if (!done) {
+        switch (ept) {
+            case 1: launch_ks<1>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
+            case 2: launch_ks<2>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
+            case 4: launch_ks<4>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
+            case 8: launch_ks<8>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
+            case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
+            default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
+        }
     }
     HIPCHK(hipGetLastError()); launch_count(ctx);
     uint32_t tot = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
@@ -602,7 +655,7 @@ extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle
     if (!count) return 0;
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     const uint64_t *p = I->d + ii * I->item_words;
-    CHECK(do_keyswitch(ctx, p + 2 * kn, 3 * kn, p, p + kn, 3 * kn, ctx->rlk.d, O->d + oi * O->item_words, count, 0));
+    CHECK(do_keyswitch(ctx, p + 2 * kn, 3 * kn, p, p + kn, 3 * kn, ctx->rlk, O->d + oi * O->item_words, count, 0));
     ctx->st.Relinarization += count;
     return 0;
 }
@@ -623,7 +676,7 @@ extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astr
         CHECK(ensure_scratch(ctx, per * c + 8192));
         uint64_t *t3 = salloc<uint64_t>(ctx, (size_t)c * 3 * kn);
         CHECK(do_multiply(ctx, pa + (size_t)s * astride * A->item_words, astride, pb + (size_t)s * bstride * B->item_words, bstride, t3, c));
-        CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk.d, O->d + (oi + s) * O->item_words, c, 0));
+        CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk, O->d + (oi + s) * O->item_words, c, 0));
     }
     ctx->st.Relinarization += count;
     return 0;
@@ -638,7 +691,7 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
     uint32_t limbs = count * 2 * ctx->hc.k;
     hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
     HIPCHK(hipGetLastError()); launch_count(ctx);
-    CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second.d, out, count, 1));
+    CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second, out, count, 1));
     ctx->st.Rotation += count;
     return 0;
 }

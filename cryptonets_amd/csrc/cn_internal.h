@@ -20,6 +20,11 @@ struct DevConsts {
     uint64_t *tw;
     uint64_t ninv[2 * CN_MAXK + 2], ninvs[2 * CN_MAXK + 2];
     uint32_t batching;               // t is prime and == 1 mod 2N: BatchEncoder available
+    // exact-FP64 transform path (moduli < 2^49): twd + m*2*n = {w[n], w^-1[n]} as doubles, same bit-reversed order
+    double *twd;
+    double qd[2 * CN_MAXK + 2], qinvd[2 * CN_MAXK + 2], ninvd[2 * CN_MAXK + 2];
+    uint32_t f64ok[2 * CN_MAXK + 2];
+    uint32_t q_f64;                  // every coefficient modulus q_j qualifies: ciphertext transforms + key switching run in FP64
     // plaintext scaling (Encryptor::preencrypt / add_plain) and fast plain lift (multiply_plain)
     uint64_t t_half, delta[CN_MAXK], rtq[CN_MAXK], lift_inc[CN_MAXK];
     // BEHZ constants (SEAL util/baseconverter.cpp)
@@ -38,3 +43,4 @@ struct DevConsts {
 int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc,
                     uint64_t *tw_host, uint32_t *index_map, char *err, size_t errlen);
 int cn_default_coeff_modulus_impl(uint32_t n, uint64_t *q);
+void cn_build_f64_tables(DevConsts *c, const uint64_t *tw_host, double *twd_host);   // twd_host: (k+kb+1)*2*n doubles

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include "cn_internal.h"
 #include "cn_ntt_core.hip.h"
+#include <type_traits>
 
 typedef unsigned __int128 u128;
 #define DEV __device__ __forceinline__
@@ -366,109 +367,153 @@ __global__ void k_galois(const uint64_t *__restrict__ src, uint64_t *__restrict_
 }
 
 // ------------------------------------------------------------------ register-radix NTT kernels (N = 2^L, L = 10..14)
-template <int L>
+DEV uint64_t modulus_of(const DevConsts *C, uint32_t mod) { return mod < C->k ? C->q[mod].q : (mod < C->k + C->kb ? C->bsk[mod - C->k].q : C->t.q); }
+
+// per-policy views of the context constants
+template <class AR> struct ArCtx;
+template <> struct ArCtx<ArU64> {
+    ArU64::Mod m; ArU64::Tw fw, iv; uint64_t ni, nis;
+    DEV ArCtx(const DevConsts *C, uint32_t mod) {
+        const uint64_t q = modulus_of(C, mod); const uint64_t *tw = tw_of(C, mod); const size_t n = C->n;
+        m = {q, 2 * q}; fw = {tw, tw + n}; iv = {tw + 2 * n, tw + 3 * n}; ni = C->ninv[mod]; nis = C->ninvs[mod];
+    }
+    DEV uint64_t load(uint64_t v) const { return v; }
+    DEV uint64_t canon(uint64_t v) const { return canon4(v, m.q); }                       // forward output in [0,4q)
+    DEV uint64_t scaled(uint64_t v) const { uint64_t o = shoup_lazy(v, ni, nis, m.q); return o >= m.q ? o - m.q : o; }   // * N^-1, canonical
+};
+template <> struct ArCtx<ArF64> {
+    ArF64::Mod m; ArF64::Tw fw, iv; double ni;
+    DEV ArCtx(const DevConsts *C, uint32_t mod) {
+        const double *tw = C->twd + (size_t)mod * 2 * C->n;
+        m = {C->qd[mod], C->qinvd[mod]}; fw = {tw}; iv = {tw + C->n}; ni = C->ninvd[mod];
+    }
+    DEV double load(uint64_t v) const { return ArF64::from_u64(v); }
+    DEV uint64_t canon(double v) const { return ArF64::to_u64(v, m); }
+    DEV uint64_t scaled(double v) const { return ArF64::to_u64(ArF64::mulmod(v, ni, m), m); }
+};
+
+template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
-    extern __shared__ __align__(16) uint64_t s[];
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
     constexpr uint32_t n = 1u << L;
     constexpr int SA = NttPlan<L>::SA;
     const uint32_t tid = threadIdx.x, mod = base_off + blockIdx.x % nmod;
-    const uint64_t q = mod < C->k ? C->q[mod].q : (mod < C->k + C->kb ? C->bsk[mod - C->k].q : C->t.q);
+    const ArCtx<AR> A(C, mod);
     uint64_t *x = data + (size_t)blockIdx.x * n;
-    const uint64_t *tw = tw_of(C, mod);
-    uint64_t v[16];
+    T v[16];
     if (!inverse) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = x[pass_index<L, SA, 0>(tid, r)];
-        ntt_forward_regs<L>(v, s, tw, tw + n, q, tid);
+        for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tid, r)]);
+        ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            ulonglong2 o; o.x = canon4(v[r], q); o.y = canon4(v[r + 1], q);
+            ulonglong2 o; o.x = A.canon(v[r]); o.y = A.canon(v[r + 1]);
             *reinterpret_cast<ulonglong2 *>(x + tail_index<L>(tid, r)) = o;
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             ulonglong2 i2 = *reinterpret_cast<const ulonglong2 *>(x + tail_index<L>(tid, r));
-            v[r] = i2.x; v[r + 1] = i2.y;
+            v[r] = A.load(i2.x); v[r + 1] = A.load(i2.y);
         }
-        ntt_inverse_regs<L>(v, s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, tid);
-        const uint64_t ni = C->ninv[mod], nis = C->ninvs[mod];
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
 #pragma unroll
-        for (int r = 0; r < 16; r++) { uint64_t o = shoup_lazy(v[r], ni, nis, q); x[pass_index<L, SA, 0>(tid, r)] = o >= q ? o - q : o; }
+        for (int r = 0; r < 16; r++) x[pass_index<L, SA, 0>(tid, r)] = A.scaled(v[r]);
     }
 }
 
-// Key switching on the register-radix core: block = (ciphertext, output limb j).  For every source limb l the 16
-// coefficients a thread owns are read ONCE; each base-2^dbc digit goes through the forward transform in registers/LDS and is
-// multiply-accumulated with the key pair (16 B/lane coalesced key loads) into canonical 64-bit accumulators; two inverse
-// transforms finish.  The digit polynomials never exist in HBM.
-template <int L>
+// Key switching on the register-radix core: block = (ciphertext, output limb j).  For every (source limb l, digit d) the
+// base-2^dbc digit of the 16 coefficients a thread owns goes through the forward transform in registers/LDS and is
+// multiply-accumulated with the key pair (16 B/lane coalesced key loads) into per-thread accumulators; two inverse transforms
+// finish and the result is added to (add0, add1).  The digit polynomials never exist in HBM.
+// U64 policy: keys are u64 residues, canonical accumulators.  F64 policy: keys were converted to doubles at upload,
+// accumulators are lazy doubles recentred every `accmax` terms.
+template <class AR> struct KsMac;
+template <> struct KsMac<ArU64> {
+    static DEV void mac(uint64_t &acc, uint64_t x, uint64_t key, const DMod &qm, const ArCtx<ArU64> &A) { acc = addmod(acc, mulmod(canon4(x, qm.q), key, qm), qm.q); }
+    static DEV void settle(uint64_t (&)[16], const ArCtx<ArU64> &) {}
+};
+template <> struct KsMac<ArF64> {
+    static DEV void mac(double &acc, double x, double key, const DMod &, const ArCtx<ArF64> &A) { acc = __dadd_rn(acc, ArF64::mulmod(x, key, A.m)); }
+    static DEV void settle(double (&a)[16], const ArCtx<ArF64> &A) { ArF64::renorm(a, A.m); }
+};
+template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
-                                                                 const uint64_t *__restrict__ add1, size_t add_stride, const uint64_t *__restrict__ key,
-                                                                 uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois) {
-    extern __shared__ __align__(16) uint64_t s[];
+                                                                 const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
+                                                                 uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
     constexpr uint32_t n = 1u << L;
     constexpr int SA = NttPlan<L>::SA;
     const uint32_t k = C->k, tid = threadIdx.x;
     const uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
     const DMod qm = C->q[j];
     const uint64_t q = qm.q;
-    const uint64_t *tw = tw_of(C, j);
+    const ArCtx<AR> A(C, j);
     const int dbc = galois ? C->gdbc : C->dbc;
     const uint64_t mask = (1ull << dbc) - 1;
     const size_t kn = (size_t)k * n;
-    uint64_t acc0[16], acc1[16];
+    T acc0[16], acc1[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
-    const uint64_t *kp = key;
+    const T *kp = reinterpret_cast<const T *>(key_);
+    uint32_t terms = 0;
     for (uint32_t l = 0; l < k; l++) {
         const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
         const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
         for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
             const int sh = dbc * (int)d;
-            uint64_t v[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                uint64_t t = (src[pass_index<L, SA, 0>(tid, r)] >> sh) & mask;      // L2-resident re-read per digit
-                if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t;
-                v[r] = t;
-            }
             uint32_t tl = tid;
             asm volatile("" : "+v"(tl));           // opaque copy of tid: keeps LDS/twiddle address math and twiddle loads inside the
                                                    // loop (hoisted as loop invariants they cost >150 VGPRs and spill)
-            ntt_forward_regs<L>(v, s, tw, tw + n, q, tl);
-            const uint64_t *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+            T v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint64_t t = (src[pass_index<L, SA, 0>(tl, r)] >> sh) & mask;      // L2-resident re-read per digit
+                if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
+                v[r] = A.load(t);                  // F64: the first recentring of the transform reduces digits >= q_j
+            }
+            if constexpr (std::is_same<T, double>::value) AR::renorm(v, A.m);
+            ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tl);
+            const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                __builtin_amdgcn_sched_barrier(0);           // bound the key loads in flight (register pressure)
-                const uint32_t pos = tail_index<L>(tid, r);
-                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(k0 + pos), b = *reinterpret_cast<const ulonglong2 *>(k1 + pos);
-                const uint64_t x0 = canon4(v[r], q), x1 = canon4(v[r + 1], q);
-                acc0[r] = addmod(acc0[r], mulmod(x0, a.x, qm), q); acc0[r + 1] = addmod(acc0[r + 1], mulmod(x1, a.y, qm), q);
-                acc1[r] = addmod(acc1[r], mulmod(x0, b.x, qm), q); acc1[r + 1] = addmod(acc1[r + 1], mulmod(x1, b.y, qm), q);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t pos = tail_index<L>(tl, r);
+                struct alignas(16) P2 { T a, b; };
+                const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+                KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+                KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
             }
+            if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
             __syncthreads();                      // LDS of this transform is reused by the next one
         }
     }
-    const uint64_t ni = C->ninv[j], nis = C->ninvs[j];
 #pragma unroll 1
     for (int p = 0; p < 2; p++) {
-        uint64_t v[16];
+        T v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
         uint32_t tl = tid;
         asm volatile("" : "+v"(tl));               // see above: no hoisting / sharing of address math across the two transforms
-        ntt_inverse_regs<L>(v, s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, tl);
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
         const uint64_t *ad = p ? add1 : add0;
         uint64_t *o = out + ((size_t)ct * 2 + p) * kn + (size_t)j * n;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t e = pass_index<L, SA, 0>(tl, r);
-            uint64_t val = shoup_lazy(v[r], ni, nis, q);
-            val = val >= q ? val - q : val;
+            uint64_t val = A.scaled(v[r]);
             if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], q);
             o[e] = val;
         }
         __syncthreads();
     }
+}
+// in-place conversion of key words to the FP64 form used by k_keyswitch_rr<L, ArF64> (exact: residues < 2^49)
+__global__ void k_u64_to_f64(uint64_t *p, size_t words) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) { double d = (double)(long long)p[i]; reinterpret_cast<double *>(p)[i] = d; }
 }

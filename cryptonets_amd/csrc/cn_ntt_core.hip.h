@@ -23,20 +23,68 @@ __host__ __device__ inline uint32_t ntt_lds_words(uint32_t n) { return n + 2u * 
 
 NTT_DEV uint64_t ntt_mulshoup(uint64_t y, uint64_t w, uint64_t ws, uint64_t q) { return y * w - __umul64hi(ws, y) * q; }
 
-// forward butterfly (Cooley-Tukey): (X, Y) -> (X + W*Y, X - W*Y), lazily in [0,4q)
-NTT_DEV void bfly_fwd(uint64_t &X, uint64_t &Y, uint64_t W, uint64_t Ws, uint64_t q, uint64_t q2) {
-    uint64_t x = X - ((X >= q2) ? q2 : 0);
-    uint64_t t = ntt_mulshoup(Y, W, Ws, q);
-    X = x + t;
-    Y = x + q2 - t;
-}
-// inverse butterfly (Gentleman-Sande): (U, V) -> (U + V, (U - V) * W), both in [0,2q)
-NTT_DEV void bfly_inv(uint64_t &U, uint64_t &V, uint64_t W, uint64_t Ws, uint64_t q, uint64_t q2) {
-    uint64_t s = U + V;
-    uint64_t d = U + q2 - V;
-    U = s - ((s >= q2) ? q2 : 0);
-    V = ntt_mulshoup(d, W, Ws, q);
-}
+// ---- arithmetic policy 1: unsigned 64-bit, Harvey lazy butterflies with Shoup twiddles (any modulus < 2^61)
+struct ArU64 {
+    typedef uint64_t T;
+    struct Mod { uint64_t q, q2; };
+    struct Tw { const uint64_t *w, *ws; };        // forward or inverse table pair
+    // (X, Y) -> (X + W*Y, X - W*Y), values lazily in [0,4q)
+    static NTT_DEV void fwd(T &X, T &Y, const Tw &t, uint32_t ti, const Mod &m) {
+        const uint64_t W = t.w[ti], Ws = t.ws[ti];
+        uint64_t x = X - ((X >= m.q2) ? m.q2 : 0);
+        uint64_t p = ntt_mulshoup(Y, W, Ws, m.q);
+        X = x + p;
+        Y = x + m.q2 - p;
+    }
+    // (U, V) -> (U + V, (U - V) * W), values in [0,2q)
+    static NTT_DEV void inv(T &U, T &V, const Tw &t, uint32_t ti, const Mod &m) {
+        const uint64_t W = t.w[ti], Ws = t.ws[ti];
+        uint64_t s = U + V, d = U + m.q2 - V;
+        U = s - ((s >= m.q2) ? m.q2 : 0);
+        V = ntt_mulshoup(d, W, Ws, m.q);
+    }
+    static NTT_DEV void renorm(T (&)[16], const Mod &) {}
+};
+
+// ---- arithmetic policy 2: exact FP64 for moduli below 2^49.4.  Coefficients are doubles holding exact (signed, lazy)
+// integers |x| < 2^53.  w*y mod q: p = w*y rounded, e = fma(w,y,-p) its exact error, h = rint(p/q) (|h - wy/q| <= 2),
+// r = fma(-h, q, p) + e is EXACT (|r| <= 2q).  v_fma_f64 is half rate like v_mad_u64_u32 but yields a 53-bit product, so a
+// butterfly is 8 FP64 instructions instead of ~60 integer ones; results are bit-identical after canonicalisation.
+struct ArF64 {
+    typedef double T;
+    struct Mod { double q, qinv; };
+    struct Tw { const double *w; };
+    static NTT_DEV double mulmod(double y, double w, const Mod &m) {
+        const double p = __dmul_rn(y, w);
+        const double e = __fma_rn(y, w, -p);
+        const double h = __builtin_rint(__dmul_rn(p, m.qinv));
+        return __dadd_rn(__fma_rn(-h, m.q, p), e);
+    }
+    static NTT_DEV double center(double x, const Mod &m) {          // |result| <= q/2 (+1 ulp of the quotient)
+        return __fma_rn(-__builtin_rint(__dmul_rn(x, m.qinv)), m.q, x);
+    }
+    static NTT_DEV void fwd(T &X, T &Y, const Tw &t, uint32_t ti, const Mod &m) {
+        const double p = mulmod(Y, t.w[ti], m);
+        Y = __dadd_rn(X, -p);
+        X = __dadd_rn(X, p);
+    }
+    static NTT_DEV void inv(T &U, T &V, const Tw &t, uint32_t ti, const Mod &m) {
+        const double s = __dadd_rn(U, V), d = __dadd_rn(U, -V);
+        U = s;
+        V = mulmod(d, t.w[ti], m);
+    }
+    // growth bound: a pass of <= 4 stages grows |x| from q/2 to <= 8.5q < 2^53 for q < 2^49.4 -> recentre once per pass
+    static NTT_DEV void renorm(T (&x)[16], const Mod &m) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = center(x[r], m);
+    }
+    static NTT_DEV uint64_t to_u64(double x, const Mod &m) {        // canonical residue of any |x| < 2^53
+        double r = center(x, m);
+        r = r < 0.0 ? __dadd_rn(r, m.q) : r;
+        return (uint64_t)(long long)r;
+    }
+    static NTT_DEV double from_u64(uint64_t v) { return (double)(long long)v; }     // v < 2^53
+};
 
 template <int L> struct NttPlan {
     static constexpr int D = (L == 14) ? 2 : 1;      // stages of the last (adjacent-coefficient) pass
@@ -58,8 +106,7 @@ template <int L, int S, int S0> NTT_DEV uint32_t pass_hi(uint32_t tid, int g) {
 }
 
 // S butterfly stages on the 16 registers (16 >> S independent groups of 2^S coefficients)
-template <int L, int S, int S0> NTT_DEV void fwd_stages(uint64_t (&x)[16], const uint64_t *__restrict__ w, const uint64_t *__restrict__ ws, uint64_t q, uint32_t tid) {
-    const uint64_t q2 = 2 * q;
+template <class AR, int L, int S, int S0> NTT_DEV void fwd_stages(typename AR::T (&x)[16], const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
 #pragma unroll
     for (int u = 0; u < S; u++) {
         __builtin_amdgcn_sched_barrier(0);            // one stage's twiddles live at a time (register pressure)
@@ -70,18 +117,16 @@ template <int L, int S, int S0> NTT_DEV void fwd_stages(uint64_t (&x)[16], const
 #pragma unroll
             for (int blk = 0; blk < (1 << u); blk++) {
                 const uint32_t ti = (1u << (S0 + u)) + ((hi << u) | (uint32_t)blk);
-                const uint64_t W = w[ti], Ws = ws[ti];
 #pragma unroll
                 for (int j = 0; j < half; j++) {
                     const int a = (g << S) + blk * 2 * half + j;
-                    bfly_fwd(x[a], x[a + half], W, Ws, q, q2);
+                    AR::fwd(x[a], x[a + half], tw, ti, m);
                 }
             }
         }
     }
 }
-template <int L, int S, int S0> NTT_DEV void inv_stages(uint64_t (&x)[16], const uint64_t *__restrict__ iw, const uint64_t *__restrict__ iws, uint64_t q, uint32_t tid) {
-    const uint64_t q2 = 2 * q;
+template <class AR, int L, int S, int S0> NTT_DEV void inv_stages(typename AR::T (&x)[16], const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
 #pragma unroll
     for (int u = S - 1; u >= 0; u--) {
         __builtin_amdgcn_sched_barrier(0);
@@ -92,21 +137,20 @@ template <int L, int S, int S0> NTT_DEV void inv_stages(uint64_t (&x)[16], const
 #pragma unroll
             for (int blk = 0; blk < (1 << u); blk++) {
                 const uint32_t ti = (1u << (S0 + u)) + ((hi << u) | (uint32_t)blk);
-                const uint64_t W = iw[ti], Ws = iws[ti];
 #pragma unroll
                 for (int j = 0; j < half; j++) {
                     const int a = (g << S) + blk * 2 * half + j;
-                    bfly_inv(x[a], x[a + half], W, Ws, q, q2);
+                    AR::inv(x[a], x[a + half], tw, ti, m);
                 }
             }
         }
     }
 }
-template <int L, int S, int S0> NTT_DEV void lds_put(const uint64_t (&x)[16], uint64_t *s, uint32_t tid) {
+template <class T, int L, int S, int S0> NTT_DEV void lds_put(const T (&x)[16], T *s, uint32_t tid) {
 #pragma unroll
     for (int r = 0; r < 16; r++) s[lds_pos(pass_index<L, S, S0>(tid, r))] = x[r];
 }
-template <int L, int S, int S0> NTT_DEV void lds_get(uint64_t (&x)[16], const uint64_t *s, uint32_t tid) {
+template <class T, int L, int S, int S0> NTT_DEV void lds_get(T (&x)[16], const T *s, uint32_t tid) {
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = s[lds_pos(pass_index<L, S, S0>(tid, r))];
 }
@@ -115,90 +159,96 @@ template <int L> NTT_DEV uint32_t tail_index(uint32_t tid, int r) {
     constexpr int D = NttPlan<L>::D, NT = NttPlan<L>::NT;
     return ((tid + (uint32_t)NT * (uint32_t)(r >> D)) << D) + (uint32_t)(r & ((1 << D) - 1));
 }
-template <int L> NTT_DEV void lds_put_tail(const uint64_t (&x)[16], uint64_t *s, uint32_t tid) {
+template <class T, int L> NTT_DEV void lds_put_tail(const T (&x)[16], T *s, uint32_t tid) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        ulonglong2 v; v.x = x[r]; v.y = x[r + 1];
-        *reinterpret_cast<ulonglong2 *>(s + lds_pos(tail_index<L>(tid, r))) = v;
+        struct alignas(16) P2 { T a, b; } v{x[r], x[r + 1]};
+        *reinterpret_cast<P2 *>(s + lds_pos(tail_index<L>(tid, r))) = v;
     }
 }
-template <int L> NTT_DEV void lds_get_tail(uint64_t (&x)[16], const uint64_t *s, uint32_t tid) {
+template <class T, int L> NTT_DEV void lds_get_tail(T (&x)[16], const T *s, uint32_t tid) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(s + lds_pos(tail_index<L>(tid, r)));
-        x[r] = v.x; x[r + 1] = v.y;
+        struct alignas(16) P2 { T a, b; };
+        const P2 v = *reinterpret_cast<const P2 *>(s + lds_pos(tail_index<L>(tid, r)));
+        x[r] = v.a; x[r + 1] = v.b;
     }
 }
-template <int L> NTT_DEV void fwd_tail(uint64_t (&x)[16], const uint64_t *__restrict__ w, const uint64_t *__restrict__ ws, uint64_t q, uint32_t tid) {
+template <class AR, int L> NTT_DEV void fwd_tail(typename AR::T (&x)[16], const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
     constexpr int D = NttPlan<L>::D, NT = NttPlan<L>::NT;
-    const uint64_t q2 = 2 * q;
     if (D == 2) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const uint32_t c = tid + (uint32_t)NT * g, t0 = (1u << (L - 2)) + c;
-            const uint64_t W = w[t0], Ws = ws[t0];
-            bfly_fwd(x[4 * g], x[4 * g + 2], W, Ws, q, q2);
-            bfly_fwd(x[4 * g + 1], x[4 * g + 3], W, Ws, q, q2);
+            AR::fwd(x[4 * g], x[4 * g + 2], tw, t0, m);
+            AR::fwd(x[4 * g + 1], x[4 * g + 3], tw, t0, m);
         }
     }
 #pragma unroll
     for (int p = 0; p < 8; p++) {
         const uint32_t pair = tail_index<L>(tid, 2 * p) >> 1, ti = (1u << (L - 1)) + pair;
-        bfly_fwd(x[2 * p], x[2 * p + 1], w[ti], ws[ti], q, q2);
+        AR::fwd(x[2 * p], x[2 * p + 1], tw, ti, m);
     }
 }
-template <int L> NTT_DEV void inv_tail(uint64_t (&x)[16], const uint64_t *__restrict__ iw, const uint64_t *__restrict__ iws, uint64_t q, uint32_t tid) {
+template <class AR, int L> NTT_DEV void inv_tail(typename AR::T (&x)[16], const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
     constexpr int D = NttPlan<L>::D, NT = NttPlan<L>::NT;
-    const uint64_t q2 = 2 * q;
 #pragma unroll
     for (int p = 0; p < 8; p++) {
         const uint32_t pair = tail_index<L>(tid, 2 * p) >> 1, ti = (1u << (L - 1)) + pair;
-        bfly_inv(x[2 * p], x[2 * p + 1], iw[ti], iws[ti], q, q2);
+        AR::inv(x[2 * p], x[2 * p + 1], tw, ti, m);
     }
     if (D == 2) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const uint32_t c = tid + (uint32_t)NT * g, t0 = (1u << (L - 2)) + c;
-            const uint64_t W = iw[t0], Ws = iws[t0];
-            bfly_inv(x[4 * g], x[4 * g + 2], W, Ws, q, q2);
-            bfly_inv(x[4 * g + 1], x[4 * g + 3], W, Ws, q, q2);
+            AR::inv(x[4 * g], x[4 * g + 2], tw, t0, m);
+            AR::inv(x[4 * g + 1], x[4 * g + 3], tw, t0, m);
         }
     }
 }
 
-// Forward transform.  In: x[r] = coefficient pass_index<L,SA,0>(tid,r) (canonical or < 4q).  Out: x[r] = value at
-// bit-reversed position tail_index<L>(tid,r), lazily in [0,4q).  `s` = LDS scratch of ntt_lds_words(N) u64.
-template <int L> NTT_DEV void ntt_forward_regs(uint64_t (&x)[16], uint64_t *s, const uint64_t *__restrict__ w, const uint64_t *__restrict__ ws, uint64_t q, uint32_t tid) {
+// Forward transform.  In: x[r] = coefficient pass_index<L,SA,0>(tid,r) (canonical).  Out: x[r] = value at bit-reversed
+// position tail_index<L>(tid,r), lazy (U64: [0,4q); F64: |x| <= 4.5q).  `s` = LDS scratch of ntt_lds_words(N) elements.
+template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
+    typedef typename AR::T T;
     constexpr int SA = NttPlan<L>::SA;
-    fwd_stages<L, SA, 0>(x, w, ws, q, tid);
-    lds_put<L, SA, 0>(x, s, tid);
+    fwd_stages<AR, L, SA, 0>(x, tw, m, tid);
+    lds_put<T, L, SA, 0>(x, s, tid);
     __syncthreads();
-    lds_get<L, 4, SA>(x, s, tid);
-    fwd_stages<L, 4, SA>(x, w, ws, q, tid);
-    lds_put<L, 4, SA>(x, s, tid);
+    lds_get<T, L, 4, SA>(x, s, tid);
+    AR::renorm(x, m);
+    fwd_stages<AR, L, 4, SA>(x, tw, m, tid);
+    lds_put<T, L, 4, SA>(x, s, tid);
     __syncthreads();
-    lds_get<L, 4, SA + 4>(x, s, tid);
-    fwd_stages<L, 4, SA + 4>(x, w, ws, q, tid);
-    lds_put<L, 4, SA + 4>(x, s, tid);
+    lds_get<T, L, 4, SA + 4>(x, s, tid);
+    AR::renorm(x, m);
+    fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
+    lds_put<T, L, 4, SA + 4>(x, s, tid);
     __syncthreads();
-    lds_get_tail<L>(x, s, tid);
-    fwd_tail<L>(x, w, ws, q, tid);
+    lds_get_tail<T, L>(x, s, tid);
+    AR::renorm(x, m);
+    fwd_tail<AR, L>(x, tw, m, tid);
 }
-// Inverse transform (without the 1/N factor).  In: x[r] = value at position tail_index<L>(tid,r), in [0,2q).
-// Out: x[r] = coefficient pass_index<L,SA,0>(tid,r), in [0,2q).
-template <int L> NTT_DEV void ntt_inverse_regs(uint64_t (&x)[16], uint64_t *s, const uint64_t *__restrict__ iw, const uint64_t *__restrict__ iws, uint64_t q, uint32_t tid) {
+// Inverse transform (without the 1/N factor).  In: x[r] = value at position tail_index<L>(tid,r) (U64: [0,2q); F64: any
+// |x| < 2^52).  Out: x[r] = coefficient pass_index<L,SA,0>(tid,r) (U64: [0,2q); F64: |x| <= 8.5q).
+template <class AR, int L> NTT_DEV void ntt_inverse_regs(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
+    typedef typename AR::T T;
     constexpr int SA = NttPlan<L>::SA;
-    inv_tail<L>(x, iw, iws, q, tid);
-    lds_put_tail<L>(x, s, tid);
+    AR::renorm(x, m);
+    inv_tail<AR, L>(x, tw, m, tid);
+    lds_put_tail<T, L>(x, s, tid);
     __syncthreads();
-    lds_get<L, 4, SA + 4>(x, s, tid);
-    inv_stages<L, 4, SA + 4>(x, iw, iws, q, tid);
-    lds_put<L, 4, SA + 4>(x, s, tid);
+    lds_get<T, L, 4, SA + 4>(x, s, tid);
+    AR::renorm(x, m);
+    inv_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
+    lds_put<T, L, 4, SA + 4>(x, s, tid);
     __syncthreads();
-    lds_get<L, 4, SA>(x, s, tid);
-    inv_stages<L, 4, SA>(x, iw, iws, q, tid);
-    lds_put<L, 4, SA>(x, s, tid);
+    lds_get<T, L, 4, SA>(x, s, tid);
+    AR::renorm(x, m);
+    inv_stages<AR, L, 4, SA>(x, tw, m, tid);
+    lds_put<T, L, 4, SA>(x, s, tid);
     __syncthreads();
-    lds_get<L, SA, 0>(x, s, tid);
-    inv_stages<L, SA, 0>(x, iw, iws, q, tid);
+    lds_get<T, L, SA, 0>(x, s, tid);
+    AR::renorm(x, m);
+    inv_stages<AR, L, SA, 0>(x, tw, m, tid);
 }

@@ -101,6 +101,7 @@ int cn_default_coeff_modulus_impl(uint32_t n, uint64_t *q) {
 int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc,
                     uint64_t *tw_host, uint32_t *index_map, char *err, size_t errlen) {
     memset(c, 0, sizeof *c);
+    // (the FP64 twiddle image is derived from tw_host by cn_build_f64_tables once tw_host is complete)
     if (k == 0 || k > CN_MAXK) { snprintf(err, errlen, "coeff modulus count %u out of range", k); return -1; }
     if (n < 4 || (n & (n - 1))) { snprintf(err, errlen, "poly modulus degree must be a power of two"); return -1; }
     if (dbc < 1 || dbc > 60 || gdbc < 1 || gdbc > 60) { snprintf(err, errlen, "decomposition bit count must be in [1,60]"); return -1; }
@@ -187,4 +188,21 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         c->rl_tot += c->rl_dig[j]; c->gk_tot += c->gk_dig[j];
     }
     return 0;
+}
+
+// FP64 image of the twiddle tables for every modulus below 2^49: twd_host[m][0] = w, [1] = w^-1 (doubles, exact).
+void cn_build_f64_tables(DevConsts *c, const uint64_t *tw_host, double *twd_host) {
+    const uint32_t n = c->n, nm = c->k + c->kb + 1;
+    c->q_f64 = 1;
+    for (uint32_t m = 0; m < nm; m++) {
+        const uint64_t q = m < c->k ? c->q[m].q : (m < c->k + c->kb ? c->bsk[m - c->k].q : c->t.q);
+        const bool usable = (q >> 49) == 0 && (m < c->k + c->kb || c->batching);
+        c->f64ok[m] = usable;
+        if (m < c->k && !usable) c->q_f64 = 0;
+        if (!usable) continue;
+        const uint64_t *w = tw_host + (size_t)m * 4 * n, *iw = w + 2 * (size_t)n;
+        double *d = twd_host + (size_t)m * 2 * n;
+        for (uint32_t i = 0; i < n; i++) { d[i] = (double)w[i]; d[n + i] = (double)iw[i]; }
+        c->qd[m] = (double)q; c->qinvd[m] = 1.0 / (double)q; c->ninvd[m] = (double)c->ninv[m];
+    }
 }

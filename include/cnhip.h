@@ -50,6 +50,9 @@ int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc
                   int device, cn_ctx **out);
 int cn_ctx_destroy(cn_ctx *ctx);
 int cn_sync(cn_ctx *ctx);
+/* tuning switches (A/B testing): "f64" = 1 (default) runs transforms of moduli < 2^49 and key switching in exact FP64
+ * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels. */
+int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
 /* number of u64 words of one key-switch key for this context (relin: which=0, galois: which=1) */

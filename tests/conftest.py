@@ -48,14 +48,16 @@ def get_oracle(name, galois=True, seed=11):
 _gpu = {}
 
 
-def get_gpu(name, galois=True):
+def get_gpu(name, galois=True, f64=True):
     """libcnhip context with the oracle's evaluation keys uploaded (keys are public material)."""
     from cryptonets_amd._native import Context
-    key = (name, galois)
+    key = (name, galois, f64)
     if key not in _gpu:
         p = PARAMS[name]
         o = get_oracle(name, galois)
         g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        if not f64:
+            g.set_option("f64", 0)          # integer (Shoup) transforms: the path moduli >= 2^49 take
         g.set_relin_key(o.relin_key())
         if galois:
             for i, e in enumerate(o.galois_elts()):

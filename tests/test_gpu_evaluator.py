@@ -237,3 +237,66 @@ def test_handle_errors_and_leak_counter():
     with pytest.raises(CnError):
         g.free(h)
     assert g.live_handles() == base
+
+
+@pytest.mark.parametrize("name", ["tiny", "c3", "c4"])
+def test_integer_transform_path(name, rng):
+    """The same ops with the exact-FP64 transforms switched off (the integer Harvey/Shoup path that moduli >= 2^49 and
+    the 61-bit BEHZ primes use) - both paths must produce the oracle's words."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True, f64=False)
+    vals, cts = enc_batch(o, rng, 3)
+    h, out = up(g, cts), g.ct_alloc(3)
+    g.ct_ntt(h, 0, 3)
+    exp = np.stack([np.concatenate([o.ntt_fwd(j % o.k, c.reshape(2 * o.k, o.n)[j]) for j in range(2 * o.k)]) for c in cts])
+    assert np.array_equal(g.ct_download(h, 0, 3), exp)
+    g.ct_ntt(h, 0, 3, inverse=True)
+    assert np.array_equal(g.ct_download(h, 0, 3), cts)
+    g.mul_relin(h, 0, h, 1, out, 0, 2)
+    got = g.ct_download(out, 0, 2)
+    for i in range(2):
+        assert np.array_equal(got[i], o.relinearize(o.multiply(cts[i], cts[i + 1])))
+    g.rotate_rows(h, 0, -7, out, 0, 3)
+    got = g.ct_download(out, 0, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], o.rotate_rows(cts[i], -7))
+    plains = rng.integers(0, o.t, size=(1, o.n), dtype=np.uint64)
+    ph = g.pt_alloc(1)
+    g.pt_upload(ph, 0, plains)
+    g.mul_plain(h, 0, ph, 0, out, 0, 3, pt_stride=0)
+    got = g.ct_download(out, 0, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], o.multiply_plain(cts[i], plains[0]))
+    for x in (h, out, ph):
+        g.free(x)
+
+
+def test_fp64_path_extreme_values():
+    """Worst-case magnitudes for the exact-FP64 butterflies: all-(q-1) and alternating 0/(q-1) coefficient vectors at the
+    49-bit primes of the N=16384 set and the 44-bit primes of the N=8192 set."""
+    for name in ("c5", "c3"):
+        o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+        rows = []
+        for pattern in range(3):
+            limbs = []
+            for _ in range(2):
+                for q in o.q:
+                    if pattern == 0:
+                        limbs.append(np.full(o.n, q - 1, dtype=np.uint64))
+                    elif pattern == 1:
+                        a = np.zeros(o.n, dtype=np.uint64); a[::2] = q - 1; limbs.append(a)
+                    else:
+                        a = np.full(o.n, q - 1, dtype=np.uint64); a[: o.n // 2] = 1; limbs.append(a)
+            rows.append(np.concatenate(limbs))
+        cts = np.stack(rows)
+        h = up(g, cts)
+        g.ct_ntt(h, 0, 3)
+        exp = np.stack([np.concatenate([o.ntt_fwd(j % o.k, c.reshape(2 * o.k, o.n)[j]) for j in range(2 * o.k)]) for c in cts])
+        assert np.array_equal(g.ct_download(h, 0, 3), exp)
+        g.ct_ntt(h, 0, 3, inverse=True)
+        assert np.array_equal(g.ct_download(h, 0, 3), cts)
+        out = g.ct_alloc(3)
+        g.rotate_rows(h, 0, 1, out, 0, 3)                 # key switch with extreme digits
+        got = g.ct_download(out, 0, 3)
+        for i in range(3):
+            assert np.array_equal(got[i], o.rotate_rows(cts[i], 1))
+        g.free(h); g.free(out)
