@@ -517,18 +517,46 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
     } else {
         for (uint32_t o = 0; o < O; o++) { memcpy(&hidx[(size_t)o * K], &gidx[(size_t)o * K], K * 4); fill(o, 0, o); }
     }
-    CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hW.size() * 8)));
-    int32_t *didx, *doidx, *dbidx; uint64_t *dW;
-    CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));
-    CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hW.data(), hW.size(), &dW));
-    // lazy-reduction interval: K' products of two values < q_max fit in 128 bits
+    // small signed weights (every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
-    int bits = 64 - __builtin_clzll(qmax);
-    uint32_t lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
+    const int bits = 64 - __builtin_clzll(qmax);
+    bool small = ctx->use_f64 && bits <= 51;
+    for (size_t x = 0; x < (size_t)O * K && small; x++) {
+        uint64_t w = W[x], a = w >= ctx->hc.t_half ? t - w : w;
+        if (a >> 20) small = false;
+    }
     const uint64_t *bias = BP ? BP->d : nullptr;
-    if (M >= 8) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
-    else if (M >= 3) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
-    else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+    if (small) {
+        std::vector<double> hWd((size_t)G * M * K);
+        auto cw = [&](uint64_t w) { return w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; };
+        if (uniform) {
+            uint32_t g = 0;
+            for (auto &kv : groups) { for (uint32_t m = 0; m < M; m++) for (uint32_t kk = 0; kk < K; kk++) hWd[((size_t)g * M + m) * K + kk] = cw(W[(size_t)kv.second[m] * K + kk]); g++; }
+        } else {
+            for (uint32_t o = 0; o < O; o++) for (uint32_t kk = 0; kk < K; kk++) hWd[(size_t)o * K + kk] = cw(W[(size_t)o * K + kk]);
+        }
+        CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hWd.size() * 8)));
+        int32_t *didx, *doidx, *dbidx; double *dWd;
+        CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));
+        CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hWd.data(), hWd.size(), &dWd));
+        const bool two = bits <= 44;                       // 2 limbs of 22 bits, else 3 limbs of 17 bits
+        const uint32_t lazy = two ? 1024u : 32768u;        // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
+#define GEMM_F64(MT_) do { uint32_t mtiles = (M + MT_ - 1) / MT_; size_t blocks = (size_t)ctx->chunks * 2 * k * mtiles * G; \
+        if (two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 2, 22>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy); \
+        else hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 3, 17>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy); } while (0)
+        if (M >= 16) GEMM_F64(20); else if (M >= 8) GEMM_F64(10); else if (M >= 3) GEMM_F64(5); else GEMM_F64(1);
+#undef GEMM_F64
+    } else {
+        CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hW.size() * 8)));
+        int32_t *didx, *doidx, *dbidx; uint64_t *dW;
+        CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));
+        CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hW.data(), hW.size(), &dW));
+        // lazy-reduction interval: K' products of two values < q_max fit in 128 bits
+        uint32_t lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
+        if (M >= 8) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+        else if (M >= 3) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+        else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+    }
     HIPCHK(hipGetLastError()); launch_count(ctx);
     for (size_t x = 0; x < (size_t)O * K; x++) if (W[x] && gidx[x] >= 0) { ctx->st.PlainMultiplication++; ctx->st.Addition++; }
     ctx->st.Addition -= O;

@@ -209,6 +209,78 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
     }
 }
 
+// FP64 variant of the scalar GEMM for SMALL SIGNED weights (|w| < 2^20 after centring mod t - every PoolLayer weight
+// round(w*scale) is): the input residue x < 2^(NL*LW) is split into NL limbs of LW bits, each limb times the weight is an
+// exact double (< 2^(LW+20)), and up to 2^(52-LW-20) such terms accumulate exactly in one v_fma_f64 per limb - two half-rate
+// FMAs per MAC instead of a 64x64->128-bit integer multiply-add (~12 half-rate instructions).  The signed weight is the same
+// for every limb j, so the table is k times smaller as well.  Folded back with one 128-bit Barrett reduction per `lazy` terms.
+template <int MT, int NL, int LW>
+__global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const double *__restrict__ Wd,
+                                                         const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
+                                                         uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy) {
+    const uint32_t n = C->n, k = C->k, limbs = 2 * k;
+    uint32_t bx = blockIdx.x;
+    const uint32_t chunk = bx % chunks; bx /= chunks;
+    const uint32_t limb = bx % limbs; bx /= limbs;
+    const uint32_t mt = bx % mtiles, g = bx / mtiles;
+    const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
+    const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
+    const DMod qm = C->q[j];
+    double acc[NL][MT];
+    uint64_t res[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        res[m] = 0;
+#pragma unroll
+        for (int l = 0; l < NL; l++) acc[l][m] = 0.0;
+    }
+    const int32_t *gi = idx + (size_t)g * K;
+    const double *gw = Wd + ((size_t)g * M + (size_t)mt * MT) * K;
+    const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
+    auto fold = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            __int128 v = 0;
+#pragma unroll
+            for (int l = NL - 1; l >= 0; l--) { v = (v << LW) + (__int128)(long long)acc[l][m]; acc[l][m] = 0.0; }
+            const bool neg = v < 0;
+            u128 a = neg ? (u128)(-v) : (u128)v;
+            uint64_t r = bred128(a, qm);
+            r = neg ? negmod(r, qm.q) : r;
+            res[m] = addmod(res[m], r, qm.q);
+        }
+    };
+    uint32_t since = 0;
+    for (uint32_t kk = 0; kk < K; kk++) {
+        const int32_t id = gi[kk];
+        if (id < 0) continue;
+        const uint64_t x = in[(size_t)id * ctw + e];
+        double xl[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x >> (l * LW)) & ((1ull << LW) - 1));
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            if ((uint32_t)m < mcnt) {
+                const double w = gw[(size_t)m * K + kk];
+#pragma unroll
+                for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
+            }
+        }
+        if (++since == lazy) { since = 0; fold(); }
+    }
+    fold();
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        if ((uint32_t)m < mcnt) {
+            const uint32_t o = g * M + mt * MT + m;
+            uint64_t r = res[m];
+            if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
+            out[(size_t)out_idx[o] * ctw + e] = r;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ HOT LOOP B: BEHZ multiply
 // Step 0/1 (fastbconv_mtilde + mont_rq): q -> Bsk, removing q-overflows via m~ = 2^32.
 // src ciphertext c = srcbase + (first + c*stride)*ctw ; writes the q copy (for the q-side NTT) and Bsk.

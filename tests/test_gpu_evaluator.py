@@ -300,3 +300,27 @@ def test_fp64_path_extreme_values():
         for i in range(3):
             assert np.array_equal(got[i], o.rotate_rows(cts[i], 1))
         g.free(h); g.free(out)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c3", "c5"])
+def test_scalar_gemm_small_signed_weights(name, rng):
+    """PoolLayer-style weights round(w*scale): small signed integers stored as residues (negative = t - |w|).  These take the
+    exact-FP64 limb-split kernel (2x22-bit limbs for <=44-bit q, 3x17-bit for the 49-bit primes); incl. the largest
+    admissible magnitude 2^20-1 and K beyond one exact-accumulation window (1024 terms) to exercise the fold."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    n_in = 6
+    vals, cts = enc_batch(o, rng, n_in)
+    h = up(g, cts)
+    for K, O in ((n_in, 23), (1100 if name == "tiny" else 40, 3)):
+        idx = rng.integers(0, n_in, size=(O, K), dtype=np.int32)
+        idx[0, 0] = -1
+        Ws = rng.integers(-(2 ** 11), 2 ** 11, size=(O, K))
+        Ws[0, 1], Ws[1, 0], Ws[2, 2] = 2 ** 20 - 1, -(2 ** 20 - 1), 0
+        if K > n_in:
+            Ws[:, :] = rng.integers(-(2 ** 20 - 1), 2 ** 20, size=(O, K))          # worst-case magnitudes through the fold
+        W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
+        out = g.ct_alloc(O)
+        g.scalar_gemm(h, W, out, 0, idx=idx)
+        assert np.array_equal(g.ct_download(out, 0, O), o.scalar_gemm(cts, W, idx)), (name, K)
+        g.free(out)
+    g.free(h)
