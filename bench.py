@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
     args = ap.parse_args()
 
     import torch
@@ -99,6 +100,8 @@ def main():
     def step():
         for ch in chans:
             ch.forward()
+            if args.serialize:
+                ch.g.sync()
 
     def sync_all():
         for ch in chans:

@@ -500,23 +500,17 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
     uint32_t G = (uint32_t)groups.size(), M = (uint32_t)groups.begin()->second.size();
     bool uniform = true;
     for (auto &g : groups) if (g.second.size() != M) uniform = false;
-    std::vector<int32_t> hidx, hoidx, hbidx; std::vector<uint64_t> hW;
+    std::vector<int32_t> hidx, hoidx, hbidx;
     if (!uniform) { G = O; M = 1; }
-    hidx.resize((size_t)G * K); hoidx.resize((size_t)G * M); hbidx.assign((size_t)G * M, 0); hW.resize((size_t)k * G * M * K);
-    auto fill = [&](uint32_t g, uint32_t m, uint32_t o) {
-        hoidx[(size_t)g * M + m] = (int32_t)(oi + o);
-        if (BP) hbidx[(size_t)g * M + m] = bias_idx[o];
-        for (uint32_t j = 0; j < k; j++) for (uint32_t kk = 0; kk < K; kk++) {
-            uint64_t w = W[(size_t)o * K + kk];
-            hW[(((size_t)j * G + g) * M + m) * K + kk] = w ? lift_scalar(ctx->hc, w, j) : 0;
-        }
-    };
+    hidx.resize((size_t)G * K); hoidx.resize((size_t)G * M); hbidx.assign((size_t)G * M, 0);
+    std::vector<uint32_t> member((size_t)G * M);                 // output index of (group, m)
     if (uniform) {
         uint32_t g = 0;
-        for (auto &kv : groups) { memcpy(&hidx[(size_t)g * K], kv.first.data(), K * 4); for (uint32_t m = 0; m < M; m++) fill(g, m, kv.second[m]); g++; }
+        for (auto &kv : groups) { memcpy(&hidx[(size_t)g * K], kv.first.data(), K * 4); for (uint32_t m = 0; m < M; m++) member[(size_t)g * M + m] = kv.second[m]; g++; }
     } else {
-        for (uint32_t o = 0; o < O; o++) { memcpy(&hidx[(size_t)o * K], &gidx[(size_t)o * K], K * 4); fill(o, 0, o); }
+        for (uint32_t o = 0; o < O; o++) { memcpy(&hidx[(size_t)o * K], &gidx[(size_t)o * K], K * 4); member[o] = o; }
     }
+    for (size_t x = 0; x < member.size(); x++) { hoidx[x] = (int32_t)(oi + member[x]); if (BP) hbidx[x] = bias_idx[member[x]]; }
     // small signed weights (every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
@@ -527,13 +521,12 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
     }
     const uint64_t *bias = BP ? BP->d : nullptr;
     if (small) {
-        std::vector<double> hWd((size_t)G * M * K);
-        auto cw = [&](uint64_t w) { return w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; };
-        if (uniform) {
-            uint32_t g = 0;
-            for (auto &kv : groups) { for (uint32_t m = 0; m < M; m++) for (uint32_t kk = 0; kk < K; kk++) hWd[((size_t)g * M + m) * K + kk] = cw(W[(size_t)kv.second[m] * K + kk]); g++; }
-        } else {
-            for (uint32_t o = 0; o < O; o++) for (uint32_t kk = 0; kk < K; kk++) hWd[(size_t)o * K + kk] = cw(W[(size_t)o * K + kk]);
+        const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
+        std::vector<double> hWd((size_t)G * mtf * K * MTf, 0.0);          // [g][mtile][kk][m], zero padded
+        for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+            const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
+            double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
+            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
         }
         CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hWd.size() * 8)));
         int32_t *didx, *doidx, *dbidx; double *dWd;
@@ -547,6 +540,13 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
         if (M >= 16) GEMM_F64(20); else if (M >= 8) GEMM_F64(10); else if (M >= 3) GEMM_F64(5); else GEMM_F64(1);
 #undef GEMM_F64
     } else {
+        const uint32_t MTi = M >= 8 ? 10 : (M >= 3 ? 5 : 1), mti = (M + MTi - 1) / MTi;
+        std::vector<uint64_t> hW((size_t)k * G * mti * K * MTi, 0);         // [j][g][mtile][kk][m], zero padded
+        for (uint32_t j = 0; j < k; j++) for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+            const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
+            uint64_t *dst = &hW[((((size_t)j * G + g) * mti + m / MTi) * K) * MTi + m % MTi];
+            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
+        }
         CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hW.size() * 8)));
         int32_t *didx, *doidx, *dbidx; uint64_t *dW;
         CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = 0;
     const int32_t *gi = idx + (size_t)g * K;
-    const uint64_t *gw = Wl + (((size_t)j * G + g) * M + (size_t)mt * MT) * K;
+    const uint64_t *gw = Wl + (((size_t)j * G + g) * mtiles + mt) * (size_t)K * MT;      // [kk][m]: the MT weights of a term are contiguous
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
     uint32_t since = 0;
     for (uint32_t kk = 0; kk < K; kk++) {
@@ -190,8 +190,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
         if (id < 0) continue;
         const uint64_t x = in[(size_t)id * ctw + e];
 #pragma unroll
-        for (int m = 0; m < MT; m++)
-            if ((uint32_t)m < mcnt) acc[m] += (u128)x * gw[(size_t)m * K + kk];
+        for (int m = 0; m < MT; m++) acc[m] += (u128)x * gw[(size_t)kk * MT + m];           // zero-padded beyond mcnt
         if (++since == lazy) {
             since = 0;
 #pragma unroll
@@ -236,7 +235,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         for (int l = 0; l < NL; l++) acc[l][m] = 0.0;
     }
     const int32_t *gi = idx + (size_t)g * K;
-    const double *gw = Wd + ((size_t)g * M + (size_t)mt * MT) * K;
+    const double *gw = Wd + ((size_t)g * mtiles + mt) * (size_t)K * MT;                  // [kk][m], zero-padded
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
     auto fold = [&]() {
 #pragma unroll
@@ -261,11 +260,9 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x >> (l * LW)) & ((1ull << LW) - 1));
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            if ((uint32_t)m < mcnt) {
-                const double w = gw[(size_t)m * K + kk];
+            const double w = gw[(size_t)kk * MT + m];
 #pragma unroll
-                for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
-            }
+            for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
         }
         if (++since == lazy) { since = 0; fold(); }
     }

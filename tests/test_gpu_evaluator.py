@@ -314,10 +314,11 @@ def test_scalar_gemm_small_signed_weights(name, rng):
     for K, O in ((n_in, 23), (1100 if name == "tiny" else 40, 3)):
         idx = rng.integers(0, n_in, size=(O, K), dtype=np.int32)
         idx[0, 0] = -1
-        Ws = rng.integers(-(2 ** 11), 2 ** 11, size=(O, K))
-        Ws[0, 1], Ws[1, 0], Ws[2, 2] = 2 ** 20 - 1, -(2 ** 20 - 1), 0
+        wmax = min(2 ** 20 - 1, (o.t - 1) // 2)                                    # centred residues: |w| < t/2
+        Ws = rng.integers(-min(2 ** 11, wmax), min(2 ** 11, wmax), size=(O, K))
+        Ws[0, 1], Ws[1, 0], Ws[2, 2] = wmax, -wmax, 0
         if K > n_in:
-            Ws[:, :] = rng.integers(-(2 ** 20 - 1), 2 ** 20, size=(O, K))          # worst-case magnitudes through the fold
+            Ws[:, :] = rng.integers(-wmax, wmax + 1, size=(O, K))                   # worst-case magnitudes through the fold
         W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
         out = g.ct_alloc(O)
         g.scalar_gemm(h, W, out, 0, idx=idx)
