@@ -51,6 +51,7 @@ struct cn_ctx {
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
     size_t ctw2;              // words of a size-2 ciphertext
     bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
+    bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
 };
 
 // ---------------------------------------------------------------- helpers
@@ -114,8 +115,14 @@ static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off,
     uint32_t n = c->hc.n;
     bool f64 = c->use_f64;
     for (uint32_t m = base_off; m < base_off + nmod; m++) f64 = f64 && c->hc.f64ok[m];
-    bool done = !c->legacy_ntt && (f64 ? launch_ntt_by_size<ArF64>(c, data, limbs, base_off, nmod, inverse)
-                                       : launch_ntt_by_size<ArU64>(c, data, limbs, base_off, nmod, inverse));
+    bool light = f64;
+    for (uint32_t m = base_off; m < base_off + nmod && light; m++) {
+        uint64_t q = m < c->hc.k ? c->hc.q[m].q : (m < c->hc.k + c->hc.kb ? c->hc.bsk[m - c->hc.k].q : c->hc.t.q);
+        if (q >> 44) light = false;
+    }
+    bool done = !c->legacy_ntt && (light ? launch_ntt_by_size<ArF64L>(c, data, limbs, base_off, nmod, inverse)
+                                   : f64 ? launch_ntt_by_size<ArF64>(c, data, limbs, base_off, nmod, inverse)
+                                         : launch_ntt_by_size<ArU64>(c, data, limbs, base_off, nmod, inverse));
     if (!done) {
         uint32_t nt = std::min<uint32_t>(512, n / 2);
         hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
@@ -171,6 +178,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     const char *env = getenv("CN_SCRATCH_GB");
     c->smax = (size_t)(env ? atof(env) : 24.0) * (1ull << 30);
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
+    c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -178,10 +186,17 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64L, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArU64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     *out = c;
@@ -205,6 +220,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!name) return fail(CN_ERR_ARG, "null option name");
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
+    if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
@@ -623,7 +639,11 @@ static bool launch_ks_by_size(cn_ctx *c, const uint64_t *target, size_t tstride,
         case 10: launch_ks_rr<10, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
         case 11: launch_ks_rr<11, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
         case 12: launch_ks_rr<12, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 13: launch_ks_rr<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 13:
+            if (c->ks_tight) hipLaunchKernelGGL((k_keyswitch_rr<13, AR, 4>), dim3(cnt * c->hc.k), dim3(NttPlan<13>::NT), (size_t)ntt_lds_words(1u << 13) * 8, c->stream, target,
+                                                tstride, add0, add1, astride, (const void *)key, out, c->dc, galois, accmax);
+            else launch_ks_rr<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax);
+            return true;
         case 14: launch_ks_rr<14, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
         default: return false;
     }
@@ -637,7 +657,8 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
         uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
         int bits = 64 - __builtin_clzll(qmax);
         uint32_t accmax = bits >= 50 ? 1u : (1u << std::min(10, 50 - bits));
-        done = launch_ks_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
+        done = bits <= 44 ? launch_ks_by_size<ArF64L>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax)
+                          : launch_ks_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
         if (!done) return fail(CN_ERR_ARG, "internal: FP64 key without FP64 kernel");
     } else if (!ctx->legacy_ntt) {
         done = launch_ks_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu);

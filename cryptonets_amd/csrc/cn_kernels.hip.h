@@ -444,17 +444,20 @@ template <> struct ArCtx<ArU64> {
     ArU64::Mod m; ArU64::Tw fw, iv; uint64_t ni, nis;
     DEV ArCtx(const DevConsts *C, uint32_t mod) {
         const uint64_t q = modulus_of(C, mod); const uint64_t *tw = tw_of(C, mod); const size_t n = C->n;
-        m = {q, 2 * q}; fw = {tw, tw + n}; iv = {tw + 2 * n, tw + 3 * n}; ni = C->ninv[mod]; nis = C->ninvs[mod];
+        typedef const NTT_GLOBAL uint64_t *GP;
+        m = {q, 2 * q}; fw = {(GP)tw, (GP)(tw + n)}; iv = {(GP)(tw + 2 * n), (GP)(tw + 3 * n)}; ni = C->ninv[mod]; nis = C->ninvs[mod];
     }
     DEV uint64_t load(uint64_t v) const { return v; }
     DEV uint64_t canon(uint64_t v) const { return canon4(v, m.q); }                       // forward output in [0,4q)
     DEV uint64_t scaled(uint64_t v) const { uint64_t o = shoup_lazy(v, ni, nis, m.q); return o >= m.q ? o - m.q : o; }   // * N^-1, canonical
 };
-template <> struct ArCtx<ArF64> {
-    ArF64::Mod m; ArF64::Tw fw, iv; double ni;
+template <int RN> struct ArCtx<ArF64T<RN>> {
+    typedef ArF64T<RN> ArF64;
+    typename ArF64::Mod m; typename ArF64::Tw fw, iv; double ni;
     DEV ArCtx(const DevConsts *C, uint32_t mod) {
         const double *tw = C->twd + (size_t)mod * 2 * C->n;
-        m = {C->qd[mod], C->qinvd[mod]}; fw = {tw}; iv = {tw + C->n}; ni = C->ninvd[mod];
+        typedef const NTT_GLOBAL double *GP;
+        m = {C->qd[mod], C->qinvd[mod]}; fw = {(GP)tw}; iv = {(GP)(tw + C->n)}; ni = C->ninvd[mod];
     }
     DEV double load(uint64_t v) const { return ArF64::from_u64(v); }
     DEV uint64_t canon(double v) const { return ArF64::to_u64(v, m); }
@@ -504,12 +507,13 @@ template <> struct KsMac<ArU64> {
     static DEV void mac(uint64_t &acc, uint64_t x, uint64_t key, const DMod &qm, const ArCtx<ArU64> &A) { acc = addmod(acc, mulmod(canon4(x, qm.q), key, qm), qm.q); }
     static DEV void settle(uint64_t (&)[16], const ArCtx<ArU64> &) {}
 };
-template <> struct KsMac<ArF64> {
+template <int RN> struct KsMac<ArF64T<RN>> {
+    typedef ArF64T<RN> ArF64;
     static DEV void mac(double &acc, double x, double key, const DMod &, const ArCtx<ArF64> &A) { acc = __dadd_rn(acc, ArF64::mulmod(x, key, A.m)); }
     static DEV void settle(double (&a)[16], const ArCtx<ArF64> &A) { ArF64::renorm(a, A.m); }
 };
-template <int L, class AR>
-__global__ void __launch_bounds__(NttPlan<L>::NT) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
+template <int L, class AR, int MINW = 1>
+__global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                                  const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
                                                                  uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
     typedef typename AR::T T;

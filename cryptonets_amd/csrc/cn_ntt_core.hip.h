@@ -17,6 +17,10 @@
 #include <stdint.h>
 
 #define NTT_DEV __device__ __forceinline__
+#define NTT_GLOBAL __attribute__((address_space(1)))      // tables are in global memory: global_load, not flat_load
+#ifndef NTT_STAGE_FENCE
+#define NTT_STAGE_FENCE 0
+#endif
 
 NTT_DEV uint32_t lds_pos(uint32_t e) { return e + 2u * (e >> 5); }
 __host__ __device__ inline uint32_t ntt_lds_words(uint32_t n) { return n + 2u * (n >> 5); }
@@ -27,7 +31,7 @@ NTT_DEV uint64_t ntt_mulshoup(uint64_t y, uint64_t w, uint64_t ws, uint64_t q) {
 struct ArU64 {
     typedef uint64_t T;
     struct Mod { uint64_t q, q2; };
-    struct Tw { const uint64_t *w, *ws; };        // forward or inverse table pair
+    struct Tw { const NTT_GLOBAL uint64_t *w; const NTT_GLOBAL uint64_t *ws; };        // forward or inverse table pair
     // (X, Y) -> (X + W*Y, X - W*Y), values lazily in [0,4q)
     static NTT_DEV void fwd(T &X, T &Y, const Tw &t, uint32_t ti, const Mod &m) {
         const uint64_t W = t.w[ti], Ws = t.ws[ti];
@@ -43,6 +47,7 @@ struct ArU64 {
         U = s - ((s >= m.q2) ? m.q2 : 0);
         V = ntt_mulshoup(d, W, Ws, m.q);
     }
+    template <int SITE> static NTT_DEV void renorm_at(T (&)[16], const Mod &) {}
     static NTT_DEV void renorm(T (&)[16], const Mod &) {}
 };
 
@@ -50,10 +55,15 @@ struct ArU64 {
 // integers |x| < 2^53.  w*y mod q: p = w*y rounded, e = fma(w,y,-p) its exact error, h = rint(p/q) (|h - wy/q| <= 2),
 // r = fma(-h, q, p) + e is EXACT (|r| <= 2q).  v_fma_f64 is half rate like v_mad_u64_u32 but yields a 53-bit product, so a
 // butterfly is 8 FP64 instructions instead of ~60 integer ones; results are bit-identical after canonicalisation.
-struct ArF64 {
+// recentring sites of a transform
+enum { RS_FWD_PASS = 0, RS_INV_START = 1, RS_INV_C = 2, RS_INV_B = 3, RS_INV_A = 4 };
+
+// RN = 1: recentre before every pass (valid for q < 2^49.4).  RN = 0: moduli <= 44 bits have 2^9 of head-room - the forward
+// transform never recentres (|x| <= q + 13*2.1q = 28.3q < 2^49), the inverse only where the doubling sum path needs it.
+template <int RN> struct ArF64T {
     typedef double T;
     struct Mod { double q, qinv; };
-    struct Tw { const double *w; };
+    struct Tw { const NTT_GLOBAL double *w; };
     static NTT_DEV double mulmod(double y, double w, const Mod &m) {
         const double p = __dmul_rn(y, w);
         const double e = __fma_rn(y, w, -p);
@@ -78,13 +88,21 @@ struct ArF64 {
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r] = center(x[r], m);
     }
+    template <int SITE> static NTT_DEV void renorm_at(T (&x)[16], const Mod &m) {
+        if (RN == 1 || SITE == RS_INV_START || SITE == RS_INV_B || SITE == RS_INV_A) renorm(x, m);
+    }
     static NTT_DEV uint64_t to_u64(double x, const Mod &m) {        // canonical residue of any |x| < 2^53
         double r = center(x, m);
         r = r < 0.0 ? __dadd_rn(r, m.q) : r;
-        return (uint64_t)(long long)r;
+        // exact integer 0 <= r < 2^52: adding 2^52 leaves r in the mantissa bits
+        return (uint64_t)__double_as_longlong(__dadd_rn(r, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull;
     }
-    static NTT_DEV double from_u64(uint64_t v) { return (double)(long long)v; }     // v < 2^53
+    static NTT_DEV double from_u64(uint64_t v) {                    // v < 2^52: build 2^52 + v bitwise, subtract 2^52
+        return __dadd_rn(__longlong_as_double((long long)(v | 0x4330000000000000ull)), -4503599627370496.0);
+    }
 };
+typedef ArF64T<1> ArF64;
+typedef ArF64T<0> ArF64L;
 
 template <int L> struct NttPlan {
     static constexpr int D = (L == 14) ? 2 : 1;      // stages of the last (adjacent-coefficient) pass
@@ -109,7 +127,7 @@ template <int L, int S, int S0> NTT_DEV uint32_t pass_hi(uint32_t tid, int g) {
 template <class AR, int L, int S, int S0> NTT_DEV void fwd_stages(typename AR::T (&x)[16], const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
 #pragma unroll
     for (int u = 0; u < S; u++) {
-        __builtin_amdgcn_sched_barrier(0);            // one stage's twiddles live at a time (register pressure)
+        if (NTT_STAGE_FENCE) __builtin_amdgcn_sched_barrier(0);            // one stage's twiddles live at a time (register pressure)
         const int half = 1 << (S - 1 - u);
 #pragma unroll
         for (int g = 0; g < (16 >> S); g++) {
@@ -129,7 +147,7 @@ template <class AR, int L, int S, int S0> NTT_DEV void fwd_stages(typename AR::T
 template <class AR, int L, int S, int S0> NTT_DEV void inv_stages(typename AR::T (&x)[16], const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
 #pragma unroll
     for (int u = S - 1; u >= 0; u--) {
-        __builtin_amdgcn_sched_barrier(0);
+        if (NTT_STAGE_FENCE) __builtin_amdgcn_sched_barrier(0);
         const int half = 1 << (S - 1 - u);
 #pragma unroll
         for (int g = 0; g < (16 >> S); g++) {
@@ -216,17 +234,17 @@ template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16]
     lds_put<T, L, SA, 0>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA>(x, s, tid);
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_stages<AR, L, 4, SA>(x, tw, m, tid);
     lds_put<T, L, 4, SA>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA + 4>(x, s, tid);
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     lds_put<T, L, 4, SA + 4>(x, s, tid);
     __syncthreads();
     lds_get_tail<T, L>(x, s, tid);
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_tail<AR, L>(x, tw, m, tid);
 }
 // Inverse transform (without the 1/N factor).  In: x[r] = value at position tail_index<L>(tid,r) (U64: [0,2q); F64: any
@@ -234,21 +252,21 @@ template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16]
 template <class AR, int L> NTT_DEV void ntt_inverse_regs(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
     typedef typename AR::T T;
     constexpr int SA = NttPlan<L>::SA;
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_INV_START>(x, m);
     inv_tail<AR, L>(x, tw, m, tid);
     lds_put_tail<T, L>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA + 4>(x, s, tid);
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_INV_C>(x, m);
     inv_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     lds_put<T, L, 4, SA + 4>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA>(x, s, tid);
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_INV_B>(x, m);
     inv_stages<AR, L, 4, SA>(x, tw, m, tid);
     lds_put<T, L, 4, SA>(x, s, tid);
     __syncthreads();
     lds_get<T, L, SA, 0>(x, s, tid);
-    AR::renorm(x, m);
+    AR::template renorm_at<RS_INV_A>(x, m);
     inv_stages<AR, L, SA, 0>(x, tw, m, tid);
 }
