@@ -70,9 +70,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libcnhip has no CPU path")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # BENCH_FORCE_DIST=1: exercise the RCCL plumbing with a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from cryptonets_amd._native import Context
@@ -128,8 +129,14 @@ def main():
     ms = g.ntt_time(ptr, limbs, 0, False, 20)
     alg_bytes = limbs * g.n * 8 * 2                      # each limb read once + written once (128 KiB per N=8192 limb)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_ntt (forward, %d limbs of N=%d u64)" % (limbs, g.n), "achieved": round(achieved, 1),
-                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+    traffic = None                                        # HBM bytes per launch from the committed PMC passes (same launch geometry)
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt_hbm_traffic.json")))
+        traffic = [v["hbm_traffic_corrected_bytes"] for kname, v in prof.items() if "k_ntt" in kname and "forward" in kname][0]
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "k_ntt_rr (forward, %d limbs of N=%d u64)" % (limbs, g.n), "achieved": round(achieved, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "ms_per_launch": round(ms, 4), "bytes_per_launch": alg_bytes}
 
     if rank == 0:
