@@ -185,6 +185,12 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -593,6 +599,34 @@ template <int K> static void launch_floor(cn_ctx *c, const uint64_t *dq, const u
     case 7: fn<7>(__VA_ARGS__); break; case 8: fn<8>(__VA_ARGS__); break; case 9: fn<9>(__VA_ARGS__); break; \
     default: return fail(CN_ERR_ARG, "ciphertext multiply supports at most 9 coefficient moduli"); }
 
+// tensor product fused into the inverse transform (register-radix sizes only); returns false when the caller must fall back
+template <int L, class AR> static void launch_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
+    hipLaunchKernelGGL((k_intt_tensor<L, AR>), dim3(cnt * 3 * Lm), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, A, B, D, c->dc, base_off, Lm);
+}
+template <class AR> static bool intt_tensor_by_size(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
+    switch (c->hc.logn) {
+        case 10: launch_intt_tensor<10, AR>(c, A, B, D, cnt, base_off, Lm); return true;
+        case 11: launch_intt_tensor<11, AR>(c, A, B, D, cnt, base_off, Lm); return true;
+        case 12: launch_intt_tensor<12, AR>(c, A, B, D, cnt, base_off, Lm); return true;
+        case 13: launch_intt_tensor<13, AR>(c, A, B, D, cnt, base_off, Lm); return true;
+        case 14: launch_intt_tensor<14, AR>(c, A, B, D, cnt, base_off, Lm); return true;
+        default: return false;
+    }
+}
+static bool run_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
+    if (c->legacy_ntt || c->hc.logn < 10 || c->hc.logn > 14) return false;
+    bool f64 = c->use_f64, light = true;
+    for (uint32_t m = base_off; m < base_off + Lm; m++) {
+        f64 = f64 && c->hc.f64ok[m];
+        uint64_t q = m < c->hc.k ? c->hc.q[m].q : c->hc.bsk[m - c->hc.k].q;
+        if (q >> 44) light = false;
+    }
+    bool ok = (f64 && light) ? intt_tensor_by_size<ArF64L>(c, A, B, D, cnt, base_off, Lm)
+              : f64         ? intt_tensor_by_size<ArF64>(c, A, B, D, cnt, base_off, Lm)
+                            : intt_tensor_by_size<ArU64>(c, A, B, D, cnt, base_off, Lm);
+    if (ok) { launch_count(c); c->st.ntt_inverse_limbs += (uint64_t)cnt * 3 * Lm; }
+    return ok;
+}
 static size_t mul_scratch_per_ct(cn_ctx *c, bool square) {
     size_t n = c->hc.n, k = c->hc.k, kb = c->hc.kb;
     size_t w = (square ? 1 : 2) * 2 * (k + kb) * n + 3 * (k + kb) * n;
@@ -612,10 +646,13 @@ static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const u
     HIPCHK(hipGetLastError()); launch_count(ctx, square ? 1 : 2);
     CHECK(run_ntt(ctx, aq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, ab, cnt * 2 * kb, k, kb, 0));
     if (!square) { CHECK(run_ntt(ctx, bq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, bb, cnt * 2 * kb, k, kb, 0)); }
-    hipLaunchKernelGGL(k_tensor, dim3(cnt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, aq, bq, dq, ctx->dc, ctx->chunks, k, 0u);
-    hipLaunchKernelGGL(k_tensor, dim3(cnt * kb * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ab, bb, db, ctx->dc, ctx->chunks, kb, k);
-    HIPCHK(hipGetLastError()); launch_count(ctx, 2);
-    CHECK(run_ntt(ctx, dq, cnt * 3 * k, 0, k, 1)); CHECK(run_ntt(ctx, db, cnt * 3 * kb, k, kb, 1));
+    if (!run_intt_tensor(ctx, aq, bq, dq, cnt, 0, k) || !run_intt_tensor(ctx, ab, bb, db, cnt, k, kb)) {
+        hipLaunchKernelGGL(k_tensor, dim3(cnt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, aq, bq, dq, ctx->dc, ctx->chunks, k, 0u);
+        hipLaunchKernelGGL(k_tensor, dim3(cnt * kb * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ab, bb, db, ctx->dc, ctx->chunks, kb, k);
+        HIPCHK(hipGetLastError()); launch_count(ctx, 2);
+        CHECK(run_ntt(ctx, dq, cnt * 3 * k, 0, k, 1)); CHECK(run_ntt(ctx, db, cnt * 3 * kb, k, kb, 1));
+    }
+    HIPCHK(hipGetLastError());
     DISPATCH_K(launch_floor, ctx, dq, db, out3, cnt);
     HIPCHK(hipGetLastError()); launch_count(ctx);
     ctx->st.Multiplication += cnt;

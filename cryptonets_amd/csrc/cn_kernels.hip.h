@@ -496,6 +496,60 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const
     }
 }
 
+// BEHZ step 2 fused into the inverse transform: block = (ciphertext, output poly p of the tensor product, limb).  The NTT-form
+// operands are read at the positions the inverse transform starts from (16 B/lane), d_p = a0*b0 | a0*b1 + a1*b0 | a1*b1 is formed
+// in registers and transformed back at once - the 3-poly NTT-form tensor never exists in HBM (saves one write + one read of
+// 3(k + k+1) limbs per ciphertext and a kernel).  A, B: [cnt][2][Lm][N]; D: [cnt][3][Lm][N] (coefficient form, canonical).
+template <class AR> struct TensorOps;
+template <> struct TensorOps<ArU64> {
+    DMod dm;
+    DEV TensorOps(const DevConsts *C, uint32_t mod) { dm = mod < C->k ? C->q[mod] : C->bsk[mod - C->k]; }
+    DEV uint64_t mul(uint64_t a, uint64_t b, const ArCtx<ArU64> &) const { return mulmod(a, b, dm); }
+    DEV uint64_t add(uint64_t a, uint64_t b) const { return addmod(a, b, dm.q); }
+};
+template <int RN> struct TensorOps<ArF64T<RN>> {
+    DEV TensorOps(const DevConsts *, uint32_t) {}
+    DEV double mul(double a, double b, const ArCtx<ArF64T<RN>> &A) const { return ArF64T<RN>::mulmod(a, b, A.m); }
+    DEV double add(double a, double b) const { return __dadd_rn(a, b); }
+};
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *__restrict__ A_, const uint64_t *__restrict__ B_, uint64_t *__restrict__ D,
+                                                                const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l = blockIdx.x % Lm, p = (blockIdx.x / Lm) % 3, ct = blockIdx.x / (3 * Lm), mod = base_off + l;
+    const ArCtx<AR> A(C, mod);
+    const TensorOps<AR> ops(C, mod);
+    const size_t Ln = (size_t)Lm * n;
+    const uint64_t *a0 = A_ + (size_t)ct * 2 * Ln + (size_t)l * n, *a1 = a0 + Ln;
+    const uint64_t *b0 = B_ + (size_t)ct * 2 * Ln + (size_t)l * n, *b1 = b0 + Ln;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        if (p == 0) {
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a0 + pos), y = *reinterpret_cast<const ulonglong2 *>(b0 + pos);
+            v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
+        } else if (p == 2) {
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a1 + pos), y = *reinterpret_cast<const ulonglong2 *>(b1 + pos);
+            v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
+        } else {
+            const ulonglong2 x0 = *reinterpret_cast<const ulonglong2 *>(a0 + pos), y1 = *reinterpret_cast<const ulonglong2 *>(b1 + pos);
+            const ulonglong2 x1 = *reinterpret_cast<const ulonglong2 *>(a1 + pos), y0 = *reinterpret_cast<const ulonglong2 *>(b0 + pos);
+            v[r] = ops.add(ops.mul(A.load(x0.x), A.load(y1.x), A), ops.mul(A.load(x1.x), A.load(y0.x), A));
+            v[r + 1] = ops.add(ops.mul(A.load(x0.y), A.load(y1.y), A), ops.mul(A.load(x1.y), A.load(y0.y), A));
+        }
+    }
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    uint64_t *o = D + ((size_t)ct * 3 + p) * Ln + (size_t)l * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(tid, r)] = A.scaled(v[r]);
+}
+
 // Key switching on the register-radix core: block = (ciphertext, output limb j).  For every (source limb l, digit d) the
 // base-2^dbc digit of the 16 coefficients a thread owns goes through the forward transform in registers/LDS and is
 // multiply-accumulated with the key pair (16 B/lane coalesced key loads) into per-thread accumulators; two inverse transforms
