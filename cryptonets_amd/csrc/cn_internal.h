@@ -33,6 +33,14 @@ struct DevConsts {
     uint64_t inv_q_mt, q_bsk[CN_MAXK + 1], inv_mt_bsk[CN_MAXK + 1], inv_q_bsk[CN_MAXK + 1];
     uint64_t inv_bhat_b[CN_MAXK], bhat_q[CN_MAXK][CN_MAXK], bhat_msk[CN_MAXK], inv_B_msk, B_q[CN_MAXK];
     uint64_t t_q[CN_MAXK], t_bsk[CN_MAXK + 1];
+    // the same BEHZ steps with the constant factors folded so that every base conversion is ONE lazy 128-bit accumulation
+    // followed by ONE Barrett reduction (exact modular identities - outputs unchanged):
+    uint64_t ex_Q_bsk[CN_MAXK + 1][CN_MAXK];   // (q/q_j mod b) * m~^-1 mod b
+    uint64_t ex_R_bsk[CN_MAXK + 1];            // (q mod b) * m~^-1 mod b
+    uint64_t fl_c1_q[CN_MAXK];                 // t * (q/q_j)^-1 mod q_j
+    uint64_t fl_T_bsk[CN_MAXK + 1];            // t * q^-1 mod b
+    uint64_t fl_N_bsk[CN_MAXK + 1][CN_MAXK];   // b - ((q/q_j mod b) * q^-1 mod b)
+    uint64_t fl_A_msk[CN_MAXK];                // (B/b_j mod m_sk) * B^-1 mod m_sk
     // key switching
     int32_t dbc, gdbc;
     uint32_t rl_dig[CN_MAXK], gk_dig[CN_MAXK], rl_tot, gk_tot;

@@ -302,13 +302,11 @@ __global__ void __launch_bounds__(256) k_behz_extend(const uint64_t *__restrict_
 #pragma unroll
     for (int b = 0; b <= K; b++) {
         const DMod bm = C->bsk[b];
-        u128 acc = 0;
+        const uint64_t rr = r >= 0x80000000ull ? r + bm.q - 0x100000000ull : r;     // centred r as a residue mod b
+        u128 acc = (u128)rr * C->ex_R_bsk[b];                                      // (x_b + q*r) * m~^-1 with the factors folded:
 #pragma unroll
-        for (int j = 0; j < K; j++) acc += (u128)y[j] * C->qhat_bsk[b][j];
-        uint64_t xb = bred128(acc, bm);
-        uint64_t rr = r >= 0x80000000ull ? r + bm.q - 0x100000000ull : r;           // centred r
-        uint64_t v = bred128((u128)C->q_bsk[b] * rr + xb, bm);
-        ob[(size_t)b * n] = mulmod(v, C->inv_mt_bsk[b], bm);
+        for (int j = 0; j < K; j++) acc += (u128)y[j] * C->ex_Q_bsk[b][j];         // one lazy accumulation, one Barrett reduction
+        ob[(size_t)b * n] = bred128(acc, bm);
     }
 }
 // Step 2: tensor product in NTT form; A,B: [cnt][2][L][N], D: [cnt][3][L][N]; L limbs with moduli base_off..
@@ -333,31 +331,28 @@ __global__ void __launch_bounds__(256) k_behz_floor(const uint64_t *__restrict__
     uint64_t *o = out + (size_t)cp * K * n + i;
     uint64_t y[K], f[K + 1], z[K];
 #pragma unroll
-    for (int j = 0; j < K; j++) y[j] = mulmod(mulmod(xq[(size_t)j * n], C->t_q[j], C->q[j]), C->inv_qhat_q[j], C->q[j]);
+    for (int j = 0; j < K; j++) y[j] = mulmod(xq[(size_t)j * n], C->fl_c1_q[j], C->q[j]);           // x * t * (q/q_j)^-1
 #pragma unroll
     for (int b = 0; b <= K; b++) {
         const DMod bm = C->bsk[b];
-        u128 acc = 0;
+        u128 acc = (u128)xb[(size_t)b * n] * C->fl_T_bsk[b];                                       // (x_b*t - conv_b) * q^-1, folded
 #pragma unroll
-        for (int j = 0; j < K; j++) acc += (u128)y[j] * C->qhat_bsk[b][j];
-        uint64_t conv = bred128(acc, bm);
-        uint64_t xt = mulmod(xb[(size_t)b * n], C->t_bsk[b], bm);
-        f[b] = mulmod(xt + (bm.q - conv), C->inv_q_bsk[b], bm);
+        for (int j = 0; j < K; j++) acc += (u128)y[j] * C->fl_N_bsk[b][j];
+        f[b] = bred128(acc, bm);
     }
     const DMod sk = C->bsk[K];
-    u128 acc = 0;
+    u128 acc = (u128)(sk.q - f[K]) * C->inv_B_msk;
 #pragma unroll
-    for (int j = 0; j < K; j++) { z[j] = mulmod(f[j], C->inv_bhat_b[j], C->bsk[j]); acc += (u128)z[j] * C->bhat_msk[j]; }
-    const uint64_t alpha = mulmod(bred128(acc, sk) + (sk.q - f[K]), C->inv_B_msk, sk);
+    for (int j = 0; j < K; j++) { z[j] = mulmod(f[j], C->inv_bhat_b[j], C->bsk[j]); acc += (u128)z[j] * C->fl_A_msk[j]; }
+    const uint64_t alpha = bred128(acc, sk);
     const bool neg = alpha > (sk.q >> 1);
 #pragma unroll
     for (int j = 0; j < K; j++) {
         const DMod qm = C->q[j];
-        u128 a2 = 0;
+        u128 a2 = neg ? (u128)C->B_q[j] * (sk.q - alpha) : (u128)(qm.q - C->B_q[j]) * alpha;        // -alpha*B (centred alpha)
 #pragma unroll
         for (int l = 0; l < K; l++) a2 += (u128)z[l] * C->bhat_q[j][l];
-        uint64_t conv = bred128(a2, qm);
-        o[(size_t)j * n] = neg ? bred128((u128)C->B_q[j] * (sk.q - alpha) + conv, qm) : bred128((u128)(qm.q - C->B_q[j]) * alpha + conv, qm);
+        o[(size_t)j * n] = bred128(a2, qm);
     }
 }
 

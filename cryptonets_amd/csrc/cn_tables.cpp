@@ -183,6 +183,19 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         c->t_bsk[b] = t % bsk[b];
     }
     c->inv_B_msk = invm_prime(prod_except(bsk.data(), k, -1, bsk[k]), bsk[k]);
+    for (uint32_t i = 0; i < k; i++) {
+        c->fl_c1_q[i] = mulm(c->t_q[i], c->inv_qhat_q[i], q[i]);
+        c->fl_A_msk[i] = mulm(c->bhat_msk[i], c->inv_B_msk, bsk[k]);
+    }
+    for (uint32_t b = 0; b <= k; b++) {
+        c->ex_R_bsk[b] = mulm(c->q_bsk[b], c->inv_mt_bsk[b], bsk[b]);
+        c->fl_T_bsk[b] = mulm(c->t_bsk[b], c->inv_q_bsk[b], bsk[b]);
+        for (uint32_t i = 0; i < k; i++) {
+            c->ex_Q_bsk[b][i] = mulm(c->qhat_bsk[b][i], c->inv_mt_bsk[b], bsk[b]);
+            uint64_t v = mulm(c->qhat_bsk[b][i], c->inv_q_bsk[b], bsk[b]);
+            c->fl_N_bsk[b][i] = v ? bsk[b] - v : 0;
+        }
+    }
     for (uint32_t j = 0; j < k; j++) {
         c->rl_dig[j] = ndigits(q[j], dbc); c->gk_dig[j] = ndigits(q[j], gdbc);
         c->rl_tot += c->rl_dig[j]; c->gk_tot += c->gk_dig[j];
