@@ -49,6 +49,9 @@ class BaseLayer:
     def GetOutputScale(self):
         return self.Source.GetOutputScale()
 
+    def OutputDimension(self):
+        return self.Source.OutputDimension()
+
     def Apply(self, m):
         raise NotImplementedError
 
@@ -218,3 +221,237 @@ class FakeLayer(BaseLayer):
 
     def Apply(self, m):
         raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------------------------ LoLa (low latency) layers
+# Pure callers of the IVector / IMatrix surface (component 15): one image packed into a few ciphertexts,
+# dense layers as plaintext-row x ciphertext dot products with rotate-and-sum.
+
+class LLConvReader(BaseLayer):
+    """NeuralNetworks/LLConvReader.cs:96-158: im2col of ONE image into a [corners x offsets] matrix (padding = 0)."""
+
+    def __init__(self, Features=None, Scale=1.0, NormalizationFactor=1.0, InputShape=None, KernelShape=None, Stride=None, Padding=None,
+                 Upperpadding=None, Lowerpadding=None, Factory=None):
+        super().__init__(None, Factory)
+        self.Features, self.Scale, self.NormalizationFactor = Features, Scale, NormalizationFactor
+        self.engine = ConvolutionEngine(InputShape, KernelShape, Stride, Padding, Upperpadding, Lowerpadding)
+
+    def PrepareNetwork(self):
+        self.Prepare()
+
+    def GetNext(self):
+        f = np.asarray(self.Features, dtype=np.float64) * self.NormalizationFactor
+        g = self.engine.gather_table()
+        mat = np.where(g >= 0, f[np.maximum(g, 0)], 0.0)
+        return RawData(mat, self.Scale)
+
+    def GetOutputScale(self):
+        return self.Scale
+
+    def OutputDimension(self):
+        return len(self.engine.Corners)
+
+
+class LLPoolLayer(BaseLayer):
+    """NeuralNetworks/LLPoolLayer.cs: convolution on the im2col matrix: per map one Mul(weight window) + bias (:112-137)."""
+
+    def __init__(self, Source=None, Factory=None, InputShape=None, KernelShape=None, Stride=None, Padding=None, Upperpadding=None,
+                 Lowerpadding=None, MapCount=None, Weights=None, Bias=None, WeightsScale=1.0, HotIndices=None):
+        super().__init__(Source, Factory)
+        self.engine = ConvolutionEngine(InputShape, KernelShape, Stride, Padding, Upperpadding, Lowerpadding, MapCount)
+        self.Weights, self.Bias, self.WeightsScale, self.HotIndices = Weights, Bias, WeightsScale, HotIndices
+        self.weightWindows = self.biasVectors = None
+
+    def GetOutputScale(self):
+        return (len(self.engine.Offsets) if self.Weights is None else self.WeightsScale) * self.Source.GetOutputScale()
+
+    def OutputDimension(self):
+        return len(self.engine.Corners) * (1 if self.Weights is None else self.engine.maps)
+
+    def Prepare(self):
+        if self.layerPrepared:
+            return
+        self.kernelSize = int(np.prod(self.engine.KernelShape)) + (1 if self.Bias is None else 0)
+        if self.Weights is None:
+            self.layerPrepared = True
+            return
+        F = self.Factory
+        win = self.engine.weight_windows(self.Weights, self.kernelSize)
+        self.weightWindows = [F.GetPlainVector(w, EVectorFormat.sparse, self.WeightsScale) for w in win]
+        hot = np.ones(len(self.engine.Corners)) if self.HotIndices is None else np.asarray(self.HotIndices, dtype=np.float64)
+        bscale = self.Source.GetOutputScale() * self.WeightsScale
+        src = self.Bias if self.Bias is not None else [self.Weights[(m + 1) * self.kernelSize - 1] for m in range(self.engine.maps)]
+        self.biasVectors = [F.GetPlainVector(hot * src[m], EVectorFormat.dense, bscale) for m in range(self.engine.maps)]
+        self.layerPrepared = True
+
+    def Apply(self, m):
+        if not self.layerPrepared:
+            self.Prepare()
+        env = self.Factory.AllocateComputationEnv()
+        if self.Weights is None:
+            vec = m.GetColumn(0)
+            for i in range(1, m.ColumnCount):
+                nxt = vec.Add(m.GetColumn(i), env)
+                if i > 1:
+                    vec.Dispose()
+                vec = nxt
+            vec.RegisterScale(vec.Scale * m.ColumnCount)
+            return self.Factory.GetMatrix([vec], EMatrixFormat.ColumnMajor, CopyVectors=False)
+        res = []
+        for k in range(len(self.biasVectors)):
+            mul = m.Mul(self.weightWindows[k], env)
+            res.append(mul.Add(self.biasVectors[k], env))
+            mul.Dispose()
+        return self.Factory.GetMatrix(res, EMatrixFormat.ColumnMajor, CopyVectors=False)
+
+
+class LLVectorizeLayer(BaseLayer):
+    """NeuralNetworks/LLVectorizeLayer.cs: stack the columns into one packed vector"""
+
+    def Apply(self, m):
+        vec = m.ConvertToColumnVector(self.Factory.AllocateComputationEnv())
+        return self.Factory.GetMatrix([vec], EMatrixFormat.ColumnMajor, CopyVectors=False)
+
+
+class LLDuplicateLayer(BaseLayer):
+    """NeuralNetworks/LLDuplicateLayer.cs:11-29"""
+
+    def __init__(self, Source=None, Factory=None, Count=1):
+        super().__init__(Source, Factory)
+        self.Count = Count
+
+    def Apply(self, m):
+        env = self.Factory.AllocateComputationEnv()
+        return self.Factory.GetMatrix([m.GetColumn(i).Duplicate(self.Count, env) for i in range(m.ColumnCount)], m.Format, CopyVectors=False)
+
+    def OutputDimension(self):
+        shift, dim = 1, self.Source.OutputDimension()
+        while shift < dim:
+            shift *= 2
+        return shift * int(self.Count)
+
+
+class LLPackedDenseLayer(BaseLayer):
+    """NeuralNetworks/LLPackedDenseLayer.cs: PackingCount weight rows share one plaintext (one per PackingShift slots); every packed
+    row is one dense MultiplyPlain + SumAllSlots(PackingShift) + bias (:64-75)."""
+
+    def __init__(self, Source=None, Factory=None, Weights=None, Bias=None, WeightsScale=1.0, PackingCount=1, PackingShift=0):
+        super().__init__(Source, Factory)
+        self.Weights, self.Bias, self.WeightsScale, self.PackingCount, self.PackingShift = Weights, Bias, WeightsScale, int(PackingCount), PackingShift
+        self.WeightsMatrix = self.BiasMatrix = None
+
+    def GetOutputScale(self):
+        return self.WeightsScale * self.Source.GetOutputScale()
+
+    def OutputDimension(self):
+        return len(self.Bias)
+
+    def Prepare(self):
+        if self.layerPrepared:
+            return
+        maps = len(self.Bias)
+        W = np.asarray(self.Weights, dtype=np.float64).reshape(maps, -1)
+        rows = (maps + self.PackingCount - 1) // self.PackingCount
+        stacked = np.zeros((rows, self.PackingCount * self.PackingShift))
+        padded = np.zeros_like(stacked)
+        for i in range(maps):
+            col, row = i % self.PackingCount, i // self.PackingCount
+            stacked[row, col * self.PackingShift: col * self.PackingShift + W.shape[1]] = W[i]
+            padded[row, (col + 1) * self.PackingShift - 1] = self.Bias[i]
+        self.BiasMatrix = self.Factory.GetPlainMatrix(padded, EMatrixFormat.RowMajor, self.Source.GetOutputScale() * self.WeightsScale)
+        self.WeightsMatrix = self.Factory.GetPlainMatrix(stacked, EMatrixFormat.RowMajor, self.WeightsScale)
+        self.layerPrepared = True
+
+    def Apply(self, m):
+        if not self.layerPrepared:
+            self.Prepare()
+        if m.ColumnCount > 1:
+            raise Exception("Expecting only one column")
+        env = self.Factory.AllocateComputationEnv()
+        vector, res = m.GetColumn(0), []
+        for k in range(self.WeightsMatrix.RowCount):
+            mul = self.WeightsMatrix.GetRow(k).DotProduct(vector, env, length=self.PackingShift)
+            res.append(mul.Add(self.BiasMatrix.GetRow(k), env))
+            mul.Dispose()
+        return self.Factory.GetMatrix(res, EMatrixFormat.ColumnMajor, CopyVectors=False)
+
+
+class LLInterleaveLayer(BaseLayer):
+    """NeuralNetworks/LLInterleaveLayer.cs: keep the selected slots of every column (mask multiply) and interleave the columns"""
+
+    def __init__(self, Source=None, Factory=None, Shift=0, SelectedIndices=None, InputGrossDimension=-1):
+        super().__init__(Source, Factory)
+        self.Shift, self.SelectedIndices, self.InputGrossDimension = Shift, list(SelectedIndices), InputGrossDimension
+        self.mask = None
+
+    def Prepare(self):
+        if self.layerPrepared:
+            return
+        if self.InputGrossDimension < 0:
+            self.InputGrossDimension = max(self.SelectedIndices) + 1
+        mv = np.zeros(self.InputGrossDimension)
+        mv[self.SelectedIndices] = 1.0
+        self.mask = self.Factory.GetPlainVector(mv, EVectorFormat.dense, 1)
+        self.layerPrepared = True
+
+    def OutputDimension(self):
+        if not self.layerPrepared:
+            self.Prepare()
+        return self.InputGrossDimension
+
+    def Apply(self, m):
+        if not self.layerPrepared:
+            self.Prepare()
+        env = self.Factory.AllocateComputationEnv()
+        clean = [m.GetColumn(i).PointwiseMultiply(self.mask, env) for i in range(m.ColumnCount)]
+        cleanMat = self.Factory.GetMatrix(clean, EMatrixFormat.ColumnMajor, CopyVectors=False)
+        interleaved = cleanMat.Interleave(self.Shift, env)
+        cleanMat.Dispose()
+        return self.Factory.GetMatrix([interleaved], EMatrixFormat.ColumnMajor, CopyVectors=False)
+
+
+class LLInterleavedDenseLayer(BaseLayer):
+    """NeuralNetworks/LLInterleavedDenseLayer.cs: dense layer whose inputs sit at the interleaved slots (:47-71)"""
+
+    def __init__(self, Source=None, Factory=None, Weights=None, Bias=None, WeightsScale=1, Shift=0, SelectedIndices=None):
+        super().__init__(Source, Factory)
+        self.Weights, self.Bias, self.WeightsScale, self.Shift, self.SelectedIndices = Weights, Bias, WeightsScale, Shift, list(SelectedIndices)
+        self.WeightsMatrix = self.BiasVector = None
+
+    def GetOutputScale(self):
+        return self.Source.GetOutputScale() * self.WeightsScale
+
+    def OutputDimension(self):
+        return len(self.Bias)
+
+    def _target_indices(self, count):
+        out, offset = [], 0
+        while count > 0:
+            for i in range(len(self.SelectedIndices)):
+                if count <= 0:
+                    break
+                out.append(self.SelectedIndices[i] + offset)
+                count -= 1
+            offset += self.Shift
+        return out
+
+    def Prepare(self):
+        if self.layerPrepared:
+            return
+        rows = len(self.Bias)
+        small = np.asarray(self.Weights, dtype=np.float64).reshape(rows, -1)
+        big = np.zeros((rows, self.Source.OutputDimension()))
+        for i, t in enumerate(self._target_indices(small.shape[1])):
+            big[:, t] = small[:, i]
+        self.BiasVector = self.Factory.GetPlainVector(self.Bias, EVectorFormat.sparse, self.GetOutputScale())
+        self.WeightsMatrix = self.Factory.GetPlainMatrix(big, EMatrixFormat.RowMajor, self.WeightsScale)
+        self.layerPrepared = True
+
+    def Apply(self, m):
+        if not self.layerPrepared:
+            self.Prepare()
+        env = self.Factory.AllocateComputationEnv()
+        mul = self.WeightsMatrix.Mul(m.GetColumn(0), env)
+        v = mul.Add(self.BiasVector, env)
+        mul.Dispose()
+        return self.Factory.GetMatrix([v], EMatrixFormat.ColumnMajor, CopyVectors=False)

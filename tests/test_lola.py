@@ -1,0 +1,72 @@
+"""LoLa-MNIST (BASELINE config 4, `LowLatencyCryptoNets/LoLaCryptonets.cs:203-278`): ONE image through
+LLPoolLayer -> Vectorize (Stack/Interleave) -> Square -> Duplicate(8) -> LLPackedDense (13 x [dense MultiplyPlain +
+SumAllSlots(1024)]) -> LLInterleave(-1) -> Square -> LLInterleavedDense, with the reference's trained weights, plaintext primes
+{557057, 638977, 737281, 786433}, N=8192, dbc 10/20.  Every rotation is a Galois key switch (HOT LOOP C).
+
+Bar: the 10 decrypted logits equal exact integer arithmetic on the scaled inputs/weights (integer equality)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_backend import make_factory
+from cryptonets_amd.layers import (EncryptLayer, LLConvReader, LLDuplicateLayer, LLInterleavedDenseLayer, LLInterleaveLayer, LLPackedDenseLayer,
+                                   LLPoolLayer, LLVectorizeLayer, SquareActivation)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cryptonets_weights.npz")
+PRIMES = (557057, 638977, 737281, 786433)
+
+
+def lola(Factory, image):
+    w = np.load(GOLD)
+    w1 = w["Weights_1"]
+    w1t = np.zeros_like(w1)
+    for i in range(845):
+        w1t[i + 845 * np.arange(100)] = w1[100 * i + np.arange(100)]
+    conv = dict(InputShape=[28, 28], KernelShape=[5, 5], Upperpadding=[1, 1], Stride=[2, 2])
+    reader = LLConvReader(Features=image, Scale=16.0, NormalizationFactor=1.0 / 256.0, Factory=Factory, **conv)
+    enc = EncryptLayer(Source=reader)
+    c1 = LLPoolLayer(Source=enc, MapCount=[5, 1], WeightsScale=32, Weights=w["Weights_0"], **conv)
+    v2 = LLVectorizeLayer(Source=c1)
+    a3 = SquareActivation(Source=v2)
+    d4 = LLDuplicateLayer(Source=a3, Count=8)
+    d5 = LLPackedDenseLayer(Source=d4, Weights=w1t, Bias=w["Biases_2"], WeightsScale=32 * 32, PackingCount=8, PackingShift=1024)
+    sel = [1023 + i * 1024 for i in range(8)]
+    i6 = LLInterleaveLayer(Source=d5, Shift=-1, SelectedIndices=sel)
+    a7 = SquareActivation(Source=i6)
+    d8 = LLInterleavedDenseLayer(Source=a7, Weights=w["Weights_3"], Bias=w["Biases_3"], WeightsScale=32, Shift=-1, SelectedIndices=sel)
+    return d8
+
+
+def int_logits(image):
+    """exact integer model (same rounding as the wrapper: round(v*scale))"""
+    from cryptonets_amd import cryptonets_mnist as cm
+    w = np.load(GOLD)
+    L = cm.layer_tables(w["Weights_0"], w["Weights_1"], w["Biases_2"], w["Weights_3"], w["Biases_3"])
+    act = [int(v) for v in np.rint(np.asarray(image) / 256.0 * 16.0)]
+    for li, T in enumerate(L):
+        out = [T["bias"][o] + sum(T["W"][o][k] * act[idx] for k, idx in enumerate(T["idx"][o]) if idx >= 0) for o in range(len(T["W"]))]
+        act = [v * v for v in out] if li < 2 else out
+    return act
+
+
+def image(seed=3):
+    r = np.random.default_rng(seed)
+    return np.where(r.random(784) < 0.81, 0, r.integers(1, 256, size=784)).astype(float)
+
+
+@pytest.mark.parametrize("backend", [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_lola_mnist_single_image(backend):
+    Factory = make_factory(backend, primes=PRIMES, n=8192, galois=True)
+    env = Factory.AllocateComputationEnv()
+    img = image()
+    net = lola(Factory, img)
+    net.PrepareNetwork()
+    out = net.GetNext()
+    got = out.GetColumn(0).DecryptFullPrecision(env)
+    exp = int_logits(img)
+    M = env.bigFactor
+    exp = [((v % M) - M) if (v % M) * 2 > M else (v % M) for v in exp]
+    assert [int(x) for x in got] == exp
+    dec = out.Decrypt(env)
+    assert dec.shape == (10, 1)
