@@ -875,6 +875,8 @@ class EncryptedSealBfvMatrix:
     IsEncrypted = property(lambda self: all(v.IsEncrypted for v in self.leVectors))
 
     def Dispose(self):
+        for buf in self.__dict__.pop("_rowpt", {}).values():
+            buf.release()
         if self.leVectors is not None and not self.DataDisposedExternaly:
             for v in self.leVectors:
                 if v is not None:
@@ -891,6 +893,14 @@ class EncryptedSealBfvMatrix:
             if ForceDenseFormat:
                 raise Exception("Forcing dense format is available only in RowMajor mode")
             return EncryptedSealBfvVector.DenseMatrixBySparseVectorMultiply(self.leVectors, v, env)
+        if self._can_batch_rows(v):
+            if ForceDenseFormat:
+                return self.RowsDotProduct(v, env, ForceOutputInColumns=True)
+            temp = self.RowsDotProduct(v, env)
+            res = EncryptedSealBfvVector.GenerateSpareOfArray(temp, env)
+            for t in temp:
+                t.Dispose()
+            return res
         if not ForceDenseFormat:
             temp = [row.DotProduct(v, env) for row in self.leVectors]
             res = EncryptedSealBfvVector.GenerateSpareOfArray(temp, env)
@@ -1007,6 +1017,92 @@ class EncryptedSealBfvMatrix:
         if self.Format != EMatrixFormat.ColumnMajor:
             raise Exception("Expecting ColumnMajor matrix")
         return EncryptedSealBfvVector.Interleave(self.leVectors, shift, env)
+
+    # ---- batched HOT LOOP C: every row of a RowMajor plaintext matrix against one packed ciphertext ---------------------
+    def _row_plaintexts(self, i, env_i):
+        """contiguous device array with the (single-block, dense) plaintext of every row for prime i - built once"""
+        cache = self.__dict__.setdefault("_rowpt", {})
+        if i not in cache:
+            rows = [r.eVectors[i] for r in self.leVectors]
+            buf = _Buf(env_i.ctx, "pt", len(rows)).view()
+            for k, r in enumerate(rows):
+                env_i.ctx.copy(r.plainDense.h, r.plainDense.first, buf.h, k, 1)
+            cache[i] = buf
+        return cache[i]
+
+    def _can_batch_rows(self, v):
+        return (self.Format == EMatrixFormat.RowMajor and v.IsEncrypted and v.Format == EVectorFormat.dense
+                and all(a.encData.count == 1 for a in v.eVectors)
+                and all((not r.IsEncrypted) and r.Format == EVectorFormat.dense and r.Dim == v.Dim
+                        and all(a.plainDense is not None and a.plainDense.count == 1 and not a.plainZero[0] for a in r.eVectors)
+                        for r in self.leVectors))
+
+    def RowsDotProduct(self, v, env, length=None, ForceOutputInColumns=False, bias=None):
+        """[row_r . v for every row r] with ONE launch chain per plaintext prime: the packed ciphertext is replicated R times,
+        multiplied by the R row plaintexts (cn_mul_plain, count R) and reduced by the rotate-and-add tree of
+        AtomicSealBfvEncryptedVector.SumAllSlots (:888-955) applied to all R ciphertexts at once (cn_rotate_rows / cn_add, count R).
+        Same ciphertext words as R sequential DotProduct calls.  Returns the list of R result vectors (or, with
+        ForceOutputInColumns, their mask-accumulated dense sum as a single vector, EncryptedSealBfvMatrix.cs:91-120);
+        `bias`: optional RowMajor plaintext matrix added row-wise (LLPackedDenseLayer.cs:72)."""
+        INT_MAX = 2 ** 31 - 1
+        R = len(self.leVectors)
+        full = length is None
+        per_prime, out_dim, out_fmt = [], None, None
+        for i, e in enumerate(env.Environments):
+            ctx, slots = e.ctx, e.SlotCount
+            src = v.eVectors[i].encData
+            pts = self._row_plaintexts(i, e)
+            work, tmp = _Buf(ctx, "ct", R), _Buf(ctx, "ct", R)
+            wv, tv = work.view(), tmp.view()
+            for r in range(R):
+                ctx.copy(src.h, src.first, work.h, r, 1)
+            ctx.mul_plain(work.h, 0, pts.h, pts.first, work.h, 0, R)
+            ln = INT_MAX if full else int(length)
+            if ln <= 0:
+                raise Exception("Can't sum over less then one element")
+            if ln > 1:
+                if ln >= slots // 2:
+                    ctx.rotate_columns(work.h, 0, tmp.h, 0, R)
+                    ctx.add(work.h, 0, tmp.h, 0, work.h, 0, R)
+                    ln = slots // 2
+                steps = 1
+                while steps < ln:
+                    ctx.rotate_rows(work.h, 0, -steps, tmp.h, 0, R)
+                    ctx.add(work.h, 0, tmp.h, 0, work.h, 0, R)
+                    steps *= 2
+            dim = 1 if ln >= slots // 2 else v.Dim
+            fmt = EVectorFormat.sparse if ln >= slots else EVectorFormat.dense
+            if ForceOutputInColumns:
+                masks = _Buf(ctx, "pt", R).view()
+                for r in range(R):
+                    mk = np.zeros(r + 1, dtype=np.uint64)
+                    mk[r] = 1
+                    ctx.encode(mk, masks.h, r)
+                ctx.mul_plain(work.h, 0, masks.h, 0, work.h, 0, R)
+                masks.release()
+                tot = _Buf(ctx, "ct", 1)
+                ctx.add_many(work.h, list(range(R)), tot.h, 0)
+                wv.release()
+                work, wv = tot, tot.view()
+            elif bias is not None:
+                bp = bias._row_plaintexts(i, e)
+                ctx.add_plain(work.h, 0, bp.h, bp.first, work.h, 0, R)
+            tv.release()
+            per_prime.append((work, wv))
+            out_dim, out_fmt = dim, fmt
+        signed = v.eVectors[0].IsSigned
+        if ForceOutputInColumns:
+            atoms = [AtomicSealBfvEncryptedVector._new(Scale=1, Dim=R, Format=EVectorFormat.dense, IsSigned=signed, encData=wv)
+                     for (_, wv) in per_prime]
+            return EncryptedSealBfvVector._of(atoms, self.leVectors[0].Scale * v.Scale)
+        res = []
+        for r in range(R):
+            atoms = [AtomicSealBfvEncryptedVector._new(Scale=1, Dim=out_dim, Format=out_fmt, IsSigned=signed, encData=work.view(r, 1))
+                     for (work, _) in per_prime]
+            res.append(EncryptedSealBfvVector._of(atoms, self.leVectors[r].Scale * v.Scale))
+        for (_, wv) in per_prime:
+            wv.release()
+        return res
 
     # ---- batched HOT LOOP A for a whole PoolLayer (PoolLayer.cs:149-229 issues one Mul per output) -----------------
     def MulManySparse(self, gather, weights, bias, out_scale, env):

@@ -369,10 +369,14 @@ class LLPackedDenseLayer(BaseLayer):
             raise Exception("Expecting only one column")
         env = self.Factory.AllocateComputationEnv()
         vector, res = m.GetColumn(0), []
-        for k in range(self.WeightsMatrix.RowCount):
-            mul = self.WeightsMatrix.GetRow(k).DotProduct(vector, env, length=self.PackingShift)
-            res.append(mul.Add(self.BiasMatrix.GetRow(k), env))
-            mul.Dispose()
+        if self.WeightsMatrix._can_batch_rows(vector):
+            # all packed rows at once: one MultiplyPlain / rotate-and-add launch chain per plaintext prime
+            res = self.WeightsMatrix.RowsDotProduct(vector, env, length=self.PackingShift, bias=self.BiasMatrix)
+        else:
+            for k in range(self.WeightsMatrix.RowCount):
+                mul = self.WeightsMatrix.GetRow(k).DotProduct(vector, env, length=self.PackingShift)
+                res.append(mul.Add(self.BiasMatrix.GetRow(k), env))
+                mul.Dispose()
         return self.Factory.GetMatrix(res, EMatrixFormat.ColumnMajor, CopyVectors=False)
 
 
