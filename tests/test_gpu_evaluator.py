@@ -325,3 +325,32 @@ def test_scalar_gemm_small_signed_weights(name, rng):
         assert np.array_equal(g.ct_download(out, 0, O), o.scalar_gemm(cts, W, idx)), (name, K)
         g.free(out)
     g.free(h)
+
+
+def test_concurrent_callers_one_context(rng):
+    """The reference calls the evaluator from Defaults.ThreadCount threads (Utils.cs:46-88): concurrent callers on ONE context
+    (ctypes releases the GIL) must all get the oracle's words."""
+    import threading
+    o, g = get_oracle("tiny", galois=True), get_gpu("tiny", galois=True)
+    vals, cts = enc_batch(o, rng, 8)
+    h = up(g, cts)
+    outs = [g.ct_alloc(2) for _ in range(8)]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                g.mul_relin(h, i, h, (i + 1) % 8, outs[i], 0, 1)
+                g.rotate_rows(h, i, -(i + 1), outs[i], 1, 1)
+        except Exception as e:          # noqa
+            errors.append(e)
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors
+    for i in range(8):
+        got = g.ct_download(outs[i], 0, 2)
+        assert np.array_equal(got[0], o.relinearize(o.multiply(cts[i], cts[(i + 1) % 8])))
+        assert np.array_equal(got[1], o.rotate_rows(cts[i], -(i + 1)))
+    for x in outs + [h]:
+        g.free(x)
