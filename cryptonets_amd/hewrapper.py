@@ -174,39 +174,45 @@ class AtomicSealBfvEncryptedVector:
         return r
 
     def _values(self, v, env):
-        """VectorToPlaintext value mapping (AtomicSealBfvVector.cs:1120-1122): round(v*Scale), negatives -> t + x"""
+        """VectorToPlaintext value mapping (AtomicSealBfvVector.cs:1120-1122): round(v*Scale), negatives -> t + x.
+        Returns a uint64 numpy array (vectorised: weight matrices have 10^8 entries)."""
         t = env.plainmodulusValue
         a = np.asarray(v)
         if a.dtype == np.uint64:
-            return [int(x) for x in a]
+            return np.ascontiguousarray(a)
         if self.Scale == 0:
             self.Scale = 1
-        out = []
-        for x in np.rint(np.asarray(v, dtype=np.float64) * self.Scale):
-            x = int(x)
-            out.append(x if (not self.IsSigned or x >= 0) else t + x)
-        return out
+        r = np.rint(np.asarray(v, dtype=np.float64) * self.Scale)
+        if r.size and float(np.max(np.abs(r))) >= 2.0 ** 62:
+            raise Exception("value does not fit the plaintext modulus")
+        w = r.astype(np.int64)
+        if self.IsSigned:
+            if w.size and (int(w.min()) <= -t or int(w.max()) >= t):
+                raise Exception("value does not fit the plaintext modulus")
+            w = np.where(w < 0, w + t, w)
+        elif w.size and int(w.min()) < 0:
+            raise Exception("value does not fit the plaintext modulus")
+        return w.astype(np.uint64)
 
     def _to_plaintexts(self, v, env):
         values = self._values(v, env)
         t = env.plainmodulusValue
-        for x in values:
-            if not 0 <= x < t:
-                raise Exception("value does not fit the plaintext modulus")
+        if values.size and int(values.max()) >= t:
+            raise Exception("value does not fit the plaintext modulus")
         self.Dim = len(values)
         if self.Format == EVectorFormat.dense:
             slots = env.SlotCount
-            blocks = max(1, -(-len(values) // slots)) if values else 0
+            blocks = -(-len(values) // slots)
             if blocks == 0:
                 raise Exception("empty vector")
             pv = _Buf(env.ctx, "pt", blocks).view()
             zero = []
             for b in range(blocks):
                 chunk = values[b * slots:(b + 1) * slots]
-                env.ctx.encode(np.array(chunk, dtype=np.uint64), pv.h, b)
-                zero.append(all(c == 0 for c in chunk))
+                env.ctx.encode(chunk, pv.h, b)
+                zero.append(not chunk.any())
             return pv, zero, None
-        return None, None, values
+        return None, None, [int(x) for x in values]
 
     def _Plain(self, v, Format, env):
         self.Format = Format
@@ -740,13 +746,20 @@ class EncryptedSealBfvVector:
         self.Scale = Scale
         self.IsSigned = True
         if v is not None or integers is not None:
+            primes = [e.plainmodulusValue for e in env.Environments]
+            res = None
             if integers is None:
-                w = [int(x) for x in np.rint(np.asarray(v, dtype=np.float64) * Scale)]       # SplitBigNumbers (:352-365)
-            else:
-                w = [int(x) for x in integers]
-            z = [x + env.bigFactor if x < 0 else x for x in w]
-            self.eVectors = [AtomicSealBfvEncryptedVector(np.array([x % e.plainmodulusValue for x in z], dtype=np.uint64), e, Scale=1,
-                                                          SignedNumbers=False, EncryptData=EncryptData, Format=Format) for e in env.Environments]
+                r = np.rint(np.asarray(v, dtype=np.float64) * Scale)              # SplitBigNumbers (:352-365)
+                if r.size == 0 or float(np.max(np.abs(r))) < 2.0 ** 62:
+                    w = r.astype(np.int64)                                        # vectorised: (X mod M) mod p = X mod p
+                    res = [np.mod(w, p).astype(np.uint64) for p in primes]
+                else:
+                    integers = [int(x) for x in r]
+            if res is None:
+                z = [int(x) + env.bigFactor if int(x) < 0 else int(x) for x in integers]
+                res = [np.array([x % p for x in z], dtype=np.uint64) for p in primes]
+            self.eVectors = [AtomicSealBfvEncryptedVector(res[i], e, Scale=1, SignedNumbers=False, EncryptData=EncryptData, Format=Format)
+                             for i, e in enumerate(env.Environments)]
 
     @classmethod
     def _of(cls, vecs, Scale=1.0):
@@ -875,8 +888,9 @@ class EncryptedSealBfvMatrix:
     IsEncrypted = property(lambda self: all(v.IsEncrypted for v in self.leVectors))
 
     def Dispose(self):
-        for buf in self.__dict__.pop("_rowpt", {}).values():
-            buf.release()
+        for cache in ("_rowpt", "_rowmask"):
+            for buf in self.__dict__.pop(cache, {}).values():
+                buf.release()
         if self.leVectors is not None and not self.DataDisposedExternaly:
             for v in self.leVectors:
                 if v is not None:
@@ -1073,13 +1087,16 @@ class EncryptedSealBfvMatrix:
             dim = 1 if ln >= slots // 2 else v.Dim
             fmt = EVectorFormat.sparse if ln >= slots else EVectorFormat.dense
             if ForceOutputInColumns:
-                masks = _Buf(ctx, "pt", R).view()
-                for r in range(R):
-                    mk = np.zeros(r + 1, dtype=np.uint64)
-                    mk[r] = 1
-                    ctx.encode(mk, masks.h, r)
+                mcache = self.__dict__.setdefault("_rowmask", {})
+                if i not in mcache:                                  # one-hot masks e_r (SumAllSlots ForceOutputInColumn, :936-945)
+                    masks = _Buf(ctx, "pt", R).view()
+                    for r in range(R):
+                        mk = np.zeros(r + 1, dtype=np.uint64)
+                        mk[r] = 1
+                        ctx.encode(mk, masks.h, r)
+                    mcache[i] = masks
+                masks = mcache[i]
                 ctx.mul_plain(work.h, 0, masks.h, 0, work.h, 0, R)
-                masks.release()
                 tot = _Buf(ctx, "ct", 1)
                 ctx.add_many(work.h, list(range(R)), tot.h, 0)
                 wv.release()

@@ -1,0 +1,95 @@
+"""LoLa-CIFAR shapes (BASELINE config 5, `CifarCryptoNet/LolaCifarCryptoNet.cs:21-168`): N=16384, 8 RNS limbs, dbc 60/60, plaintext
+primes {957181001729, 957181034497}; 3x32x32 image -> LLPoolLayer (83 maps of 3x8x8, stride 2) -> Vectorize (83x196 = 16268 slots,
+both batching rows) -> Square -> LLDenseLayer(ForceDenseFormat) with the 5488 x 16268 unrolled convolution matrix (per row: dense
+MultiplyPlain + RotateColumns + 13 RotateRows + mask) -> Square -> LLDenseLayer 10 x 5488.  The trained CifarWeight.csv is a
+missing blob of the reference (.MISSING_LARGE_BLOBS:2): synthetic weights of the same shapes.
+
+GPU only (77 k key switches per plaintext prime); the decrypted residues of the 10 logits must equal the Z_p integer model."""
+import numpy as np
+import pytest
+
+from cryptonets_amd.convolution import ConvolutionEngine
+from cryptonets_amd.hewrapper import EVectorFormat
+from cryptonets_amd.layers import EncryptLayer, LLConvReader, LLDenseLayer, LLPoolLayer, LLVectorizeLayer, SquareActivation
+
+PRIMES = (957181001729, 957181034497)
+
+
+def mulmod(a, b, p):
+    b = np.asarray(b, dtype=np.uint64)
+    hi = (a * (b >> np.uint64(20))) % p
+    return (hi * np.uint64(1 << 20) + a * (b & np.uint64(0xFFFFF))) % p
+
+
+def dense_weights(eng, w):
+    """ConvolutionEngine.GetDenseWeights vectorised (ConvolutionEngine.cs:117-144)"""
+    g = eng.gather_table()                                         # [corners, offsets] -> input index or -1
+    ksz = int(np.prod(eng.KernelShape))
+    kidx = np.array([eng.Location(None, o, eng.KernelShape) for o in eng.Offsets])
+    rows, cols = eng.maps * len(eng.Corners), int(np.prod(eng.InputShape))
+    mat = np.zeros((rows, cols))
+    for i in range(len(eng.Corners)):
+        ok = g[i] >= 0
+        for m in range(eng.maps):
+            mat[m * len(eng.Corners) + i, g[i][ok]] = w[kidx[ok] + m * ksz]
+    return mat
+
+
+@pytest.mark.gpu
+def test_lola_cifar_shapes_end_to_end():
+    from oracle_backend import make_factory
+    rng = np.random.default_rng(5)
+    Factory = make_factory("gpu", primes=PRIMES, n=16384, dbc=60, gdbc=60, small_modulus_count=8, galois=True)
+    env = Factory.AllocateComputationEnv()
+    img = rng.integers(0, 256, size=3 * 32 * 32).astype(float)
+    w0 = np.rint(rng.normal(0, 0.05, 83 * 192) * 256) / 256
+    b0 = np.rint(rng.normal(0, 0.05, 83) * 256) / 256
+    w1 = np.rint(rng.normal(0, 0.02, 112 * 8300) * 512) / 512
+    b1 = np.rint(rng.normal(0, 0.05, 112) * 512) / 512
+    w2 = np.rint(rng.normal(0, 0.05, 10 * 5488) * 512) / 512
+    b2 = np.rint(rng.normal(0, 0.05, 10) * 512) / 512
+    conv = dict(InputShape=[3, 32, 32], KernelShape=[3, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
+    reader = LLConvReader(Features=img, Scale=8.0, NormalizationFactor=1.0 / 256.0, Factory=Factory, **conv)
+    enc = EncryptLayer(Source=reader)
+    c1 = LLPoolLayer(Source=enc, MapCount=[83, 1, 1], WeightsScale=256.0, Weights=w0, Bias=b0, **conv)
+    v2 = LLVectorizeLayer(Source=c1)
+    a3 = SquareActivation(Source=v2)
+    eng = ConvolutionEngine([83, 14, 14], [83, 10, 10], [83, 2, 2], Upperpadding=[0, 4, 4], Lowerpadding=[0, 4, 4], MapCount=[112, 1, 1])
+    W1 = dense_weights(eng, w1)
+    assert W1.shape == (5488, 16268)
+    d4 = LLDenseLayer(Source=a3, WeightsScale=512.0, Weights=W1.reshape(-1), Bias=eng.GetDenseBias(b1), InputFormat=EVectorFormat.dense, ForceDenseFormat=True)
+    a5 = SquareActivation(Source=d4)
+    d6 = LLDenseLayer(Source=a5, Weights=w2, Bias=b2, WeightsScale=512.0, InputFormat=EVectorFormat.dense)
+    d6.PrepareNetwork()
+    out = d6.GetNext()
+    # integer model modulo each plaintext prime
+    x = np.rint(img / 256.0 * 8.0).astype(np.int64)
+    g = reader.engine.gather_table()                                # [196, 192]
+    patches = np.where(g >= 0, x[np.maximum(g, 0)], 0)              # [196, 192]
+    W0i = np.rint(w0.reshape(83, 192) * 256).astype(np.int64)
+    B0i = np.rint(b0 * 8 * 256).astype(np.int64)
+    act1 = (patches @ W0i.T + B0i).T.reshape(-1)                    # map-major stacking: 83 x 196
+    s1 = (8 * 256) ** 2
+    W1i = np.rint(W1 * 512).astype(np.int64)
+    B1i = [int(round(float(b) * s1 * 512)) for b in eng.GetDenseBias(b1)]
+    W2i = np.rint(w2.reshape(10, 5488) * 512).astype(np.int64)
+    s2 = (s1 * 512) ** 2
+    B2i = [int(round(float(b) * s2 * 512)) for b in b2]
+    for i, e in enumerate(env.Environments):
+        p = np.uint64(e.plainmodulusValue)
+        a1 = np.mod(act1, int(p)).astype(np.uint64)
+        a1 = mulmod(a1, a1, p)
+        acc = np.zeros(5488, dtype=np.uint64)
+        W1p = np.mod(W1i, int(p)).astype(np.uint64)
+        for c0 in range(0, 16268, 512):
+            acc = (acc + (mulmod(W1p[:, c0:c0 + 512], a1[None, c0:c0 + 512], p) % p).sum(axis=1) % p) % p
+        a2 = (acc + np.array([b % int(p) for b in B1i], dtype=np.uint64)) % p
+        a2 = mulmod(a2, a2, p)
+        W2p = np.mod(W2i, int(p)).astype(np.uint64)
+        lg = np.zeros(10, dtype=np.uint64)
+        for c0 in range(0, 5488, 512):
+            lg = (lg + (mulmod(W2p[:, c0:c0 + 512], a2[None, c0:c0 + 512], p) % p).sum(axis=1) % p) % p
+        lg = (lg + np.array([b % int(p) for b in B2i], dtype=np.uint64)) % p
+        got = out.GetColumn(0).eVectors[i]._decrypt_ints(e)
+        assert [int(v) for v in got] == [int(v) for v in lg], "prime %d" % int(p)
+    out.Dispose()
