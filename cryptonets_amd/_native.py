@@ -93,6 +93,12 @@ SIGNATURES = {
     "cn_apply_galois": (C.c_int, [_CTX, _H, _u32, C.c_uint64, _H, _u32, _u32]),
     "cn_rotate_rows": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _u32]),
     "cn_rotate_columns": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_keygen": (C.c_int, [_CTX, C.c_uint64, C.c_int]),
+    "cn_set_public_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
+    "cn_set_secret_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
+    "cn_get_key": (C.c_int, [_CTX, C.c_int, C.c_uint64, U64P, C.c_size_t]),
+    "cn_encrypt": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32, _u32, C.c_uint64]),
+    "cn_decrypt": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32]),
     "cn_ntt_forward": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
     "cn_ntt_inverse": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
     "cn_ct_ntt": (C.c_int, [_CTX, _H, _u32, _u32, C.c_int]),
@@ -306,6 +312,30 @@ class Context:
 
     def rotate_columns(self, src, ii, out, oi, count=1):
         self._chk(self.L.cn_rotate_columns(self._h, src, ii, out, oi, count))
+
+    # ---- client side on the device
+    def keygen(self, seed, galois=True):
+        self._chk(self.L.cn_keygen(self._h, seed, int(galois)))
+
+    def set_public_key(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._chk(self.L.cn_set_public_key(self._h, _p64(w), w.size))
+
+    def set_secret_key(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._chk(self.L.cn_set_secret_key(self._h, _p64(w), w.size))
+
+    def get_key(self, which, elt=0):
+        words = {0: self.key_words(False), 1: self.key_words(True), 2: self.ctw, 3: self.ctw // 2}[which]
+        out = np.empty(words, dtype=np.uint64)
+        self._chk(self.L.cn_get_key(self._h, which, elt, _p64(out), words))
+        return out
+
+    def encrypt(self, pt, pi, out, oi, count=1, seed=1, pt_stride=1):
+        self._chk(self.L.cn_encrypt(self._h, pt, pi, pt_stride, out, oi, count, seed))
+
+    def decrypt(self, ct, ci, count, pt_out, pi):
+        self._chk(self.L.cn_decrypt(self._h, ct, ci, count, pt_out, pi))
 
     # ---- raw transforms / timing / stats
     def ct_ntt(self, h, first, count, inverse=False):

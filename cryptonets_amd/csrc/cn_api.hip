@@ -44,6 +44,8 @@ struct cn_ctx {
     double *twd = nullptr;
     bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
     std::map<uint64_t, KsKey> gk;
+    uint64_t *sk = nullptr, *pk = nullptr;   // client-side keys (NTT form) when the data owner's GPU runs keygen/encrypt/decrypt
+    uint64_t rng_item = 0;                    // running polynomial counter of the Philox streams
     char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
     cn_stats st{};
     hipEvent_t ev0, ev1;
@@ -185,6 +187,10 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -215,6 +221,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     for (auto &kv : ctx->bufs) (void)hipFree(kv.second.d);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
+    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -818,6 +825,182 @@ extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps,
 }
 extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
     return cn_apply_galois(ctx, in, ii, 2ull * ctx->hc.n - 1, out, oi, count);
+}
+
+// ---------------------------------------------------------------- client side on the device
+static int set_plain_key(cn_ctx *ctx, uint64_t **slot, const uint64_t *words, size_t count, size_t expect) {
+    if (!words || count != expect) return fail(CN_ERR_ARG, "key has %zu words, expected %zu", count, expect);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!*slot) HIPCHK(hipMalloc((void **)slot, expect * 8));
+    HIPCHK(hipMemcpy(*slot, words, expect * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2); }
+extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); }
+// which: 0 relin, 1 galois(elt), 2 public, 3 secret.  Exports u64 residues (FP64-form keys are converted back).
+extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, size_t count) {
+    LOCK;
+    const uint64_t *src = nullptr; size_t words = 0; bool f64 = false;
+    if (which == 0) { src = ctx->rlk.d; words = cn_key_words(ctx, 0); f64 = ctx->rlk.f64; }
+    else if (which == 1) { auto it = ctx->gk.find(elt); if (it != ctx->gk.end()) { src = it->second.d; f64 = it->second.f64; } words = cn_key_words(ctx, 1); }
+    else if (which == 2) { src = ctx->pk; words = ctx->ctw2; }
+    else if (which == 3) { src = ctx->sk; words = ctx->ctw2 / 2; }
+    if (!src) return fail(CN_ERR_NOKEY, "key not present");
+    if (!host || count != words) return fail(CN_ERR_ARG, "key has %zu words", words);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(host, src, words * 8, hipMemcpyDeviceToHost));
+    if (f64) for (size_t i = 0; i < words; i++) { double d; memcpy(&d, &host[i], 8); host[i] = (uint64_t)d; }
+    return 0;
+}
+static int sample_poly(cn_ctx *ctx, uint64_t *dst, uint32_t polys, int kind, uint64_t seed, uint64_t stream) {
+    hipLaunchKernelGGL(k_sample, dim3(polys * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, dst, ctx->dc, ctx->chunks, kind, seed, stream, ctx->rng_item);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    ctx->rng_item += polys;
+    return 0;
+}
+// one key-switch key for the NTT-form target polynomial snew: [(l,d)][2][k][N]
+static int gen_ksk(cn_ctx *ctx, const uint64_t *snew, int dbc, const uint32_t *dig, uint32_t tot, uint64_t seed, uint64_t *key, uint64_t *e) {
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
+    uint64_t *p = key;
+    for (uint32_t l = 0; l < k; l++) {
+        const uint64_t ql = ctx->hc.q[l].q; unsigned __int128 f = 1;
+        for (uint32_t d = 0; d < dig[l]; d++, p += 2 * kn) {
+            CHECK(sample_poly(ctx, p + kn, 1, 2, seed, 3));                 // a: uniform, directly in the NTT domain
+            CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
+            CHECK(run_ntt(ctx, e, k, 0, k, 0));
+            hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, p + kn, e, ctx->sk, snew, (uint64_t)f, (int)l, p, ctx->dc, ctx->chunks);
+            HIPCHK(hipGetLastError()); launch_count(ctx);
+            f = (f << dbc) % ql;
+        }
+    }
+    (void)tot;
+    return 0;
+}
+static int adopt_ksk(cn_ctx *ctx, KsKey &slot, uint64_t *dev, size_t words) {          // takes ownership of a device buffer
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (slot.owned && slot.d) HIPCHK(hipFree(slot.d));
+    slot = {dev, true, false};
+    if (ctx->use_f64 && ctx->hc.q_f64 && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) {
+        hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, dev, words);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        slot.f64 = true;
+    }
+    return 0;
+}
+// KeyGenerator (AtomicSealBfvVector.cs:62-74,163-173 runs it inside SEAL): secret, public, relinearisation and the default Galois
+// key set (2N-1, 3^(2^i), 3^(-2^i)) generated on the device from a Philox stream.
+extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
+    LOCK;
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
+    if (!ctx->sk) HIPCHK(hipMalloc((void **)&ctx->sk, kn * 8));
+    if (!ctx->pk) HIPCHK(hipMalloc((void **)&ctx->pk, 2 * kn * 8));
+    CHECK(ensure_scratch(ctx, al(kn * 8) * 4));
+    uint64_t *e = salloc<uint64_t>(ctx, kn), *snew = salloc<uint64_t>(ctx, kn), *tmp = salloc<uint64_t>(ctx, kn);
+    ctx->rng_item = 0;
+    CHECK(sample_poly(ctx, ctx->sk, 1, 0, seed, 0));
+    CHECK(run_ntt(ctx, ctx->sk, k, 0, k, 0));
+    // public key (-(a s + e), a)
+    CHECK(sample_poly(ctx, ctx->pk + kn, 1, 2, seed, 3));
+    CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
+    CHECK(run_ntt(ctx, e, k, 0, k, 0));
+    hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->pk + kn, e, ctx->sk, ctx->sk, 0ull, -1, ctx->pk, ctx->dc, ctx->chunks);
+    HIPCHK(hipGetLastError());
+    // relinearisation key: target s^2
+    hipLaunchKernelGGL(k_mul_limbs, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->sk, ctx->sk, snew, ctx->dc, ctx->chunks);
+    HIPCHK(hipGetLastError());
+    uint64_t *rl; size_t rlw = cn_key_words(ctx, 0);
+    HIPCHK(hipMalloc((void **)&rl, rlw * 8));
+    CHECK(gen_ksk(ctx, snew, ctx->hc.dbc, ctx->hc.rl_dig, ctx->hc.rl_tot, seed, rl, e));
+    CHECK(adopt_ksk(ctx, ctx->rlk, rl, rlw));
+    if (with_galois) {
+        const uint64_t m = 2ull * n; std::vector<uint64_t> elts{m - 1};
+        uint64_t p3 = 3, ip3 = 0;
+        for (uint64_t x = 1; x < m; x += 2) if (((x * 3) & (m - 1)) == 1) { ip3 = x; break; }
+        for (uint32_t i = 0; i + 1 < ctx->hc.logn; i++) { elts.push_back(p3); p3 = (p3 * p3) & (m - 1); elts.push_back(ip3); ip3 = (ip3 * ip3) & (m - 1); }
+        size_t gw = cn_key_words(ctx, 1);
+        for (uint64_t elt : elts) {
+            HIPCHK(hipMemcpyAsync(tmp, ctx->sk, kn * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CHECK(run_ntt(ctx, tmp, k, 0, k, 1));
+            hipLaunchKernelGGL(k_galois, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, tmp, snew, ctx->dc, ctx->chunks, elt);
+            HIPCHK(hipGetLastError());
+            CHECK(run_ntt(ctx, snew, k, 0, k, 0));
+            uint64_t *gk; HIPCHK(hipMalloc((void **)&gk, gw * 8));
+            CHECK(gen_ksk(ctx, snew, ctx->hc.gdbc, ctx->hc.gk_dig, ctx->hc.gk_tot, seed, gk, e));
+            CHECK(adopt_ksk(ctx, ctx->gk[elt], gk, gw));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+template <int L, class AR> static void launch_enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0) {
+    hipLaunchKernelGGL((k_encrypt_tail<L, AR>), dim3(cnt * 2 * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, u, c->pk, pt, pts, out, c->dc, seed, item0);
+}
+template <class AR> static bool enc_tail_by_size(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0) {
+    switch (c->hc.logn) {
+        case 10: launch_enc_tail<10, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
+        case 11: launch_enc_tail<11, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
+        case 12: launch_enc_tail<12, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
+        case 13: launch_enc_tail<13, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
+        case 14: launch_enc_tail<14, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
+        default: return false;
+    }
+}
+// Encryptor.Encrypt (AtomicSealBfvVector.cs:1211,1227): (pk0 u + e1 + Delta m [+ r_t(q)], pk1 u + e2); pt = 0 encrypts zero
+extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) {
+    LOCK; GETCT(O, out, 2);
+    if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
+    if (!range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
+    const uint64_t *ptd = nullptr;
+    if (pt) { Buffer *P = getbuf(ctx, pt, 1); if (!P || !range_ok(P, pi, pt_stride ? count : 1, pt_stride ? pt_stride : 1)) return fail(CN_ERR_ARG, "invalid plaintext range"); ptd = P->d + (size_t)pi * ctx->hc.n; }
+    if (!count) return 0;
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
+    CHECK(ensure_scratch(ctx, al((size_t)count * kn * 8)));
+    uint64_t *u = salloc<uint64_t>(ctx, (size_t)count * kn);
+    const uint64_t item0 = ctx->rng_item;
+    CHECK(sample_poly(ctx, u, count, 0, seed, 0));
+    CHECK(run_ntt(ctx, u, count * k, 0, k, 0));
+    bool f64 = ctx->use_f64 && ctx->hc.q_f64;
+    bool ok = f64 ? enc_tail_by_size<ArF64>(ctx, u, ptd, pt_stride ? n : 0, O->d + oi * O->item_words, count, seed, item0)
+                  : enc_tail_by_size<ArU64>(ctx, u, ptd, pt_stride ? n : 0, O->d + oi * O->item_words, count, seed, item0);
+    if (!ok) return fail(CN_ERR_ARG, "unsupported size");
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    return 0;
+}
+#define DISPATCH_K2(fn, ...) switch (ctx->hc.k) { \
+    case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; \
+    case 5: fn<5>(__VA_ARGS__); break; case 6: fn<6>(__VA_ARGS__); break; case 7: fn<7>(__VA_ARGS__); break; case 8: fn<8>(__VA_ARGS__); break; \
+    case 9: fn<9>(__VA_ARGS__); break; default: return fail(CN_ERR_ARG, "at most 9 coefficient moduli"); }
+template <int K> static void launch_dec_scale(cn_ctx *c, const uint64_t *c0, size_t stride, const uint64_t *acc, uint64_t *plain, uint32_t cnt) {
+    hipLaunchKernelGGL(k_decrypt_scale<K>, dim3(cnt * c->chunks), dim3(c->bs), 0, c->stream, c0, stride, acc, plain, c->dc, c->chunks);
+}
+// Decryptor.Decrypt (AtomicSealBfvVector.cs:1042,1085): m = round(t (c0 + c1 s + c2 s^2) / q) mod t
+extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi) {
+    LOCK; GETCT(I, ct, 0); GETPT(P, pt_out);
+    if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
+    if (!ctx->hc.inv_g_t) return fail(CN_ERR_ARG, "device decryption needs a prime plain modulus");
+    if (!range_ok(I, ci, count) || !range_ok(P, pi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
+    CHECK(ensure_scratch(ctx, al((size_t)count * kn * 8) * 3 + al(kn * 8)));
+    uint64_t *acc = salloc<uint64_t>(ctx, (size_t)count * kn), *tmp = salloc<uint64_t>(ctx, (size_t)count * kn), *sp = salloc<uint64_t>(ctx, kn);
+    const uint64_t *base = I->d + ci * I->item_words;
+    HIPCHK(hipMemcpy2DAsync(acc, kn * 8, base + kn, I->item_words * 8, kn * 8, count, hipMemcpyDeviceToDevice, ctx->stream));
+    CHECK(run_ntt(ctx, acc, count * k, 0, k, 0));
+    hipLaunchKernelGGL(k_mul_limbs_bcast, dim3(count * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, acc, ctx->sk, (const uint64_t *)nullptr, acc, ctx->dc, ctx->chunks);
+    if (I->size == 3) {
+        hipLaunchKernelGGL(k_mul_limbs, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->sk, ctx->sk, sp, ctx->dc, ctx->chunks);
+        HIPCHK(hipMemcpy2DAsync(tmp, kn * 8, base + 2 * kn, I->item_words * 8, kn * 8, count, hipMemcpyDeviceToDevice, ctx->stream));
+        CHECK(run_ntt(ctx, tmp, count * k, 0, k, 0));
+        hipLaunchKernelGGL(k_mul_limbs_bcast, dim3(count * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, tmp, sp, acc, acc, ctx->dc, ctx->chunks);
+    }
+    HIPCHK(hipGetLastError()); launch_count(ctx, 2);
+    CHECK(run_ntt(ctx, acc, count * k, 0, k, 1));
+    DISPATCH_K2(launch_dec_scale, ctx, base, I->item_words, acc, P->d + (size_t)pi * n, count);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    for (uint32_t c = 0; c < count; c++) P->pt_zero[pi + c] = 0;      // unknown: treated as non-zero
+    return 0;
 }
 
 // ---------------------------------------------------------------- raw transforms / timing / stats

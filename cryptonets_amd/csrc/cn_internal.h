@@ -41,6 +41,9 @@ struct DevConsts {
     uint64_t fl_T_bsk[CN_MAXK + 1];            // t * q^-1 mod b
     uint64_t fl_N_bsk[CN_MAXK + 1][CN_MAXK];   // b - ((q/q_j mod b) * q^-1 mod b)
     uint64_t fl_A_msk[CN_MAXK];                // (B/b_j mod m_sk) * B^-1 mod m_sk
+    // decryption with the {t, gamma} BEHZ rounding (SEAL decryptor.cpp)
+    DMod gamma;
+    uint64_t tg_q[CN_MAXK], qhat_t[CN_MAXK], qhat_g[CN_MAXK], neg_inv_q_t, neg_inv_q_g, inv_g_t;
     // key switching
     int32_t dbc, gdbc;
     uint32_t rl_dig[CN_MAXK], gk_dig[CN_MAXK], rl_tot, gk_tot;

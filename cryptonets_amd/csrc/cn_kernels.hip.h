@@ -639,3 +639,130 @@ __global__ void k_u64_to_f64(uint64_t *p, size_t words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < words) { double d = (double)(long long)p[i]; reinterpret_cast<double *>(p)[i] = d; }
 }
+
+// ------------------------------------------------------------------ client-side operations on the device
+// KeyGenerator / Encryptor / Decryptor of the data owner, for deployments where the client has a GPU too.  Randomness is a
+// counter-based Philox4x32-10 stream keyed by a caller seed: reproducible and statistically sound, NOT a certified DRBG.
+struct Philox { uint32_t c[4]; };
+DEV Philox philox(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {{c0, c1, c2, c3}};
+}
+// streams: 0 = ternary, 1/2 = noise polys, 3 = uniform
+DEV int32_t sample_ternary(uint64_t seed, uint64_t stream, uint64_t item, uint32_t i) {
+    for (uint32_t tr = 0;; tr++) {
+        Philox p = philox(seed, (stream << 32) | tr, (item << 20) | i);
+#pragma unroll
+        for (int w = 0; w < 4; w++) for (int b = 0; b < 32; b += 2) { uint32_t v = (p.c[w] >> b) & 3; if (v != 3) return (int32_t)v - 1; }
+    }
+}
+DEV int32_t sample_noise(uint64_t seed, uint64_t stream, uint64_t item, uint32_t i) {      // clipped normal sigma 3.2, 6 sigma, cast
+    for (uint32_t tr = 0;; tr++) {
+        Philox p = philox(seed, (stream << 32) | tr, (item << 20) | i);
+        const double u1 = ((double)(((uint64_t)p.c[0] << 21) ^ (p.c[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+        const double u2 = ((double)(((uint64_t)p.c[2] << 21) ^ (p.c[3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+        const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2) * 3.2;
+        if (fabs(g) <= 19.2) return (int32_t)g;
+    }
+}
+DEV uint64_t sample_uniform(uint64_t seed, uint64_t stream, uint64_t item, uint32_t i, uint64_t q) {
+    const uint64_t lim = ~0ull - (~0ull % q) - 1;
+    for (uint32_t tr = 0;; tr++) {
+        Philox p = philox(seed, (stream << 32) | tr, (item << 20) | i);
+        uint64_t v = ((uint64_t)p.c[0] << 32) | p.c[1];
+        if (v <= lim) return v % q;
+        v = ((uint64_t)p.c[2] << 32) | p.c[3];
+        if (v <= lim) return v % q;
+    }
+}
+// out[item][j][i]: kind 0 ternary residues, kind 1 noise residues, kind 2 uniform residues mod q_j (item = blockIdx / (k*chunks))
+__global__ void k_sample(uint64_t *out, const DevConsts *__restrict__ C, uint32_t chunks, int kind, uint64_t seed, uint64_t stream, uint64_t item0) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, j = limb % k; const uint64_t item = item0 + limb / k, q = C->q[j].q;
+    uint64_t v;
+    if (kind == 2) v = sample_uniform(seed, stream, item * k + j, i, q);
+    else { int32_t s = kind == 0 ? sample_ternary(seed, stream, item, i) : sample_noise(seed, stream, item, i); v = s >= 0 ? (uint64_t)s : q - (uint64_t)(-s); }
+    out[(size_t)limb * C->n + i] = v;
+}
+// b = -(a*s + e) (+ f * snew on limb `hot`), all NTT form; a, e, b: [k][N]; s, snew: [k][N]; f[k] factor per limb
+__global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, uint64_t factor, int hot, uint64_t *b,
+                        const DevConsts *__restrict__ C, uint32_t chunks) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const DMod qm = C->q[limb]; size_t o = (size_t)limb * C->n + i;
+    uint64_t v = negmod(addmod(mulmod(a[o], s[o], qm), e[o], qm.q), qm.q);
+    if ((int)limb == hot) v = addmod(v, mulmod(snew[o], factor, qm), qm.q);
+    b[o] = v;
+}
+__global__ void k_mul_limbs(const uint64_t *a, const uint64_t *b, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {   // NTT-form product, [k][N]
+    uint32_t limb, i; decode(chunks, limb, i);
+    size_t x = (size_t)limb * C->n + i; o[x] = mulmod(a[x], b[x], C->q[limb % C->k]);
+}
+// o[ct][j] = a[ct][j] * b[j] (+ add[ct][j]): b broadcast over ciphertexts, NTT form
+__global__ void k_mul_limbs_bcast(const uint64_t *a, const uint64_t *b, const uint64_t *add, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t j = limb % C->k; const DMod qm = C->q[j];
+    size_t x = (size_t)limb * C->n + i;
+    uint64_t v = mulmod(a[x], b[(size_t)j * C->n + i], qm);
+    o[x] = add ? addmod(v, add[x], qm.q) : v;
+}
+// encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t *__restrict__ u, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pt,
+                                                                 uint32_t pt_stride_words, uint64_t *__restrict__ out, const DevConsts *__restrict__ C,
+                                                                 uint64_t seed, uint64_t item0) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, p = (blockIdx.x / k) & 1, ct = blockIdx.x / (2 * k);
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t *uu = u + ((size_t)ct * k + j) * n, *pp = pk + ((size_t)p * k + j) * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(uu + pos), y = *reinterpret_cast<const ulonglong2 *>(pp + pos);
+        v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
+    }
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    uint64_t *o = out + (((size_t)ct * 2 + p) * k + j) * n;
+    const uint64_t q = C->q[j].q;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(tid, r);
+        uint64_t val = A.scaled(v[r]);
+        const int32_t ns = sample_noise(seed, 1 + p, item0 + ct, e);
+        val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
+        if (p == 0 && pt) val = addmod(val, scale_plain(C, pt[(size_t)ct * pt_stride_words + e], j), q);
+        o[e] = val;
+    }
+}
+// decryption tail: x_j = c0_j + acc_j (coefficient form), then m = round(t*x/q) mod t by the {t, gamma} trick
+template <int K>
+__global__ void __launch_bounds__(256) k_decrypt_scale(const uint64_t *__restrict__ c0, size_t ct_stride, const uint64_t *__restrict__ acc, uint64_t *__restrict__ plain,
+                                                       const DevConsts *__restrict__ C, uint32_t chunks) {
+    const uint32_t n = C->n;
+    const uint32_t ct = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;
+    const DMod tm = C->t, gm = C->gamma;
+    u128 at = 0, ag = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const DMod qm = C->q[j];
+        uint64_t x = addmod(c0[(size_t)ct * ct_stride + (size_t)j * n + i], acc[((size_t)ct * K + j) * n + i], qm.q);
+        uint64_t y = mulmod(mulmod(x, C->tg_q[j], qm), C->inv_qhat_q[j], qm);
+        at += (u128)y * C->qhat_t[j]; ag += (u128)y * C->qhat_g[j];
+    }
+    const uint64_t vt = mulmod(bred128(at, tm), C->neg_inv_q_t, tm), vg = mulmod(bred128(ag, gm), C->neg_inv_q_g, gm);
+    const uint64_t r = vg > (gm.q >> 1) ? addmod(vt, (gm.q - vg) % tm.q, tm.q) : submod(vt, vg % tm.q, tm.q);
+    plain[(size_t)ct * n + i] = r ? mulmod(r, C->inv_g_t, tm) : 0;
+}

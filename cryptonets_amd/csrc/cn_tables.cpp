@@ -183,6 +183,20 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         c->t_bsk[b] = t % bsk[b];
     }
     c->inv_B_msk = invm_prime(prod_except(bsk.data(), k, -1, bsk[k]), bsk[k]);
+    {   // decryption constants; gamma = second largest 61-bit prime == 1 mod 2^18 (aux[1])
+        const uint64_t g = aux[1];
+        set_mod(c->gamma, g);
+        for (uint32_t i = 0; i < k; i++) {
+            c->tg_q[i] = mulm(t % q[i], g % q[i], q[i]);
+            c->qhat_t[i] = prod_except(q, k, (int)i, t);
+            c->qhat_g[i] = prod_except(q, k, (int)i, g);
+        }
+        // t need not be prime for BFV in general, but every plain modulus of the reference is (batching): inverse by Fermat
+        uint64_t qt = prod_except(q, k, -1, t), qg = prod_except(q, k, -1, g);
+        uint64_t iqt = is_prime_u64(t) ? invm_prime(qt, t) : 0, iqg = invm_prime(qg, g);
+        c->neg_inv_q_t = iqt ? t - iqt : 0; c->neg_inv_q_g = g - iqg;
+        c->inv_g_t = is_prime_u64(t) ? invm_prime(g % t, t) : 0;
+    }
     for (uint32_t i = 0; i < k; i++) {
         c->fl_c1_q[i] = mulm(c->t_q[i], c->inv_qhat_q[i], q[i]);
         c->fl_A_msk[i] = mulm(c->bhat_msk[i], c->inv_B_msk, bsk[k]);

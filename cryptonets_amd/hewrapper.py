@@ -122,7 +122,9 @@ class AtomicSealBfvEncryptedEnvironment:
         """KeyGenerator + SetKeys (AtomicSealBfvVector.cs:62-74,163-173): keys are made by the client, the public
         evaluation keys are uploaded to HBM."""
         self.client.generate_keys(with_galois)
-        self.ctx.set_relin_key(self.client.relin_key())
+        rk = self.client.relin_key()
+        if rk is not None:                       # a device-side client has already installed its keys in the context
+            self.ctx.set_relin_key(rk)
         if with_galois:
             for elt, words in self.client.galois_keys().items():
                 self.ctx.set_galois_key(elt, words)
@@ -224,15 +226,18 @@ class AtomicSealBfvEncryptedVector:
         self.Format = Format
         pv, _, sparse = self._to_plaintexts(v, env)
         ctx = env.ctx
-        if sparse is None:
-            plains = ctx.pt_download(pv.h, 0, pv.count)
-            pv.release()
+        if sparse is not None:
+            polys = np.zeros((len(sparse), ctx.n), dtype=np.uint64)
+            polys[:, 0] = np.array(sparse, dtype=np.uint64)                # Plaintext(hex) = constant polynomial
+            pv = _Buf(ctx, "pt", len(sparse)).view()
+            ctx.pt_upload(pv.h, 0, polys)
+        self.encData = _Buf(ctx, "ct", pv.count).view()
+        if hasattr(env.client, "encrypt_device"):                          # Encryptor on the device: no host round trip
+            env.client.encrypt_device(pv.h, 0, pv.count, self.encData.h, 0)
         else:
-            plains = np.zeros((len(sparse), ctx.n), dtype=np.uint64)
-            plains[:, 0] = np.array(sparse, dtype=np.uint64)
-        self.encData = _Buf(ctx, "ct", len(plains)).view()
-        cts = np.stack([env.client.encrypt(p) for p in plains])
-        ctx.ct_upload(self.encData.h, 0, cts)
+            plains = ctx.pt_download(pv.h, 0, pv.count)
+            ctx.ct_upload(self.encData.h, 0, np.stack([env.client.encrypt(p) for p in plains]))
+        pv.release()
 
     # -- properties -------------------------------------------------------------------------------------------
     @property
@@ -599,8 +604,11 @@ class AtomicSealBfvEncryptedVector:
         res = []
         n_items = self._blocks()
         if self.encData is not None:
-            cts = ctx.ct_download(self.encData.h, self.encData.first, self.encData.count)
-            plains = np.stack([env.client.decrypt(c) for c in cts])
+            if hasattr(env.client, "decrypt_device"):
+                plains = env.client.decrypt_device(self.encData.h, self.encData.first, self.encData.count)
+            else:
+                cts = ctx.ct_download(self.encData.h, self.encData.first, self.encData.count)
+                plains = np.stack([env.client.decrypt(c) for c in cts])
         elif self.plainDense is not None:
             plains = ctx.pt_download(self.plainDense.h, self.plainDense.first, self.plainDense.count)
         else:
@@ -1194,7 +1202,11 @@ class EncryptedSealBfvFactory:
         envs = []
         for t in primes:
             ctx = context_factory(n, t, q, DecompositionBitCount, GaloisDecompositionBitCount)
-            client = client_factory(t, n, q, DecompositionBitCount, GaloisDecompositionBitCount) if client_factory else None
+            if client_factory is not None:
+                client = client_factory(t, n, q, DecompositionBitCount, GaloisDecompositionBitCount)
+            else:
+                from .client import DeviceClient                   # keygen / encrypt / decrypt on the device
+                client = DeviceClient(ctx, seed=0x5EA1 ^ t)
             e = AtomicSealBfvEncryptedEnvironment(ctx, client)
             if client is not None:
                 e.GenerateEncryptionKeys(with_galois=galois)

@@ -128,6 +128,18 @@ int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle 
 /* Evaluator.RotateColumns(/Inplace) (AtomicSealBfvVector.cs:709,914,1391) */
 int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count);
 
+/* ---- client side on the device (what SEAL's KeyGenerator / Encryptor / Decryptor do for
+ * AtomicSealBfvEncryptedEnvironment.SetKeys / Encrypt / Decrypt, AtomicSealBfvVector.cs:62-74,1030-1110,1202-1232), for data
+ * owners that have a GPU.  Randomness: counter-based Philox4x32-10 keyed by `seed` (reproducible; not a certified DRBG). ---- */
+int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois);          /* secret, public, relin (dbc) and default Galois (gdbc) keys */
+int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count);   /* [2][k][N], NTT form */
+int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count);   /* [k][N], NTT form */
+int cn_get_key(cn_ctx *ctx, int which /*0 relin,1 galois,2 public,3 secret*/, uint64_t galois_elt, uint64_t *host, size_t count);
+/* Encryptor.Encrypt of `count` dense plaintexts (pt = 0: encryptions of zero; pt_stride 0: the same plaintext) */
+int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed);
+/* Decryptor.Decrypt of size-2 or size-3 ciphertexts into dense plaintexts */
+int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi);
+
 /* ---- raw transforms (kernel benchmarks / parity tests of the NTT itself) --------------- */
 /* in-place negacyclic NTT over `limbs` limbs of N words at a device pointer; limb i uses modulus
  * (i % nmod) of base 0 (coeff moduli q) or base 1 (BEHZ Bsk moduli).  Async on the ctx stream. */

@@ -85,6 +85,13 @@ class Oracle:
     def _arr(self, ptr, words):
         return np.ctypeslib.as_array(ptr, shape=(words,)).copy()
 
+    def import_keys(self, sk, pk):
+        sk = np.ascontiguousarray(sk, dtype=np.uint64); pk = np.ascontiguousarray(pk, dtype=np.uint64)
+        self.L.cno_import_keys(self.h, _p(sk), _p(pk))
+
+    def public_key(self):
+        return self._arr(self.L.cno_public_key(self.h), 2 * self.k * self.n)
+
     def secret_key(self):
         return self._arr(self.L.cno_secret_key(self.h), self.k * self.n)
 

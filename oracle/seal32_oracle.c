@@ -418,6 +418,13 @@ void cno_keygen(cno_ctx *c, uint64_t seed, int with_galois) {
     }
     free(s2);
 }
+/* import a key pair made elsewhere (e.g. by libcnhip's device keygen) so the oracle can decrypt / encrypt under it */
+void cno_import_keys(cno_ctx *c, const uint64_t *sk, const uint64_t *pk) {
+    size_t kn = (size_t)c->k * c->n;
+    free(c->sk); free(c->pk);
+    c->sk = malloc(8 * kn); c->pk = malloc(8 * 2 * kn);
+    memcpy(c->sk, sk, 8 * kn); memcpy(c->pk, pk, 8 * 2 * kn);
+}
 const uint64_t *cno_secret_key(const cno_ctx *c) { return c->sk; }
 const uint64_t *cno_public_key(const cno_ctx *c) { return c->pk; }
 const uint64_t *cno_relin_key(const cno_ctx *c) { return c->rlk; }

@@ -1,0 +1,168 @@
+"""Client-side operations on the device: cn_keygen / cn_encrypt / cn_decrypt.
+
+Fresh encryption is randomised (and SEAL's RNG is not reproducible), so the checks are:
+  * cross-implementation round trips: oracle decrypts what the GPU encrypted and vice versa, under device-generated keys;
+  * key STRUCTURE: every component of the device-made public / relinearisation / Galois keys is (-(a*s + e) + f*s', a) with a
+    small error polynomial |e| <= 19 (clipped normal, sigma 3.2) - checked with the oracle's transforms;
+  * distribution sanity of the Philox-driven samplers;
+  * the reference's known-answer tests run with the device client (no oracle in the loop) in test_basic_operations-style.
+"""
+import numpy as np
+import pytest
+
+from conftest import PARAMS
+
+pytestmark = pytest.mark.gpu
+
+
+def make(name, seed=77, galois=True):
+    from cryptonets_amd._native import Context
+    from oracle.cno import Oracle
+    p = PARAMS[name]
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    g.keygen(seed, galois=galois)
+    o = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"])
+    o.import_keys(g.get_key(3), g.get_key(2))
+    return g, o
+
+
+def centered(x, q):
+    x = x.astype(np.int64)
+    return np.where(x > q // 2, x - q, x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c3", "c5"])
+def test_encrypt_decrypt_cross_implementation(name, rng):
+    g, o = make(name, galois=False)
+    vals = rng.integers(0, o.t, size=(3, o.n), dtype=np.uint64)
+    plains = np.stack([o.encode(v) for v in vals])
+    ph, ch, dh = g.pt_alloc(3), g.ct_alloc(3), g.pt_alloc(3)
+    g.pt_upload(ph, 0, plains)
+    g.encrypt(ph, 0, ch, 0, 3, seed=5)
+    cts = g.ct_download(ch, 0, 3)
+    for i in range(3):                                            # GPU encrypt -> oracle decrypt
+        assert np.array_equal(o.decode(o.decrypt(cts[i])), vals[i])
+    assert not np.array_equal(cts[0][:o.n], cts[1][:o.n])
+    g.encrypt(ph, 0, ch, 0, 3, seed=5)                            # a second call continues the stream: fresh randomness
+    assert not np.array_equal(g.ct_download(ch, 0, 1)[0], cts[0])
+    g.decrypt(ch, 0, 3, dh, 0)                                    # GPU decrypt of GPU ciphertexts
+    assert np.array_equal(g.pt_download(dh, 0, 3), plains)
+    oc = np.stack([o.encrypt(p) for p in plains])                 # oracle encrypt -> GPU decrypt
+    g.ct_upload(ch, 0, oc)
+    g.decrypt(ch, 0, 3, dh, 0)
+    assert np.array_equal(g.pt_download(dh, 0, 3), plains)
+    # decode on the device as well
+    assert np.array_equal(g.decode(dh, 1), vals[1])
+    # fresh noise is small: c0 + c1 s - Delta m has |.| <= a few hundred
+    x = o.dot_with_secret(cts[0]).reshape(o.k, o.n)
+    ref = o.dot_with_secret(o.add_plain(np.zeros_like(cts[0]), plains[0])).reshape(o.k, o.n)
+    for j in range(o.k):
+        e = centered((x[j] + o.q[j] - ref[j]) % o.q[j], o.q[j])
+        assert np.abs(e).max() < 64 * np.sqrt(o.n), np.abs(e).max()
+    # encryption of zero (PoolLayer padded taps, AtomicSealBfvVector.cs:566)
+    g.encrypt(0, 0, ch, 0, 1, seed=9)
+    assert not o.decrypt(g.ct_download(ch, 0, 1)[0]).any()
+    for h in (ph, ch, dh):
+        g.free(h)
+
+
+def test_decrypt_size3(rng):
+    g, o = make("c3", galois=False)
+    vals = rng.integers(0, o.t, size=(2, o.n), dtype=np.uint64)
+    cts = np.stack([o.encrypt(o.encode(v)) for v in vals])
+    h, h3, dh = g.ct_alloc(2), g.ct_alloc(1, 3), g.pt_alloc(1)
+    g.ct_upload(h, 0, cts)
+    g.multiply(h, 0, h, 1, h3, 0, 1)
+    g.decrypt(h3, 0, 1, dh, 0)
+    exp = np.array([int(a) * int(b) % o.t for a, b in zip(vals[0], vals[1])], dtype=np.uint64)
+    assert np.array_equal(g.decode(dh, 0), exp)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_device_keys_have_the_right_structure(name):
+    g, o = make(name, galois=True)
+    n, k = o.n, o.k
+    sk = g.get_key(3).reshape(k, n)
+    pk = g.get_key(2).reshape(2, k, n)
+
+    def err(b, a, j, extra=None):
+        """INTT(b + a*s (- extra)) centred: must be the small error polynomial (negated)"""
+        v = (b.astype(object) + a.astype(object) * sk[j].astype(object)) % o.q[j]
+        if extra is not None:
+            v = (v - extra) % o.q[j]
+        return centered(o.ntt_inv(j, np.array(v, dtype=np.uint64)), o.q[j])
+    # secret key is ternary
+    for j in range(k):
+        s = centered(o.ntt_inv(j, sk[j]), o.q[j])
+        assert set(np.unique(s)) <= {-1, 0, 1}
+        if j == 0:
+            counts = [(s == v).mean() for v in (-1, 0, 1)]
+            assert all(0.25 < c < 0.42 for c in counts), counts
+    for j in range(k):
+        e = err(pk[0, j], pk[1, j], j)
+        assert np.abs(e).max() <= 19 and 2.0 < e.std() < 4.5
+    # relinearisation key: message 2^(dbc d) s^2 on limb l only
+    rl = g.get_key(0).reshape(-1, 2, k, n)
+    dig = [len(range(0, int(q).bit_length(), o.dbc)) for q in o.q]
+    comp = 0
+    for l in range(k):
+        for d in range(dig[l]):
+            for j in (l, (l + 1) % k):
+                extra = None
+                if j == l:
+                    f = pow(2, o.dbc * d, o.q[l])
+                    extra = (sk[l].astype(object) ** 2 * f) % o.q[l]
+                e = err(rl[comp, 0, j], rl[comp, 1, j], j, extra)
+                assert np.abs(e).max() <= 19, (l, d, j)
+            comp += 1
+    assert comp == rl.shape[0]
+    # Galois key for 2N-1 (column swap): message sigma(s) with the first digit on limb 0
+    elt = 2 * n - 1
+    gk = g.get_key(1, elt).reshape(-1, 2, k, n)
+    s0 = o.ntt_inv(0, sk[0])
+    sig = np.zeros(n, dtype=np.uint64)
+    for i in range(n):
+        raw = i * elt
+        sig[raw & (n - 1)] = (o.q[0] - s0[i]) % o.q[0] if (raw >> int(np.log2(n))) & 1 else s0[i]
+    e = err(gk[0, 0, 0], gk[0, 1, 0], 0, o.ntt_fwd(0, sig).astype(object))
+    assert np.abs(e).max() <= 19
+    # and the keys work: rotate + multiply on the device, decrypt on the device
+    vals = np.arange(n, dtype=np.uint64) % o.t
+    ph, ch, dh = g.pt_alloc(1), g.ct_alloc(2), g.pt_alloc(1)
+    g.encode(vals, ph, 0)
+    g.encrypt(ph, 0, ch, 0, 1, seed=3)
+    g.rotate_rows(ch, 0, -3, ch, 1, 1)
+    g.mul_relin(ch, 0, ch, 1, ch, 1, 1)
+    g.decrypt(ch, 1, 1, dh, 0)
+    half = n // 2
+    rot = np.concatenate([np.roll(vals[:half], 3), np.roll(vals[half:], 3)])
+    assert np.array_equal(g.decode(dh, 0), np.array([int(a) * int(b) % o.t for a, b in zip(vals, rot)], dtype=np.uint64))
+
+
+def test_reference_kats_with_the_device_client():
+    """HE Wrapper Tests/BasicOperations.cs values through the default factory with keygen / encrypt / decrypt on the GPU - no
+    oracle anywhere in the loop."""
+    from cryptonets_amd.hewrapper import EMatrixFormat, EncryptedSealBfvFactory, EVectorFormat
+    F = EncryptedSealBfvFactory()                                  # default: N=4096, 5 plaintext primes, DeviceClient
+    env = F.AllocateComputationEnv()
+    v1 = np.array([-1, 9, 3, 20, 1000, -6945], dtype=float)
+    v2 = np.array([8, -22, 5, 4, 254, -12], dtype=float)
+    e1, e2 = F.GetEncryptedVector(v1, EVectorFormat.dense, 12.0), F.GetEncryptedVector(v2, EVectorFormat.dense, 12.0)
+    p2 = F.GetPlainVector(v2, EVectorFormat.dense, 12.0)
+    assert np.array_equal(e1.Decrypt(env), v1)
+    assert np.array_equal(e1.Add(e2, env).Decrypt(env), v1 + v2)
+    assert np.array_equal(e1.PointwiseMultiply(e2, env).Decrypt(env), v1 * v2)
+    assert np.array_equal(e1.PointwiseMultiply(p2, env).Decrypt(env), v1 * v2)
+    assert e1.DotProduct(e2, env).Decrypt(env)[0] == float(v1 @ v2)
+    assert e1.DotProduct(e2, env, length=4).Decrypt(env)[3] == float(v1[:4] @ v2[:4])
+    m = np.array([[1, -2, 3, -44, 5, 7], [99, 12, -88, 22, 16, 13]], dtype=float)
+    mat = F.GetEncryptedMatrix(m, EMatrixFormat.ColumnMajor, 12.0)
+    sp = F.GetEncryptedVector(v1, EVectorFormat.sparse, 12.0)
+    assert np.array_equal(mat.Mul(sp, env).Decrypt(env), m @ v1)
+    dup = e1.Duplicate(10, env)
+    exp = np.zeros(8)
+    exp[:6] = v1
+    assert np.array_equal(dup.Decrypt(env), np.tile(exp, 10))
+    data = np.array([[0, 0, 1, 0, 0, 2], [0, 0, 3, 0, 0, 4], [0, 0, 5, 0, 0, 6]], dtype=float).T
+    mm = F.GetEncryptedMatrix(data, EMatrixFormat.ColumnMajor, 10)
+    assert list(mm.Interleave(-1, env).Decrypt(env)) == [5, 3, 1, 6, 4, 2]
