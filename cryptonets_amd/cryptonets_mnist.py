@@ -114,3 +114,42 @@ def constant_plaintext(n):
         p[0] = v
         return p
     return enc
+
+
+# ------------------------------------------------------------------ exact functional model (plain integers mod p)
+def mulmod_u64(a, b, p):
+    """(a*b) mod p for uint64 arrays with a, b < p < 2^40 (no overflow: 20-bit split of b)"""
+    b = np.asarray(b, dtype=np.uint64)
+    hi = (a * (b >> np.uint64(20))) % p
+    return (hi * np.uint64(1 << 20) + a * (b & np.uint64(0xFFFFF))) % p
+
+
+def model_mod_p(x_int, layers, p):
+    """The network over Z_p on the scaled integer inputs x_int [samples, 784]: what every slot of the decrypted logits of the
+    plaintext-prime channel p must equal (conv+bias, square, dense+bias, square, dense+bias)."""
+    p = np.uint64(p)
+    act = np.asarray(x_int, dtype=np.int64)
+    act = np.mod(act, int(p)).astype(np.uint64)
+    for li, L in enumerate(layers):
+        W = residues(L["W"], int(p))
+        bias = np.array([b % int(p) for b in L["bias"]], dtype=np.uint64)
+        O, K = W.shape
+        out = np.zeros((act.shape[0], O), dtype=np.uint64)
+        rows = {}
+        for o in range(O):
+            rows.setdefault(L["idx"][o].tobytes(), []).append(o)
+        for key, outs in rows.items():
+            idx = np.frombuffer(key, dtype=np.int32)
+            acc = np.zeros((act.shape[0], len(outs)), dtype=np.uint64)
+            for k in range(K):
+                if idx[k] >= 0:
+                    acc = (acc + mulmod_u64(act[:, idx[k]][:, None], W[outs, k][None, :], p)) % p
+            out[:, outs] = (acc + bias[outs][None, :]) % p
+        act = mulmod_u64(out, out, p) if li < 2 else out
+    return act
+
+
+def synthetic_images(count, seed=1):
+    """MNIST-like sparsity: a pixel is 0 with probability 0.81, else uniform in 1..255"""
+    r = np.random.default_rng(seed)
+    return np.where(r.random((count, 784)) < 0.81, 0, r.integers(1, 256, size=(count, 784))).astype(float)
