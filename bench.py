@@ -62,6 +62,12 @@ def main():
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: RCCL / HIP runtime banners are C stdio writes to fd 1 (flushed at exit), so fd 1 is
+    # pointed at stderr for the whole run and the result line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,7 +184,7 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

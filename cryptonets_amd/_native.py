@@ -120,7 +120,7 @@ def lib():
             raise ImportError(
                 "cryptonets_amd: %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("CNHIP_LIB", LIB_PATH))    # CNHIP_LIB: developer override for A/B kernel builds (tools/)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the ABI and the header diverge
             fn.restype = res
