@@ -53,6 +53,8 @@ struct cn_ctx {
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
     size_t ctw2;              // words of a size-2 ciphertext
     bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
+    int ks_wide = -1;         // -1 auto (small batches), 0 never, 1 always: two-launch key switch spread over the chip (latency variant)
+    void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
 };
 
@@ -141,6 +143,15 @@ extern "C" const char *cn_last_error(void) { return g_err; }
 extern "C" int cn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int cn_default_coeff_modulus(uint32_t n, uint64_t *q) { return cn_default_coeff_modulus_impl(n, q); }
 
+template <class K> static int big_lds(K kern, size_t bytes) {
+    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+template <int L, class AR> static int big_lds_policy(size_t bytes) {      // every register-radix kernel of one (size, arithmetic policy)
+    CHECK(big_lds(k_ntt_rr<L, AR>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
+    CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
+    return 0;
+}
 template <int EPT> static int set_ks_attr(size_t bytes) {
     HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
@@ -182,34 +193,15 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     size_t lds = (size_t)ntt_lds_words(n) * 8;
-    if (lds > 48 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
+        CHECK(big_lds(k_ntt, lds));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_encrypt_tail<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_intt_tensor<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArF64L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64L, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ntt_rr<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArU64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArF64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<13, ArU64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_keyswitch_rr<14, ArF64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CHECK((big_lds_policy<13, ArU64>(lds))); CHECK((big_lds_policy<14, ArU64>(lds)));
+        CHECK((big_lds_policy<13, ArF64>(lds))); CHECK((big_lds_policy<14, ArF64>(lds)));
+        CHECK((big_lds_policy<13, ArF64L>(lds))); CHECK((big_lds_policy<14, ArF64L>(lds)));
+        CHECK(big_lds(k_encrypt_tail<13, ArU64>, lds)); CHECK(big_lds(k_encrypt_tail<14, ArU64>, lds));
+        CHECK(big_lds(k_encrypt_tail<13, ArF64>, lds)); CHECK(big_lds(k_encrypt_tail<14, ArF64>, lds));
+        CHECK(big_lds(k_keyswitch_rr<13, ArU64, 4>, lds)); CHECK(big_lds(k_keyswitch_rr<13, ArF64, 4>, lds)); CHECK(big_lds(k_keyswitch_rr<13, ArF64L, 4>, lds));
     }
     *out = c;
     return 0;
@@ -221,7 +213,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     for (auto &kv : ctx->bufs) (void)hipFree(kv.second.d);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
-    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk);
+    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -234,6 +226,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
+    if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
@@ -692,20 +685,60 @@ static bool launch_ks_by_size(cn_ctx *c, const uint64_t *target, size_t tstride,
         default: return false;
     }
 }
+template <int L, class AR>
+static void launch_ks_wide(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
+                           const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
+    const uint32_t tot = galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;
+    const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
+    hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
+                       galois, tot);
+    hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out, c->dc,
+                       tot, accmax);
+    launch_count(c);
+}
+template <class AR>
+static bool launch_ks_wide_by_size(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
+                                   const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
+    switch (c->hc.logn) {
+        case 10: launch_ks_wide<10, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 11: launch_ks_wide<11, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 12: launch_ks_wide<12, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 13: launch_ks_wide<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 14: launch_ks_wide<14, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        default: return false;
+    }
+}
+static const uint32_t KS_WIDE_MAX_BLOCKS = 160;      // auto: below this many (ct, limb) workgroups the fused kernel leaves most CUs idle
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                         const KsKey &key, uint64_t *out, uint32_t cnt, int galois) {
     uint32_t n = ctx->hc.n, nt = std::min<uint32_t>(1024, n), ept = n / nt;
     bool done = false;
+    const uint32_t tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
+    bool wide = !ctx->legacy_ntt && ctx->hc.logn >= 10 && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * ctx->hc.k <= KS_WIDE_MAX_BLOCKS));
+    if (wide) {
+        size_t need = (size_t)cnt * tot_dig * ctx->ctw2 * 8;
+        if (need > ctx->smax) wide = false;
+        else if (need > ctx->ks_part_cap) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->ks_part) HIPCHK(hipFree(ctx->ks_part));
+            ctx->ks_part = nullptr; ctx->ks_part_cap = 0;
+            HIPCHK(hipMalloc(&ctx->ks_part, need));
+            ctx->ks_part_cap = need;
+        }
+    }
     if (key.f64) {
         // lazy FP64 accumulators: |term| <= 2.1 q, keep the sum below 2^52
         uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
         int bits = 64 - __builtin_clzll(qmax);
         uint32_t accmax = bits >= 50 ? 1u : (1u << std::min(10, 50 - bits));
-        done = bits <= 44 ? launch_ks_by_size<ArF64L>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax)
-                          : launch_ks_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
+        if (wide) done = bits <= 44 ? launch_ks_wide_by_size<ArF64L>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax)
+                                    : launch_ks_wide_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
+        else done = bits <= 44 ? launch_ks_by_size<ArF64L>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax)
+                               : launch_ks_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
         if (!done) return fail(CN_ERR_ARG, "internal: FP64 key without FP64 kernel");
     } else if (!ctx->legacy_ntt) {
-        done = launch_ks_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu);
+        done = wide ? launch_ks_wide_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu)
+                    : launch_ks_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu);
     }
     if (!done) {
         switch (ept) {

@@ -555,11 +555,13 @@ template <class AR> struct KsMac;
 template <> struct KsMac<ArU64> {
     static DEV void mac(uint64_t &acc, uint64_t x, uint64_t key, const DMod &qm, const ArCtx<ArU64> &A) { acc = addmod(acc, mulmod(canon4(x, qm.q), key, qm), qm.q); }
     static DEV void settle(uint64_t (&)[16], const ArCtx<ArU64> &) {}
+    static DEV uint64_t sum(uint64_t acc, uint64_t x, const DMod &qm) { return addmod(acc, x, qm.q); }
 };
 template <int RN> struct KsMac<ArF64T<RN>> {
     typedef ArF64T<RN> ArF64;
     static DEV void mac(double &acc, double x, double key, const DMod &, const ArCtx<ArF64> &A) { acc = __dadd_rn(acc, ArF64::mulmod(x, key, A.m)); }
     static DEV void settle(double (&a)[16], const ArCtx<ArF64> &A) { ArF64::renorm(a, A.m); }
+    static DEV double sum(double acc, double x, const DMod &) { return __dadd_rn(acc, x); }
 };
 #ifndef KS_MAC_FENCE
 #define KS_MAC_FENCE 0      // FP64 path: letting the scheduler interleave key loads with the MACs measured 11-14 % faster (same VGPRs)
@@ -635,6 +637,93 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
             o[e] = val;
         }
         __syncthreads();
+    }
+}
+// Latency variant of the key switch for SMALL batches (LoLa: one image = 1..13 ciphertexts per rotation): the fused kernel above
+// runs count*k workgroups, each pushing all digit transforms through one CU in sequence - 5 busy CUs of 256 at count 1.  Here
+// the digit transforms are spread over the chip and the sum is a second launch:
+//   k_ks_digit_mac : block = (ct, digit g, output limb j): digit -> forward transform -> times the key pair -> partial products
+//                    part[ct][g][2][k][N] (transform order, same 16 B/lane pattern as the key reads)
+//   k_ks_sum_intt  : block = (ct, j, component p): sum of the partials over g -> inverse transform -> (+ add_p) -> out
+// Same residues as the fused kernel (exact arithmetic in both), HBM traffic 2 * tot * 2kN words per ciphertext more.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
+                                                                  void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t tot) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t j = blockIdx.x % k, g = (blockIdx.x / k) % tot, ct = blockIdx.x / (k * tot);
+    uint32_t l = 0, d = g;
+    for (;; l++) { const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l]; if (d < nd) break; d -= nd; }
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const ArCtx<AR> A(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc, sh = dbc * (int)d;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        uint64_t t = (src[pass_index<L, SA, 0>(tid, r)] >> sh) & mask;
+        if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
+        v[r] = A.load(t);
+    }
+    if constexpr (std::is_same<T, double>::value) AR::renorm(v, A.m);
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    const T *k0 = reinterpret_cast<const T *>(key_) + (size_t)g * 2 * kn + (size_t)j * n, *k1 = k0 + kn;
+    T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * tot + g) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;
+    struct alignas(16) P2 { T a, b; };
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+        P2 x = {0, 0}, y = {0, 0};
+        KsMac<AR>::mac(x.a, v[r], a.a, qm, A); KsMac<AR>::mac(x.b, v[r + 1], a.b, qm, A);
+        KsMac<AR>::mac(y.a, v[r], b.a, qm, A); KsMac<AR>::mac(y.b, v[r + 1], b.b, qm, A);
+        *reinterpret_cast<P2 *>(o0 + pos) = x; *reinterpret_cast<P2 *>(o1 + pos) = y;
+    }
+}
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__restrict__ part_, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
+                                                                 size_t add_stride, uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t tot,
+                                                                 uint32_t accmax) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t p = blockIdx.x & 1, j = (blockIdx.x >> 1) % k, ct = blockIdx.x / (2 * k);
+    const DMod qm = C->q[j];
+    const ArCtx<AR> A(C, j);
+    const size_t kn = (size_t)k * n;
+    const T *src = reinterpret_cast<const T *>(part_) + ((size_t)ct * tot * 2 + p) * kn + (size_t)j * n;
+    struct alignas(16) P2 { T a, b; };
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = 0;
+    uint32_t terms = 0;
+    for (uint32_t g = 0; g < tot; g++, src += 2 * kn) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const P2 x = *reinterpret_cast<const P2 *>(src + tail_index<L>(tid, r));
+            v[r] = KsMac<AR>::sum(v[r], x.a, qm); v[r + 1] = KsMac<AR>::sum(v[r + 1], x.b, qm);
+        }
+        if (++terms == accmax) { terms = 0; KsMac<AR>::settle(v, A); }
+    }
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    const uint64_t *ad = p ? add1 : add0;
+    uint64_t *o = out + ((size_t)ct * 2 + p) * kn + (size_t)j * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(tid, r);
+        uint64_t val = A.scaled(v[r]);
+        if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], qm.q);
+        o[e] = val;
     }
 }
 // in-place conversion of key words to the FP64 form used by k_keyswitch_rr<L, ArF64> (exact: residues < 2^49)

@@ -51,7 +51,10 @@ int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc
 int cn_ctx_destroy(cn_ctx *ctx);
 int cn_sync(cn_ctx *ctx);
 /* tuning switches (A/B testing): "f64" = 1 (default) runs transforms of moduli < 2^49 and key switching in exact FP64
- * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels. */
+ * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels;
+ * "ks_wide" = -1 (default: automatic for small batches) / 0 / 1 selects the two-launch key switch that spreads the digit
+ * transforms of a few ciphertexts over the whole chip (single-image latency) instead of the fused one-launch kernel;
+ * "ks_tight" = 1 the 128-VGPR fused variant.  All variants produce identical words. */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);

@@ -354,3 +354,30 @@ def test_concurrent_callers_one_context(rng):
         assert np.array_equal(got[1], o.rotate_rows(cts[i], -(i + 1)))
     for x in outs + [h]:
         g.free(x)
+
+
+@pytest.mark.parametrize("name,f64", [("tiny", True), ("c3", True), ("c3", False), ("c4", True), ("c5", True), ("default4096", False)])
+def test_key_switch_variants_agree(name, f64, rng):
+    """The fused one-launch key switch (batches) and the two-launch variant that spreads the digit transforms of a few ciphertexts
+    over the chip (single-image latency; automatic below 160 (ct, limb) workgroups) must both give the oracle's words - for
+    relinearisation and for rotations, on the FP64 and on the integer path."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True, f64=f64)
+    vals, cts = enc_batch(o, rng, 3)
+    h, out = up(g, cts), g.ct_alloc(3)
+    exp_mul = [o.relinearize(o.multiply(cts[i], cts[(i + 1) % 3])) for i in range(3)]
+    exp_rot = [o.rotate_rows(c, -3) for c in cts]
+    exp_col = [o.rotate_columns(c) for c in cts]
+    try:
+        for wide in (0, 1):
+            g.set_option("ks_wide", wide)
+            for i in range(3):
+                g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_mul)), wide
+            g.rotate_rows(h, 0, -3, out, 0, 3)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_rot)), wide
+            g.rotate_columns(h, 0, out, 0, 3)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_col)), wide
+    finally:
+        g.set_option("ks_wide", -1)
+    for x in (h, out):
+        g.free(x)
