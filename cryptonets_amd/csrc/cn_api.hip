@@ -53,12 +53,18 @@ struct cn_ctx {
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
     size_t ctw2;              // words of a size-2 ciphertext
     bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
+    // freed ciphertext / plaintext arrays are kept per size and handed out again: every op of a context is ordered on its
+    // stream, so reuse needs no synchronisation, while hipFree / hipMalloc cost ~60 / ~25 us and a device-wide sync each
+    // (a LoLa inference allocates and frees ~300 temporaries per plaintext prime)
+    std::unordered_map<size_t, std::vector<uint64_t *>> pool;
+    size_t pool_bytes = 0, pool_max;
     int ks_wide = -1;         // -1 auto (small batches), 0 never, 1 always: two-launch key switch spread over the chip (latency variant)
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
 };
 
 // ---------------------------------------------------------------- helpers
+static void pool_flush(cn_ctx *ctx);
 static int use(cn_ctx *c) { HIPCHK(hipSetDevice(c->device)); return 0; }
 
 static int ensure_scratch(cn_ctx *c, size_t bytes) {
@@ -190,6 +196,8 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->ctw2 = (size_t)2 * k * n;
     const char *env = getenv("CN_SCRATCH_GB");
     c->smax = (size_t)(env ? atof(env) : 24.0) * (1ull << 30);
+    env = getenv("CN_POOL_GB");
+    c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     size_t lds = (size_t)ntt_lds_words(n) * 8;
@@ -211,6 +219,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->bufs) (void)hipFree(kv.second.d);
+    pool_flush(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
     (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part);
@@ -273,11 +282,35 @@ extern "C" uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps) {
 }
 
 // ---------------------------------------------------------------- buffers
+static void pool_flush(cn_ctx *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool) for (uint64_t *p : kv.second) (void)hipFree(p);
+    ctx->pool.clear(); ctx->pool_bytes = 0;
+}
+static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end() && !it->second.empty()) {
+        *out = it->second.back(); it->second.pop_back(); ctx->pool_bytes -= bytes;
+        return 0;
+    }
+    if (hipMalloc((void **)out, bytes) != hipSuccess) {          // out of memory: give the cached arrays back and retry once
+        (void)hipGetLastError();
+        pool_flush(ctx);
+        HIPCHK(hipMalloc((void **)out, bytes));
+    }
+    return 0;
+}
+static int dev_release(cn_ctx *ctx, uint64_t *p, size_t bytes) {
+    if (ctx->pool_bytes + bytes <= ctx->pool_max) { ctx->pool[bytes].push_back(p); ctx->pool_bytes += bytes; return 0; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(p));
+    return 0;
+}
 static int alloc_buf(cn_ctx *ctx, int kind, uint32_t count, uint32_t size, cn_handle *out) {
     if (!out || !count) return fail(CN_ERR_ARG, "bad allocation request");
     Buffer b; b.kind = kind; b.count = count; b.size = size;
     b.item_words = kind == 0 ? (size_t)size * ctx->hc.k * ctx->hc.n : ctx->hc.n;
-    HIPCHK(hipMalloc((void **)&b.d, b.item_words * 8 * count));
+    CHECK(dev_alloc(ctx, b.item_words * 8 * count, &b.d));
     if (kind == 1) b.pt_zero.assign(count, 1);
     cn_handle h = ctx->next_handle++;
     ctx->bufs[h] = std::move(b);
@@ -292,8 +325,7 @@ extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
     LOCK;
     auto it = ctx->bufs.find(h);
     if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(it->second.d));
+    CHECK(dev_release(ctx, it->second.d, it->second.item_words * 8 * it->second.count));
     ctx->bufs.erase(it);
     return 0;
 }

@@ -97,6 +97,34 @@ def _gather(ctx, views):
     return tmp.h, idx, tmp
 
 
+# ------------------------------------------------------------------------------------------------ CRT fan-out
+PARALLEL_PRIMES = True
+_crt_pool = None
+
+
+def _fan_out(envs, fn):
+    """ForEveryEncryptedVector (EncryptedSealBfvVector.cs:225-236): the reference issues every operation as one Task per
+    plaintext prime.  Here each prime is a device context with its own HIP stream; issuing from one host thread per prime
+    (ctypes drops the GIL inside libcnhip) keeps the streams fed concurrently, which is what bounds single-image latency."""
+    global _crt_pool
+    if len(envs) == 1 or not PARALLEL_PRIMES:
+        return [fn(i, e) for i, e in enumerate(envs)]
+    if _crt_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _crt_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="crt")
+    futures = [_crt_pool.submit(fn, i, e) for i, e in enumerate(envs)]
+    results, first_error = [], None
+    for f in futures:                       # wait for every prime before raising: no task may outlive the call
+        try:
+            results.append(f.result())
+        except Exception as ex:             # noqa: BLE001 - re-raised below
+            first_error = first_error or ex
+            results.append(None)
+    if first_error is not None:
+        raise first_error
+    return results
+
+
 # ------------------------------------------------------------------------------------------------ atomic layer
 class AtomicSealBfvEncryptedEnvironment:
     """One plaintext modulus = one device context + its evaluation keys (AtomicSealBfvVector.cs:19-206)."""
@@ -238,6 +266,16 @@ class AtomicSealBfvEncryptedVector:
             plains = ctx.pt_download(pv.h, 0, pv.count)
             ctx.ct_upload(self.encData.h, 0, np.stack([env.client.encrypt(p) for p in plains]))
         pv.release()
+
+    # -- persistence (AtomicSealBfvVector.cs:1273-1345) ------------------------------------------------------------
+    def Write(self, stream, env):
+        from . import serialization
+        serialization.write_atomic_vector(stream, self, env)
+
+    @staticmethod
+    def Read(stream, env):
+        from . import serialization
+        return serialization.read_atomic_vector(stream, env)
 
     # -- properties -------------------------------------------------------------------------------------------
     @property
@@ -799,7 +837,7 @@ class EncryptedSealBfvVector:
             v.RegisterDim(dim)
 
     def _each(self, fn, env):
-        return [fn(i, e) for i, e in enumerate(env.Environments)]
+        return _fan_out(env.Environments, fn)
 
     @staticmethod
     def Interleave(vecs, shift, env):
@@ -858,6 +896,17 @@ class EncryptedSealBfvVector:
         I = [i for i, s in enumerate(selections) if s is not None]
         sel, sh = [selections[i] for i in I], [shifts[i] for i in I]
         return EncryptedSealBfvVector._of(self._each(lambda i, e: self.eVectors[i].Permute([x.eVectors[i] for x in sel], sh, outputDim, e), env), self.Scale)
+
+    def Write(self, stream, env):
+        """EncryptedSealBfvVector.cs:430-439"""
+        from . import serialization
+        serialization.write_vector(stream, self, env)
+
+    @staticmethod
+    def Read(stream, env):
+        """EncryptedSealBfvVector.cs:414-429"""
+        from . import serialization
+        return serialization.read_vector(stream, env)
 
     def _join(self, split, env, signed=True):
         """JoinSplitNumbers (EncryptedSealBfvVector.cs:381-411)"""
@@ -968,7 +1017,8 @@ class EncryptedSealBfvMatrix:
             r.leVectors = [a.PointwiseMultiply(b, env) for a, b in zip(self.leVectors, m.leVectors)]
             return r
         out = [[None] * len(env.Environments) for _ in range(cols)]
-        for i, e in enumerate(env.Environments):
+
+        def one_prime(i, e):
             ctx = e.ctx
             av = [c.eVectors[i] for c in self.leVectors]
             bv = [c.eVectors[i] for c in m.leVectors]
@@ -997,6 +1047,7 @@ class EncryptedSealBfvMatrix:
             for t in (ta, tb):
                 if t is not None:
                     t.release()
+        _fan_out(env.Environments, one_prime)
         r.leVectors = [EncryptedSealBfvVector._of(out[c], self.leVectors[c].Scale * m.leVectors[c].Scale) for c in range(cols)]
         return r
 
@@ -1031,6 +1082,17 @@ class EncryptedSealBfvMatrix:
     def RegisterScale(self, scale):
         for v in self.leVectors:
             v.RegisterScale(scale)
+
+    def Write(self, stream, env):
+        """EncryptedSealBfvMatrix.cs:199-208"""
+        from . import serialization
+        serialization.write_matrix(stream, self, env)
+
+    @staticmethod
+    def Read(stream, env):
+        """EncryptedSealBfvMatrix.cs:182-197"""
+        from . import serialization
+        return serialization.read_matrix(stream, env)
 
     def ConvertToColumnVector(self, env):
         return EncryptedSealBfvVector.Stack(self.leVectors, env)
@@ -1069,8 +1131,8 @@ class EncryptedSealBfvMatrix:
         INT_MAX = 2 ** 31 - 1
         R = len(self.leVectors)
         full = length is None
-        per_prime, out_dim, out_fmt = [], None, None
-        for i, e in enumerate(env.Environments):
+
+        def one_prime(i, e):
             ctx, slots = e.ctx, e.SlotCount
             src = v.eVectors[i].encData
             pts = self._row_plaintexts(i, e)
@@ -1113,8 +1175,10 @@ class EncryptedSealBfvMatrix:
                 bp = bias._row_plaintexts(i, e)
                 ctx.add_plain(work.h, 0, bp.h, bp.first, work.h, 0, R)
             tv.release()
-            per_prime.append((work, wv))
-            out_dim, out_fmt = dim, fmt
+            return work, wv, dim, fmt
+        done = _fan_out(env.Environments, one_prime)
+        per_prime = [(w, x) for (w, x, _, _) in done]
+        out_dim, out_fmt = done[0][2], done[0][3]
         signed = v.eVectors[0].IsSigned
         if ForceOutputInColumns:
             atoms = [AtomicSealBfvEncryptedVector._new(Scale=1, Dim=R, Format=EVectorFormat.dense, IsSigned=signed, encData=wv)
@@ -1137,8 +1201,8 @@ class EncryptedSealBfvMatrix:
         if self.Format != EMatrixFormat.ColumnMajor:
             raise Exception("Expecting ColumnMajor matrix")
         O = len(weights)
-        per_prime = []
-        for i, e in enumerate(env.Environments):
+
+        def one_prime(i, e):
             ctx, p = e.ctx, e.plainmodulusValue
             cols = [c.eVectors[i] for c in self.leVectors]
             if any(c.encData is None or c.encData.count != 1 for c in cols):
@@ -1165,7 +1229,8 @@ class EncryptedSealBfvMatrix:
                     tmp.release()
                 if bias is not None:
                     bp.release()
-            per_prime.append(res)
+            return res
+        per_prime = _fan_out(env.Environments, one_prime)
         dim = self.leVectors[0].Dim
         vecs = []
         for o in range(O):
@@ -1212,6 +1277,40 @@ class EncryptedSealBfvFactory:
                 e.GenerateEncryptionKeys(with_galois=galois)
             envs.append(e)
         self.referenceEnvironment = EncryptedSealBfvEnvironment(envs, ParentFactory=self)
+
+    @classmethod
+    def Load(cls, source, device=0, context_factory=None, client_factory=None):
+        """EncryptedSealBfvFactory(string fileName) / (Stream stream) (IFactory.cs:262-276): environments from the zip key
+        container.  `client_factory(ctx)` overrides the client built on each loaded context (default DeviceClient)."""
+        from . import serialization
+        if context_factory is None:
+            from ._native import Context
+
+            def context_factory(n_, t_, q_, dbc_, gdbc_):
+                return Context(n_, t_, q=q_, dbc=dbc_, gdbc=gdbc_, device=device)
+        self = cls.__new__(cls)
+        if isinstance(source, (str, bytes)):
+            with open(source, "rb") as f:
+                envs = serialization.load_environments(f, context_factory, client_factory)
+        else:
+            envs = serialization.load_environments(source, context_factory, client_factory)
+        self.referenceEnvironment = EncryptedSealBfvEnvironment(envs, ParentFactory=self)
+        return self
+
+    def Save(self, target, withPrivateKeys=False):
+        """IFactory.cs:296-304: zip of one key stream per plaintext prime; the secret keys only on request"""
+        from . import serialization
+        if isinstance(target, (str, bytes)):
+            with open(target, "wb") as f:
+                serialization.save_environments(f, self.referenceEnvironment.Environments, withPrivateKeys)
+            return None
+        return serialization.save_environments(target, self.referenceEnvironment.Environments, withPrivateKeys)
+
+    def LoadVector(self, stream):
+        return EncryptedSealBfvVector.Read(stream, self.referenceEnvironment)
+
+    def LoadMatrix(self, stream):
+        return EncryptedSealBfvMatrix.Read(stream, self.referenceEnvironment)
 
     def AllocateComputationEnv(self):
         return self.referenceEnvironment

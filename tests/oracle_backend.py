@@ -39,7 +39,19 @@ class OracleBackend:
         self.o = oracle
         self.n, self.t, self.q, self.k = oracle.n, oracle.t, list(oracle.q), oracle.k
         self.ctw = oracle.ctw
+        self.dbc, self.gdbc = oracle.dbc, oracle.gdbc
         self.bufs, self.next = {}, 1
+
+    # keys (cn_get_key / cn_has_galois_key)
+    def get_key(self, which, elt=0):
+        if which == 0:
+            return self.o.relin_key()
+        if which == 1:
+            return self.o.galois_key(self.o.galois_elts().index(elt))
+        return self.o.public_key() if which == 2 else self.o.secret_key()
+
+    def has_galois_key(self, elt):
+        return elt in self.o.galois_elts()
 
     # buffers
     def ct_alloc(self, count, size=2):
