@@ -1,7 +1,10 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" on CPU for tests).
 
-The path shards with NO data-path collective: independent ciphertext batches are dealt round-robin to ranks.
-The only collective is one broadcast of the (public) evaluation keys at start-up; timing uses max-over-ranks.
+The path shards with NO data-path collective: independent ciphertext batches are dealt round-robin to ranks
+(throughput), or - for the latency of ONE inference - the independent plaintext-prime channels are (SURVEY 8e (2):
+`EncryptedSealBfvVector.cs:225-236` fans every op out per prime, the channels only meet in the client's CRT join after
+decryption, `:381-395`).  The only collectives are one broadcast of the (public) evaluation keys at start-up and, for the
+prime split, one gather of the decrypted residues on the client; timing uses max-over-ranks.
 """
 import numpy as np
 
@@ -33,3 +36,34 @@ def max_over_ranks(seconds, device, dist):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shard_primes(primes, rank, world):
+    """plaintext-prime channels of one inference dealt to ranks: rank r owns primes[r], primes[r + world], ..."""
+    return list(primes[rank::world])
+
+
+def crt_join_over_ranks(residues, primes, dist, signed=True):
+    """CRT join (EncryptedSealBfvVector.cs:381-395) of residues produced on different ranks.
+
+    residues: dict {prime: integer array} for the primes THIS rank owns; primes: the full list in factory order.  Every rank
+    returns the joined python-int list (values centred in (-M/2, M/2] when signed)."""
+    parts = [residues]
+    if dist is not None:
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, {int(p): np.asarray(v).tolist() for p, v in residues.items()})
+    merged = {}
+    for part in parts:
+        merged.update({int(p): v for p, v in part.items()})
+    if sorted(merged) != sorted(int(p) for p in primes):
+        raise ValueError("CRT join: residues for primes %s, expected %s" % (sorted(merged), sorted(primes)))
+    M = 1
+    for p in primes:
+        M *= int(p)
+    coef = [(M // int(p)) * pow((M // int(p)) % int(p), -1, int(p)) for p in primes]
+    n = len(next(iter(merged.values())))
+    out = []
+    for i in range(n):
+        v = sum(c * int(merged[int(p)][i]) for c, p in zip(coef, primes)) % M
+        out.append(v - M if signed and 2 * v > M else v)
+    return out
