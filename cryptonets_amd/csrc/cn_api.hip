@@ -41,7 +41,7 @@ struct cn_ctx {
     std::unordered_map<cn_handle, Buffer> bufs;
     cn_handle next_handle = 1;
     KsKey rlk{nullptr, false, false};
-    double *twd = nullptr;
+    double *twd = nullptr, *twdh = nullptr;
     bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
     std::map<uint64_t, KsKey> gk;
     uint64_t *sk = nullptr, *pk = nullptr;   // client-side keys (NTT form) when the data owner's GPU runs keygen/encrypt/decrypt
@@ -58,6 +58,7 @@ struct cn_ctx {
     // (a LoLa inference allocates and frees ~300 temporaries per plaintext prime)
     std::unordered_map<size_t, std::vector<uint64_t *>> pool;
     size_t pool_bytes = 0, pool_max;
+    bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     int ks_wide = -1;         // -1 auto (small batches), 0 never, 1 always: two-launch key switch spread over the chip (latency variant)
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
@@ -188,6 +189,14 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         HIPCHK(hipMalloc((void **)&c->twd, twd.size() * 8));
         HIPCHK(hipMemcpy(c->twd, twd.data(), twd.size() * 8, hipMemcpyHostToDevice));
         c->hc.twd = c->twd;
+        c->hc.twdh = nullptr;
+        if (c->hc.logn == 14 && c->hc.q_f64) {                  // N = 16384: half tables of the split key switch
+            std::vector<double> th((size_t)k * 4 * (n / 2), 0.0);
+            cn_build_half_tables(&c->hc, tw.data(), th.data());
+            HIPCHK(hipMalloc((void **)&c->twdh, th.size() * 8));
+            HIPCHK(hipMemcpy(c->twdh, th.data(), th.size() * 8, hipMemcpyHostToDevice));
+            c->hc.twdh = c->twdh;
+        }
         c->use_f64 = !(getenv("CN_NO_F64") && atoi(getenv("CN_NO_F64")));
     }
     HIPCHK(hipMalloc((void **)&c->dc, sizeof(DevConsts)));
@@ -209,6 +218,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         CHECK((big_lds_policy<13, ArF64L>(lds))); CHECK((big_lds_policy<14, ArF64L>(lds)));
         CHECK(big_lds(k_encrypt_tail<13, ArU64>, lds)); CHECK(big_lds(k_encrypt_tail<14, ArU64>, lds));
         CHECK(big_lds(k_encrypt_tail<13, ArF64>, lds)); CHECK(big_lds(k_encrypt_tail<14, ArF64>, lds));
+        CHECK(big_lds(k_keyswitch_split14<ArF64>, (size_t)ntt_lds_words(8192) * 8)); CHECK(big_lds(k_keyswitch_split14<ArF64L>, (size_t)ntt_lds_words(8192) * 8));
         CHECK(big_lds(k_keyswitch_rr<13, ArU64, 4>, lds)); CHECK(big_lds(k_keyswitch_rr<13, ArF64, 4>, lds)); CHECK(big_lds(k_keyswitch_rr<13, ArF64L, 4>, lds));
     }
     *out = c;
@@ -223,7 +233,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
     (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part);
-    (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->dc);
+    (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -236,6 +246,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
+    if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
@@ -747,9 +758,10 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     bool done = false;
     const uint32_t tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     bool wide = !ctx->legacy_ntt && ctx->hc.logn >= 10 && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * ctx->hc.k <= KS_WIDE_MAX_BLOCKS));
-    if (wide) {
-        size_t need = (size_t)cnt * tot_dig * ctx->ctw2 * 8;
-        if (need > ctx->smax) wide = false;
+    const bool split14 = !wide && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14;
+    if (wide || split14) {
+        size_t need = (size_t)cnt * (wide ? tot_dig : 1) * ctx->ctw2 * 8;
+        if (wide && need > ctx->smax) wide = false;
         else if (need > ctx->ks_part_cap) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (ctx->ks_part) HIPCHK(hipFree(ctx->ks_part));
@@ -757,6 +769,21 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
             HIPCHK(hipMalloc(&ctx->ks_part, need));
             ctx->ks_part_cap = need;
         }
+    }
+    if (split14 && !wide) {
+        uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+        const int bits = 64 - __builtin_clzll(qmax);
+        const uint32_t accmax = bits >= 50 ? 1u : (1u << std::min(10, 50 - bits)), k = ctx->hc.k;
+        const size_t lds = (size_t)ntt_lds_words(8192) * 8;
+        if (bits <= 44) hipLaunchKernelGGL((k_keyswitch_split14<ArF64L>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
+                                           (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, accmax);
+        else hipLaunchKernelGGL((k_keyswitch_split14<ArF64>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
+                                (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, accmax);
+        hipLaunchKernelGGL(k_ks_combine14, dim3(cnt * 2 * k * (ctx->hc.n / 512)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ks_part, add0, add1, astride,
+                           out, ctx->dc);
+        HIPCHK(hipGetLastError()); launch_count(ctx, 2);
+        ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot_dig * k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * k;
+        return 0;
     }
     if (key.f64) {
         // lazy FP64 accumulators: |term| <= 2.1 q, keep the sum below 2^52

@@ -25,6 +25,11 @@ struct DevConsts {
     double qd[2 * CN_MAXK + 2], qinvd[2 * CN_MAXK + 2], ninvd[2 * CN_MAXK + 2];
     uint32_t f64ok[2 * CN_MAXK + 2];
     uint32_t q_f64;                  // every coefficient modulus q_j qualifies: ciphertext transforms + key switching run in FP64
+    // N = 16384 key switch as two N/2-point transforms per limb (k_keyswitch_split14): sub-transform h of a 2N'-point transform
+    // uses root[2m' + h m' + g] where a standalone N'-point transform uses root[m' + g]; twdh + ((j*2 + dir)*2 + h)*N' holds those
+    // tables (dir 0 forward, 1 inverse); ninv_w[j] = N^-1 * root^-1[1] closes the last inverse stage
+    double *twdh;
+    uint64_t ninv_w[CN_MAXK];
     // plaintext scaling (Encryptor::preencrypt / add_plain) and fast plain lift (multiply_plain)
     uint64_t t_half, delta[CN_MAXK], rtq[CN_MAXK], lift_inc[CN_MAXK];
     // BEHZ constants (SEAL util/baseconverter.cpp)
@@ -55,3 +60,4 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
                     uint64_t *tw_host, uint32_t *index_map, char *err, size_t errlen);
 int cn_default_coeff_modulus_impl(uint32_t n, uint64_t *q);
 void cn_build_f64_tables(DevConsts *c, const uint64_t *tw_host, double *twd_host);   // twd_host: (k+kb+1)*2*n doubles
+void cn_build_half_tables(DevConsts *c, const uint64_t *tw_host, double *twdh_host);  // twdh_host: k*2*2*(n/2) doubles

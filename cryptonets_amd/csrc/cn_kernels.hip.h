@@ -162,6 +162,17 @@ __global__ void k_mul_scalar(const uint64_t *a, const uint64_t *__restrict__ sc,
 }
 
 // ------------------------------------------------------------------ HOT LOOP A: scalar GEMM
+// Workgroup -> (coefficient chunk, limb, output tile mt, group g).  The mtiles output tiles of one (chunk, limb, g) read the SAME
+// input elements; workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles take ids b, b+8, b+16, ...
+// - same XCD, adjacent in time: the K input elements are fetched from HBM once and re-read from that XCD's L2 (dense 845->100:
+// 5 tiles; without this every tile streamed the 528 MB of input ciphertexts again).
+DEV void gemm_block_coords(uint32_t b, uint32_t chunks, uint32_t limbs, uint32_t mtiles, uint32_t G, uint32_t &chunk, uint32_t &limb, uint32_t &mt, uint32_t &g) {
+    const uint32_t D = chunks * limbs * G;
+    uint32_t d;
+    if ((D & 7) == 0) { const uint32_t r = b >> 3; mt = r % mtiles; d = (r / mtiles) * 8 + (b & 7); }
+    else { d = b % D; mt = b / D; }
+    chunk = d % chunks; limb = (d / chunks) % limbs; g = d / (chunks * limbs);
+}
 // Group g gathers K input ciphertexts idx[g][:] once and produces M outputs (register tile MT):
 //   out[out_idx[g][m]] = sum_k Wl[j][g][m][k] * in[idx[g][k]]  (+ scaled bias)   per limb j, coefficient i.
 // Products accumulate lazily in 128 bits; one Barrett reduction per `lazy` terms.
@@ -171,10 +182,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
                                                      uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
                                                      uint32_t K, uint32_t mtiles, uint32_t lazy) {
     const uint32_t n = C->n, k = C->k, limbs = 2 * k;
-    uint32_t bx = blockIdx.x;
-    const uint32_t chunk = bx % chunks; bx /= chunks;
-    const uint32_t limb = bx % limbs; bx /= limbs;
-    const uint32_t mt = bx % mtiles, g = bx / mtiles;
+    uint32_t chunk, limb, mt, g;
+    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];
@@ -219,10 +228,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
                                                          uint32_t K, uint32_t mtiles, uint32_t lazy) {
     const uint32_t n = C->n, k = C->k, limbs = 2 * k;
-    uint32_t bx = blockIdx.x;
-    const uint32_t chunk = bx % chunks; bx /= chunks;
-    const uint32_t limb = bx % limbs; bx /= limbs;
-    const uint32_t mt = bx % mtiles, g = bx / mtiles;
+    uint32_t chunk, limb, mt, g;
+    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];
@@ -639,6 +646,99 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
         __syncthreads();
     }
 }
+// N = 16384 key switch without spills.  k_keyswitch_rr<14> needs 1024 threads per limb, which caps a thread at 128 VGPRs - the
+// 2 x 16 accumulators + 16 coefficients + twiddles do not fit and go to scratch.  A 2N'-point negacyclic transform is one
+// butterfly stage over (i, i + N') followed by two independent N'-point transforms with re-indexed root tables (DevConsts::twdh),
+// and the key multiply-accumulate is pointwise - so block = (ct, output limb j, half h) runs the N' = 8192 machinery of
+// k_keyswitch_rr<13> (512 threads, 204 VGPRs, no scratch) on its half: stage 0 is folded into the digit load (both inputs of the
+// butterfly are read, one output kept), keys are read at h*N' + position.  The two inverse sub-transforms leave through `half`
+// and k_ks_combine14 applies the last inverse stage (u + v, (u - v) w^-1), the N^-1 scaling and the (c0, c1) addends.
+template <class AR>
+__global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
+                                                                        uint64_t *__restrict__ half, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value, "FP64 policies only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr int L = 13;
+    constexpr uint32_t n2 = 1u << L, n = 2 * n2;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t h = blockIdx.x & 1, j = (blockIdx.x >> 1) % k, ct = blockIdx.x / (2 * k);
+    const DMod qm = C->q[j];
+    const ArCtx<AR> A(C, j);
+    typedef const NTT_GLOBAL double *GP;
+    const typename AR::Tw fwh = {(GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2)}, ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    T acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const T *kp = reinterpret_cast<const T *>(key_);
+    uint32_t terms = 0;
+    for (uint32_t l = 0; l < k; l++) {
+        const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+            const int sh = dbc * (int)d;
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));           // as in k_keyswitch_rr: keep address math and twiddle loads inside the loop
+            T v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t e = pass_index<L, SA, 0>(tl, r);
+                T X = A.load((src[e] >> sh) & mask), Y = A.load((src[e + n2] >> sh) & mask);
+                AR::fwd(X, Y, A.fw, 1, A.m);        // stage 0 of the 2N'-point transform: (x + w y, x - w y), w = root[1]
+                v[r] = h ? Y : X;
+            }
+            AR::renorm(v, A.m);
+            ntt_forward_regs<AR, L>(v, s, fwh, A.m, tl);
+            const T *k0 = kp + (size_t)j * n + (size_t)h * n2, *k1 = k0 + kn;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t pos = tail_index<L>(tl, r);
+                struct alignas(16) P2 { T a, b; };
+                const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+                KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+                KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
+            }
+            if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
+            __syncthreads();
+        }
+    }
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        ntt_inverse_regs<AR, L>(v, s, ivh, A.m, tl);
+        uint64_t *o = half + ((size_t)ct * 2 + p) * kn + (size_t)j * n + (size_t)h * n2;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(tl, r)] = A.canon(v[r]);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict__ half, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
+                                                       size_t add_stride, uint64_t *__restrict__ out, const DevConsts *__restrict__ C) {
+    const uint32_t n = C->n, n2 = n >> 1, k = C->k, chunks = n2 / 256;
+    const uint32_t i = (blockIdx.x % chunks) * 256 + threadIdx.x, limb = blockIdx.x / chunks;      // limb = (ct*2 + p)*k + j
+    const uint32_t j = limb % k, p = (limb / k) & 1, ct = limb / (2 * k);
+    const DMod qm = C->q[j];
+    const uint64_t *x = half + (size_t)limb * n;
+    const uint64_t u = x[i], v = x[i + n2];
+    uint64_t lo = mulmod(addmod(u, v, qm.q), C->ninv[j], qm), hi = mulmod(submod(u, v, qm.q), C->ninv_w[j], qm);
+    const uint64_t *ad = p ? add1 : add0;
+    if (ad) {
+        const uint64_t *a = ad + (size_t)ct * add_stride + (size_t)j * n;
+        lo = addmod(lo, a[i], qm.q); hi = addmod(hi, a[i + n2], qm.q);
+    }
+    uint64_t *o = out + (size_t)limb * n;
+    o[i] = lo; o[i + n2] = hi;
+}
+
 // Latency variant of the key switch for SMALL batches (LoLa: one image = 1..13 ciphertexts per rotation): the fused kernel above
 // runs count*k workgroups, each pushing all digit transforms through one CU in sequence - 5 busy CUs of 256 at count 1.  Here
 // the digit transforms are spread over the chip and the sum is a second launch:

@@ -233,3 +233,21 @@ void cn_build_f64_tables(DevConsts *c, const uint64_t *tw_host, double *twd_host
         c->qd[m] = (double)q; c->qinvd[m] = 1.0 / (double)q; c->ninvd[m] = (double)c->ninv[m];
     }
 }
+
+// half tables of k_keyswitch_split14 (see cn_internal.h); also fills ninv_w
+void cn_build_half_tables(DevConsts *c, const uint64_t *tw_host, double *twdh_host) {
+    const uint32_t n = c->n, n2 = n / 2;
+    for (uint32_t j = 0; j < c->k; j++) {
+        const uint64_t *w = tw_host + (size_t)j * 4 * n, *iw = w + 2 * (size_t)n;
+        for (int dir = 0; dir < 2; dir++) {
+            const uint64_t *src = dir ? iw : w;
+            for (uint32_t h = 0; h < 2; h++) {
+                double *d = twdh_host + ((size_t)(j * 2 + dir) * 2 + h) * n2;
+                d[0] = 0.0;
+                for (uint32_t m = 1; m < n2; m <<= 1)
+                    for (uint32_t g = 0; g < m; g++) d[m + g] = (double)src[2 * m + h * m + g];
+            }
+        }
+        c->ninv_w[j] = (uint64_t)((u128)c->ninv[j] * iw[1] % c->q[j].q);
+    }
+}

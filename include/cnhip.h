@@ -54,7 +54,8 @@ int cn_sync(cn_ctx *ctx);
  * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels;
  * "ks_wide" = -1 (default: automatic for small batches) / 0 / 1 selects the two-launch key switch that spreads the digit
  * transforms of a few ciphertexts over the whole chip (single-image latency) instead of the fused one-launch kernel;
- * "ks_tight" = 1 the 128-VGPR fused variant.  All variants produce identical words. */
+ * "ks_tight" = 1 the 128-VGPR fused variant; "ks_split14" = 1 (default) runs the N = 16384 key switch as two 8192-point
+ * halves per limb (no register spills), 0 = the fused 1024-thread kernel.  All variants produce identical words. */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);

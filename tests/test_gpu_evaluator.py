@@ -358,9 +358,9 @@ def test_concurrent_callers_one_context(rng):
 
 @pytest.mark.parametrize("name,f64", [("tiny", True), ("c3", True), ("c3", False), ("c4", True), ("c5", True), ("default4096", False)])
 def test_key_switch_variants_agree(name, f64, rng):
-    """The fused one-launch key switch (batches) and the two-launch variant that spreads the digit transforms of a few ciphertexts
-    over the chip (single-image latency; automatic below 160 (ct, limb) workgroups) must both give the oracle's words - for
-    relinearisation and for rotations, on the FP64 and on the integer path."""
+    """The fused one-launch key switch (batches), the two-launch variant that spreads the digit transforms of a few ciphertexts
+    over the chip (single-image latency; automatic below 160 (ct, limb) workgroups) and, at N = 16384, the two-halves kernel
+    must all give the oracle's words - for relinearisation and for rotations, on the FP64 and on the integer path."""
     o, g = get_oracle(name, galois=True), get_gpu(name, galois=True, f64=f64)
     vals, cts = enc_batch(o, rng, 3)
     h, out = up(g, cts), g.ct_alloc(3)
@@ -368,8 +368,10 @@ def test_key_switch_variants_agree(name, f64, rng):
     exp_rot = [o.rotate_rows(c, -3) for c in cts]
     exp_col = [o.rotate_columns(c) for c in cts]
     try:
-        for wide in (0, 1):
+        # (ks_wide, ks_split14): fused, two-launch, and - N = 16384 only - the fused 1024-thread kernel instead of the two-halves one
+        for wide, split in ((0, 1), (1, 1)) + (((0, 0),) if o.n == 16384 else ()):
             g.set_option("ks_wide", wide)
+            g.set_option("ks_split14", split)
             for i in range(3):
                 g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
             assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_mul)), wide
@@ -379,5 +381,6 @@ def test_key_switch_variants_agree(name, f64, rng):
             assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_col)), wide
     finally:
         g.set_option("ks_wide", -1)
+        g.set_option("ks_split14", 1)
     for x in (h, out):
         g.free(x)
