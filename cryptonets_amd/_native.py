@@ -93,6 +93,8 @@ SIGNATURES = {
     "cn_apply_galois": (C.c_int, [_CTX, _H, _u32, C.c_uint64, _H, _u32, _u32]),
     "cn_rotate_rows": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _u32]),
     "cn_rotate_columns": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_rotate_rows_add": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _H, _u32, _u32]),
+    "cn_rotate_columns_add": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
     "cn_keygen": (C.c_int, [_CTX, C.c_uint64, C.c_int]),
     "cn_set_public_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
     "cn_set_secret_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
@@ -309,6 +311,13 @@ class Context:
 
     def rotate_rows(self, src, ii, steps, out, oi, count=1):
         self._chk(self.L.cn_rotate_rows(self._h, src, ii, steps, out, oi, count))
+
+    def rotate_rows_add(self, src, ii, steps, acc, ai, out, oi, count=1):
+        """out = acc + RotateRows(src, steps) (fused rotate-and-add of SumAllSlots)"""
+        self._chk(self.L.cn_rotate_rows_add(self._h, src, ii, steps, acc, ai, out, oi, count))
+
+    def rotate_columns_add(self, src, ii, acc, ai, out, oi, count=1):
+        self._chk(self.L.cn_rotate_columns_add(self._h, src, ii, acc, ai, out, oi, count))
 
     def rotate_columns(self, src, ii, out, oi, count=1):
         self._chk(self.L.cn_rotate_columns(self._h, src, ii, out, oi, count))

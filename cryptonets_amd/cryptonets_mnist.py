@@ -26,12 +26,26 @@ def _round_scaled(values, scale):
     return [int(round(float(v) * float(scale))) for v in values]
 
 
-def layer_tables(weights0, weights1, biases2, weights3, biases3):
+def _corner_tiles(eng, gather, tile):
+    """Blocks of tile x tile neighbouring output positions of the convolution and the union of the input pixels they read.
+    All outputs of a block share ONE gather list (taps an output does not use get weight 0), so the scalar GEMM reads each
+    input ciphertext of the block once for tile^2 * maps outputs: 5x5 windows at stride 2 overlap 3/5 per axis, a 2x2 block
+    reads 49 pixels instead of 4 x 25.  Same sums, same ciphertext words - only fewer passes over HBM."""
+    coords = [sorted(set(c[d] for c in eng.Corners)) for d in range(len(eng.Corners[0]))]
+    key = [tuple(coords[d].index(c[d]) // tile for d in range(len(c))) for c in eng.Corners]
+    names = {k: i for i, k in enumerate(sorted(set(key)))}
+    tile_of = [names[k] for k in key]
+    unions = [sorted({int(g) for c, t in enumerate(tile_of) if t == i for g in gather[c] if g >= 0}) for i in range(len(names))]
+    return tile_of, unions
+
+
+def layer_tables(weights0, weights1, biases2, weights3, biases3, conv_tile=2):
     """Integer (scaled, signed) weight / bias tables and gather indices of the three PoolLayers.
 
     weights0: 130 doubles (5 maps x 26, last of each 26 is the bias), weights1: 84500 (845x100, transposed by
     CryptoNets.Transpose, CryptoNets.cs:112-123), weights3: 1000 (10x100).  Returns a list of dicts with
-    idx [O,K] int32, W [O,K] python ints, bias [O] python ints, in the reference's output order (map-major)."""
+    idx [O,K] int32, W [O,K] python ints, bias [O] python ints, in the reference's output order (map-major).
+    conv_tile: outputs of conv_tile x conv_tile neighbouring positions share a gather list (1 = one list per position)."""
     layers = []
     # --- conv (no-bias branch of PoolLayer.Apply, PoolLayer.cs:196-227): kernelSize = 25 + 1
     eng = ConvolutionEngine([28, 28], [5, 5], [2, 2], Upperpadding=[1, 1], MapCount=[5, 1])
@@ -39,15 +53,23 @@ def layer_tables(weights0, weights1, biases2, weights3, biases3):
     gather = eng.gather_table()                                   # [169, 25]
     win = eng.weight_windows(weights0, ks)                        # [5, 25]
     O = eng.maps * len(eng.Corners)
-    idx = np.zeros((O, gather.shape[1]), dtype=np.int32)
+    tile_of, unions = _corner_tiles(eng, gather, conv_tile)
+    kmax = max(len(u) for u in unions)
+    idx = np.full((O, kmax), -1, dtype=np.int32)
     W, bias = [], []
     s_in = INPUT_SCALE
     for m in range(eng.maps):
         wrow = _round_scaled(win[m], WEIGHT_SCALE)
         b = _round_scaled([weights0[(m + 1) * ks - 1]], s_in * WEIGHT_SCALE)[0]
         for c in range(len(eng.Corners)):
-            idx[m * len(eng.Corners) + c] = gather[c]
-            W.append(wrow)
+            u = unions[tile_of[c]]
+            pos = {g: i for i, g in enumerate(u)}
+            row = [0] * kmax
+            for t, g in enumerate(gather[c]):
+                if g >= 0:                                     # padded taps contribute nothing (PoolLayer.cs:68-80: Enc(0))
+                    row[pos[int(g)]] = wrow[t]
+            idx[m * len(eng.Corners) + c, :len(u)] = u
+            W.append(row)
             bias.append(b)
     layers.append(dict(idx=idx, W=W, bias=bias, scale=s_in * WEIGHT_SCALE))
     s = (s_in * WEIGHT_SCALE) ** 2

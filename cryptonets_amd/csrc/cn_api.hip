@@ -58,6 +58,7 @@ struct cn_ctx {
     // (a LoLa inference allocates and frees ~300 temporaries per plaintext prime)
     std::unordered_map<size_t, std::vector<uint64_t *>> pool;
     size_t pool_bytes = 0, pool_max;
+    const uint64_t *ks_extra = nullptr; size_t ks_extra_stride = 0;   // fused "+ accumulator" of the next key switch (cn_*_add entry points)
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     int ks_wide = -1;         // -1 auto (small batches), 0 never, 1 always: two-launch key switch spread over the chip (latency variant)
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
@@ -587,7 +588,8 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
     const uint64_t *bias = BP ? BP->d : nullptr;
     if (small) {
         const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
-        std::vector<double> hWd((size_t)G * mtf * K * MTf, 0.0);          // [g][mtile][kk][m], zero padded
+        std::vector<double> hWd((size_t)G * mtf * K * MTf + 8 * MTf, 0.0);   // [g][mtile][kk][m], zero padded; + 8 rows: the kernel's software
+                                                                               // pipeline reads (and multiplies by 0) up to 7 terms past a block
         for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
             const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
             double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
@@ -710,7 +712,7 @@ template <int L, class AR>
 static void launch_ks_rr(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                          const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
     hipLaunchKernelGGL((k_keyswitch_rr<L, AR>), dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, target, tstride, add0,
-                       add1, astride, (const void *)key, out, c->dc, galois, accmax);
+                       add1, astride, (const void *)key, out, c->dc, galois, accmax, c->ks_extra, c->ks_extra_stride);
 }
 template <class AR>
 static bool launch_ks_by_size(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
@@ -721,7 +723,7 @@ static bool launch_ks_by_size(cn_ctx *c, const uint64_t *target, size_t tstride,
         case 12: launch_ks_rr<12, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
         case 13:
             if (c->ks_tight) hipLaunchKernelGGL((k_keyswitch_rr<13, AR, 4>), dim3(cnt * c->hc.k), dim3(NttPlan<13>::NT), (size_t)ntt_lds_words(1u << 13) * 8, c->stream, target,
-                                                tstride, add0, add1, astride, (const void *)key, out, c->dc, galois, accmax);
+                                                tstride, add0, add1, astride, (const void *)key, out, c->dc, galois, accmax, c->ks_extra, c->ks_extra_stride);
             else launch_ks_rr<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax);
             return true;
         case 14: launch_ks_rr<14, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
@@ -736,7 +738,7 @@ static void launch_ks_wide(cn_ctx *c, const uint64_t *target, size_t tstride, co
     hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
                        galois, tot);
     hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out, c->dc,
-                       tot, accmax);
+                       tot, accmax, c->ks_extra, c->ks_extra_stride);
     launch_count(c);
 }
 template <class AR>
@@ -780,7 +782,8 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
         else hipLaunchKernelGGL((k_keyswitch_split14<ArF64>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
                                 (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, accmax);
         hipLaunchKernelGGL(k_ks_combine14, dim3(cnt * 2 * k * (ctx->hc.n / 512)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ks_part, add0, add1, astride,
-                           out, ctx->dc);
+                           out, ctx->dc, ctx->ks_extra, ctx->ks_extra_stride);
+        ctx->ks_extra = nullptr;
         HIPCHK(hipGetLastError()); launch_count(ctx, 2);
         ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot_dig * k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * k;
         return 0;
@@ -808,7 +811,13 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
             case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
             default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
         }
+        if (ctx->ks_extra) {                 // the radix-2 fallback kernel has no fused accumulator: one element-wise add behind it
+            if (ctx->ks_extra_stride != ctx->ctw2) return fail(CN_ERR_ARG, "internal: accumulator stride");
+            hipLaunchKernelGGL(k_addsub, dim3(cnt * 2 * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, out, ctx->ks_extra, out, ctx->dc, ctx->chunks, 0);
+            launch_count(ctx);
+        }
     }
+    ctx->ks_extra = nullptr;
     HIPCHK(hipGetLastError()); launch_count(ctx);
     uint32_t tot = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot * ctx->hc.k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * ctx->hc.k;
@@ -869,15 +878,18 @@ extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astr
 
 // ---------------------------------------------------------------- rotations
 // in/out device pointers to size-2 ciphertext arrays; tmp holds count size-2 ciphertexts
-static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *out, uint64_t *tmp, uint32_t count) {
+// acc != nullptr: out = acc + galois(in) in the same launches (acc may alias out and/or in)
+static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *out, uint64_t *tmp, uint32_t count, const uint64_t *acc = nullptr) {
     auto it = ctx->gk.find(elt);
     if (it == ctx->gk.end() || !it->second.d) return fail(CN_ERR_NOKEY, "Galois key not present");
+    ctx->ks_extra = acc; ctx->ks_extra_stride = ctx->ctw2;
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     uint32_t limbs = count * 2 * ctx->hc.k;
     hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
     HIPCHK(hipGetLastError()); launch_count(ctx);
     CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second, out, count, 1));
     ctx->st.Rotation += count;
+    if (acc) ctx->st.Addition += count;
     return 0;
 }
 extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t elt, cn_handle out, uint32_t oi, uint32_t count) {
@@ -889,6 +901,11 @@ extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t 
     return do_galois(ctx, I->d + ii * I->item_words, elt, O->d + oi * O->item_words, tmp, count);
 }
 // Evaluator::rotate_internal: direct key if present, otherwise non-adjacent-form decomposition
+static bool has_direct_key(cn_ctx *ctx, int steps) {
+    uint64_t elt = cn_galois_elt_from_step(ctx, steps);
+    auto it = ctx->gk.find(elt);
+    return elt && it != ctx->gk.end() && it->second.d;
+}
 static int rotate_rec(cn_ctx *ctx, uint64_t *cur, int steps, uint64_t *tmp, uint32_t count) {
     if (steps == 0) return 0;
     uint64_t elt = cn_galois_elt_from_step(ctx, steps);
@@ -912,8 +929,40 @@ extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps,
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
     uint64_t *o = O->d + oi * O->item_words; const uint64_t *i = I->d + ii * I->item_words;
+    if (steps != 0 && has_direct_key(ctx, steps)) return do_galois(ctx, i, cn_galois_elt_from_step(ctx, steps), o, tmp, count);   // one hop: no staging copy
     if (o != i) HIPCHK(hipMemcpyAsync(o, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return rotate_rec(ctx, o, steps, tmp, count);
+}
+// out = acc + RotateRows(in, steps): the rotate-and-add step of SumAllSlots (AtomicSealBfvVector.cs:862-868) with the addition
+// fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
+extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    const uint64_t *i = I->d + ii * I->item_words, *a = A->d + ai * A->item_words; uint64_t *o = O->d + oi * O->item_words;
+    if (steps == 0) { CHECK(addsub(ctx, in, ii, acc, ai, out, oi, count, 0)); ctx->st.Addition += count; return 0; }
+    if (has_direct_key(ctx, steps)) {
+        CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+        uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
+        return do_galois(ctx, i, cn_galois_elt_from_step(ctx, steps), o, tmp, count, a);
+    }
+    // multi-hop (NAF) rotation: rotate into a staging array, then one element-wise add
+    CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8) * 2));
+    uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2), *stage = salloc<uint64_t>(ctx, count * ctx->ctw2);
+    HIPCHK(hipMemcpyAsync(stage, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CHECK(rotate_rec(ctx, stage, steps, tmp, count));
+    hipLaunchKernelGGL(k_addsub, dim3(count * 2 * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, a, stage, o, ctx->dc, ctx->chunks, 0);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    ctx->st.Addition += count;
+    return 0;
+}
+extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+    uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
+    return do_galois(ctx, I->d + ii * I->item_words, 2ull * ctx->hc.n - 1, O->d + oi * O->item_words, tmp, count, A->d + ai * A->item_words);
 }
 extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
     return cn_apply_galois(ctx, in, ii, 2ull * ctx->hc.n - 1, out, oi, count);

@@ -193,15 +193,16 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
     const int32_t *gi = idx + (size_t)g * K;
     const uint64_t *gw = Wl + (((size_t)j * G + g) * mtiles + mt) * (size_t)K * MT;      // [kk][m]: the MT weights of a term are contiguous
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
-    uint32_t since = 0;
-    for (uint32_t kk = 0; kk < K; kk++) {
-        const int32_t id = gi[kk];
-        if (id < 0) continue;
-        const uint64_t x = in[(size_t)id * ctw + e];
+    for (uint32_t k0 = 0; k0 < K; k0 += lazy) {            // reduction between blocks of `lazy` terms (see k_scalar_gemm_f64)
+        const uint32_t k1 = min(K, k0 + lazy);
+        for (uint32_t kk = k0; kk < k1; kk++) {
+            const int32_t id = gi[kk];
+            if (id < 0) continue;
+            const uint64_t x = in[(size_t)id * ctw + e];
 #pragma unroll
-        for (int m = 0; m < MT; m++) acc[m] += (u128)x * gw[(size_t)kk * MT + m];           // zero-padded beyond mcnt
-        if (++since == lazy) {
-            since = 0;
+            for (int m = 0; m < MT; m++) acc[m] += (u128)x * gw[(size_t)kk * MT + m];       // zero-padded beyond mcnt
+        }
+        if (k1 < K) {
 #pragma unroll
             for (int m = 0; m < MT; m++) acc[m] = bred128(acc[m], qm);
         }
@@ -257,23 +258,48 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             res[m] = addmod(res[m], r, qm.q);
         }
     };
-    uint32_t since = 0;
-    for (uint32_t kk = 0; kk < K; kk++) {
-        const int32_t id = gi[kk];
-        if (id < 0) continue;
-        const uint64_t x = in[(size_t)id * ctw + e];
-        double xl[NL];
+    // blocks of `lazy` terms with the fold BETWEEN the inner loops: a fold test inside the term loop gets if-converted by the
+    // compiler (the whole 128-bit fold executed every iteration under v_cndmask - 30x the instructions of the 2*MT FMAs)
+    // Software pipeline: a term is one dependent scalar load (gather index) + one global load, ~1 us of latency against
+    // 2*MT*NL FMAs.  Two register sets ping-pong: the input elements of the NEXT PF terms are requested before the FMAs of the
+    // current PF terms are issued.  Fetch and compute are branch-free (padded taps and terms past the block read as x = 0 and
+    // multiply whatever weight row follows - the table carries 8 spare rows), so the waits stay exact.
+    constexpr int PF = 4;
+    auto fetch = [&](uint64_t (&x)[PF], uint32_t kk, uint32_t k1) {
 #pragma unroll
-        for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x >> (l * LW)) & ((1ull << LW) - 1));
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-            const double w = gw[(size_t)kk * MT + m];
-#pragma unroll
-            for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
+        for (int p = 0; p < PF; p++) {
+            const int32_t id = gi[min(kk + p, K - 1)];
+            const bool ok = kk + p < k1 && id >= 0;
+            const uint64_t v = in[(size_t)max(id, 0) * ctw + e];
+            x[p] = ok ? v : 0;
         }
-        if (++since == lazy) { since = 0; fold(); }
+    };
+    auto terms = [&](const uint64_t (&x)[PF], uint32_t kk) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            double xl[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x[p] >> (l * LW)) & ((1ull << LW) - 1));
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const double w = gw[(size_t)(kk + p) * MT + m];
+#pragma unroll
+                for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
+            }
+        }
+    };
+    for (uint32_t k0 = 0; k0 < K; k0 += lazy) {
+        const uint32_t k1 = min(K, k0 + lazy);
+        uint64_t xa[PF], xb[PF];
+        fetch(xa, k0, k1);
+        for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
+            fetch(xb, kk + PF, k1);
+            terms(xa, kk);
+            fetch(xa, kk + 2 * PF, k1);
+            terms(xb, kk + PF);
+        }
+        fold();
     }
-    fold();
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         if ((uint32_t)m < mcnt) {
@@ -576,7 +602,8 @@ template <int RN> struct KsMac<ArF64T<RN>> {
 template <int L, class AR, int MINW = 1>
 __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                                  const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
-                                                                 uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+                                                                 uint64_t *out, const DevConsts *__restrict__ C, int galois, uint32_t accmax,
+                                                                 const uint64_t *extra, size_t ex_stride) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -641,6 +668,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
             const uint32_t e = pass_index<L, SA, 0>(tl, r);
             uint64_t val = A.scaled(v[r]);
             if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], q);
+            if (extra) val = addmod(val, extra[(size_t)ct * ex_stride + (size_t)p * kn + (size_t)j * n + e], q);   // fused "+ accumulator" (may alias out)
             o[e] = val;
         }
         __syncthreads();
@@ -722,7 +750,8 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
     }
 }
 __global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict__ half, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
-                                                       size_t add_stride, uint64_t *__restrict__ out, const DevConsts *__restrict__ C) {
+                                                       size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, const uint64_t *extra,
+                                                       size_t ex_stride) {
     const uint32_t n = C->n, n2 = n >> 1, k = C->k, chunks = n2 / 256;
     const uint32_t i = (blockIdx.x % chunks) * 256 + threadIdx.x, limb = blockIdx.x / chunks;      // limb = (ct*2 + p)*k + j
     const uint32_t j = limb % k, p = (limb / k) & 1, ct = limb / (2 * k);
@@ -734,6 +763,10 @@ __global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict
     if (ad) {
         const uint64_t *a = ad + (size_t)ct * add_stride + (size_t)j * n;
         lo = addmod(lo, a[i], qm.q); hi = addmod(hi, a[i + n2], qm.q);
+    }
+    if (extra) {
+        const uint64_t *x2 = extra + (size_t)ct * ex_stride + ((size_t)p * k + j) * n;
+        lo = addmod(lo, x2[i], qm.q); hi = addmod(hi, x2[i + n2], qm.q);
     }
     uint64_t *o = out + (size_t)limb * n;
     o[i] = lo; o[i + n2] = hi;
@@ -789,8 +822,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
 }
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__restrict__ part_, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
-                                                                 size_t add_stride, uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t tot,
-                                                                 uint32_t accmax) {
+                                                                 size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, uint32_t tot,
+                                                                 uint32_t accmax, const uint64_t *extra, size_t ex_stride) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -823,6 +856,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__re
         const uint32_t e = pass_index<L, SA, 0>(tid, r);
         uint64_t val = A.scaled(v[r]);
         if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], qm.q);
+        if (extra) val = addmod(val, extra[(size_t)ct * ex_stride + (size_t)p * kn + (size_t)j * n + e], qm.q);
         o[e] = val;
     }
 }

@@ -510,8 +510,7 @@ class AtomicSealBfvEncryptedVector:
     @staticmethod
     def _RotateRowsAndAdd(ctx, c_h, c_i, steps, agg_h, agg_i, tmp_h, tmp_i):
         """AtomicSealBfvVector.cs:862-868: agg += RotateRows(c, -steps)"""
-        ctx.rotate_rows(c_h, c_i, -steps, tmp_h, tmp_i, 1)
-        ctx.add(agg_h, agg_i, tmp_h, tmp_i, agg_h, agg_i, 1)
+        ctx.rotate_rows_add(c_h, c_i, -steps, agg_h, agg_i, agg_h, agg_i, 1)      # rotation + AddInplace in one launch chain
 
     def SumAllSlots(self, env, length=None, ForceOutputInColumn=None):
         """AtomicSealBfvVector.cs:877-955 (length None = Int32.MaxValue = full sum)"""
@@ -535,8 +534,7 @@ class AtomicSealBfvEncryptedVector:
         else:
             ctx.copy(self.encData.h, self.encData.first, work.h, 2, 1)
         if length >= slots // 2:
-            ctx.rotate_columns(work.h, 2, work.h, 1, 1)
-            ctx.add(work.h, 2, work.h, 1, work.h, 0, 1)
+            ctx.rotate_columns_add(work.h, 2, work.h, 2, work.h, 0, 1)
             length = slots // 2
         else:
             ctx.copy(work.h, 2, work.h, 0, 1)
@@ -1136,8 +1134,8 @@ class EncryptedSealBfvMatrix:
             ctx, slots = e.ctx, e.SlotCount
             src = v.eVectors[i].encData
             pts = self._row_plaintexts(i, e)
-            work, tmp = _Buf(ctx, "ct", R), _Buf(ctx, "ct", R)
-            wv, tv = work.view(), tmp.view()
+            work = _Buf(ctx, "ct", R)
+            wv = work.view()
             for r in range(R):
                 ctx.copy(src.h, src.first, work.h, r, 1)
             ctx.mul_plain(work.h, 0, pts.h, pts.first, work.h, 0, R)
@@ -1146,13 +1144,11 @@ class EncryptedSealBfvMatrix:
                 raise Exception("Can't sum over less then one element")
             if ln > 1:
                 if ln >= slots // 2:
-                    ctx.rotate_columns(work.h, 0, tmp.h, 0, R)
-                    ctx.add(work.h, 0, tmp.h, 0, work.h, 0, R)
+                    ctx.rotate_columns_add(work.h, 0, work.h, 0, work.h, 0, R)
                     ln = slots // 2
                 steps = 1
                 while steps < ln:
-                    ctx.rotate_rows(work.h, 0, -steps, tmp.h, 0, R)
-                    ctx.add(work.h, 0, tmp.h, 0, work.h, 0, R)
+                    ctx.rotate_rows_add(work.h, 0, -steps, work.h, 0, work.h, 0, R)
                     steps *= 2
             dim = 1 if ln >= slots // 2 else v.Dim
             fmt = EVectorFormat.sparse if ln >= slots else EVectorFormat.dense
@@ -1174,7 +1170,6 @@ class EncryptedSealBfvMatrix:
             elif bias is not None:
                 bp = bias._row_plaintexts(i, e)
                 ctx.add_plain(work.h, 0, bp.h, bp.first, work.h, 0, R)
-            tv.release()
             return work, wv, dim, fmt
         done = _fan_out(env.Environments, one_prime)
         per_prime = [(w, x) for (w, x, _, _) in done]

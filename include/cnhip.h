@@ -131,6 +131,11 @@ int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t galois_elt,
 int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count);
 /* Evaluator.RotateColumns(/Inplace) (AtomicSealBfvVector.cs:709,914,1391) */
 int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count);
+/* out[i] = acc[i] + RotateRows(in[i], steps) / + RotateColumns(in[i]): the rotate-and-add step of SumAllSlots / RotateRowsAndAdd
+ * (AtomicSealBfvVector.cs:862-868, 888-955) with the addition fused into the last key-switch kernel; acc and in may alias
+ * out.  Same words as the rotation followed by cn_add. */
+int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count);
+int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count);
 
 /* ---- client side on the device (what SEAL's KeyGenerator / Encryptor / Decryptor do for
  * AtomicSealBfvEncryptedEnvironment.SetKeys / Encrypt / Decrypt, AtomicSealBfvVector.cs:62-74,1030-1110,1202-1232), for data

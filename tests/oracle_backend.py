@@ -147,6 +147,14 @@ class OracleBackend:
         for i in range(count):
             self.bufs[out][oi + i] = self.o.rotate_rows(self.bufs[src][ii + i], steps)
 
+    def rotate_rows_add(self, src, ii, steps, acc, ai, out, oi, count=1):
+        for c in range(count):
+            self.bufs[out][oi + c] = self.o.add(self.bufs[acc][ai + c], self.o.rotate_rows(self.bufs[src][ii + c], steps))
+
+    def rotate_columns_add(self, src, ii, acc, ai, out, oi, count=1):
+        for c in range(count):
+            self.bufs[out][oi + c] = self.o.add(self.bufs[acc][ai + c], self.o.rotate_columns(self.bufs[src][ii + c]))
+
     def rotate_columns(self, src, ii, out, oi, count=1):
         for i in range(count):
             self.bufs[out][oi + i] = self.o.rotate_columns(self.bufs[src][ii + i])
