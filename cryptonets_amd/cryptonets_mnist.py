@@ -53,8 +53,12 @@ def layer_tables(weights0, weights1, biases2, weights3, biases3, conv_tile=2):
     gather = eng.gather_table()                                   # [169, 25]
     win = eng.weight_windows(weights0, ks)                        # [5, 25]
     O = eng.maps * len(eng.Corners)
-    tile_of, unions = _corner_tiles(eng, gather, conv_tile)
-    kmax = max(len(u) for u in unions)
+    if conv_tile == 1:                                         # the reference's own lists: one per output position, taps in Offsets order
+        tile_of, unions = list(range(len(eng.Corners))), None
+        kmax = gather.shape[1]
+    else:
+        tile_of, unions = _corner_tiles(eng, gather, conv_tile)
+        kmax = max(len(u) for u in unions)
     idx = np.full((O, kmax), -1, dtype=np.int32)
     W, bias = [], []
     s_in = INPUT_SCALE
@@ -62,6 +66,11 @@ def layer_tables(weights0, weights1, biases2, weights3, biases3, conv_tile=2):
         wrow = _round_scaled(win[m], WEIGHT_SCALE)
         b = _round_scaled([weights0[(m + 1) * ks - 1]], s_in * WEIGHT_SCALE)[0]
         for c in range(len(eng.Corners)):
+            if unions is None:
+                idx[m * len(eng.Corners) + c] = gather[c]
+                W.append(wrow)
+                bias.append(b)
+                continue
             u = unions[tile_of[c]]
             pos = {g: i for i, g in enumerate(u)}
             row = [0] * kmax

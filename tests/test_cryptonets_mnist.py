@@ -73,7 +73,7 @@ def int_model_mod_p(x_int, layers, p):
 
 
 def test_layer_tables_match_reference_geometry():
-    L = cm.layer_tables(*weights())
+    L = cm.layer_tables(*weights(), conv_tile=1)
     assert L[0]["idx"].shape == (845, 25) and (L[0]["idx"] < 0).sum() == 129 * 5       # padded taps
     assert len(L[1]["W"]) == 100 and len(L[1]["W"][0]) == 845 and len(L[2]["W"]) == 10
     w0, w1, b2, w3, b3 = weights()
@@ -82,11 +82,24 @@ def test_layer_tables_match_reference_geometry():
     assert L[1]["bias"][5] == int(round(b2[5] * 2 ** 28)) and L[2]["bias"][9] == int(round(b3[9] * 2 ** 61))
 
 
+def test_tiled_conv_tables_are_the_same_sums():
+    """conv_tile=2 (what bench.py runs): 2x2 neighbouring output positions share one gather list of <= 49 pixels; every output
+    still has exactly the reference's (input, weight) terms - the extra entries carry weight 0."""
+    ref, til = cm.layer_tables(*weights(), conv_tile=1)[0], cm.layer_tables(*weights())[0]
+    assert til["idx"].shape == (845, 49) and len({r.tobytes() for r in til["idx"]}) == 49
+    assert til["bias"] == ref["bias"] and til["scale"] == ref["scale"]
+    for o in range(845):
+        want = {(int(g), w) for g, w in zip(ref["idx"][o], ref["W"][o]) if g >= 0 and w != 0}
+        got = {(int(g), w) for g, w in zip(til["idx"][o], til["W"][o]) if g >= 0 and w != 0}
+        assert got == want
+        assert all(w == 0 for g, w in zip(til["idx"][o], til["W"][o]) if g < 0)
+
+
 def test_layer_classes_and_bench_tables_agree():
     """PoolLayer (mirror of the reference class) and cryptonets_mnist.layer_tables (what bench.py runs) derive the same
     integer weights, biases and gather indices."""
     net, (conv, d3, d5) = build_network(None, np.zeros((1, 784)))
-    L = cm.layer_tables(*weights())
+    L = cm.layer_tables(*weights(), conv_tile=1)
     for layer, T in zip((conv, d3, d5), L):
         layer.Prepare()
         corners, maps = len(layer.engine.Corners), layer.engine.maps
