@@ -530,11 +530,11 @@ extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64
 // HOT LOOP A
 template <int MT>
 static void launch_gemm(cn_ctx *ctx, const uint64_t *in, const int32_t *idx, const uint64_t *Wl, const int32_t *oidx, const uint64_t *bias,
-                        const int32_t *bidx, uint64_t *out, uint32_t G, uint32_t M, uint32_t K, uint32_t lazy) {
+                        const int32_t *bidx, uint64_t *out, uint32_t G, uint32_t M, uint32_t K, uint32_t lazy, uint32_t Kp) {
     uint32_t mtiles = (M + MT - 1) / MT;
     size_t blocks = (size_t)ctx->chunks * 2 * ctx->hc.k * mtiles * G;
     hipLaunchKernelGGL(k_scalar_gemm<MT>, dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, in, idx, Wl, oidx, bias, bidx, out, ctx->dc,
-                       ctx->chunks, G, M, K, mtiles, lazy);
+                       ctx->chunks, G, M, K, mtiles, lazy, Kp);
 }
 extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
                               const int32_t *bias_idx, cn_handle out, uint32_t oi) {
@@ -563,20 +563,23 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
     // group outputs that gather the same inputs (PoolLayer: every map of one corner shares its patch)
     std::map<std::vector<int32_t>, std::vector<uint32_t>> groups;
     for (uint32_t o = 0; o < O; o++) groups[std::vector<int32_t>(gidx.begin() + (size_t)o * K, gidx.begin() + (size_t)(o + 1) * K)].push_back(o);
-    uint32_t G = (uint32_t)groups.size(), M = (uint32_t)groups.begin()->second.size();
-    bool uniform = true;
-    for (auto &g : groups) if (g.second.size() != M) uniform = false;
-    std::vector<int32_t> hidx, hoidx, hbidx;
-    if (!uniform) { G = O; M = 1; }
-    hidx.resize((size_t)G * K); hoidx.resize((size_t)G * M); hbidx.assign((size_t)G * M, 0);
-    std::vector<uint32_t> member((size_t)G * M);                 // output index of (group, m)
-    if (uniform) {
+    // groups may differ in size (a tiled convolution has smaller tiles at the border): M = the largest, the missing members of
+    // smaller groups get output index -1 (nothing stored) and all-zero weight rows
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t G = (uint32_t)groups.size(), M = 0;
+    for (auto &g : groups) M = std::max<uint32_t>(M, (uint32_t)g.second.size());
+    const uint32_t Kp = ((K + 7) & ~7u) + 8;                     // gather rows padded with -1 to 16 B multiples (+ 8 spare): the kernels read 4 at a time
+    std::vector<int32_t> hidx((size_t)G * Kp, -1), hoidx((size_t)G * M, -1), hbidx((size_t)G * M, 0);
+    std::vector<uint32_t> member((size_t)G * M, NONE);           // output index of (group, m)
+    {
         uint32_t g = 0;
-        for (auto &kv : groups) { memcpy(&hidx[(size_t)g * K], kv.first.data(), K * 4); for (uint32_t m = 0; m < M; m++) member[(size_t)g * M + m] = kv.second[m]; g++; }
-    } else {
-        for (uint32_t o = 0; o < O; o++) { memcpy(&hidx[(size_t)o * K], &gidx[(size_t)o * K], K * 4); member[o] = o; }
+        for (auto &kv : groups) {
+            memcpy(&hidx[(size_t)g * Kp], kv.first.data(), K * 4);
+            for (uint32_t m = 0; m < kv.second.size(); m++) member[(size_t)g * M + m] = kv.second[m];
+            g++;
+        }
     }
-    for (size_t x = 0; x < member.size(); x++) { hoidx[x] = (int32_t)(oi + member[x]); if (BP) hbidx[x] = bias_idx[member[x]]; }
+    for (size_t x = 0; x < member.size(); x++) if (member[x] != NONE) { hoidx[x] = (int32_t)(oi + member[x]); if (BP) hbidx[x] = bias_idx[member[x]]; }
     // small signed weights (every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
@@ -591,6 +594,7 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
         std::vector<double> hWd((size_t)G * mtf * K * MTf + 8 * MTf, 0.0);   // [g][mtile][kk][m], zero padded; + 8 rows: the kernel's software
                                                                                // pipeline reads (and multiplies by 0) up to 7 terms past a block
         for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+            if (member[(size_t)g * M + m] == NONE) continue;
             const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
             double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
             for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
@@ -602,14 +606,15 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
         const bool two = bits <= 44;                       // 2 limbs of 22 bits, else 3 limbs of 17 bits
         const uint32_t lazy = two ? 1024u : 32768u;        // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
 #define GEMM_F64(MT_) do { uint32_t mtiles = (M + MT_ - 1) / MT_; size_t blocks = (size_t)ctx->chunks * 2 * k * mtiles * G; \
-        if (two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 2, 22>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy); \
-        else hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 3, 17>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy); } while (0)
+        if (two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 2, 22>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp); \
+        else hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 3, 17>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp); } while (0)
         if (M >= 16) GEMM_F64(20); else if (M >= 8) GEMM_F64(10); else if (M >= 3) GEMM_F64(5); else GEMM_F64(1);
 #undef GEMM_F64
     } else {
         const uint32_t MTi = M >= 8 ? 10 : (M >= 3 ? 5 : 1), mti = (M + MTi - 1) / MTi;
         std::vector<uint64_t> hW((size_t)k * G * mti * K * MTi, 0);         // [j][g][mtile][kk][m], zero padded
         for (uint32_t j = 0; j < k; j++) for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+            if (member[(size_t)g * M + m] == NONE) continue;
             const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
             uint64_t *dst = &hW[((((size_t)j * G + g) * mti + m / MTi) * K) * MTi + m % MTi];
             for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
@@ -620,9 +625,9 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
         CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hW.data(), hW.size(), &dW));
         // lazy-reduction interval: K' products of two values < q_max fit in 128 bits
         uint32_t lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
-        if (M >= 8) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
-        else if (M >= 3) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
-        else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy);
+        if (M >= 8) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp);
+        else if (M >= 3) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp);
+        else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp);
     }
     HIPCHK(hipGetLastError()); launch_count(ctx);
     for (size_t x = 0; x < (size_t)O * K; x++) if (W[x] && gidx[x] >= 0) { ctx->st.PlainMultiplication++; ctx->st.Addition++; }

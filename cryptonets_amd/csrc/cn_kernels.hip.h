@@ -180,7 +180,7 @@ template <int MT>
 __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const uint64_t *__restrict__ Wl,
                                                      const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
                                                      uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                     uint32_t K, uint32_t mtiles, uint32_t lazy) {
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp) {
     const uint32_t n = C->n, k = C->k, limbs = 2 * k;
     uint32_t chunk, limb, mt, g;
     gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
     u128 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = 0;
-    const int32_t *gi = idx + (size_t)g * K;
+    const int32_t *gi = idx + (size_t)g * Kp;                                            // row pitch Kp: 16 B aligned, -1 beyond K
     const uint64_t *gw = Wl + (((size_t)j * G + g) * mtiles + mt) * (size_t)K * MT;      // [kk][m]: the MT weights of a term are contiguous
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
     for (uint32_t k0 = 0; k0 < K; k0 += lazy) {            // reduction between blocks of `lazy` terms (see k_scalar_gemm_f64)
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
     }
 #pragma unroll
     for (int m = 0; m < MT; m++) {
-        if ((uint32_t)m < mcnt) {
+        if ((uint32_t)m < mcnt && out_idx[g * M + mt * MT + m] >= 0) {          // -1: padding member of a smaller group
             const uint32_t o = g * M + mt * MT + m;
             uint64_t r = bred128(acc[m], qm);
             if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
@@ -227,7 +227,7 @@ template <int MT, int NL, int LW>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const double *__restrict__ Wd,
                                                          const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                         uint32_t K, uint32_t mtiles, uint32_t lazy) {
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp) {
     const uint32_t n = C->n, k = C->k, limbs = 2 * k;
     uint32_t chunk, limb, mt, g;
     gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 #pragma unroll
         for (int l = 0; l < NL; l++) acc[l][m] = 0.0;
     }
-    const int32_t *gi = idx + (size_t)g * K;
+    const int32_t *gi = idx + (size_t)g * Kp;                                            // row pitch Kp: 16 B aligned, -1 beyond K
     const double *gw = Wd + ((size_t)g * mtiles + mt) * (size_t)K * MT;                  // [kk][m], zero-padded
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
     auto fold = [&]() {
@@ -266,11 +266,13 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     // multiply whatever weight row follows - the table carries 8 spare rows), so the waits stay exact.
     constexpr int PF = 4;
     auto fetch = [&](uint64_t (&x)[PF], uint32_t kk, uint32_t k1) {
+        // ONE 16 B scalar load for the PF gather indices (four dependent s_load_dword + wait chains cost more than the FMAs)
+        const int4 ids = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4), 16));
+        const int32_t id[PF] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
         for (int p = 0; p < PF; p++) {
-            const int32_t id = gi[min(kk + p, K - 1)];
-            const bool ok = kk + p < k1 && id >= 0;
-            const uint64_t v = in[(size_t)max(id, 0) * ctw + e];
+            const bool ok = kk + p < k1 && id[p] >= 0;
+            const uint64_t v = in[(size_t)max(id[p], 0) * ctw + e];
             x[p] = ok ? v : 0;
         }
     };
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     }
 #pragma unroll
     for (int m = 0; m < MT; m++) {
-        if ((uint32_t)m < mcnt) {
+        if ((uint32_t)m < mcnt && out_idx[g * M + mt * MT + m] >= 0) {
             const uint32_t o = g * M + mt * MT + m;
             uint64_t r = res[m];
             if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
@@ -610,6 +612,10 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
     constexpr uint32_t n = 1u << L;
     constexpr int SA = NttPlan<L>::SA;
     const uint32_t k = C->k, tid = threadIdx.x;
+    // (ct, j) with j fastest: the k workgroups of a ciphertext run together and share its source limbs through L2 / MALL.  (A
+    // limb-major order that lets an XCD's workgroups share one key slice in L2 was measured: no gain at N = 8192 - the 15.6 MB of
+    // keys stream from the infinity cache fast enough - and 30 % slower at N = 16384, where the source limbs then come from HBM
+    // once per (limb, half) workgroup.)
     const uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
     const DMod qm = C->q[j];
     const uint64_t q = qm.q;

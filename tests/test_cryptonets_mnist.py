@@ -83,9 +83,9 @@ def test_layer_tables_match_reference_geometry():
 
 
 def test_tiled_conv_tables_are_the_same_sums():
-    """conv_tile=2 (what bench.py runs): 2x2 neighbouring output positions share one gather list of <= 49 pixels; every output
-    still has exactly the reference's (input, weight) terms - the extra entries carry weight 0."""
-    ref, til = cm.layer_tables(*weights(), conv_tile=1)[0], cm.layer_tables(*weights())[0]
+    """conv_tile=2: 2x2 neighbouring output positions share one gather list of <= 49 pixels; every output still has exactly the
+    reference's (input, weight) terms - the extra entries carry weight 0."""
+    ref, til = cm.layer_tables(*weights(), conv_tile=1)[0], cm.layer_tables(*weights(), conv_tile=2)[0]
     assert til["idx"].shape == (845, 49) and len({r.tobytes() for r in til["idx"]}) == 49
     assert til["bias"] == ref["bias"] and til["scale"] == ref["scale"]
     for o in range(845):

@@ -138,6 +138,18 @@ def test_scalar_gemm(name, rng):
     out2 = g.ct_alloc(O2)
     g.scalar_gemm(h, W2, out2, 0)
     assert np.array_equal(g.ct_download(out2, 0, O2), o.scalar_gemm(cts, W2))
+    # groups of different sizes (tiled convolution: border tiles hold fewer outputs) - 6, 3 and 1 outputs sharing a gather list,
+    # interleaved in the output order, for general and for small signed weights
+    rows = [corners[0]] * 6 + [corners[1]] * 3 + [corners[2]]
+    perm = rng.permutation(len(rows))
+    idx3 = np.stack([rows[i] for i in perm]).astype(np.int32)
+    for W3 in (rng.integers(0, o.t, size=(10, K), dtype=np.uint64),
+               (rng.integers(-min(500, (o.t - 1) // 2), min(500, (o.t - 1) // 2) + 1, size=(10, K)) % o.t).astype(np.uint64)):
+        W3[:, 0] = 1                                              # every output keeps a non-zero term
+        out3 = g.ct_alloc(10)
+        g.scalar_gemm(h, W3, out3, 0, idx=idx3)
+        assert np.array_equal(g.ct_download(out3, 0, 10), o.scalar_gemm(cts, W3, idx3))
+        g.free(out3)
     # an output with no non-zero term is an error (reference: AddMany of an empty list)
     from cryptonets_amd._native import CnError
     W2[3] = 0
