@@ -631,6 +631,13 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
     for (uint32_t l = 0; l < k; l++) {
         const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
         const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        uint64_t raw[16];                          // the source words of limb l stay in registers for all of its digits
+        {
+            uint32_t t0 = tid;
+            asm volatile("" : "+v"(t0));
+#pragma unroll
+            for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
+        }
         for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
             const int sh = dbc * (int)d;
             uint32_t tl = tid;
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
             T v[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                uint64_t t = (src[pass_index<L, SA, 0>(tl, r)] >> sh) & mask;      // L2-resident re-read per digit
+                uint64_t t = (raw[r] >> sh) & mask;
                 if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
                 v[r] = A.load(t);                  // F64: the first recentring of the transform reduces digits >= q_j
             }

@@ -2,6 +2,8 @@
 // What SEALContext.Create / SmallNTTTables / BaseConverter::generate compute inside SEAL 3.2
 // for `AtomicSealBfvEncryptedEnvironment.GenerateEncryptionKeys` (AtomicSealBfvVector.cs:163-173).
 #include "cn_internal.h"
+#include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -120,6 +122,32 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
     std::vector<uint64_t> bsk(k + 1);
     for (uint32_t i = 0; i < k; i++) bsk[i] = aux[i + 2];
     bsk[k] = aux[0];
+    // FP64-friendly auxiliary base.  The words BEHZ multiplication returns do not depend on WHICH primes form Bsk: the m~-corrected
+    // extension represents the same integer (c + u q)/m~ in any base, the tensor product is an integer convolution, fast_floor
+    // yields floor(t d / q) - beta with beta a function of the q-base residues only, and the Shenoy-Kumaresan conversion back to q
+    // is exact whenever |floor(t d / q)| < B m_sk / 2.  SEAL's k+1 primes of 61 bits need integer (Shoup) transforms; k+1 primes just
+    // below 2^49 run on the exact-FP64 transform kernels like the data primes do.  Used when every q_j < 2^49 and the base is large
+    // enough with 2 bits to spare:  log2(t) + log2(N) + log2(q) + 2 < log2(B m_sk)   (|d| <= N q^2 / 2 (1 + eps)).
+    // CN_SEAL_AUX=1 keeps SEAL's base (A/B runs and the parity test that both bases give the oracle's words).
+    {
+        bool small = !(getenv("CN_SEAL_AUX") && atoi(getenv("CN_SEAL_AUX")));
+        long double need = log2l((long double)t) + (long double)c->logn + 2.0L;
+        for (uint32_t j = 0; j < k; j++) { if (q[j] >> 49) small = false; need += log2l((long double)q[j]); }
+        if (small) {
+            std::vector<uint64_t> sm;
+            for (uint64_t x = (1ull << 49) - 2ull * n + 1; sm.size() < (size_t)k + 1 && x > (1ull << 48); x -= 2ull * n) {
+                bool used = false;
+                for (uint32_t j = 0; j < k; j++) if (q[j] == x) used = true;
+                if (!used && is_prime_u64(x)) sm.push_back(x);
+            }
+            long double have = 0;
+            for (uint64_t x : sm) have += log2l((long double)x);
+            if (sm.size() == (size_t)k + 1 && need < have) {
+                for (uint32_t i = 0; i < k; i++) bsk[i] = sm[i + 1];
+                bsk[k] = sm[0];
+            }
+        }
+    }
     for (uint32_t i = 0; i <= k; i++) set_mod(c->bsk[i], bsk[i]);
     // twiddles
     for (uint32_t m = 0; m < k + c->kb; m++) {

@@ -396,3 +396,29 @@ def test_key_switch_variants_agree(name, f64, rng):
         g.set_option("ks_split14", 1)
     for x in (h, out):
         g.free(x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c3"])
+def test_behz_auxiliary_base_does_not_change_the_words(name, rng, monkeypatch):
+    """libcnhip extends to k+1 auxiliary primes just below 2^49 (exact-FP64 transforms) where SEAL - and the oracle - use k+1 primes
+    of 61 bits: the product ciphertext is the same integer polynomial floor(t d / q) - beta reduced mod q_j for ANY sufficiently
+    large auxiliary base.  CN_SEAL_AUX=1 selects SEAL's base (integer transforms on the Bsk limbs); both must equal the oracle."""
+    from cryptonets_amd._native import Context
+    o = get_oracle(name, galois=False)
+    p = PARAMS[name]
+    vals, cts = enc_batch(o, rng, 3)
+    exp = [o.relinearize(o.multiply(cts[i], cts[(i + 1) % 3])) for i in range(3)]
+    exp3 = o.multiply(cts[0], cts[1])
+    for seal_aux in ("1", "0"):
+        monkeypatch.setenv("CN_SEAL_AUX", seal_aux)
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        g.set_relin_key(o.relin_key())
+        h, out, out3 = up(g, cts), g.ct_alloc(3), g.ct_alloc(1, 3)
+        g.multiply(h, 0, h, 1, out3, 0, 1)
+        assert np.array_equal(g.ct_download(out3, 0, 1, size=3)[0], exp3), seal_aux
+        for i in range(3):
+            g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
+        assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp)), seal_aux
+        g.mul_relin(h, 0, h, 0, out, 0, 3)                          # squares
+        assert np.array_equal(g.ct_download(out, 0, 3), o.mul_relin_batch(cts, cts)), seal_aux
+        g.close()
