@@ -225,6 +225,15 @@ template <class AR, int L> NTT_DEV void inv_tail(typename AR::T (&x)[16], const 
     }
 }
 
+// The exchange between the two middle passes never leaves a wave: after pass A the transform splits into independent blocks of
+// 2^(8+D) coefficients, and passes B and C of such a block are both owned by the same 2^(4+D) <= 64 consecutive threads.  LDS
+// operations of one wave execute in order, so that exchange needs no workgroup barrier - only a scheduling fence.  (One of three
+// s_barrier per transform removed; with 2 waves per SIMD that share every barrier, barrier stalls are the main idle time.)
+NTT_DEV void ntt_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // Forward transform.  In: x[r] = coefficient pass_index<L,SA,0>(tid,r) (canonical).  Out: x[r] = value at bit-reversed
 // position tail_index<L>(tid,r), lazy (U64: [0,4q); F64: |x| <= 4.5q).  `s` = LDS scratch of ntt_lds_words(N) elements.
 template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
@@ -237,7 +246,7 @@ template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16]
     AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_stages<AR, L, 4, SA>(x, tw, m, tid);
     lds_put<T, L, 4, SA>(x, s, tid);
-    __syncthreads();
+    ntt_wave_sync();                      // pass B -> C stays inside the 2^(4+D) threads that own one 2^(8+D)-coefficient block
     lds_get<T, L, 4, SA + 4>(x, s, tid);
     AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
@@ -260,7 +269,7 @@ template <class AR, int L> NTT_DEV void ntt_inverse_regs(typename AR::T (&x)[16]
     AR::template renorm_at<RS_INV_C>(x, m);
     inv_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     lds_put<T, L, 4, SA + 4>(x, s, tid);
-    __syncthreads();
+    ntt_wave_sync();                      // pass C -> B: wave-local, see ntt_forward_regs
     lds_get<T, L, 4, SA>(x, s, tid);
     AR::template renorm_at<RS_INV_B>(x, m);
     inv_stages<AR, L, 4, SA>(x, tw, m, tid);
