@@ -153,6 +153,11 @@ def main():
         gg.free(dh)
         verified = verified and bool(np.array_equal(got, cm.model_mod_p(x_int[:256], layers, gg.t)))
 
+    if dist is not None:                                  # every rank checked its own batch: report the conjunction
+        flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
+
     # ---- roofline of the dominant kernel: the batched N=8192 RNS NTT, timed with HIP events on the ctx stream
     g = chans[0].g
     limbs = 845 * 2 * g.k
