@@ -86,6 +86,80 @@ class InputLayer(BaseLayer):
         return self.Scale
 
 
+class BatchReader(BaseLayer):
+    """NeuralNetworks/BatchReader.cs: the reference's TSV input layer.  Sparse format (default, `DataPreprocess/GetMNIST.cs`
+    output): `label <TAB> dim <TAB> index:value <TAB> ...`; dense format: one value per column, the label in `LabelColumn`
+    (no label when LabelColumn >= the column count).  GetNext reads up to MaxSlots lines = one batch (one sample per slot),
+    values times NormalizationFactor, stored at Scale; `Labels` holds the batch's labels (:59-109)."""
+
+    def __init__(self, FileName=None, MaxSlots=-1, NormalizationFactor=1.0, Scale=1.0, SparseFormat=True, LabelColumn=0, Factory=None):
+        super().__init__(None, Factory)
+        self.MaxSlots, self.NormalizationFactor, self.Scale = MaxSlots, NormalizationFactor, Scale
+        self.SparseFormat, self.LabelColumn = SparseFormat, LabelColumn
+        self.Labels, self._sr, self._dim = None, None, -1
+        if FileName is not None:
+            self.FileName = FileName
+
+    @property
+    def FileName(self):
+        return self._file_name
+
+    @FileName.setter
+    def FileName(self, value):
+        self._file_name = value
+        if self._sr is not None:
+            self._sr.close()
+        self._sr = open(value, "r")
+        self._dim = -1
+
+    def PrepareNetwork(self):
+        self.Prepare()
+
+    def Apply(self, m):
+        return self.GetNext()
+
+    def GetNext(self):
+        labels, rows = [], []
+        while len(labels) < self.MaxSlots:
+            line = self._sr.readline()
+            if line == "":
+                break
+            f = line.rstrip("\r\n").split("\t")
+            if self.SparseFormat:
+                labels.append(int(f[0]))
+                self._dim = int(f[1])
+                row = np.zeros(self._dim)
+                for item in f[2:]:
+                    c, v = item.split(":")
+                    row[int(c)] = float(v) * self.NormalizationFactor
+            else:
+                dim = len(f)
+                if self.LabelColumn >= dim:
+                    labels.append(2 ** 31 - 1)
+                    row = np.array([float(x) for x in f])
+                else:
+                    labels.append(int(f[self.LabelColumn]))
+                    row = np.array([float(x) for k, x in enumerate(f) if k != self.LabelColumn])
+                self._dim = len(row)
+                row = row * self.NormalizationFactor
+            rows.append(row)
+        self.Labels = np.array(labels, dtype=np.int64)
+        if not rows:
+            raise Exception("BatchReader: end of file")
+        return RawData(np.stack(rows), self.Scale)
+
+    def GetOutputScale(self):
+        return self.Scale
+
+    def OutputDimension(self):
+        return self._dim
+
+    def Dispose(self):
+        if self._sr is not None:
+            self._sr.close()
+            self._sr = None
+
+
 class EncryptLayer(BaseLayer):
     """NeuralNetworks/EncryptLayer.cs:12-19: encrypt the already-scaled integers at scale 1, then register the scale."""
 

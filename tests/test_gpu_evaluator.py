@@ -422,3 +422,41 @@ def test_behz_auxiliary_base_does_not_change_the_words(name, rng, monkeypatch):
         g.mul_relin(h, 0, h, 0, out, 0, 3)                          # squares
         assert np.array_equal(g.ct_download(out, 0, 3), o.mul_relin_batch(cts, cts)), seal_aux
         g.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4", "c5"])
+def test_fused_rotate_and_add(name, rng):
+    """cn_rotate_rows_add / cn_rotate_columns_add = rotation followed by cn_add, word for word: direct keys, NAF multi-hop
+    steps, step 0, in-place accumulators (agg += rot(c), work = work + rot(work)) and both key-switch variants."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    vals, cts = enc_batch(o, rng, 4)
+    h, out = up(g, cts), g.ct_alloc(2)
+    half = o.n // 2
+    try:
+        for wide in (0, 1):
+            g.set_option("ks_wide", wide)
+            for steps in (-1, 4, -3, 7 if half > 7 else 3, 0):
+                g.rotate_rows_add(h, 0, steps, h, 2, out, 0, 2)
+                got = g.ct_download(out, 0, 2)
+                for i in range(2):
+                    rot = cts[i] if steps == 0 else o.rotate_rows(cts[i], steps)
+                    assert np.array_equal(got[i], o.add(cts[i + 2], rot)), (wide, steps)
+            g.rotate_columns_add(h, 0, h, 2, out, 0, 2)
+            got = g.ct_download(out, 0, 2)
+            for i in range(2):
+                assert np.array_equal(got[i], o.add(cts[i + 2], o.rotate_columns(cts[i])))
+            # in place: out = out + rot(out) (SumAllSlots step), then agg += rot(c)
+            g.copy(h, 0, out, 0, 2)
+            g.rotate_rows_add(out, 0, -2, out, 0, out, 0, 2)
+            exp = [o.add(c, o.rotate_rows(c, -2)) for c in cts[:2]]
+            assert np.array_equal(g.ct_download(out, 0, 2), np.stack(exp))
+            g.rotate_rows_add(h, 2, -5, out, 0, out, 0, 2)
+            exp = [o.add(e, o.rotate_rows(c, -5)) for e, c in zip(exp, cts[2:])]
+            assert np.array_equal(g.ct_download(out, 0, 2), np.stack(exp))
+    finally:
+        g.set_option("ks_wide", -1)
+    from cryptonets_amd._native import CnError
+    with pytest.raises(CnError):
+        g.rotate_rows_add(h, 3, 1, h, 0, out, 0, 2)                # source range runs past the array
+    for x in (h, out):
+        g.free(x)

@@ -111,3 +111,28 @@ def test_small_cnn_end_to_end(backend):
     assert dec.shape == (samples, 3)
     assert np.array_equal(dec, y3.astype(float))
     out.Dispose()
+
+
+def test_batch_reader_tsv_formats(tmp_path):
+    """NeuralNetworks/BatchReader.cs:59-109: sparse `label dim idx:val ...` and dense TSV lines, MaxSlots lines per batch,
+    NormalizationFactor applied to the values, RawMatrix rounding at Scale."""
+    from cryptonets_amd.layers import BatchReader
+    sparse = tmp_path / "mnist.tsv"
+    sparse.write_text("7\t6\t1:255\t4:128\n2\t6\t0:64\n9\t6\n")
+    r = BatchReader(str(sparse), MaxSlots=2, NormalizationFactor=1.0 / 256.0, Scale=16.0)
+    b = r.GetNext()
+    assert list(r.Labels) == [7, 2] and b.Scale == 16.0 and r.OutputDimension() == 6
+    assert np.array_equal(b.Data, np.array([[0, 16, 0, 0, 8, 0], [4, 0, 0, 0, 0, 0]], dtype=float))      # round(v/256*16)
+    b = r.GetNext()                                                # the remaining line
+    assert list(r.Labels) == [9] and not b.Data.any()
+    with pytest.raises(Exception):
+        r.GetNext()
+    dense = tmp_path / "dense.tsv"
+    dense.write_text("1.5\t3\t-2\n0.25\t5\t4\n")
+    r = BatchReader(str(dense), MaxSlots=8, SparseFormat=False, LabelColumn=1, Scale=4.0)
+    b = r.GetNext()
+    assert list(r.Labels) == [3, 5] and np.array_equal(b.Data, np.array([[6, -8], [1, 16]], dtype=float))
+    r = BatchReader(str(dense), MaxSlots=1, SparseFormat=False, LabelColumn=7, Scale=1.0)          # no label column
+    b = r.GetNext()
+    assert r.Labels[0] == 2 ** 31 - 1 and b.Data.shape == (1, 3)
+    r.Dispose()
