@@ -638,10 +638,12 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
 
 // ---------------------------------------------------------------- BEHZ multiply / key switching
 template <int K> static void launch_extend(cn_ctx *c, const uint64_t *src, uint32_t stride, uint64_t *aq, uint64_t *ab, uint32_t cnt) {
-    hipLaunchKernelGGL(k_behz_extend<K>, dim3(cnt * 2 * c->chunks), dim3(c->bs), 0, c->stream, src, stride, aq, ab, c->dc, c->chunks);
+    if (c->hc.behz_f64 && c->use_f64) hipLaunchKernelGGL(k_behz_extend_f64<K>, dim3(cnt * 2 * c->chunks), dim3(c->bs), 0, c->stream, src, stride, aq, ab, c->dc, c->chunks);
+    else hipLaunchKernelGGL(k_behz_extend<K>, dim3(cnt * 2 * c->chunks), dim3(c->bs), 0, c->stream, src, stride, aq, ab, c->dc, c->chunks);
 }
 template <int K> static void launch_floor(cn_ctx *c, const uint64_t *dq, const uint64_t *db, uint64_t *out, uint32_t cnt) {
-    hipLaunchKernelGGL(k_behz_floor<K>, dim3(cnt * 3 * c->chunks), dim3(c->bs), 0, c->stream, dq, db, out, c->dc, c->chunks);
+    if (c->hc.behz_f64 && c->use_f64) hipLaunchKernelGGL(k_behz_floor_f64<K>, dim3(cnt * 3 * c->chunks), dim3(c->bs), 0, c->stream, dq, db, out, c->dc, c->chunks);
+    else hipLaunchKernelGGL(k_behz_floor<K>, dim3(cnt * 3 * c->chunks), dim3(c->bs), 0, c->stream, dq, db, out, c->dc, c->chunks);
 }
 #define DISPATCH_K(fn, ...) switch (ctx->hc.k) { \
     case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; \

@@ -46,6 +46,14 @@ struct DevConsts {
     uint64_t fl_T_bsk[CN_MAXK + 1];            // t * q^-1 mod b
     uint64_t fl_N_bsk[CN_MAXK + 1][CN_MAXK];   // b - ((q/q_j mod b) * q^-1 mod b)
     uint64_t fl_A_msk[CN_MAXK];                // (B/b_j mod m_sk) * B^-1 mod m_sk
+    // FP64 image of the folded BEHZ constants (exact: every value < 2^49), used by k_behz_extend_f64 / k_behz_floor_f64 when all
+    // data AND auxiliary primes are below 2^49 (behz_f64 = 1)
+    uint32_t behz_f64;
+    struct BehzD {
+        double mt_inv_qhat_q[CN_MAXK], ex_R_bsk[CN_MAXK + 1], ex_Q_bsk[CN_MAXK + 1][CN_MAXK];
+        double fl_c1_q[CN_MAXK], fl_T_bsk[CN_MAXK + 1], fl_N_bsk[CN_MAXK + 1][CN_MAXK];
+        double inv_bhat_b[CN_MAXK], fl_A_msk[CN_MAXK], inv_B_msk, bhat_q[CN_MAXK][CN_MAXK], B_q[CN_MAXK];
+    } bd;
     // decryption with the {t, gamma} BEHZ rounding (SEAL decryptor.cpp)
     DMod gamma;
     uint64_t tg_q[CN_MAXK], qhat_t[CN_MAXK], qhat_g[CN_MAXK], neg_inv_q_t, neg_inv_q_g, inv_g_t;

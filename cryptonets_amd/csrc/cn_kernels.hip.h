@@ -344,6 +344,82 @@ __global__ void __launch_bounds__(256) k_behz_extend(const uint64_t *__restrict_
         ob[(size_t)b * n] = bred128(acc, bm);
     }
 }
+// The same two element-wise steps in exact FP64 (DevConsts::behz_f64: every data and auxiliary prime < 2^49).  The integer
+// versions spend ~2700 / ~1450 VALU instructions per coefficient, mostly in 128-bit Barrett reductions and 64x64->128
+// products assembled from 32-bit pieces; here a term of a base conversion is ArF64::mulmod (6 FP64 instructions, |r| <= 2.1 p), a
+// conversion of <= 6 terms is summed exactly in one double and reduced once.  Representatives: the CRT coefficients
+// y_j = [x (q/q_j)^-1]_{q_j} MUST be canonical (another representative changes the q-overflow count and with it the words
+// SEAL produces); residues that are only re-reduced (f_b, z_j, alpha) may stay lazy - z_j + s b_j shifts the Shenoy-Kumaresan
+// sum by s B and alpha by s, which cancels.
+typedef ArF64T<1> BzF;
+DEV double bz_canon(double x, const BzF::Mod &m) { double r = BzF::center(x, m); return r < 0.0 ? __dadd_rn(r, m.q) : r; }
+template <int K>
+__global__ void __launch_bounds__(256) k_behz_extend_f64(const uint64_t *__restrict__ src, uint32_t stride, uint64_t *__restrict__ aq, uint64_t *__restrict__ ab,
+                                                         const DevConsts *__restrict__ C, uint32_t chunks) {
+    const uint32_t n = C->n;
+    const uint32_t cp = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;   // cp = ct*2 + poly
+    const uint32_t ct = cp >> 1, p = cp & 1;
+    const uint64_t *x = src + ((size_t)ct * stride * 2 + p) * K * n + i;
+    uint64_t *oq = aq + (size_t)cp * K * n + i, *ob = ab + (size_t)cp * (K + 1) * n + i;
+    double y[K];
+    uint32_t mt = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint64_t v = x[(size_t)j * n];
+        oq[(size_t)j * n] = v;
+        const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
+        y[j] = bz_canon(BzF::mulmod(BzF::from_u64(v), C->bd.mt_inv_qhat_q[j], mq), mq);       // canonical: feeds the mod-m~ sum
+        mt += (uint32_t)__double_as_longlong(__dadd_rn(y[j], 4503599627370496.0)) * (uint32_t)C->qhat_mt[j];   // low 32 bits of y (exact integer < 2^49)
+    }
+    const double r = (double)(int32_t)(0u - mt * (uint32_t)C->inv_q_mt);                       // centred r = -x q^-1 mod m~ = 2^32
+#pragma unroll
+    for (int b = 0; b <= K; b++) {
+        const BzF::Mod mb = {C->qd[K + b], C->qinvd[K + b]};
+        double acc = BzF::mulmod(r, C->bd.ex_R_bsk[b], mb);
+#pragma unroll
+        for (int j = 0; j < K; j++) acc = __dadd_rn(acc, BzF::mulmod(y[j], C->bd.ex_Q_bsk[b][j], mb));
+        ob[(size_t)b * n] = BzF::to_u64(acc, mb);
+    }
+}
+template <int K>
+__global__ void __launch_bounds__(256) k_behz_floor_f64(const uint64_t *__restrict__ dq, const uint64_t *__restrict__ db, uint64_t *__restrict__ out,
+                                                        const DevConsts *__restrict__ C, uint32_t chunks) {
+    const uint32_t n = C->n;
+    const uint32_t cp = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;   // cp = ct*3 + poly
+    const uint64_t *xq = dq + (size_t)cp * K * n + i, *xb = db + (size_t)cp * (K + 1) * n + i;
+    uint64_t *o = out + (size_t)cp * K * n + i;
+    double y[K], f[K + 1], z[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
+        y[j] = bz_canon(BzF::mulmod(BzF::from_u64(xq[(size_t)j * n]), C->bd.fl_c1_q[j], mq), mq);     // [x t (q/q_j)^-1]_{q_j}, canonical
+    }
+#pragma unroll
+    for (int b = 0; b <= K; b++) {
+        const BzF::Mod mb = {C->qd[K + b], C->qinvd[K + b]};
+        double acc = BzF::mulmod(BzF::from_u64(xb[(size_t)b * n]), C->bd.fl_T_bsk[b], mb);          // (x_b t - conv_b) q^-1, folded
+#pragma unroll
+        for (int j = 0; j < K; j++) acc = __dadd_rn(acc, BzF::mulmod(y[j], C->bd.fl_N_bsk[b][j], mb));
+        f[b] = acc;                                                                                    // |f| <= 12.6 b < 2^53
+    }
+    const BzF::Mod msk = {C->qd[2 * K], C->qinvd[2 * K]};
+    double acc = BzF::mulmod(-f[K], C->bd.inv_B_msk, msk);
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const BzF::Mod mb = {C->qd[K + j], C->qinvd[K + j]};
+        z[j] = BzF::mulmod(f[j], C->bd.inv_bhat_b[j], mb);
+        acc = __dadd_rn(acc, BzF::mulmod(z[j], C->bd.fl_A_msk[j], msk));
+    }
+    const double alpha = BzF::center(acc, msk);                                                        // centred alpha_sk
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
+        double a2 = BzF::mulmod(-alpha, C->bd.B_q[j], mq);
+#pragma unroll
+        for (int l = 0; l < K; l++) a2 = __dadd_rn(a2, BzF::mulmod(z[l], C->bd.bhat_q[j][l], mq));
+        o[(size_t)j * n] = BzF::to_u64(a2, mq);
+    }
+}
 // Step 2: tensor product in NTT form; A,B: [cnt][2][L][N], D: [cnt][3][L][N]; L limbs with moduli base_off..
 __global__ void k_tensor(const uint64_t *__restrict__ A, const uint64_t *__restrict__ B, uint64_t *__restrict__ D, const DevConsts *__restrict__ C,
                          uint32_t chunks, uint32_t L, uint32_t base_off) {

@@ -260,6 +260,22 @@ void cn_build_f64_tables(DevConsts *c, const uint64_t *tw_host, double *twd_host
         for (uint32_t i = 0; i < n; i++) { d[i] = (double)w[i]; d[n + i] = (double)iw[i]; }
         c->qd[m] = (double)q; c->qinvd[m] = 1.0 / (double)q; c->ninvd[m] = (double)c->ninv[m];
     }
+    // BEHZ element-wise steps in FP64: needs every data and auxiliary modulus on the FP64 path
+    c->behz_f64 = 1;
+    for (uint32_t m = 0; m < c->k + c->kb; m++) if (!c->f64ok[m]) c->behz_f64 = 0;
+    if (c->behz_f64) {
+        const uint32_t k = c->k;
+        for (uint32_t i = 0; i < k; i++) {
+            c->bd.mt_inv_qhat_q[i] = (double)c->mt_inv_qhat_q[i]; c->bd.fl_c1_q[i] = (double)c->fl_c1_q[i];
+            c->bd.inv_bhat_b[i] = (double)c->inv_bhat_b[i]; c->bd.fl_A_msk[i] = (double)c->fl_A_msk[i]; c->bd.B_q[i] = (double)c->B_q[i];
+            for (uint32_t j = 0; j < k; j++) c->bd.bhat_q[i][j] = (double)c->bhat_q[i][j];
+        }
+        for (uint32_t b = 0; b <= k; b++) {
+            c->bd.ex_R_bsk[b] = (double)c->ex_R_bsk[b]; c->bd.fl_T_bsk[b] = (double)c->fl_T_bsk[b];
+            for (uint32_t i = 0; i < k; i++) { c->bd.ex_Q_bsk[b][i] = (double)c->ex_Q_bsk[b][i]; c->bd.fl_N_bsk[b][i] = (double)c->fl_N_bsk[b][i]; }
+        }
+        c->bd.inv_B_msk = (double)c->inv_B_msk;
+    }
 }
 
 // half tables of k_keyswitch_split14 (see cn_internal.h); also fills ninv_w
