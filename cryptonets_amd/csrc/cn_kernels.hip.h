@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
                 if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
                 v[r] = A.load(t);                  // F64: the first recentring of the transform reduces digits >= q_j
             }
-            if constexpr (std::is_same<T, double>::value) AR::renorm(v, A.m);
+            if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }     // digits below q_j need no recentring (uniform branch)
             ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tl);
             const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
 #pragma unroll
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
         if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
         v[r] = A.load(t);
     }
-    if constexpr (std::is_same<T, double>::value) AR::renorm(v, A.m);
+    if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
     ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
     const T *k0 = reinterpret_cast<const T *>(key_) + (size_t)g * 2 * kn + (size_t)j * n, *k1 = k0 + kn;
     T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * tot + g) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;
