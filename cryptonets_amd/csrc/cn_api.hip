@@ -76,7 +76,11 @@ static int ensure_scratch(cn_ctx *c, size_t bytes) {
     if (c->scratch) HIPCHK(hipFree(c->scratch));
     c->scratch = nullptr; c->scap = 0;
     size_t want = bytes + (bytes >> 3) + (1 << 20);
-    HIPCHK(hipMalloc((void **)&c->scratch, want));
+    if (hipMalloc((void **)&c->scratch, want) != hipSuccess) {      // HBM full: return the cached handle arrays and retry once
+        (void)hipGetLastError();
+        pool_flush(c);
+        HIPCHK(hipMalloc((void **)&c->scratch, want));
+    }
     c->scap = want;
     return 0;
 }
