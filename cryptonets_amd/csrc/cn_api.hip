@@ -60,7 +60,8 @@ struct cn_ctx {
     size_t pool_bytes = 0, pool_max;
     const uint64_t *ks_extra = nullptr; size_t ks_extra_stride = 0;   // fused "+ accumulator" of the next key switch (cn_*_add entry points)
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
-    int ks_wide = -1;         // -1 auto (small batches), 0 never, 1 always: two-launch key switch spread over the chip (latency variant)
+    int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
+    bool ks_per_limb = false; // set per call by do_keyswitch
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
 };
@@ -161,7 +162,7 @@ template <class K> static int big_lds(K kern, size_t bytes) {
 }
 template <int L, class AR> static int big_lds_policy(size_t bytes) {      // every register-radix kernel of one (size, arithmetic policy)
     CHECK(big_lds(k_ntt_rr<L, AR>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
-    CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
+    CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
     return 0;
 }
 template <int EPT> static int set_ks_attr(size_t bytes) {
@@ -746,10 +747,17 @@ static void launch_ks_wide(cn_ctx *c, const uint64_t *target, size_t tstride, co
                            const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
     const uint32_t tot = galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;
     const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
-    hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
-                       galois, tot);
-    hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out, c->dc,
-                       tot, accmax, c->ks_extra, c->ks_extra_stride);
+    if (c->ks_per_limb) {           // one partial per (ct, source limb): k*k workgroups per ciphertext, k partials to sum
+        hipLaunchKernelGGL((k_ks_limb_mac<L, AR>), dim3(cnt * k * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
+                           galois, accmax);
+        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out,
+                           c->dc, k, 0xffffffffu, c->ks_extra, c->ks_extra_stride);
+    } else {                        // one partial per (ct, digit)
+        hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
+                           galois, tot);
+        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out,
+                           c->dc, tot, accmax, c->ks_extra, c->ks_extra_stride);
+    }
     launch_count(c);
 }
 template <class AR>
@@ -764,16 +772,20 @@ static bool launch_ks_wide_by_size(cn_ctx *c, const uint64_t *target, size_t tst
         default: return false;
     }
 }
-static const uint32_t KS_WIDE_MAX_BLOCKS = 160;      // auto: below this many (ct, limb) workgroups the fused kernel leaves most CUs idle
+// auto: the fused kernel runs cnt*k workgroups.  Up to 32 of them (1-6 ciphertexts) every digit gets its own workgroup; up to 160
+// every source limb does; above that the fused kernel fills the chip by itself.
+static const uint32_t KS_DIGIT_MAX_BLOCKS = 32, KS_WIDE_MAX_BLOCKS = 160;
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                         const KsKey &key, uint64_t *out, uint32_t cnt, int galois) {
     uint32_t n = ctx->hc.n, nt = std::min<uint32_t>(1024, n), ept = n / nt;
     bool done = false;
     const uint32_t tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     bool wide = !ctx->legacy_ntt && ctx->hc.logn >= 10 && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * ctx->hc.k <= KS_WIDE_MAX_BLOCKS));
+    ctx->ks_per_limb = ctx->ks_wide == 2 || (ctx->ks_wide < 0 && cnt * ctx->hc.k > KS_DIGIT_MAX_BLOCKS && ctx->hc.logn < 14);   // N = 16384: 1024-thread
+                                                                                    // workgroups cannot hold two accumulator sets without spilling
     const bool split14 = !wide && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14;
     if (wide || split14) {
-        size_t need = (size_t)cnt * (wide ? tot_dig : 1) * ctx->ctw2 * 8;
+        size_t need = (size_t)cnt * (wide ? (ctx->ks_per_limb ? ctx->hc.k : tot_dig) : 1) * ctx->ctw2 * 8;
         if (wide && need > ctx->smax) wide = false;
         else if (need > ctx->ks_part_cap) {
             HIPCHK(hipStreamSynchronize(ctx->stream));

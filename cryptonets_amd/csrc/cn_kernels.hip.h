@@ -909,6 +909,76 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
         *reinterpret_cast<P2 *>(o0 + pos) = x; *reinterpret_cast<P2 *>(o1 + pos) = y;
     }
 }
+// Middle ground for batches of ~7-32 ciphertexts: block = (ct, source limb l, output limb j) runs the digits of ONE source limb
+// through the fused loop (accumulators in registers) and leaves one partial pair per (ct, l): k*k workgroups per ciphertext
+// instead of k (fused) or digits*k (k_ks_digit_mac), and k_ks_sum_intt adds k partials instead of all digits.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
+                                                                 void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t j = blockIdx.x % k, l = (blockIdx.x / k) % k, ct = blockIdx.x / (k * k);
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const ArCtx<AR> A(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    uint32_t g0 = 0;                                   // index of the first digit of limb l in the key
+    for (uint32_t i = 0; i < l; i++) g0 += galois ? C->gk_dig[i] : C->rl_dig[i];
+    const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+    const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    uint64_t raw[16];
+    {
+        uint32_t t0 = tid;
+        asm volatile("" : "+v"(t0));
+#pragma unroll
+        for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
+    }
+    T acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const T *kp = reinterpret_cast<const T *>(key_) + (size_t)g0 * 2 * kn;
+    uint32_t terms = 0;
+    for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+        const int sh = dbc * (int)d;
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            uint64_t t = (raw[r] >> sh) & mask;
+            if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
+            v[r] = A.load(t);
+        }
+        if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
+        ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tl);
+        const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t pos = tail_index<L>(tl, r);
+            struct alignas(16) P2 { T a, b; };
+            const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+            KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+            KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
+        }
+        if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
+        __syncthreads();
+    }
+    KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A);        // partials leave recentred: k of them are summed without a check
+    T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * k + l) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;
+    struct alignas(16) P2 { T a, b; };
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        *reinterpret_cast<P2 *>(o0 + pos) = P2{acc0[r], acc0[r + 1]};
+        *reinterpret_cast<P2 *>(o1 + pos) = P2{acc1[r], acc1[r + 1]};
+    }
+}
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__restrict__ part_, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
                                                                  size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, uint32_t tot,

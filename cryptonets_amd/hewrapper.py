@@ -12,6 +12,7 @@ AtomicSealBfvVector.cs:62-74,1042,1211) is behind the small `ClientCrypto` inter
 secret key.  BatchEncoder (public math) runs on the device (cn_encode / cn_decode).
 """
 import enum
+import os
 import math
 
 import numpy as np
@@ -98,14 +99,16 @@ def _gather(ctx, views):
 
 
 # ------------------------------------------------------------------------------------------------ CRT fan-out
-PARALLEL_PRIMES = True
+PARALLEL_PRIMES = os.environ.get("CN_PARALLEL_PRIMES", "0") != "0"
 _crt_pool = None
 
 
 def _fan_out(envs, fn):
     """ForEveryEncryptedVector (EncryptedSealBfvVector.cs:225-236): the reference issues every operation as one Task per
-    plaintext prime.  Here each prime is a device context with its own HIP stream; issuing from one host thread per prime
-    (ctypes drops the GIL inside libcnhip) keeps the streams fed concurrently, which is what bounds single-image latency."""
+    plaintext prime.  Here each prime is a device context with its own HIP stream and every libcnhip call only ENQUEUES work, so
+    one host thread walking the primes in turn already keeps the streams busy; the Task-per-prime form (CN_PARALLEL_PRIMES=1,
+    one host thread per prime, ctypes drops the GIL inside libcnhip) was measured SLOWER for single-image LoLa - 27 ms vs 17.7 ms
+    per image - the four threads spend their time handing the GIL to each other between ~25 us calls."""
     global _crt_pool
     if len(envs) == 1 or not PARALLEL_PRIMES:
         return [fn(i, e) for i, e in enumerate(envs)]

@@ -52,8 +52,8 @@ int cn_ctx_destroy(cn_ctx *ctx);
 int cn_sync(cn_ctx *ctx);
 /* tuning switches (A/B testing): "f64" = 1 (default) runs transforms of moduli < 2^49 and key switching in exact FP64
  * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels;
- * "ks_wide" = -1 (default: automatic for small batches) / 0 / 1 selects the two-launch key switch that spreads the digit
- * transforms of a few ciphertexts over the whole chip (single-image latency) instead of the fused one-launch kernel;
+ * "ks_wide" = -1 (default: automatic by batch size) / 0 fused one-launch kernel / 1 two launches with one workgroup per digit
+ * (1-6 ciphertexts: single-image latency) / 2 two launches with one workgroup per source limb (7-32 ciphertexts);
  * "ks_tight" = 1 the 128-VGPR fused variant; "ks_split14" = 1 (default) runs the N = 16384 key switch as two 8192-point
  * halves per limb (no register spills), 0 = the fused 1024-thread kernel.  All variants produce identical words. */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);

@@ -381,7 +381,7 @@ def test_key_switch_variants_agree(name, f64, rng):
     exp_col = [o.rotate_columns(c) for c in cts]
     try:
         # (ks_wide, ks_split14): fused, two-launch, and - N = 16384 only - the fused 1024-thread kernel instead of the two-halves one
-        for wide, split in ((0, 1), (1, 1)) + (((0, 0),) if o.n == 16384 else ()):
+        for wide, split in ((0, 1), (1, 1), (2, 1)) + (((0, 0),) if o.n == 16384 else ()):
             g.set_option("ks_wide", wide)
             g.set_option("ks_split14", split)
             for i in range(3):
@@ -433,7 +433,7 @@ def test_fused_rotate_and_add(name, rng):
     h, out = up(g, cts), g.ct_alloc(2)
     half = o.n // 2
     try:
-        for wide in (0, 1):
+        for wide in (0, 1, 2):
             g.set_option("ks_wide", wide)
             for steps in (-1, 4, -3, 7 if half > 7 else 3, 0):
                 g.rotate_rows_add(h, 0, steps, h, 2, out, 0, 2)
