@@ -95,6 +95,8 @@ SIGNATURES = {
     "cn_rotate_columns": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
     "cn_rotate_rows_add": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _H, _u32, _u32]),
     "cn_rotate_columns_add": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
+    "cn_sum_slots": (C.c_int, [_CTX, _H, _u32, _u32, _u32]),
+    "cn_rowdot_batch": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32, _u32, _H, _u32]),
     "cn_keygen": (C.c_int, [_CTX, C.c_uint64, C.c_int]),
     "cn_set_public_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
     "cn_set_secret_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
@@ -315,6 +317,14 @@ class Context:
     def rotate_rows_add(self, src, ii, steps, acc, ai, out, oi, count=1):
         """out = acc + RotateRows(src, steps) (fused rotate-and-add of SumAllSlots)"""
         self._chk(self.L.cn_rotate_rows_add(self._h, src, ii, steps, acc, ai, out, oi, count))
+
+    def sum_slots(self, h, first, count, length=0):
+        """in-place SumAllSlots(length) of `count` single-block ciphertexts (length 0 = every slot)"""
+        self._chk(self.L.cn_sum_slots(self._h, h, first, count, length))
+
+    def rowdot_batch(self, v, vi, pt, pi, rows, length, out, oi):
+        """out[oi + r] = SumAllSlots(v[vi] * pt[pi + r], length) for r < rows"""
+        self._chk(self.L.cn_rowdot_batch(self._h, v, vi, pt, pi, rows, length, out, oi))
 
     def rotate_columns_add(self, src, ii, acc, ai, out, oi, count=1):
         self._chk(self.L.cn_rotate_columns_add(self._h, src, ii, acc, ai, out, oi, count))

@@ -484,23 +484,25 @@ extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
     if (subtract) ctx->st.PlainSubtraction += count; else ctx->st.PlainAddition += count;
     return 0;
 }
-extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pstride, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
-    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1)) return fail(CN_ERR_ARG, "index out of range");
+// out[c] = a[c * (a_bcast ? 0 : 1)] * pt[c * pstride]; a_bcast: ONE ciphertext against `count` plaintexts (row-dot batches)
+static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
+    if (!range_ok(A, ai, a_bcast ? 1 : count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1))
+        return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
     for (uint32_t c = 0; c < npt; c++) if (P->pt_zero[pi + c * pstride]) return fail(CN_ERR_ZERO, "plain cannot be zero");
     CHECK(ensure_scratch(ctx, al((size_t)npt * k * n * 8)));
     uint64_t *lift = salloc<uint64_t>(ctx, (size_t)npt * k * n);
-    // lift every referenced plaintext into the k limbs, NTT it
-    for (uint32_t c = 0; c < npt; c++) {
-        hipLaunchKernelGGL(k_lift_plain, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, P->d + (size_t)(pi + c * pstride) * n,
-                           lift + (size_t)c * k * n, ctx->dc, ctx->chunks);
-    }
-    HIPCHK(hipGetLastError()); launch_count(ctx, npt);
+    // lift every referenced plaintext into the k limbs (one launch), NTT them
+    hipLaunchKernelGGL(k_lift_plain, dim3(npt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, P->d + (size_t)pi * n, lift, ctx->dc, ctx->chunks, pstride ? pstride : 1u);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
     CHECK(run_ntt(ctx, lift, npt * k, 0, k, 0));
     uint64_t *o = O->d + oi * O->item_words;
-    if (o != A->d + ai * A->item_words) HIPCHK(hipMemcpyAsync(o, A->d + ai * A->item_words, count * A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    const uint64_t *src = A->d + ai * A->item_words;
+    if (a_bcast) {
+        for (uint32_t c = 0; c < count; c++)
+            if (o + c * A->item_words != src) HIPCHK(hipMemcpyAsync(o + c * A->item_words, src, A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (o != src) HIPCHK(hipMemcpyAsync(o, src, count * A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     uint32_t limbs = count * A->size * k;
     CHECK(run_ntt(ctx, o, limbs, 0, k, 0));
     hipLaunchKernelGGL(k_dyadic_pt, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, o, lift, pstride ? 1u : 0u, ctx->dc, ctx->chunks, A->size);
@@ -508,6 +510,10 @@ extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
     CHECK(run_ntt(ctx, o, limbs, 0, k, 1));
     ctx->st.PlainMultiplication += count;
     return 0;
+}
+extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pstride, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    return mul_plain_impl(ctx, A, ai, false, P, pi, pstride, O, oi, count);
 }
 static uint64_t lift_scalar(const DevConsts &hc, uint64_t w, uint32_t j) { return w >= hc.t_half ? w + hc.lift_inc[j] : w; }
 extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars, uint32_t sstride, cn_handle out, uint32_t oi, uint32_t count) {
@@ -958,12 +964,16 @@ extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps,
 }
 // out = acc + RotateRows(in, steps): the rotate-and-add step of SumAllSlots (AtomicSealBfvVector.cs:862-868) with the addition
 // fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
-extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+static int rotate_rows_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     const uint64_t *i = I->d + ii * I->item_words, *a = A->d + ai * A->item_words; uint64_t *o = O->d + oi * O->item_words;
-    if (steps == 0) { CHECK(addsub(ctx, in, ii, acc, ai, out, oi, count, 0)); ctx->st.Addition += count; return 0; }
+    if (steps == 0) {
+        hipLaunchKernelGGL(k_addsub, dim3(count * 2 * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, i, a, o, ctx->dc, ctx->chunks, 0);
+        HIPCHK(hipGetLastError()); launch_count(ctx);
+        ctx->st.Addition += count;
+        return 0;
+    }
     if (has_direct_key(ctx, steps)) {
         CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
         uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
@@ -979,13 +989,45 @@ extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int st
     ctx->st.Addition += count;
     return 0;
 }
-extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+static int rotate_columns_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
     return do_galois(ctx, I->d + ii * I->item_words, 2ull * ctx->hc.n - 1, O->d + oi * O->item_words, tmp, count, A->d + ai * A->item_words);
+}
+extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    return rotate_rows_add_impl(ctx, I, ii, steps, A, ai, O, oi, count);
+}
+extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    return rotate_columns_add_impl(ctx, I, ii, A, ai, O, oi, count);
+}
+// SumAllSlots(length) of AtomicSealBfvVector.cs:888-935 on `count` single-block ciphertexts at once, in place: the column swap when
+// length >= N/2, then log2 rotate-and-add steps (RotateRows(-2^s) + AddInplace).  length 0 = all N slots.
+static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count, uint32_t length) {
+    const uint32_t n = ctx->hc.n, half = n / 2;
+    uint32_t len = length ? length : n;
+    if (len >= half) { CHECK(rotate_columns_add_impl(ctx, H, first, H, first, H, first, count)); len = half; }
+    for (uint32_t steps = 1; steps < len; steps *= 2) CHECK(rotate_rows_add_impl(ctx, H, first, -(int)steps, H, first, H, first, count));
+    return 0;
+}
+extern "C" int cn_sum_slots(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint32_t length) {
+    LOCK; GETCT(H, h, 2);
+    if (!range_ok(H, first, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    return sum_slots_impl(ctx, H, first, count, length);
+}
+// out[r] = SumAllSlots(v * pt[r], length) for r < rows: every row of a plaintext matrix against ONE packed ciphertext
+// (EncryptedSealBfvMatrix.Mul row-major, EncryptedSealBfvMatrix.cs:79-120 -> DotProduct, AtomicSealBfvVector.cs:963-977).
+extern "C" int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle pt, uint32_t pi, uint32_t rows, uint32_t length, cn_handle out, uint32_t oi) {
+    LOCK; GETCT(V, v, 2); GETCT(O, out, 2); GETPT(P, pt);
+    if (!rows) return 0;
+    if (V == O && vi >= oi && vi < oi + rows) return fail(CN_ERR_ARG, "row-dot batch cannot overwrite its input");
+    CHECK(mul_plain_impl(ctx, V, vi, true, P, pi, 1, O, oi, rows));
+    if (length == 1) return 0;
+    return sum_slots_impl(ctx, O, oi, rows, length);
 }
 extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
     return cn_apply_galois(ctx, in, ii, 2ull * ctx->hc.n - 1, out, oi, count);

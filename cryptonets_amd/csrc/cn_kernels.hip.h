@@ -139,10 +139,10 @@ __global__ void k_add_plain(const uint64_t *a, const uint64_t *pt, uint32_t pt_s
     out[o] = x;
 }
 // lifted[pi][j][i] = fast plain lift of pt[pi][i] into q_j (multiply_plain)
-__global__ void k_lift_plain(const uint64_t *pt, uint64_t *lifted, const DevConsts *__restrict__ C, uint32_t chunks) {
+__global__ void k_lift_plain(const uint64_t *pt, uint64_t *lifted, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t pitch) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t k = C->k, j = limb % k, pi = limb / k;
-    uint64_t m = pt[(size_t)pi * C->n + i];
+    uint64_t m = pt[(size_t)pi * pitch * C->n + i];          // plaintext pi of the batch sits `pitch` plaintexts after plaintext pi-1
     lifted[(size_t)limb * C->n + i] = m >= C->t_half ? m + C->lift_inc[j] : m;
 }
 // x[ct][p][j][i] *= ptn[(ct*pstride)][j][i]   (both in NTT form)

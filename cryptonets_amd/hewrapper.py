@@ -536,15 +536,10 @@ class AtomicSealBfvEncryptedVector:
             ctx.add_many(self.encData.h, [self.encData.first + i for i in range(self.encData.count)], work.h, 2)
         else:
             ctx.copy(self.encData.h, self.encData.first, work.h, 2, 1)
+        ctx.copy(work.h, 2, work.h, 0, 1)
+        ctx.sum_slots(work.h, 0, 1, 0 if length >= slots else length)      # column swap + log2 rotate-and-add steps in one call
         if length >= slots // 2:
-            ctx.rotate_columns_add(work.h, 2, work.h, 2, work.h, 0, 1)
             length = slots // 2
-        else:
-            ctx.copy(work.h, 2, work.h, 0, 1)
-        steps = 1
-        while steps < length:
-            self._RotateRowsAndAdd(ctx, work.h, 0, steps, work.h, 0, work.h, 1)
-            steps *= 2
         if ForceOutputInColumn is not None:
             col = ForceOutputInColumn
             mask = np.zeros(col + 1, dtype=np.uint64)
@@ -1139,20 +1134,13 @@ class EncryptedSealBfvMatrix:
             pts = self._row_plaintexts(i, e)
             work = _Buf(ctx, "ct", R)
             wv = work.view()
-            for r in range(R):
-                ctx.copy(src.h, src.first, work.h, r, 1)
-            ctx.mul_plain(work.h, 0, pts.h, pts.first, work.h, 0, R)
             ln = INT_MAX if full else int(length)
             if ln <= 0:
                 raise Exception("Can't sum over less then one element")
-            if ln > 1:
-                if ln >= slots // 2:
-                    ctx.rotate_columns_add(work.h, 0, work.h, 0, work.h, 0, R)
-                    ln = slots // 2
-                steps = 1
-                while steps < ln:
-                    ctx.rotate_rows_add(work.h, 0, -steps, work.h, 0, work.h, 0, R)
-                    steps *= 2
+            # replicate + MultiplyPlain + the SumAllSlots rotate-and-add tree for all R rows: ONE library call per prime
+            ctx.rowdot_batch(src.h, src.first, pts.h, pts.first, R, 0 if ln >= slots else ln, work.h, 0)
+            if ln >= slots // 2:
+                ln = slots // 2
             dim = 1 if ln >= slots // 2 else v.Dim
             fmt = EVectorFormat.sparse if ln >= slots else EVectorFormat.dense
             if ForceOutputInColumns:

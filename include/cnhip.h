@@ -136,6 +136,13 @@ int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uin
  * out.  Same words as the rotation followed by cn_add. */
 int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count);
 int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count);
+/* HOT LOOP C in one call.  cn_sum_slots: SumAllSlots(length) (AtomicSealBfvVector.cs:888-935) of `count` single-block ciphertexts
+ * h[first..], in place: column swap + add when length >= N/2, then RotateRows(-2^s) + AddInplace for 2^s < length; length 0 = all
+ * slots.  cn_rowdot_batch: out[oi + r] = SumAllSlots(v[vi] * pt[pi + r], length), r < rows - every row of a row-major plaintext
+ * matrix against one packed ciphertext (EncryptedSealBfvMatrix.cs:79-120, LLDenseLayer / LLPackedDenseLayer /
+ * LLInterleavedDenseLayer).  Same words as the per-row MultiplyPlain / RotateRows / Add sequence of the reference. */
+int cn_sum_slots(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint32_t length);
+int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle pt, uint32_t pi, uint32_t rows, uint32_t length, cn_handle out, uint32_t oi);
 
 /* ---- client side on the device (what SEAL's KeyGenerator / Encryptor / Decryptor do for
  * AtomicSealBfvEncryptedEnvironment.SetKeys / Encrypt / Decrypt, AtomicSealBfvVector.cs:62-74,1030-1110,1202-1232), for data

@@ -155,6 +155,23 @@ class OracleBackend:
         for c in range(count):
             self.bufs[out][oi + c] = self.o.add(self.bufs[acc][ai + c], self.o.rotate_columns(self.bufs[src][ii + c]))
 
+    def sum_slots(self, h, first, count, length=0):
+        half = self.n // 2
+        ln = length if length else self.n
+        if ln >= half:
+            self.rotate_columns_add(h, first, h, first, h, first, count)
+            ln = half
+        steps = 1
+        while steps < ln:
+            self.rotate_rows_add(h, first, -steps, h, first, h, first, count)
+            steps *= 2
+
+    def rowdot_batch(self, v, vi, pt, pi, rows, length, out, oi):
+        for r in range(rows):
+            self.bufs[out][oi + r] = self.o.multiply_plain(self.bufs[v][vi], self.bufs[pt][pi + r])
+        if length != 1:
+            self.sum_slots(out, oi, rows, length)
+
     def rotate_columns(self, src, ii, out, oi, count=1):
         for i in range(count):
             self.bufs[out][oi + i] = self.o.rotate_columns(self.bufs[src][ii + i])

@@ -460,3 +460,53 @@ def test_fused_rotate_and_add(name, rng):
         g.rotate_rows_add(h, 3, 1, h, 0, out, 0, 2)                # source range runs past the array
     for x in (h, out):
         g.free(x)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_sum_slots_and_rowdot_batch(name, rng):
+    """cn_sum_slots / cn_rowdot_batch (HOT LOOP C in one call) = the reference's per-row MultiplyPlain, RotateColumns + Add,
+    RotateRows(-2^s) + Add sequence, word for word; decrypted: slot sums of v * w_r."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    n, half, R = o.n, o.n // 2, 3
+    vals = rng.integers(0, 50, size=n, dtype=np.uint64)
+    ct = o.encrypt(o.encode(vals))
+    w = rng.integers(1, 20, size=(R, n), dtype=np.uint64)
+    pts = np.stack([o.encode(r) for r in w])
+    h, ph, out = g.ct_alloc(1), g.pt_alloc(R), g.ct_alloc(R + 1)
+    g.ct_upload(h, 0, ct[None, :])
+    g.pt_upload(ph, 0, pts)
+
+    def reference(length):
+        res = []
+        for r in range(R):
+            c = o.multiply_plain(ct, pts[r])
+            ln = length if length else n
+            if ln >= half:
+                c = o.add(c, o.rotate_columns(c))
+                ln = half
+            s = 1
+            while s < ln:
+                c = o.add(c, o.rotate_rows(c, -s))
+                s *= 2
+            res.append(c)
+        return np.stack(res)
+    for length in (0, half, 8, 1):
+        g.rowdot_batch(h, 0, ph, 0, R, length, out, 1)
+        got = g.ct_download(out, 1, R)
+        assert np.array_equal(got, reference(length)), length
+    # full sum: every slot of row r holds sum(v * w_r) mod t
+    g.rowdot_batch(h, 0, ph, 0, R, 0, out, 1)
+    dec = o.decode(o.decrypt(g.ct_download(out, 1, 1)[0]))
+    assert int(dec[0]) == int(np.sum(vals.astype(object) * w[0].astype(object)) % o.t) and len(set(int(x) for x in dec)) == 1
+    # sum_slots alone, in place, on a batch of 2
+    g.ct_upload(out, 0, np.stack([ct, ct]))
+    g.sum_slots(out, 0, 2, 4)
+    c = ct
+    for s in (1, 2):
+        c = o.add(c, o.rotate_rows(c, -s))
+    assert np.array_equal(g.ct_download(out, 0, 2), np.stack([c, c]))
+    from cryptonets_amd._native import CnError
+    with pytest.raises(CnError):
+        g.rowdot_batch(out, 1, ph, 0, R, 0, out, 0)                # output range covers the input
+    for x in (h, ph, out):
+        g.free(x)
