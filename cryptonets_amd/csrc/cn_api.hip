@@ -58,10 +58,8 @@ struct cn_ctx {
     // (a LoLa inference allocates and frees ~300 temporaries per plaintext prime)
     std::unordered_map<size_t, std::vector<uint64_t *>> pool;
     size_t pool_bytes = 0, pool_max;
-    const uint64_t *ks_extra = nullptr; size_t ks_extra_stride = 0;   // fused "+ accumulator" of the next key switch (cn_*_add entry points)
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
-    bool ks_per_limb = false; // set per call by do_keyswitch
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
 };
@@ -721,135 +719,117 @@ static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const u
     ctx->st.Multiplication += cnt;
     return 0;
 }
-template <int EPT>
-static void launch_ks(cn_ctx *c, uint32_t nt, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                      const uint64_t *key, uint64_t *out, uint32_t cnt, int galois) {
-    hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, target, tstride, add0, add1, astride, key, out, c->dc, galois);
+// One key switch of `cnt` ciphertexts: out[ct] = (add0[ct], add1[ct]) + KeySwitch(target[ct]) (+ extra[ct] - the fused accumulator of
+// the cn_*_add entry points).  target / add0 / add1 / extra are strided per ciphertext (in words), out is dense size-2.
+struct KsArgs {
+    const uint64_t *target; size_t tstride;
+    const uint64_t *add0, *add1; size_t astride;
+    const uint64_t *key; uint64_t *out; uint32_t cnt; int galois;
+    const uint64_t *extra; size_t xstride;
+    uint32_t accmax;          // FP64 accumulators: terms between recentrings
+    int mode;                 // 0 fused, 1 two launches / workgroup per digit, 2 two launches / workgroup per source limb
+};
+template <int EPT> static void launch_ks_legacy(cn_ctx *c, uint32_t nt, const KsArgs &a) {
+    hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(a.cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride, a.key,
+                       a.out, c->dc, a.galois);
 }
-template <int L, class AR>
-static void launch_ks_rr(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                         const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
-    hipLaunchKernelGGL((k_keyswitch_rr<L, AR>), dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, target, tstride, add0,
-                       add1, astride, (const void *)key, out, c->dc, galois, accmax, c->ks_extra, c->ks_extra_stride);
+template <int L, class AR, int MINW = 1> static void launch_ks_fused(cn_ctx *c, const KsArgs &a) {
+    hipLaunchKernelGGL((k_keyswitch_rr<L, AR, MINW>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, a.target, a.tstride,
+                       a.add0, a.add1, a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride);
 }
-template <class AR>
-static bool launch_ks_by_size(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                              const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
-    switch (c->hc.logn) {
-        case 10: launch_ks_rr<10, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 11: launch_ks_rr<11, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 12: launch_ks_rr<12, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 13:
-            if (c->ks_tight) hipLaunchKernelGGL((k_keyswitch_rr<13, AR, 4>), dim3(cnt * c->hc.k), dim3(NttPlan<13>::NT), (size_t)ntt_lds_words(1u << 13) * 8, c->stream, target,
-                                                tstride, add0, add1, astride, (const void *)key, out, c->dc, galois, accmax, c->ks_extra, c->ks_extra_stride);
-            else launch_ks_rr<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax);
-            return true;
-        case 14: launch_ks_rr<14, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        default: return false;
-    }
-}
-template <int L, class AR>
-static void launch_ks_wide(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                           const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
-    const uint32_t tot = galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;
+template <int L, class AR> static void launch_ks_two_phase(cn_ctx *c, const KsArgs &a) {
+    const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;
     const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
-    if (c->ks_per_limb) {           // one partial per (ct, source limb): k*k workgroups per ciphertext, k partials to sum
-        hipLaunchKernelGGL((k_ks_limb_mac<L, AR>), dim3(cnt * k * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
-                           galois, accmax);
-        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out,
-                           c->dc, k, 0xffffffffu, c->ks_extra, c->ks_extra_stride);
+    if (a.mode == 2) {              // one partial per (ct, source limb): k*k workgroups per ciphertext, k partials to sum
+        hipLaunchKernelGGL((k_ks_limb_mac<L, AR>), dim3(a.cnt * k * k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, (const void *)a.key, c->ks_part,
+                           c->dc, a.galois, a.accmax);
+        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(a.cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, a.add0, a.add1, a.astride,
+                           a.out, c->dc, k, 0xffffffffu, a.extra, a.xstride);
     } else {                        // one partial per (ct, digit)
-        hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, target, tstride, (const void *)key, c->ks_part, c->dc,
-                           galois, tot);
-        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, add0, add1, astride, out,
-                           c->dc, tot, accmax, c->ks_extra, c->ks_extra_stride);
+        hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(a.cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, (const void *)a.key, c->ks_part,
+                           c->dc, a.galois, tot);
+        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(a.cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, a.add0, a.add1, a.astride,
+                           a.out, c->dc, tot, a.accmax, a.extra, a.xstride);
     }
     launch_count(c);
 }
-template <class AR>
-static bool launch_ks_wide_by_size(cn_ctx *c, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                                   const uint64_t *key, uint64_t *out, uint32_t cnt, int galois, uint32_t accmax) {
+template <int L, class AR> static void launch_ks_rr(cn_ctx *c, const KsArgs &a) {
+    if (a.mode) { launch_ks_two_phase<L, AR>(c, a); return; }
+    if constexpr (L == 13) { if (c->ks_tight) { launch_ks_fused<L, AR, 4>(c, a); return; } }      // 128-VGPR variant (A/B only)
+    launch_ks_fused<L, AR>(c, a);
+}
+template <class AR> static bool launch_ks_by_size(cn_ctx *c, const KsArgs &a) {
     switch (c->hc.logn) {
-        case 10: launch_ks_wide<10, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 11: launch_ks_wide<11, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 12: launch_ks_wide<12, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 13: launch_ks_wide<13, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
-        case 14: launch_ks_wide<14, AR>(c, target, tstride, add0, add1, astride, key, out, cnt, galois, accmax); return true;
+        case 10: launch_ks_rr<10, AR>(c, a); return true;
+        case 11: launch_ks_rr<11, AR>(c, a); return true;
+        case 12: launch_ks_rr<12, AR>(c, a); return true;
+        case 13: launch_ks_rr<13, AR>(c, a); return true;
+        case 14: launch_ks_rr<14, AR>(c, a); return true;
         default: return false;
     }
+}
+static int ensure_ks_part(cn_ctx *ctx, size_t need) {
+    if (need <= ctx->ks_part_cap) return 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->ks_part) HIPCHK(hipFree(ctx->ks_part));
+    ctx->ks_part = nullptr; ctx->ks_part_cap = 0;
+    HIPCHK(hipMalloc(&ctx->ks_part, need));
+    ctx->ks_part_cap = need;
+    return 0;
 }
 // auto: the fused kernel runs cnt*k workgroups.  Up to 32 of them (1-6 ciphertexts) every digit gets its own workgroup; up to 160
 // every source limb does; above that the fused kernel fills the chip by itself.
 static const uint32_t KS_DIGIT_MAX_BLOCKS = 32, KS_WIDE_MAX_BLOCKS = 160;
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                        const KsKey &key, uint64_t *out, uint32_t cnt, int galois) {
-    uint32_t n = ctx->hc.n, nt = std::min<uint32_t>(1024, n), ept = n / nt;
-    bool done = false;
-    const uint32_t tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
-    bool wide = !ctx->legacy_ntt && ctx->hc.logn >= 10 && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * ctx->hc.k <= KS_WIDE_MAX_BLOCKS));
-    ctx->ks_per_limb = ctx->ks_wide == 2 || (ctx->ks_wide < 0 && cnt * ctx->hc.k > KS_DIGIT_MAX_BLOCKS && ctx->hc.logn < 14);   // N = 16384: 1024-thread
-                                                                                    // workgroups cannot hold two accumulator sets without spilling
-    const bool split14 = !wide && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14;
-    if (wide || split14) {
-        size_t need = (size_t)cnt * (wide ? (ctx->ks_per_limb ? ctx->hc.k : tot_dig) : 1) * ctx->ctw2 * 8;
-        if (wide && need > ctx->smax) wide = false;
-        else if (need > ctx->ks_part_cap) {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (ctx->ks_part) HIPCHK(hipFree(ctx->ks_part));
-            ctx->ks_part = nullptr; ctx->ks_part_cap = 0;
-            HIPCHK(hipMalloc(&ctx->ks_part, need));
-            ctx->ks_part_cap = need;
-        }
+                        const KsKey &key, uint64_t *out, uint32_t cnt, int galois, const uint64_t *extra = nullptr, size_t xstride = 0) {
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
+    uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+    const int bits = 64 - __builtin_clzll(qmax);
+    KsArgs a{target, tstride, add0, add1, astride, key.d, out, cnt, galois, extra, xstride,
+             key.f64 ? (bits >= 50 ? 1u : (1u << std::min(10, 50 - bits))) : 0xffffffffu,     // lazy FP64 accumulators: |term| <= 2.1 q, sum below 2^52
+             0};
+    const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;                // register-radix kernels available
+    if (rr && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * k <= KS_WIDE_MAX_BLOCKS))) {
+        // N = 16384: 1024-thread workgroups cannot hold two accumulator sets without spilling -> per-digit only
+        a.mode = ctx->ks_wide == 2 || (ctx->ks_wide < 0 && cnt * k > KS_DIGIT_MAX_BLOCKS && ctx->hc.logn < 14) ? 2 : 1;
+        const size_t need = (size_t)cnt * (a.mode == 2 ? k : tot_dig) * ctx->ctw2 * 8;
+        if (need > ctx->smax) a.mode = 0; else CHECK(ensure_ks_part(ctx, need));
     }
-    if (split14 && !wide) {
-        uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
-        const int bits = 64 - __builtin_clzll(qmax);
-        const uint32_t accmax = bits >= 50 ? 1u : (1u << std::min(10, 50 - bits)), k = ctx->hc.k;
+    if (a.mode == 0 && rr && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14) {   // N = 16384 as two 8192-point halves per limb
+        CHECK(ensure_ks_part(ctx, (size_t)cnt * ctx->ctw2 * 8));
         const size_t lds = (size_t)ntt_lds_words(8192) * 8;
         if (bits <= 44) hipLaunchKernelGGL((k_keyswitch_split14<ArF64L>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
-                                           (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, accmax);
+                                           (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, a.accmax);
         else hipLaunchKernelGGL((k_keyswitch_split14<ArF64>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
-                                (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, accmax);
-        hipLaunchKernelGGL(k_ks_combine14, dim3(cnt * 2 * k * (ctx->hc.n / 512)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ks_part, add0, add1, astride,
-                           out, ctx->dc, ctx->ks_extra, ctx->ks_extra_stride);
-        ctx->ks_extra = nullptr;
-        HIPCHK(hipGetLastError()); launch_count(ctx, 2);
-        ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot_dig * k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * k;
-        return 0;
-    }
-    if (key.f64) {
-        // lazy FP64 accumulators: |term| <= 2.1 q, keep the sum below 2^52
-        uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
-        int bits = 64 - __builtin_clzll(qmax);
-        uint32_t accmax = bits >= 50 ? 1u : (1u << std::min(10, 50 - bits));
-        if (wide) done = bits <= 44 ? launch_ks_wide_by_size<ArF64L>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax)
-                                    : launch_ks_wide_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
-        else done = bits <= 44 ? launch_ks_by_size<ArF64L>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax)
-                               : launch_ks_by_size<ArF64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, accmax);
-        if (!done) return fail(CN_ERR_ARG, "internal: FP64 key without FP64 kernel");
-    } else if (!ctx->legacy_ntt) {
-        done = wide ? launch_ks_wide_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu)
-                    : launch_ks_by_size<ArU64>(ctx, target, tstride, add0, add1, astride, key.d, out, cnt, galois, 0xffffffffu);
-    }
-    if (!done) {
-        switch (ept) {
-            case 1: launch_ks<1>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
-            case 2: launch_ks<2>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
-            case 4: launch_ks<4>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
-            case 8: launch_ks<8>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
-            case 16: launch_ks<16>(ctx, nt, target, tstride, add0, add1, astride, key.d, out, cnt, galois); break;
-            default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
-        }
-        if (ctx->ks_extra) {                 // the radix-2 fallback kernel has no fused accumulator: one element-wise add behind it
-            if (ctx->ks_extra_stride != ctx->ctw2) return fail(CN_ERR_ARG, "internal: accumulator stride");
-            hipLaunchKernelGGL(k_addsub, dim3(cnt * 2 * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, out, ctx->ks_extra, out, ctx->dc, ctx->chunks, 0);
-            launch_count(ctx);
+                                (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, a.accmax);
+        hipLaunchKernelGGL(k_ks_combine14, dim3(cnt * 2 * k * (n / 512)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ks_part, add0, add1, astride, out, ctx->dc,
+                           extra, xstride);
+        launch_count(ctx);
+    } else {
+        bool done = false;
+        if (key.f64) {
+            done = rr && (bits <= 44 ? launch_ks_by_size<ArF64L>(ctx, a) : launch_ks_by_size<ArF64>(ctx, a));
+            if (!done) return fail(CN_ERR_ARG, "internal: FP64 key without FP64 kernel");
+        } else if (rr) done = launch_ks_by_size<ArU64>(ctx, a);
+        if (!done) {                          // radix-2 LDS fallback (N < 1024, legacy_ntt): no fused accumulator -> one element-wise add behind it
+            const uint32_t nt = std::min<uint32_t>(1024, n);
+            switch (n / nt) {
+                case 1: launch_ks_legacy<1>(ctx, nt, a); break;
+                case 2: launch_ks_legacy<2>(ctx, nt, a); break;
+                case 4: launch_ks_legacy<4>(ctx, nt, a); break;
+                case 8: launch_ks_legacy<8>(ctx, nt, a); break;
+                case 16: launch_ks_legacy<16>(ctx, nt, a); break;
+                default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
+            }
+            if (extra) {
+                if (xstride != ctx->ctw2) return fail(CN_ERR_ARG, "internal: accumulator stride");
+                hipLaunchKernelGGL(k_addsub, dim3(cnt * 2 * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, out, extra, out, ctx->dc, ctx->chunks, 0);
+                launch_count(ctx);
+            }
         }
     }
-    ctx->ks_extra = nullptr;
     HIPCHK(hipGetLastError()); launch_count(ctx);
-    uint32_t tot = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
-    ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot * ctx->hc.k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * ctx->hc.k;
+    ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot_dig * k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * k;
     return 0;
 }
 static uint32_t chunk_for(cn_ctx *ctx, size_t per_ct, uint32_t count) {
@@ -911,12 +891,12 @@ extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astr
 static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *out, uint64_t *tmp, uint32_t count, const uint64_t *acc = nullptr) {
     auto it = ctx->gk.find(elt);
     if (it == ctx->gk.end() || !it->second.d) return fail(CN_ERR_NOKEY, "Galois key not present");
-    ctx->ks_extra = acc; ctx->ks_extra_stride = ctx->ctw2;
+
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     uint32_t limbs = count * 2 * ctx->hc.k;
     hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
     HIPCHK(hipGetLastError()); launch_count(ctx);
-    CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second, out, count, 1));
+    CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second, out, count, 1, acc, ctx->ctw2));
     ctx->st.Rotation += count;
     if (acc) ctx->st.Addition += count;
     return 0;
