@@ -87,6 +87,8 @@ SIGNATURES = {
     "cn_mul_plain": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32, _H, _u32, _u32]),
     "cn_mul_scalar": (C.c_int, [_CTX, _H, _u32, U64P, _u32, _H, _u32, _u32]),
     "cn_scalar_gemm": (C.c_int, [_CTX, _H, I32P, U64P, _u32, _u32, _H, I32P, _H, _u32]),
+    "cn_gemm_plan_create": (C.c_int, [_CTX, I32P, U64P, _u32, _u32, _H, I32P, C.POINTER(_H)]),
+    "cn_gemm_plan_apply": (C.c_int, [_CTX, _H, _H, _H, _u32]),
     "cn_multiply": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
     "cn_relinearize": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
     "cn_mul_relin": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32, _u32, _H, _u32, _u32]),
@@ -298,6 +300,27 @@ class Context:
             assert bias_idx.shape == (O,)
             bp = bias_idx.ctypes.data_as(I32P)
         self._chk(self.L.cn_scalar_gemm(self._h, src, ip, _p64(W), O, K, bias_pt, bp, out, oi))
+
+    def gemm_plan(self, W, idx=None, bias_pt=0, bias_idx=None):
+        """plan a scalar GEMM once (weights and gather tables stay in HBM); returns a handle for gemm_apply / free"""
+        W = np.ascontiguousarray(W, dtype=np.uint64)
+        O, K = W.shape
+        ip = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            assert idx.shape == (O, K)
+            ip = idx.ctypes.data_as(I32P)
+        bp = None
+        if bias_pt:
+            bias_idx = np.ascontiguousarray(bias_idx, dtype=np.int32)
+            assert bias_idx.shape == (O,)
+            bp = bias_idx.ctypes.data_as(I32P)
+        h = _H()
+        self._chk(self.L.cn_gemm_plan_create(self._h, ip, _p64(W), O, K, bias_pt, bp, C.byref(h)))
+        return h.value
+
+    def gemm_apply(self, plan, src, out, oi):
+        self._chk(self.L.cn_gemm_plan_apply(self._h, plan, src, out, oi))
 
     def multiply(self, a, ai, b, bi, out3, oi, count=1):
         self._chk(self.L.cn_multiply(self._h, a, ai, b, bi, out3, oi, count))

@@ -126,7 +126,9 @@ class CryptoNetsChannel:
             uniq, inv = np.unique(bias, return_inverse=True)
             bh = ctx.pt_alloc(len(uniq))
             ctx.pt_upload(bh, 0, np.stack([encode_constant(int(v)) for v in uniq]))
-            self.layers.append(dict(idx=L["idx"], W=W, bias_pt=bh, bias_idx=inv.astype(np.int32)))
+            # the layer's weights are planned once and stay in HBM (cn_gemm_plan_create); forward() only launches
+            plan = ctx.gemm_plan(W, idx=L["idx"], bias_pt=bh, bias_idx=inv.astype(np.int32))
+            self.layers.append(dict(idx=L["idx"], W=W, bias_pt=bh, bias_idx=inv.astype(np.int32), plan=plan))
         self.h_in = ctx.ct_alloc(784)
         self.h1, self.h2 = ctx.ct_alloc(845), ctx.ct_alloc(845)
         self.h3, self.h4 = ctx.ct_alloc(100), ctx.ct_alloc(100)
@@ -134,11 +136,11 @@ class CryptoNetsChannel:
 
     def forward(self):
         g, L = self.g, self.layers
-        g.scalar_gemm(self.h_in, L[0]["W"], self.h1, 0, idx=L[0]["idx"], bias_pt=L[0]["bias_pt"], bias_idx=L[0]["bias_idx"])
+        g.gemm_apply(L[0]["plan"], self.h_in, self.h1, 0)
         g.mul_relin(self.h1, 0, self.h1, 0, self.h2, 0, 845)
-        g.scalar_gemm(self.h2, L[1]["W"], self.h3, 0, idx=L[1]["idx"], bias_pt=L[1]["bias_pt"], bias_idx=L[1]["bias_idx"])
+        g.gemm_apply(L[1]["plan"], self.h2, self.h3, 0)
         g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
-        g.scalar_gemm(self.h4, L[2]["W"], self.h5, 0, idx=L[2]["idx"], bias_pt=L[2]["bias_pt"], bias_idx=L[2]["bias_idx"])
+        g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
 
 
 def constant_plaintext(n):

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -22,8 +23,10 @@ static int fail(int code, const char *fmt, ...) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(CN_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
 #define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+struct GemmPlan;
 struct Buffer {
-    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array
+    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array, 2 = scalar GEMM plan
+    std::shared_ptr<GemmPlan> plan;
     uint32_t count, size;     // size = polys per ciphertext
     uint64_t *d;
     size_t item_words;
@@ -47,6 +50,7 @@ struct cn_ctx {
     uint64_t *sk = nullptr, *pk = nullptr;   // client-side keys (NTT form) when the data owner's GPU runs keygen/encrypt/decrypt
     uint64_t rng_item = 0;                    // running polynomial counter of the Philox streams
     char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
+    std::vector<std::unique_ptr<char[]>> staged;   // host blocks of in-flight upload_tmp copies
     cn_stats st{};
     hipEvent_t ev0, ev1;
     uint32_t bs, chunks;      // element-wise geometry
@@ -66,6 +70,7 @@ struct cn_ctx {
 
 // ---------------------------------------------------------------- helpers
 static void pool_flush(cn_ctx *ctx);
+static int free_gemm_plan(cn_ctx *ctx, Buffer &b);
 static int use(cn_ctx *c) { HIPCHK(hipSetDevice(c->device)); return 0; }
 
 static int ensure_scratch(cn_ctx *c, size_t bytes) {
@@ -89,10 +94,17 @@ template <class T> static T *salloc(cn_ctx *c, size_t count) {
     if (c->soff + b > c->scap) return nullptr;
     T *p = (T *)(c->scratch + c->soff); c->soff += b; return p;
 }
+// Small host tables (gather indices, weight tiles) travel with an asynchronous copy on the context stream.  The caller's buffer is
+// usually a local std::vector, so the bytes are first moved into a staging block the context keeps alive until the stream has
+// drained (checked lazily) - the copy never reads memory that has gone out of scope, whatever the runtime does with pageable sources.
 template <class T> static int upload_tmp(cn_ctx *c, const T *host, size_t count, T **dev) {
     *dev = salloc<T>(c, count);
     if (!*dev) return fail(CN_ERR_HIP, "internal: scratch exhausted");
-    HIPCHK(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (!c->staged.empty() && hipStreamQuery(c->stream) == hipSuccess) c->staged.clear();
+    (void)hipGetLastError();                                   // hipStreamQuery reports hipErrorNotReady through the sticky error as well
+    c->staged.emplace_back(new char[count * sizeof(T)]);
+    memcpy(c->staged.back().get(), host, count * sizeof(T));
+    HIPCHK(hipMemcpyAsync(*dev, c->staged.back().get(), count * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 static Buffer *getbuf(cn_ctx *c, cn_handle h, int kind) {
@@ -232,7 +244,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->bufs) (void)hipFree(kv.second.d);
+    for (auto &kv : ctx->bufs) { if (kv.second.kind == 2) (void)free_gemm_plan(ctx, kv.second); else (void)hipFree(kv.second.d); }
     pool_flush(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
@@ -253,7 +265,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
 }
-extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; }
 extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
 extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ? ctx->hc.gk_tot : ctx->hc.rl_tot) * ctx->ctw2; }
 
@@ -340,7 +352,8 @@ extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
     LOCK;
     auto it = ctx->bufs.find(h);
     if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    CHECK(dev_release(ctx, it->second.d, it->second.item_words * 8 * it->second.count));
+    if (it->second.kind == 2) CHECK(free_gemm_plan(ctx, it->second));
+    else CHECK(dev_release(ctx, it->second.d, it->second.item_words * 8 * it->second.count));
     ctx->bufs.erase(it);
     return 0;
 }
@@ -539,20 +552,32 @@ extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64
 // HOT LOOP A
 template <int MT>
 static void launch_gemm(cn_ctx *ctx, const uint64_t *in, const int32_t *idx, const uint64_t *Wl, const int32_t *oidx, const uint64_t *bias,
-                        const int32_t *bidx, uint64_t *out, uint32_t G, uint32_t M, uint32_t K, uint32_t lazy, uint32_t Kp) {
+                        const int32_t *bidx, uint64_t *out, uint32_t G, uint32_t M, uint32_t K, uint32_t lazy, uint32_t Kp, uint32_t obase) {
     uint32_t mtiles = (M + MT - 1) / MT;
     size_t blocks = (size_t)ctx->chunks * 2 * ctx->hc.k * mtiles * G;
     hipLaunchKernelGGL(k_scalar_gemm<MT>, dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, in, idx, Wl, oidx, bias, bidx, out, ctx->dc,
-                       ctx->chunks, G, M, K, mtiles, lazy, Kp);
+                       ctx->chunks, G, M, K, mtiles, lazy, Kp, obase);
 }
-extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
-                              const int32_t *bias_idx, cn_handle out, uint32_t oi) {
-    LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
+// A scalar GEMM is planned once per (gather table, weight matrix): validation, grouping of the outputs that share a gather list,
+// weight tiles in the kernel's layout.  A plan can live in HBM (cn_gemm_plan_create: the weights of a layer are uploaded once, every
+// inference only launches) or in the per-call scratch (cn_scalar_gemm).
+struct GemmPlan {
+    uint32_t O = 0, K = 0, Kp = 0, G = 0, M = 0, MT = 0, lazy = 0, max_in = 0;
+    bool small = false, two = false, has_bias = false;
+    cn_handle bias_pt = 0; uint32_t bias_count = 0;
+    uint64_t nnz = 0;                        // non-zero, non-padded terms (statistics)
+    std::vector<char> host;                  // [idx | out_idx | bias_idx | weights], each 256 B aligned
+    size_t off_oidx = 0, off_bidx = 0, off_w = 0;
+    char *dev = nullptr;                     // persistent plans: device copy of `host`
+};
+static int free_gemm_plan(cn_ctx *ctx, Buffer &b) {
+    if (b.plan && b.plan->dev) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.plan->dev)); b.plan->dev = nullptr; }
+    return 0;
+}
+static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, Buffer *BP, cn_handle bias_pt, const int32_t *bias_idx,
+                           GemmPlan &P) {
     if (!O || !K || !W) return fail(CN_ERR_ARG, "empty scalar GEMM");
-    if (!range_ok(OB, oi, O)) return fail(CN_ERR_ARG, "output index out of range");
-    if (I == OB) return fail(CN_ERR_ARG, "scalar GEMM cannot run in place");
-    Buffer *BP = nullptr;
-    if (bias_pt) { BP = getbuf(ctx, bias_pt, 1); if (!BP || !bias_idx) return fail(CN_ERR_ARG, "invalid bias plaintext handle"); }
+    if (bias_pt && (!BP || !bias_idx)) return fail(CN_ERR_ARG, "invalid bias plaintext handle");
     const uint32_t k = ctx->hc.k; const uint64_t t = ctx->hc.t.q;
     // validate + default gather (identity) + reference semantics: zero weights are skipped, all-zero row is an error
     std::vector<int32_t> gidx((size_t)O * K);
@@ -562,8 +587,8 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
             int32_t id = idx ? idx[(size_t)o * K + kk] : (int32_t)kk;
             uint64_t w = W[(size_t)o * K + kk];
             if (w >= t) return fail(CN_ERR_ARG, "weight >= plain modulus");
-            if (id >= (int32_t)I->count) return fail(CN_ERR_ARG, "input index out of range");
-            if (id >= 0 && w) any = true;
+            if (id >= 0) P.max_in = std::max<uint32_t>(P.max_in, (uint32_t)id + 1);
+            if (id >= 0 && w) { any = true; P.nnz++; }
             gidx[(size_t)o * K + kk] = id;
         }
         if (!any) return fail(CN_ERR_ARG, "output %u has no non-zero term (AddMany of nothing)", o);
@@ -588,7 +613,7 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
             g++;
         }
     }
-    for (size_t x = 0; x < member.size(); x++) if (member[x] != NONE) { hoidx[x] = (int32_t)(oi + member[x]); if (BP) hbidx[x] = bias_idx[member[x]]; }
+    for (size_t x = 0; x < member.size(); x++) if (member[x] != NONE) { hoidx[x] = (int32_t)member[x]; if (BP) hbidx[x] = bias_idx[member[x]]; }   // relative to the output base
     // small signed weights (every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
@@ -597,7 +622,8 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
         uint64_t w = W[x], a = w >= ctx->hc.t_half ? t - w : w;
         if (a >> 20) small = false;
     }
-    const uint64_t *bias = BP ? BP->d : nullptr;
+    P.O = O; P.K = K; P.Kp = Kp; P.G = G; P.M = M; P.small = small; P.has_bias = BP != nullptr; P.bias_pt = bias_pt; P.bias_count = BP ? BP->count : 0;
+    std::vector<char> wbytes;
     if (small) {
         const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
         std::vector<double> hWd((size_t)G * mtf * K * MTf + 8 * MTf, 0.0);   // [g][mtile][kk][m], zero padded; + 8 rows: the kernel's software
@@ -608,17 +634,9 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
             double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
             for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
         }
-        CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hWd.size() * 8)));
-        int32_t *didx, *doidx, *dbidx; double *dWd;
-        CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));
-        CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hWd.data(), hWd.size(), &dWd));
-        const bool two = bits <= 44;                       // 2 limbs of 22 bits, else 3 limbs of 17 bits
-        const uint32_t lazy = two ? 1024u : 32768u;        // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
-#define GEMM_F64(MT_) do { uint32_t mtiles = (M + MT_ - 1) / MT_; size_t blocks = (size_t)ctx->chunks * 2 * k * mtiles * G; \
-        if (two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 2, 22>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp); \
-        else hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 3, 17>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp); } while (0)
-        if (M >= 16) GEMM_F64(20); else if (M >= 8) GEMM_F64(10); else if (M >= 3) GEMM_F64(5); else GEMM_F64(1);
-#undef GEMM_F64
+        P.MT = MTf; P.two = bits <= 44;                     // 2 limbs of 22 bits, else 3 limbs of 17 bits
+        P.lazy = P.two ? 1024u : 32768u;                     // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
+        wbytes.assign((const char *)hWd.data(), (const char *)(hWd.data() + hWd.size()));
     } else {
         const uint32_t MTi = M >= 8 ? 10 : (M >= 3 ? 5 : 1), mti = (M + MTi - 1) / MTi;
         std::vector<uint64_t> hW((size_t)k * G * mti * K * MTi, 0);         // [j][g][mtile][kk][m], zero padded
@@ -628,21 +646,82 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
             uint64_t *dst = &hW[((((size_t)j * G + g) * mti + m / MTi) * K) * MTi + m % MTi];
             for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
         }
-        CHECK(ensure_scratch(ctx, al(hidx.size() * 4) + al(hoidx.size() * 4) + al(hbidx.size() * 4) + al(hW.size() * 8)));
-        int32_t *didx, *doidx, *dbidx; uint64_t *dW;
-        CHECK(upload_tmp(ctx, hidx.data(), hidx.size(), &didx)); CHECK(upload_tmp(ctx, hoidx.data(), hoidx.size(), &doidx));
-        CHECK(upload_tmp(ctx, hbidx.data(), hbidx.size(), &dbidx)); CHECK(upload_tmp(ctx, hW.data(), hW.size(), &dW));
+        P.MT = MTi;
         // lazy-reduction interval: K' products of two values < q_max fit in 128 bits
-        uint32_t lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
-        if (M >= 8) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp);
-        else if (M >= 3) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp);
-        else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp);
+        P.lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
+        wbytes.assign((const char *)hW.data(), (const char *)(hW.data() + hW.size()));
+    }
+    P.off_oidx = al(hidx.size() * 4); P.off_bidx = P.off_oidx + al(hoidx.size() * 4); P.off_w = P.off_bidx + al(hbidx.size() * 4);
+    P.host.assign(P.off_w + al(wbytes.size()), 0);
+    memcpy(P.host.data(), hidx.data(), hidx.size() * 4);
+    memcpy(P.host.data() + P.off_oidx, hoidx.data(), hoidx.size() * 4);
+    memcpy(P.host.data() + P.off_bidx, hbidx.data(), hbidx.size() * 4);
+    memcpy(P.host.data() + P.off_w, wbytes.data(), wbytes.size());
+    return 0;
+}
+// tables: device image of P.host (scratch or the plan's own allocation)
+static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buffer *I, Buffer *OB, uint32_t oi) {
+    if (!range_ok(OB, oi, P.O)) return fail(CN_ERR_ARG, "output index out of range");
+    if (I == OB) return fail(CN_ERR_ARG, "scalar GEMM cannot run in place");
+    if (P.max_in > I->count) return fail(CN_ERR_ARG, "input index out of range");
+    const uint64_t *bias = nullptr;
+    if (P.has_bias) {
+        Buffer *BP = getbuf(ctx, P.bias_pt, 1);
+        if (!BP || BP->count < P.bias_count) return fail(CN_ERR_ARG, "invalid bias plaintext handle");
+        bias = BP->d;
+    }
+    const int32_t *didx = (const int32_t *)tables, *doidx = (const int32_t *)(tables + P.off_oidx), *dbidx = (const int32_t *)(tables + P.off_bidx);
+    const uint32_t k = ctx->hc.k, G = P.G, M = P.M, K = P.K, Kp = P.Kp, lazy = P.lazy;
+    if (P.small) {
+        const double *dWd = (const double *)(tables + P.off_w);
+#define GEMM_F64(MT_) do { uint32_t mtiles = (M + MT_ - 1) / MT_; size_t blocks = (size_t)ctx->chunks * 2 * k * mtiles * G; \
+        if (P.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 2, 22>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp, oi); \
+        else hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 3, 17>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp, oi); } while (0)
+        if (P.MT == 20) GEMM_F64(20); else if (P.MT == 10) GEMM_F64(10); else if (P.MT == 5) GEMM_F64(5); else GEMM_F64(1);
+#undef GEMM_F64
+    } else {
+        const uint64_t *dW = (const uint64_t *)(tables + P.off_w);
+        if (P.MT == 10) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp, oi);
+        else if (P.MT == 5) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp, oi);
+        else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp, oi);
     }
     HIPCHK(hipGetLastError()); launch_count(ctx);
-    for (size_t x = 0; x < (size_t)O * K; x++) if (W[x] && gidx[x] >= 0) { ctx->st.PlainMultiplication++; ctx->st.Addition++; }
-    ctx->st.Addition -= O;
-    if (BP) ctx->st.PlainAddition += O;
+    ctx->st.PlainMultiplication += P.nnz; ctx->st.Addition += P.nnz - P.O;
+    if (P.has_bias) ctx->st.PlainAddition += P.O;
     return 0;
+}
+extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
+                              const int32_t *bias_idx, cn_handle out, uint32_t oi) {
+    LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
+    Buffer *BP = bias_pt ? getbuf(ctx, bias_pt, 1) : nullptr;
+    GemmPlan P;
+    CHECK(build_gemm_plan(ctx, idx, W, O, K, BP, bias_pt, bias_idx, P));
+    CHECK(ensure_scratch(ctx, al(P.host.size())));
+    char *tables; CHECK(upload_tmp(ctx, P.host.data(), P.host.size(), &tables));
+    return run_gemm_plan(ctx, P, tables, I, OB, oi);
+}
+// Plan once, apply per inference: the weight tiles and gather tables stay in HBM (cn_free releases the plan).
+extern "C" int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt, const int32_t *bias_idx,
+                                   cn_handle *plan) {
+    LOCK;
+    if (!plan) return fail(CN_ERR_ARG, "null argument");
+    Buffer *BP = bias_pt ? getbuf(ctx, bias_pt, 1) : nullptr;
+    std::shared_ptr<GemmPlan> P = std::make_shared<GemmPlan>();
+    CHECK(build_gemm_plan(ctx, idx, W, O, K, BP, bias_pt, bias_idx, *P));
+    HIPCHK(hipMalloc((void **)&P->dev, P->host.size()));
+    HIPCHK(hipMemcpy(P->dev, P->host.data(), P->host.size(), hipMemcpyHostToDevice));
+    P->host.clear(); P->host.shrink_to_fit();
+    Buffer b; b.kind = 2; b.count = O; b.size = 0; b.d = nullptr; b.item_words = 0; b.plan = P;
+    cn_handle h = ctx->next_handle++;
+    ctx->bufs[h] = std::move(b);
+    *plan = h;
+    return 0;
+}
+extern "C" int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi) {
+    LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
+    Buffer *PB = getbuf(ctx, plan, 2);
+    if (!PB || !PB->plan) return fail(CN_ERR_ARG, "invalid scalar GEMM plan handle");
+    return run_gemm_plan(ctx, *PB->plan, PB->plan->dev, I, OB, oi);
 }
 
 // ---------------------------------------------------------------- BEHZ multiply / key switching

@@ -180,7 +180,7 @@ template <int MT>
 __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const uint64_t *__restrict__ Wl,
                                                      const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
                                                      uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp) {
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase) {
     const uint32_t n = C->n, k = C->k, limbs = 2 * k;
     uint32_t chunk, limb, mt, g;
     gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
             const uint32_t o = g * M + mt * MT + m;
             uint64_t r = bred128(acc[m], qm);
             if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
-            out[(size_t)out_idx[o] * ctw + e] = r;
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
         }
     }
 }
@@ -227,7 +227,7 @@ template <int MT, int NL, int LW>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const double *__restrict__ Wd,
                                                          const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp) {
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase) {
     const uint32_t n = C->n, k = C->k, limbs = 2 * k;
     uint32_t chunk, limb, mt, g;
     gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             const uint32_t o = g * M + mt * MT + m;
             uint64_t r = res[m];
             if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
-            out[(size_t)out_idx[o] * ctw + e] = r;
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
         }
     }
 }

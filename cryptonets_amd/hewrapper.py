@@ -1180,10 +1180,12 @@ class EncryptedSealBfvMatrix:
         return res
 
     # ---- batched HOT LOOP A for a whole PoolLayer (PoolLayer.cs:149-229 issues one Mul per output) -----------------
-    def MulManySparse(self, gather, weights, bias, out_scale, env):
+    def MulManySparse(self, gather, weights, bias, out_scale, env, cache=None):
         """out[o] = sum_k weights[o][k] * column[gather[o][k]] + bias[o]  for all outputs in one scalar GEMM per prime.
         gather: int32 [O,K] (-1 = padded tap), weights: integer rows (scaled, signed), bias: integers or None.
-        Equivalent to O calls of Mul(sparse plain weight window) followed by Add(dense plain bias)."""
+        Equivalent to O calls of Mul(sparse plain weight window) followed by Add(dense plain bias).  `cache`: a dict owned by the
+        calling layer - the planned GEMM (weight tiles, gather tables, bias plaintexts in HBM) is kept there per plaintext prime and
+        only launched on the next inference (cn_gemm_plan_create / cn_gemm_plan_apply)."""
         if self.Format != EMatrixFormat.ColumnMajor:
             raise Exception("Expecting ColumnMajor matrix")
         O = len(weights)
@@ -1194,10 +1196,18 @@ class EncryptedSealBfvMatrix:
             if any(c.encData is None or c.encData.count != 1 for c in cols):
                 raise Exception("batched PoolLayer expects single-block encrypted columns")
             h, idx, tmp = _gather(ctx, [c.encData for c in cols])
+            res = _Buf(ctx, "ct", O)
+            key = (i, tuple(idx), None if bias is None else tuple(int(b) for b in bias))      # the bias depends on the input scale
+            if cache is not None and key in cache and hasattr(ctx, "gemm_apply"):
+                try:
+                    ctx.gemm_apply(cache[key][0], h, res.h, 0)
+                finally:
+                    if tmp is not None:
+                        tmp.release()
+                return res
             g = np.asarray(gather, dtype=np.int64)
             gidx = np.where(g >= 0, np.asarray(idx, dtype=np.int64)[np.maximum(g, 0)], -1).astype(np.int32)
             W = np.array([[int(x) % p for x in row] for row in weights], dtype=np.uint64)
-            res = _Buf(ctx, "ct", O)
             bh, bidx = 0, None
             if bias is not None:
                 bvals = [int(b) % p for b in bias]
@@ -1208,6 +1218,15 @@ class EncryptedSealBfvMatrix:
                 polys[:, 0] = np.array(uniq, dtype=np.uint64)      # Encode(constant vector) = constant polynomial
                 ctx.pt_upload(bp.h, 0, polys)
                 bh, bidx = bp.h, np.array([pos[v] for v in bvals], dtype=np.int32)
+            if cache is not None and hasattr(ctx, "gemm_plan"):
+                try:
+                    plan = ctx.gemm_plan(W, idx=gidx, bias_pt=bh, bias_idx=bidx)
+                    cache[key] = (plan, bp if bias is not None else None)      # the plan references the bias plaintexts: keep both
+                    ctx.gemm_apply(plan, h, res.h, 0)
+                finally:
+                    if tmp is not None:
+                        tmp.release()
+                return res
             try:
                 ctx.scalar_gemm(h, W, res.h, 0, idx=gidx, bias_pt=bh, bias_idx=bidx)
             finally:

@@ -221,7 +221,7 @@ class PoolLayer(BaseLayer):
         if self.Weights is None:
             # pool without convolve (PoolLayer.cs:122-147): sum of the window, scale multiplied by the window size
             ones = [[1] * self.gather.shape[1] for _ in range(corners)]
-            return m.MulManySparse(self.gather, ones, None, m.Scale * len(self.engine.Offsets), env)
+            return m.MulManySparse(self.gather, ones, None, m.Scale * len(self.engine.Offsets), env, cache=self.__dict__.setdefault("_gemm_plans", {}))
         if self.Bias is not None:
             bias_src = [self.Bias[mi] for mi in range(maps)]
         else:
@@ -234,7 +234,7 @@ class PoolLayer(BaseLayer):
                 gather.append(self.gather[c])
                 weights.append(self.weightWindows[mi])
                 bias.append(bias_int[mi])
-        return m.MulManySparse(np.array(gather, dtype=np.int32), weights, bias, bscale, env)
+        return m.MulManySparse(np.array(gather, dtype=np.int32), weights, bias, bscale, env, cache=self.__dict__.setdefault("_gemm_plans", {}))
 
 
 class LLDenseLayer(BaseLayer):

@@ -112,6 +112,11 @@ int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars
  * an output whose weights are all zero is an error like SEAL's AddMany of nothing. */
 int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K,
                    cn_handle bias_pt, const int32_t *bias_idx, cn_handle out, uint32_t oi);
+/* The same GEMM planned once: validation, grouping and the weight tiles in kernel layout are built and uploaded by
+ * cn_gemm_plan_create (the layer's weights then live in HBM), cn_gemm_plan_apply only launches.  Release with cn_free. */
+int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
+                        const int32_t *bias_idx, cn_handle *plan);
+int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi);
 
 /* ---- non-linear ops ------------------------------------------------------------------ */
 /* Evaluator.Multiply (BEHZ), size2 x size2 -> size3 (AtomicSealBfvVector.cs:461,546,786,839,1457) */

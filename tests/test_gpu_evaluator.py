@@ -510,3 +510,42 @@ def test_sum_slots_and_rowdot_batch(name, rng):
         g.rowdot_batch(out, 1, ph, 0, R, 0, out, 0)                # output range covers the input
     for x in (h, ph, out):
         g.free(x)
+
+
+def test_scalar_gemm_plan_is_the_one_shot_gemm(rng):
+    """cn_gemm_plan_create + cn_gemm_plan_apply (weights resident in HBM, launch only) = cn_scalar_gemm, on fresh inputs, at an output
+    offset, for small signed and for general weights; the plan is a handle (leak counter, cn_free)."""
+    o, g = get_oracle("c3", galois=False), get_gpu("c3", galois=False)
+    vals, cts = enc_batch(o, rng, 6)
+    h = up(g, cts)
+    idx = np.array([[0, 1, 2, -1], [0, 1, 2, -1], [3, 4, 5, 2], [5, 4, -1, -1], [3, 4, 5, 2]], dtype=np.int32)
+    bias_vals = rng.integers(0, o.t, size=2, dtype=np.uint64)
+    bias_plain = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in bias_vals])
+    bh = g.pt_alloc(2)
+    g.pt_upload(bh, 0, bias_plain)
+    bias_idx = np.array([0, 1, 0, 1, 1], dtype=np.int32)
+    live = g.live_handles()
+    for W in ((rng.integers(-300, 301, size=(5, 4)) % o.t).astype(np.uint64), rng.integers(1, o.t, size=(5, 4), dtype=np.uint64)):
+        W[:, 0] = np.maximum(W[:, 0], 1)
+        plan = g.gemm_plan(W, idx=idx, bias_pt=bh, bias_idx=bias_idx)
+        out = g.ct_alloc(7)
+        exp = o.add_plain_batch(o.scalar_gemm(cts, W, idx), bias_plain[bias_idx])
+        g.gemm_apply(plan, h, out, 2)
+        assert np.array_equal(g.ct_download(out, 2, 5), exp)
+        # the same plan on new inputs
+        vals2, cts2 = enc_batch(o, rng, 6)
+        g.ct_upload(h, 0, cts2)
+        g.gemm_apply(plan, h, out, 0)
+        assert np.array_equal(g.ct_download(out, 0, 5), o.add_plain_batch(o.scalar_gemm(cts2, W, idx), bias_plain[bias_idx]))
+        g.ct_upload(h, 0, cts)
+        from cryptonets_amd._native import CnError
+        small = g.ct_alloc(3)
+        with pytest.raises(CnError):
+            g.gemm_apply(plan, small, out, 0)                      # the plan gathers input 5
+        with pytest.raises(CnError):
+            g.gemm_apply(plan, h, out, 3)                          # 5 outputs do not fit behind offset 3
+        for x in (plan, out, small):
+            g.free(x)
+    assert g.live_handles() == live
+    for x in (h, bh):
+        g.free(x)
