@@ -170,8 +170,11 @@ template <class K> static int big_lds(K kern, size_t bytes) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
+// dynamic LDS of the fused key switch with LDS-resident forward twiddles: exchange image + table
+template <int L> static size_t ks_twl_lds() { return ((size_t)ntt_lds_words(1u << L) + (1u << L)) * 8; }
 template <int L, class AR> static int big_lds_policy(size_t bytes) {      // every register-radix kernel of one (size, arithmetic policy)
     CHECK(big_lds(k_ntt_rr<L, AR>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
+    if constexpr (KsFwd<AR, L>::lds) CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>()));
     CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
     return 0;
 }
@@ -226,6 +229,9 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     size_t lds = (size_t)ntt_lds_words(n) * 8;
+    if (n == 4096) {                       // N = 4096: image + LDS twiddle table of the fused FP64 key switch = 66.5 KiB
+        CHECK(big_lds(k_keyswitch_rr<12, ArF64, 1, true>, ks_twl_lds<12>())); CHECK(big_lds(k_keyswitch_rr<12, ArF64L, 1, true>, ks_twl_lds<12>()));
+    }
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
         CHECK(big_lds(k_ntt, lds));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
@@ -812,7 +818,18 @@ template <int EPT> static void launch_ks_legacy(cn_ctx *c, uint32_t nt, const Ks
     hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(a.cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride, a.key,
                        a.out, c->dc, a.galois);
 }
+// the LDS copy of the twiddle table pays once a workgroup runs enough digit transforms of its modulus
+static const uint32_t KS_TWL_MIN_DIGITS = 12;
 template <int L, class AR, int MINW = 1> static void launch_ks_fused(cn_ctx *c, const KsArgs &a) {
+    const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot;
+    if constexpr (KsFwd<AR, L>::lds && MINW == 1) {
+        if (tot >= KS_TWL_MIN_DIGITS) {
+            const size_t lds = ks_twl_lds<L>();
+            hipLaunchKernelGGL((k_keyswitch_rr<L, AR, 1, true>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, a.add0, a.add1,
+                               a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_keyswitch_rr<L, AR, MINW>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, a.target, a.tstride,
                        a.add0, a.add1, a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride);
 }

@@ -662,6 +662,17 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *
 // finish and the result is added to (add0, add1).  The digit polynomials never exist in HBM.
 // U64 policy: keys are u64 residues, canonical accumulators.  F64 policy: keys were converted to doubles at upload,
 // accumulators are lazy doubles recentred every `accmax` terms.
+// forward-transform policy of the key-switch kernels: FP64 policies read their twiddles from an LDS copy of the table
+// (N <= 8192: image + table = 132 KiB of the 160 KiB; the N = 16384 image alone is 136 KiB)
+template <class AR, int L> struct KsFwd { typedef AR P; static constexpr bool lds = false; };
+template <int RN, int L> struct KsFwd<ArF64T<RN>, L> { typedef typename std::conditional<(L <= 13), ArF64LdsT<RN>, ArF64T<RN>>::type P; static constexpr bool lds = L <= 13; };
+// copy `words` doubles of a global table behind the exchange image (all threads; caller synchronises)
+DEV void stage_table(double *dst, const NTT_GLOBAL double *src, uint32_t words, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid * 2; i < words; i += nthreads * 2) {
+        const double a = src[i], b = src[i + 1];               // adjacent lanes, adjacent pairs: 16 B per lane either way
+        dst[i] = a; dst[i + 1] = b;
+    }
+}
 template <class AR> struct KsMac;
 template <> struct KsMac<ArU64> {
     static DEV void mac(uint64_t &acc, uint64_t x, uint64_t key, const DMod &qm, const ArCtx<ArU64> &A) { acc = addmod(acc, mulmod(canon4(x, qm.q), key, qm), qm.q); }
@@ -677,7 +688,7 @@ template <int RN> struct KsMac<ArF64T<RN>> {
 #ifndef KS_MAC_FENCE
 #define KS_MAC_FENCE 0      // FP64 path: letting the scheduler interleave key loads with the MACs measured 11-14 % faster (same VGPRs)
 #endif
-template <int L, class AR, int MINW = 1>
+template <int L, class AR, int MINW = 1, bool TWL = false>
 __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                                  const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
                                                                  uint64_t *out, const DevConsts *__restrict__ C, int galois, uint32_t accmax,
@@ -702,6 +713,16 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
     T acc0[16], acc1[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    // TWL: forward twiddles from an LDS copy of the table (FP64 policies, N <= 8192, enough digits per workgroup to pay for staging it)
+    typedef typename std::conditional<TWL, typename KsFwd<AR, L>::P, AR>::type FW;
+    typename FW::Tw fwt;
+    if constexpr (TWL) {
+        static_assert(KsFwd<AR, L>::lds, "LDS twiddles need an FP64 policy and N <= 8192");
+        double *tws = reinterpret_cast<double *>(smem) + ntt_lds_words(n);
+        stage_table(tws, A.fw.w, n, tid, NttPlan<L>::NT);
+        fwt.w = (const __attribute__((address_space(3))) double *)tws;
+        __syncthreads();
+    } else fwt = A.fw;
     const T *kp = reinterpret_cast<const T *>(key_);
     uint32_t terms = 0;
     for (uint32_t l = 0; l < k; l++) {
@@ -727,7 +748,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
                 v[r] = A.load(t);                  // F64: the first recentring of the transform reduces digits >= q_j
             }
             if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }     // digits below q_j need no recentring (uniform branch)
-            ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tl);
+            ntt_forward_regs<FW, L>(v, s, fwt, A.m, tl);
             const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -785,6 +806,8 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
     const DMod qm = C->q[j];
     const ArCtx<AR> A(C, j);
     typedef const NTT_GLOBAL double *GP;
+    // (an LDS copy of the half's table, as in k_keyswitch_rr, was measured: -30 % - with one digit per limb a workgroup runs only
+    // k = 8 transforms, too few to pay for staging 64 KiB)
     const typename AR::Tw fwh = {(GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2)}, ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
     const int dbc = galois ? C->gdbc : C->dbc;
     const uint64_t mask = (1ull << dbc) - 1;

@@ -103,6 +103,24 @@ template <int RN> struct ArF64T {
 };
 typedef ArF64T<1> ArF64;
 typedef ArF64T<0> ArF64L;
+// The same arithmetic with the twiddle table in LDS: a kernel that pushes many transforms of ONE modulus through a workgroup (the key
+// switch: 25 digits per output limb) copies the 8 N-byte table next to the exchange image once; a twiddle is then a ds_read (~64
+// cycles) instead of a global load from L2 (~600 cycles, issued after every barrier of the transform with 2 waves per SIMD to hide it).
+template <int RN> struct ArF64LdsT : ArF64T<RN> {
+    typedef typename ArF64T<RN>::T T;
+    typedef typename ArF64T<RN>::Mod Mod;
+    struct Tw { const __attribute__((address_space(3))) double *w; };
+    static NTT_DEV void fwd(T &X, T &Y, const Tw &t, uint32_t ti, const Mod &m) {
+        const double p = ArF64T<RN>::mulmod(Y, t.w[ti], m);
+        Y = __dadd_rn(X, -p);
+        X = __dadd_rn(X, p);
+    }
+    static NTT_DEV void inv(T &U, T &V, const Tw &t, uint32_t ti, const Mod &m) {
+        const double s = __dadd_rn(U, V), d = __dadd_rn(U, -V);
+        U = s;
+        V = ArF64T<RN>::mulmod(d, t.w[ti], m);
+    }
+};
 
 template <int L> struct NttPlan {
     static constexpr int D = (L == 14) ? 2 : 1;      // stages of the last (adjacent-coefficient) pass
