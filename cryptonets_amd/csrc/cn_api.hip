@@ -223,7 +223,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->bs = std::min<uint32_t>(256, n); c->chunks = n / c->bs;
     c->ctw2 = (size_t)2 * k * n;
     const char *env = getenv("CN_SCRATCH_GB");
-    c->smax = (size_t)(env ? atof(env) : 24.0) * (1ull << 30);
+    c->smax = (size_t)((env ? atof(env) : 24.0) * (double)(1ull << 30));
     env = getenv("CN_POOL_GB");
     c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));

@@ -549,3 +549,30 @@ def test_scalar_gemm_plan_is_the_one_shot_gemm(rng):
     assert g.live_handles() == live
     for x in (h, bh):
         g.free(x)
+
+
+def test_small_scratch_and_no_pool(rng, monkeypatch):
+    """CN_SCRATCH_GB caps the per-call scratch arena: a batch that does not fit is processed in chunks (here: 13 MiB per ciphertext at
+    C3 against a 40 MiB cap -> chunks of 3); CN_POOL_GB=0 turns the handle pool off.  Same words either way."""
+    from cryptonets_amd._native import Context
+    monkeypatch.setenv("CN_SCRATCH_GB", "0.04")
+    monkeypatch.setenv("CN_POOL_GB", "0")
+    o = get_oracle("c3", galois=False)
+    p = PARAMS["c3"]
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    g.set_relin_key(o.relin_key())
+    vals, cts = enc_batch(o, rng, 7)
+    h, out, out3 = up(g, cts), g.ct_alloc(7), g.ct_alloc(7, 3)
+    g.mul_relin(h, 0, h, 0, out, 0, 7)
+    assert np.array_equal(g.ct_download(out, 0, 7), o.mul_relin_batch(cts, cts))
+    g.multiply(h, 0, h, 1, out3, 0, 6)
+    got = g.ct_download(out3, 0, 6, size=3)
+    for i in range(6):
+        assert np.array_equal(got[i], o.multiply(cts[i], cts[i + 1]))
+    for x in (h, out, out3):
+        g.free(x)
+    tmp = [g.ct_alloc(2) for _ in range(4)]                        # alloc / free cycles without the pool
+    for x in tmp:
+        g.free(x)
+    assert g.live_handles() == 0
+    g.close()
