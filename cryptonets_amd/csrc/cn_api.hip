@@ -623,7 +623,7 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
     // small signed weights (every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
-    bool small = ctx->use_f64 && bits <= 51;
+    bool small = ctx->use_f64 && bits <= 49;                     // the kernel folds its limb sums with exact-FP64 modular arithmetic (q < 2^49.4)
     for (size_t x = 0; x < (size_t)O * K && small; x++) {
         uint64_t w = W[x], a = w >= ctx->hc.t_half ? t - w : w;
         if (a >> 20) small = false;

@@ -161,6 +161,9 @@ __global__ void k_mul_scalar(const uint64_t *a, const uint64_t *__restrict__ sc,
     out[o] = mulmod(a[o], sc[(size_t)ct * sstride * k + j], C->q[j]);
 }
 
+// element-wise exact-FP64 modular arithmetic (per-coefficient kernels: GEMM fold, BEHZ extend / floor)
+typedef ArF64T<1> BzF;
+DEV double bz_canon(double x, const BzF::Mod &m) { double r = BzF::center(x, m); return r < 0.0 ? __dadd_rn(r, m.q) : r; }
 // ------------------------------------------------------------------ HOT LOOP A: scalar GEMM
 // Workgroup -> (coefficient chunk, limb, output tile mt, group g).  The mtiles output tiles of one (chunk, limb, g) read the SAME
 // input elements; workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles take ids b, b+8, b+16, ...
@@ -234,28 +237,28 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];
-    double acc[NL][MT];
-    uint64_t res[MT];
+    double acc[NL][MT], res[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) {
-        res[m] = 0;
+        res[m] = 0.0;
 #pragma unroll
         for (int l = 0; l < NL; l++) acc[l][m] = 0.0;
     }
     const int32_t *gi = idx + (size_t)g * Kp;                                            // row pitch Kp: 16 B aligned, -1 beyond K
     const double *gw = Wd + ((size_t)g * mtiles + mt) * (size_t)K * MT;                  // [kk][m], zero-padded
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
+    // fold: value = sum_l acc[l] * 2^(l*LW) mod q_j, in exact FP64 (q_j < 2^49): Horner with one modular multiply per limb.  (The
+    // 128-bit integer version - double -> int128 conversions and a Barrett reduction per output - cost more instructions than the 25
+    // terms of a convolution window.)
+    const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
     auto fold = [&]() {
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            __int128 v = 0;
+            double r = acc[NL - 1][m];
+            acc[NL - 1][m] = 0.0;
 #pragma unroll
-            for (int l = NL - 1; l >= 0; l--) { v = (v << LW) + (__int128)(long long)acc[l][m]; acc[l][m] = 0.0; }
-            const bool neg = v < 0;
-            u128 a = neg ? (u128)(-v) : (u128)v;
-            uint64_t r = bred128(a, qm);
-            r = neg ? negmod(r, qm.q) : r;
-            res[m] = addmod(res[m], r, qm.q);
+            for (int l = NL - 2; l >= 0; l--) { r = __dadd_rn(BzF::mulmod(r, (double)(1u << LW), mq), acc[l][m]); acc[l][m] = 0.0; }
+            res[m] = BzF::center(__dadd_rn(res[m], r), mq);       // |res| <= q/2 between folds, |r| < 2^53 - q
         }
     };
     // blocks of `lazy` terms with the fold BETWEEN the inner loops: a fold test inside the term loop gets if-converted by the
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     for (int m = 0; m < MT; m++) {
         if ((uint32_t)m < mcnt && out_idx[g * M + mt * MT + m] >= 0) {
             const uint32_t o = g * M + mt * MT + m;
-            uint64_t r = res[m];
+            uint64_t r = BzF::to_u64(res[m], mq);
             if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
             out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
         }
@@ -351,8 +354,6 @@ __global__ void __launch_bounds__(256) k_behz_extend(const uint64_t *__restrict_
 // y_j = [x (q/q_j)^-1]_{q_j} MUST be canonical (another representative changes the q-overflow count and with it the words
 // SEAL produces); residues that are only re-reduced (f_b, z_j, alpha) may stay lazy - z_j + s b_j shifts the Shenoy-Kumaresan
 // sum by s B and alpha by s, which cancels.
-typedef ArF64T<1> BzF;
-DEV double bz_canon(double x, const BzF::Mod &m) { double r = BzF::center(x, m); return r < 0.0 ? __dadd_rn(r, m.q) : r; }
 template <int K>
 __global__ void __launch_bounds__(256) k_behz_extend_f64(const uint64_t *__restrict__ src, uint32_t stride, uint64_t *__restrict__ aq, uint64_t *__restrict__ ab,
                                                          const DevConsts *__restrict__ C, uint32_t chunks) {
