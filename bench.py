@@ -185,7 +185,10 @@ def main():
                "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
                                       "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM",
-                          "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world},
+                          "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world,
+                          "arithmetic": "exact modular integers over 43-49-bit RNS primes (results are u64 words, bit-identical to the integer "
+                                        "oracle); products evaluated with error-free FP64 instruction sequences where the modulus is below 2^49, "
+                                        "64-bit integer instructions otherwise"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
