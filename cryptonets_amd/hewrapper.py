@@ -476,6 +476,55 @@ class AtomicSealBfvEncryptedVector:
                 ctx.mul_plain(ev.encData.h, ev.encData.first, self.plainDense.h, self.plainDense.first + i, t.encData.h, i, 1)
         return t
 
+    def _encrypt_zero_into(self, env, buf_h, index):
+        """encryptor.Encrypt(PlainZero) (AtomicSealBfvVector.cs:566,588): a fresh encryption of zero from the client"""
+        ctx = env.ctx
+        if hasattr(env.client, "encrypt_device"):
+            z = _Buf(ctx, "pt", 1).view()
+            ctx.pt_upload(z.h, 0, np.zeros((1, ctx.n), dtype=np.uint64))
+            env.client.encrypt_device(z.h, 0, 1, buf_h, index)
+            z.release()
+        else:
+            ctx.ct_upload(buf_h, index, np.asarray(env.client.encrypt(np.zeros(ctx.n, dtype=np.uint64)))[None, :])
+
+    def SparseMultiply(self, v, colIndex, env):
+        """AtomicSealBfvVector.cs:529-598: every block of this (dense) vector times ELEMENT colIndex of the sparse vector v.
+        (No caller in the reference's networks - kept for interface parity)"""
+        ev = v
+        if colIndex >= ev.Dim:
+            raise Exception("index exceeds dimension")
+        if ev.Format != EVectorFormat.sparse:
+            raise Exception("expecting sparse format")
+        if ev.encData is None and self.encData is None:
+            raise Exception("at least one argument is expected to be encrypted")
+        if self.IsSigned != ev.IsSigned:
+            raise Exception("can't mix signed and unsigned numbers.")
+        ctx = env.ctx
+        t = AtomicSealBfvEncryptedVector._new(Scale=self.Scale * ev.Scale, Dim=self.Dim, Format=EVectorFormat.dense, IsSigned=self.IsSigned)
+        if self.encData is not None and ev.encData is not None:
+            n = self.encData.count
+            t.encData = _Buf(ctx, "ct", n).view()
+            ctx.mul_relin(ev.encData.h, ev.encData.first + colIndex, self.encData.h, self.encData.first, t.encData.h, 0, n, a_stride=0, b_stride=1)
+            return t
+        if self.encData is None:                       # plain dense blocks x one encrypted element
+            n = self.plainDense.count
+            t.encData = _Buf(ctx, "ct", n).view()
+            for i in range(n):
+                if self.plainZero[i]:
+                    self._encrypt_zero_into(env, t.encData.h, i)
+                else:
+                    ctx.mul_plain(ev.encData.h, ev.encData.first + colIndex, self.plainDense.h, self.plainDense.first + i, t.encData.h, i, 1)
+            return t
+        n = self.encData.count                         # encrypted blocks x one plain constant
+        t.encData = _Buf(ctx, "ct", n).view()
+        w = ev.plainSparse[colIndex]
+        if w == 0:
+            for i in range(n):
+                self._encrypt_zero_into(env, t.encData.h, i)
+        else:
+            ctx.mul_scalar(self.encData.h, self.encData.first, np.array([w], dtype=np.uint64), t.encData.h, 0, n, broadcast=True)
+        return t
+
     def PointwiseMultiply(self, v, env):
         """AtomicSealBfvVector.cs:813-860"""
         ev = v

@@ -176,3 +176,30 @@ def test_error_behaviour_matches_reference(fx):
         fx.plain2.PointwiseMultiply(fx.plain2, fx.env)
     with pytest.raises(Exception, match="expecting a sparse vector"):
         fx.mat.Mul(fx.enc1, fx.env)
+
+
+def test_SparseMultiply_atomic(fx):
+    """AtomicSealBfvEncryptedVector.SparseMultiply (AtomicSealBfvVector.cs:529-598; no test in the reference): every block of a dense
+    vector times ONE element of a sparse vector - encrypted x encrypted, plain x encrypted, encrypted x plain, and the zero-operand
+    branches that return a fresh encryption of zero."""
+    from cryptonets_amd.hewrapper import EncryptedSealBfvVector
+    F, env = fx.Factory, fx.env
+    sparse_vals = np.array([3, 0, -5], dtype=float)
+    dense_e, dense_p = fx.enc1, F.GetPlainVector(values1, EVectorFormat.dense, scale)
+    sp_e, sp_p = F.GetEncryptedVector(sparse_vals, EVectorFormat.sparse, 1.0), F.GetPlainVector(sparse_vals, EVectorFormat.sparse, 1.0)
+    zero_p = F.GetPlainVector(np.zeros(6), EVectorFormat.dense, scale)
+
+    def run(a, b, col):
+        atoms = [x.SparseMultiply(y, col, e) for x, y, e in zip(a.eVectors, b.eVectors, env.Environments)]
+        return EncryptedSealBfvVector._of(atoms, a.Scale * b.Scale).Decrypt(env)
+    Compare(values1 * -5, run(dense_e, sp_e, 2))
+    Compare(values1 * 3, run(dense_p, sp_e, 0))
+    Compare(values1 * -5, run(dense_e, sp_p, 2))
+    Compare(np.zeros(6), run(dense_e, sp_p, 1))                    # plain zero constant -> Enc(0)
+    Compare(np.zeros(6), run(zero_p, sp_e, 0))                     # zero plaintext block -> Enc(0)
+    with pytest.raises(Exception):
+        run(dense_e, sp_e, 3)                                      # index exceeds dimension
+    with pytest.raises(Exception):
+        run(dense_e, fx.enc2, 0)                                   # expecting sparse format
+    with pytest.raises(Exception):
+        run(dense_p, sp_p, 0)                                      # at least one argument is expected to be encrypted
