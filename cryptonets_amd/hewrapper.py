@@ -796,11 +796,10 @@ class AtomicSealBfvEncryptedVector:
                 # the reference multiplies without relinearising here (:1457) and would then fail to rotate a size-3
                 # ciphertext; encrypted selections are therefore relinearised
                 ctx.mul_relin(self.encData.h, self.encData.first, s.encData.h, s.encData.first, work.h, 1, 1)
-            ctx.rotate_rows(work.h, 1, shifts[i], work.h, 1, 1)
             if i == first:
-                ctx.copy(work.h, 1, work.h, 0, 1)
+                ctx.rotate_rows(work.h, 1, shifts[i], work.h, 0, 1)
             else:
-                ctx.add(work.h, 0, work.h, 1, work.h, 0, 1)
+                ctx.rotate_rows_add(work.h, 1, shifts[i], work.h, 0, work.h, 0, 1)     # res += rot(x * sel_i)
         if first < 0:
             raise Exception("permuting with no selected values is illigal")
         res = _Buf(ctx, "ct", 1).view()

@@ -326,6 +326,251 @@ class LLConvReader(BaseLayer):
         return len(self.engine.Corners)
 
 
+class LLSingleLineReader(BaseLayer):
+    """NeuralNetworks/LLSingleLineReader.cs: one TSV line = one image per GetNext (formats as BatchReader), returned as a
+    single-column matrix at Scale; None at end of file (:62-110)."""
+
+    def __init__(self, FileName=None, NormalizationFactor=1.0, Scale=1.0, SparseFormat=True, LabelColumn=0, Factory=None):
+        super().__init__(None, Factory)
+        self.NormalizationFactor, self.Scale, self.SparseFormat, self.LabelColumn = NormalizationFactor, Scale, SparseFormat, LabelColumn
+        self.Labels, self._sr, self._dim = None, None, -1
+        if FileName is not None:
+            self.FileName = FileName
+
+    @property
+    def FileName(self):
+        return self._file_name
+
+    @FileName.setter
+    def FileName(self, value):
+        self._file_name = value
+        if self._sr is not None:
+            self._sr.close()
+        self._sr = open(value, "r")
+        self._dim = -1
+
+    def PrepareNetwork(self):
+        self.Prepare()
+
+    def Apply(self, m):
+        return self.GetNext()
+
+    def GetNext(self):
+        line = self._sr.readline()
+        if line == "":
+            return None
+        f = line.rstrip("\r\n").split("\t")
+        if self.SparseFormat:
+            self.Labels = np.array([int(f[0])], dtype=np.int64)
+            self._dim = int(f[1])
+            features = np.zeros(self._dim)
+            for item in f[2:]:
+                c, v = item.split(":")
+                features[int(c)] = float(v) * self.NormalizationFactor
+        else:                                                    # dense format: NormalizationFactor is NOT applied (:86-103)
+            if self.LabelColumn >= len(f):
+                self.Labels = np.array([2 ** 31 - 1], dtype=np.int64)
+                features = np.array([float(x) for x in f])
+            else:
+                self.Labels = np.array([int(f[self.LabelColumn])], dtype=np.int64)
+                features = np.array([float(x) for k, x in enumerate(f) if k != self.LabelColumn])
+            self._dim = len(features)
+        return RawData(features[:, None], self.Scale)
+
+    def GetOutputScale(self):
+        return self.Scale
+
+    def OutputDimension(self):
+        return self._dim
+
+    def Dispose(self):
+        if self._sr is not None:
+            self._sr.close()
+            self._sr = None
+
+
+class LLPreConvLayer(BaseLayer):
+    """NeuralNetworks/LLPreConvLayer.cs: the im2col of a convolution done HOMOMORPHICALLY on one packed image: for every kernel offset
+    the pixels that offset selects are masked out block-wise (one block per residue of the corner row modulo the stride) and moved
+    with `Permute` so that all offsets end up aligned slot for slot (:73-147).  Output: [outputDim x offsets] column-major;
+    `HotIndices` marks the slots that hold a convolution window, `RearrangeWeights` puts per-corner weights into that slot order."""
+
+    def __init__(self, Source=None, Factory=None, InputShape=None, KernelShape=None, Stride=None, Padding=None, Upperpadding=None,
+                 Lowerpadding=None, UseAxisForBlocks=None):
+        super().__init__(Source, Factory)
+        self.engine = ConvolutionEngine(InputShape, KernelShape, Stride, Padding, Upperpadding, Lowerpadding)
+        self.UseAxisForBlocks = UseAxisForBlocks
+        self.outputDim, self.shifts, self.masks, self.CornersMap, self._hot = -1, None, None, None, None
+
+    @property
+    def HotIndices(self):
+        if not self.layerPrepared:
+            self.Prepare()
+        return self._hot
+
+    def _block_offsets(self):
+        """BlockOffset (:31-60): odometer over the axes used for blocks, digit i in [0, Stride[i]), weight = row-major pitch"""
+        E = self.engine
+        nd = len(E.Stride)
+        pitch = [1] * nd
+        for i in range(1, nd):
+            pitch[i] = pitch[i - 1] * E.InputShape[i - 1]
+        block, offset, out = [0] * nd, 0, []
+        while True:
+            out.append(offset)
+            go = False
+            for i in range(nd):
+                if not self.UseAxisForBlocks[i]:
+                    continue
+                block[i] += 1
+                offset += pitch[i]
+                if block[i] < E.Stride[i]:
+                    go = True
+                    break
+                offset -= block[i] * pitch[i]
+                block[i] = 0
+            if not go:
+                return out
+
+    def Prepare(self):
+        if self.layerPrepared:
+            return
+        E, F = self.engine, self.Factory
+        if self.UseAxisForBlocks is None:
+            self.UseAxisForBlocks = [True] * len(E.InputShape)
+        n_off = len(E.Offsets)
+        dim = int(np.prod(E.InputShape))
+        block_offsets = self._block_offsets()
+        nb = len(block_offsets)
+        projections = sorted({c[0] for c in E.Corners}, key=[c[0] for c in E.Corners].index)
+        expected = len(projections) / float(nb)
+        small, large = int(np.floor(expected)), int(np.ceil(expected))
+        n_large = len(projections) - nb * small
+        self.CornersMap = [-1] * len(E.Corners)
+        self.masks, self.shifts = [], []
+        for i in range(n_off):
+            selections = [[] for _ in range(nb)]
+            sh = [0] * nb
+            for j in range(nb):
+                this_block = small if j > n_large else large
+                sh[j] = (E.Location(None, E.Offsets[i], E.InputShape) if j == 0
+                         else sh[j - 1] + block_offsets[j - 1] - block_offsets[j] + this_block * E.Stride[0] * dim // E.InputShape[0])
+            for j, corner in enumerate(E.Corners):
+                location = E.Location(corner, E.Offsets[i], E.InputShape)
+                corner_id = (corner[0] - E.Corners[0][0]) // E.Stride[0]
+                block = corner_id // large if corner_id < large * n_large else n_large + (corner_id - large * n_large) // small
+                if location >= 0:
+                    selections[block].append(location)
+                    m = location - sh[block]
+                    if self.CornersMap[j] >= 0 and self.CornersMap[j] != m:
+                        raise Exception("Internal Error")
+                    self.CornersMap[j] = m
+            row = []
+            for sel in selections:
+                if sel:
+                    v = np.zeros(dim)
+                    v[sel] = 1.0
+                    row.append(F.GetPlainVector(v, EVectorFormat.dense, 1))
+                else:
+                    row.append(None)
+            self.masks.append(row)
+            self.shifts.append(sh)
+        per_row = dim // E.InputShape[0]
+        large_max = 0 if n_large == 0 else per_row * (1 + E.Stride[0] * (large - 1)) + block_offsets[n_large - 1]
+        small_max = per_row * (1 + E.Stride[0] * (small - 1)) + block_offsets[-1]
+        self.outputDim = max(large_max, small_max)
+        self._hot = np.zeros(self.outputDim)
+        for x in self.CornersMap:
+            self._hot[x] = 1.0
+        self.layerPrepared = True
+
+    def Apply(self, m):
+        if m.ColumnCount != 1:
+            raise Exception("Expecting only a single column")
+        if not self.layerPrepared:
+            self.Prepare()
+        env = self.Factory.AllocateComputationEnv()
+        v = m.GetColumn(0)
+        res = [v.Permute(self.masks[k], self.shifts[k], self.outputDim, env) for k in range(len(self.masks))]
+        return self.Factory.GetMatrix(res, EMatrixFormat.ColumnMajor, CopyVectors=False)
+
+    def OutputDimension(self):
+        if not self.layerPrepared:
+            self.Prepare()
+        return self.outputDim
+
+    def RearrangeWeights(self, weights):
+        """:156-169: per-corner weights [map][corner] -> [map][slot of that corner]"""
+        if not self.layerPrepared:
+            self.Prepare()
+        weights = np.asarray(weights, dtype=np.float64)
+        corners = len(self.engine.Corners)
+        maps = len(weights) // corners
+        out = np.zeros(maps * self.outputDim)
+        for i in range(maps):
+            for j in range(corners):
+                out[i * self.outputDim + self.CornersMap[j]] = weights[j + i * corners]
+        return out
+
+    def Dispose(self):
+        if self.masks is not None:
+            for row in self.masks:
+                for v in row:
+                    if v is not None:
+                        v.Dispose()
+        self.masks = None
+
+
+class TimingLayer(BaseLayer):
+    """NeuralNetworks/TimingLayer.cs: a pass-through layer that starts / stops named wall-clock counters (the reference brackets the
+    evaluated layers with it: "Batch-Time" CryptoNets.cs:31,74, "Prediction-Time" LoLaCryptonets.cs:66-67).  Device work is
+    asynchronous here, so a stopping layer first waits for the streams of the environment."""
+    TotalTimeMS, N, StartTime = {}, {}, {}
+
+    def __init__(self, Source=None, Factory=None, StartCounters=(), StopCounters=()):
+        super().__init__(Source, Factory)
+        self.StartCounters, self.StopCounters = list(StartCounters), list(StopCounters)
+
+    @classmethod
+    def GetStats(cls, multiLines=False):
+        return ("\n" if multiLines else "\t").join("%s %.2f" % (k, v / cls.N[k]) for k, v in cls.TotalTimeMS.items())
+
+    @classmethod
+    def Reset(cls):
+        cls.TotalTimeMS.clear()
+        cls.N.clear()
+        cls.StartTime.clear()
+
+    def Apply(self, m):
+        import time
+        if self.StopCounters or self.StartCounters:
+            try:
+                for e in self.Factory.AllocateComputationEnv().Environments:
+                    e.ctx.sync()
+            except AttributeError:
+                pass
+        now = time.perf_counter()
+        for c in self.StartCounters:
+            TimingLayer.StartTime[c] = now
+        for c in self.StopCounters:
+            if c in TimingLayer.StartTime:
+                TimingLayer.TotalTimeMS[c] = TimingLayer.TotalTimeMS.get(c, 0.0) + 1e3 * (now - TimingLayer.StartTime[c])
+                TimingLayer.N[c] = TimingLayer.N.get(c, 0) + 1
+        return m
+
+
+class WeightsReader:
+    """NeuralNetworks/WeightsReader.cs: one array per CSV line, for the weights file and the biases file"""
+
+    def __init__(self, weightsCsvPath, biasesCsvPath):
+        self.Weights, self.Biases = self._read(weightsCsvPath), self._read(biasesCsvPath)
+
+    @staticmethod
+    def _read(path):
+        with open(path, "r") as f:
+            return [np.array([float(x) for x in line.split(",")]) for line in f.read().splitlines() if line != ""]
+
+
 class LLPoolLayer(BaseLayer):
     """NeuralNetworks/LLPoolLayer.cs: convolution on the im2col matrix: per map one Mul(weight window) + bias (:112-137)."""
 

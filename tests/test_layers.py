@@ -136,3 +136,64 @@ def test_batch_reader_tsv_formats(tmp_path):
     b = r.GetNext()
     assert r.Labels[0] == 2 ** 31 - 1 and b.Data.shape == (1, 3)
     r.Dispose()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_PreConvLayer(backend):
+    """NeuralNetworksTest/LayersTest.cs:84-152, on ENCRYPTED data (the reference runs it on its Raw factory): LLPreConvLayer turns one
+    packed 28x28 image into the 25 aligned offset vectors of a 5x5 / stride 2 / upper-pad 1 convolution with masks + Permute."""
+    from cryptonets_amd.layers import LLPreConvLayer
+    Factory = factory(backend)
+    layer = LLPreConvLayer(Factory=Factory, InputShape=[28, 28], KernelShape=[5, 5], Upperpadding=[1, 1], Stride=[2, 2])
+    layer.Prepare()
+    inp = np.arange(1, 28 * 28 + 1, dtype=float)
+    v = Factory.GetEncryptedVector(inp, EVectorFormat.dense, 1)
+    res = layer.Apply(Factory.GetMatrix([v], EMatrixFormat.ColumnMajor))
+    dec = np.asarray(res.Decrypt(Factory.AllocateComputationEnv()))
+    assert dec.shape == (196, 25) and layer.OutputDimension() == 196
+    values = set()
+    for j in range(196):
+        val = int(dec[j, 0])
+        if val != 0:
+            assert val not in values
+            values.add(val)
+            x, y = (val - 1) // 28, (val - 1) % 28
+            assert x % 2 == 0 and y % 2 == 0 and 0 <= x < 26 and 0 <= y < 26
+    assert len(values) == 13 * 13
+    assert int(layer.HotIndices.sum()) == 13 * 13 and all(layer.HotIndices[j] == (dec[j, 0] != 0) for j in range(196))
+    for i in range(1, 25):
+        dx, dy = i // 5, i % 5
+        delta = dy * 28 + dx
+        for j in range(196):
+            val, val0 = dec[j, i], dec[j, 0]
+            if val0 == 0:
+                assert val == 0
+            else:
+                y, x = int(val0 - 1) // 28, int(val0 - 1) % 28
+                assert val == (0 if (x + dx >= 28 or y + dy >= 28) else val0 + delta)
+    # RearrangeWeights: per-corner weights land on the slot of their corner
+    w = np.arange(1, 2 * 169 + 1, dtype=float)
+    r = layer.RearrangeWeights(w)
+    assert r.shape == (2 * 196,) and sorted(r[r != 0]) == list(w) and r[layer.CornersMap[5]] == w[5] and r[196 + layer.CornersMap[7]] == w[169 + 7]
+
+
+def test_single_line_reader_timing_layer_weights_reader(tmp_path):
+    from cryptonets_amd.layers import LLSingleLineReader, TimingLayer, WeightsReader
+    f = tmp_path / "one.tsv"
+    f.write_text("4\t5\t0:128\t3:64\n1\t5\t4:255\n")
+    r = LLSingleLineReader(str(f), NormalizationFactor=1.0 / 256.0, Scale=8.0)
+    m = r.GetNext()
+    assert list(r.Labels) == [4] and m.Data.shape == (5, 1) and list(m.Data[:, 0]) == [4, 0, 0, 2, 0] and r.OutputDimension() == 5
+    m = r.GetNext()
+    assert list(r.Labels) == [1] and m.Data[4, 0] == 8.0
+    assert r.GetNext() is None
+    TimingLayer.Reset()
+    src = FakeLayer()
+    start, stop = TimingLayer(Source=src, StartCounters=["t"]), TimingLayer(Source=src, StopCounters=["t", "never-started"])
+    tok = object()
+    assert start.Apply(tok) is tok and stop.Apply(tok) is tok
+    assert TimingLayer.N == {"t": 1} and TimingLayer.GetStats().startswith("t ")
+    (tmp_path / "w.csv").write_text("1,2.5,-3\n4\n")
+    (tmp_path / "b.csv").write_text("0.5,0.25\n")
+    wr = WeightsReader(str(tmp_path / "w.csv"), str(tmp_path / "b.csv"))
+    assert [list(x) for x in wr.Weights] == [[1, 2.5, -3], [4]] and list(wr.Biases[0]) == [0.5, 0.25]
