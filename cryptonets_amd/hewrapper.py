@@ -1146,6 +1146,45 @@ class EncryptedSealBfvMatrix:
             raise Exception("Expecting ColumnMajor matrix")
         return EncryptedSealBfvVector.Interleave(self.leVectors, shift, env)
 
+    def MulColumnsByPlain(self, plain, env):
+        """Every column PointwiseMultiply(plain) with ONE MultiplyPlain launch chain per plaintext prime (LLInterleaveLayer masks all
+        its columns with the same selection vector, LLInterleaveLayer.cs:40-47).  Same words as the per-column loop."""
+        if self.Format != EMatrixFormat.ColumnMajor:
+            raise Exception("Expecting ColumnMajor matrix")
+        cols = self.leVectors
+        ok = all(c.IsEncrypted and c.Format == EVectorFormat.dense and all(a.encData.count == 1 for a in c.eVectors) and c.Dim == cols[0].Dim
+                 for c in cols) and (not plain.IsEncrypted) and plain.Format == EVectorFormat.dense and plain.Dim == cols[0].Dim \
+            and all(a.plainDense is not None and a.plainDense.count == 1 and not a.plainZero[0] for a in plain.eVectors)
+        if not ok:
+            r = EncryptedSealBfvMatrix(Format=self.Format)
+            r.leVectors = [c.PointwiseMultiply(plain, env) for c in cols]
+            return r
+
+        def one_prime(i, e):
+            ctx = e.ctx
+            h, idx, tmp = _gather(ctx, [c.eVectors[i].encData for c in cols])
+            res = _Buf(ctx, "ct", len(cols))
+            pd = plain.eVectors[i].plainDense
+            try:
+                if idx == list(range(idx[0], idx[0] + len(idx))):
+                    ctx.mul_plain(h, idx[0], pd.h, pd.first, res.h, 0, len(cols), pt_stride=0)
+                else:
+                    for j, src in enumerate(idx):
+                        ctx.mul_plain(h, src, pd.h, pd.first, res.h, j, 1)
+            finally:
+                if tmp is not None:
+                    tmp.release()
+            return res
+        per_prime = _fan_out(env.Environments, one_prime)
+        vecs = []
+        for j, c in enumerate(cols):
+            atoms = [AtomicSealBfvEncryptedVector._new(Scale=c.eVectors[i].Scale * plain.eVectors[i].Scale, Dim=c.eVectors[i].Dim, Format=EVectorFormat.dense,
+                                                       IsSigned=c.eVectors[i].IsSigned, encData=per_prime[i].view(j, 1)) for i in range(len(env.Environments))]
+            vecs.append(EncryptedSealBfvVector._of(atoms, c.Scale * plain.Scale))
+        r = EncryptedSealBfvMatrix(Format=self.Format)
+        r.leVectors = vecs
+        return r
+
     # ---- batched HOT LOOP C: every row of a RowMajor plaintext matrix against one packed ciphertext ---------------------
     def _row_plaintexts(self, i, env_i):
         """contiguous device array with the (single-block, dense) plaintext of every row for prime i - built once"""

@@ -726,8 +726,7 @@ class LLInterleaveLayer(BaseLayer):
         if not self.layerPrepared:
             self.Prepare()
         env = self.Factory.AllocateComputationEnv()
-        clean = [m.GetColumn(i).PointwiseMultiply(self.mask, env) for i in range(m.ColumnCount)]
-        cleanMat = self.Factory.GetMatrix(clean, EMatrixFormat.ColumnMajor, CopyVectors=False)
+        cleanMat = m.MulColumnsByPlain(self.mask, env)               # all columns x the selection mask in one launch chain per prime
         interleaved = cleanMat.Interleave(self.Shift, env)
         cleanMat.Dispose()
         return self.Factory.GetMatrix([interleaved], EMatrixFormat.ColumnMajor, CopyVectors=False)
