@@ -1267,12 +1267,13 @@ class EncryptedSealBfvMatrix:
         return res
 
     # ---- batched HOT LOOP A for a whole PoolLayer (PoolLayer.cs:149-229 issues one Mul per output) -----------------
-    def MulManySparse(self, gather, weights, bias, out_scale, env, cache=None):
+    def MulManySparse(self, gather, weights, bias, out_scale, env, cache=None, bias_vectors=None):
         """out[o] = sum_k weights[o][k] * column[gather[o][k]] + bias[o]  for all outputs in one scalar GEMM per prime.
         gather: int32 [O,K] (-1 = padded tap), weights: integer rows (scaled, signed), bias: integers or None.
         Equivalent to O calls of Mul(sparse plain weight window) followed by Add(dense plain bias).  `cache`: a dict owned by the
         calling layer - the planned GEMM (weight tiles, gather tables, bias plaintexts in HBM) is kept there per plaintext prime and
-        only launched on the next inference (cn_gemm_plan_create / cn_gemm_plan_apply)."""
+        only launched on the next inference (cn_gemm_plan_create / cn_gemm_plan_apply).  `bias_vectors`: instead of integer
+        constants, one dense plaintext vector per output (LLPoolLayer adds `hot * bias`, LLPoolLayer.cs:128-134)."""
         if self.Format != EMatrixFormat.ColumnMajor:
             raise Exception("Expecting ColumnMajor matrix")
         O = len(weights)
@@ -1284,7 +1285,7 @@ class EncryptedSealBfvMatrix:
                 raise Exception("batched PoolLayer expects single-block encrypted columns")
             h, idx, tmp = _gather(ctx, [c.encData for c in cols])
             res = _Buf(ctx, "ct", O)
-            key = (i, tuple(idx), None if bias is None else tuple(int(b) for b in bias))      # the bias depends on the input scale
+            key = (i, tuple(idx), None if bias is None else tuple(int(b) for b in bias), bias_vectors is not None)   # the bias depends on the input scale
             if cache is not None and key in cache and hasattr(ctx, "gemm_apply"):
                 try:
                     ctx.gemm_apply(cache[key][0], h, res.h, 0)
@@ -1296,7 +1297,13 @@ class EncryptedSealBfvMatrix:
             gidx = np.where(g >= 0, np.asarray(idx, dtype=np.int64)[np.maximum(g, 0)], -1).astype(np.int32)
             W = np.array([[int(x) % p for x in row] for row in weights], dtype=np.uint64)
             bh, bidx = 0, None
-            if bias is not None:
+            if bias_vectors is not None:
+                bp = _Buf(ctx, "pt", O).view()
+                for o_, bv in enumerate(bias_vectors):
+                    pd = bv.eVectors[i].plainDense
+                    ctx.copy(pd.h, pd.first, bp.h, o_, 1)
+                bh, bidx = bp.h, np.arange(O, dtype=np.int32)
+            elif bias is not None:
                 bvals = [int(b) % p for b in bias]
                 uniq = sorted(set(bvals))
                 pos = {v: j for j, v in enumerate(uniq)}
@@ -1308,7 +1315,7 @@ class EncryptedSealBfvMatrix:
             if cache is not None and hasattr(ctx, "gemm_plan"):
                 try:
                     plan = ctx.gemm_plan(W, idx=gidx, bias_pt=bh, bias_idx=bidx)
-                    cache[key] = (plan, bp if bias is not None else None)      # the plan references the bias plaintexts: keep both
+                    cache[key] = (plan, bp if (bias is not None or bias_vectors is not None) else None)      # the plan references the bias plaintexts: keep both
                     ctx.gemm_apply(plan, h, res.h, 0)
                 finally:
                     if tmp is not None:
@@ -1319,7 +1326,7 @@ class EncryptedSealBfvMatrix:
             finally:
                 if tmp is not None:
                     tmp.release()
-                if bias is not None:
+                if bias is not None or bias_vectors is not None:
                     bp.release()
             return res
         per_prime = _fan_out(env.Environments, one_prime)

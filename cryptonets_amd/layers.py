@@ -597,6 +597,7 @@ class LLPoolLayer(BaseLayer):
         F = self.Factory
         win = self.engine.weight_windows(self.Weights, self.kernelSize)
         self.weightWindows = [F.GetPlainVector(w, EVectorFormat.sparse, self.WeightsScale) for w in win]
+        self.weightInts = [[int(round(float(x) * float(self.WeightsScale))) for x in w] for w in win]       # the same rounding as GetPlainVector
         hot = np.ones(len(self.engine.Corners)) if self.HotIndices is None else np.asarray(self.HotIndices, dtype=np.float64)
         bscale = self.Source.GetOutputScale() * self.WeightsScale
         src = self.Bias if self.Bias is not None else [self.Weights[(m + 1) * self.kernelSize - 1] for m in range(self.engine.maps)]
@@ -616,8 +617,16 @@ class LLPoolLayer(BaseLayer):
                 vec = nxt
             vec.RegisterScale(vec.Scale * m.ColumnCount)
             return self.Factory.GetMatrix([vec], EMatrixFormat.ColumnMajor, CopyVectors=False)
+        maps, K = len(self.biasVectors), m.ColumnCount
+        batched = (hasattr(m, "MulManySparse") and all(c.IsEncrypted and c.Format == EVectorFormat.dense for c in m.leVectors)
+                   and all(a.encData.count == 1 for c in m.leVectors for a in c.eVectors) and all(any(w) for w in self.weightInts))
+        if batched:
+            # the `maps` (Mul + Add) pairs as ONE scalar GEMM with dense bias plaintexts per plaintext prime, planned once
+            gather = np.tile(np.arange(K, dtype=np.int32), (maps, 1))
+            return m.MulManySparse(gather, self.weightInts, None, m.Scale * self.WeightsScale, env, cache=self.__dict__.setdefault("_gemm_plans", {}),
+                                   bias_vectors=self.biasVectors)
         res = []
-        for k in range(len(self.biasVectors)):
+        for k in range(maps):
             mul = m.Mul(self.weightWindows[k], env)
             res.append(mul.Add(self.biasVectors[k], env))
             mul.Dispose()
