@@ -233,7 +233,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         CHECK(big_lds(k_keyswitch_rr<12, ArF64, 1, true>, ks_twl_lds<12>())); CHECK(big_lds(k_keyswitch_rr<12, ArF64L, 1, true>, ks_twl_lds<12>()));
     }
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
-        CHECK(big_lds(k_ntt, lds));
+        CHECK(big_lds(k_ntt, lds)); CHECK(big_lds(k_galois_lds, (size_t)n * 8));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
         CHECK((big_lds_policy<13, ArU64>(lds))); CHECK((big_lds_policy<14, ArU64>(lds)));
         CHECK((big_lds_policy<13, ArF64>(lds))); CHECK((big_lds_policy<14, ArF64>(lds)));
@@ -990,7 +990,8 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
 
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     uint32_t limbs = count * 2 * ctx->hc.k;
-    hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
+    if (ctx->hc.n >= 1024) hipLaunchKernelGGL(k_galois_lds, dim3(limbs), dim3(std::min<uint32_t>(1024, ctx->hc.n / 4)), (size_t)ctx->hc.n * 8, ctx->stream, in, tmp, ctx->dc, elt);
+    else hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
     HIPCHK(hipGetLastError()); launch_count(ctx);
     CHECK(do_keyswitch(ctx, tmp + kn, 2 * kn, tmp, nullptr, 2 * kn, it->second, out, count, 1, acc, ctx->ctw2));
     ctx->st.Rotation += count;
