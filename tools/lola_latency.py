@@ -10,6 +10,9 @@ import test_lola as T
 Factory = make_factory("gpu", primes=T.PRIMES, n=8192, galois=True)
 env = Factory.AllocateComputationEnv()
 img = T.image()
+if os.environ.get("LOLA_KS_WIDE"):                       # A/B of the key-switch variants: -1 auto, 0 fused, 1 per digit, 2 per source limb
+    for e in env.Environments:
+        e.ctx.set_option("ks_wide", int(os.environ["LOLA_KS_WIDE"]))
 net = T.lola(Factory, img)
 net.PrepareNetwork()
 layers = []
