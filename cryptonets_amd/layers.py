@@ -9,18 +9,15 @@ import numpy as np
 
 from .convolution import ConvolutionEngine
 from .hewrapper import EMatrixFormat, EVectorFormat
+from .raw import Defaults, RawMatrix
 
 
-class RawData:
-    """What a reader layer hands to EncryptLayer: RawMatrix semantics (`HE Wrapper/RawMatrix.cs:19-26`): the stored data
-    is round(m * scale)."""
+class RawData(RawMatrix):
+    """What a reader layer hands to EncryptLayer: a RawMatrix of `Defaults.RawFactory` (`BatchReader.cs:51,126`,
+    `LLConvReader.cs:73`): the stored data is round(m * scale) (`HE Wrapper/RawMatrix.cs:19-26`)."""
 
     def __init__(self, m, scale):
-        self.Scale = scale
-        self.Data = np.rint(np.asarray(m, dtype=np.float64) * scale)
-
-    def Dispose(self):
-        self.Data = None
+        super().__init__(np.asarray(m, dtype=np.float64), scale, EMatrixFormat.ColumnMajor, Defaults.RawFactory.BlockSize)
 
 
 class BaseLayer:
@@ -618,7 +615,7 @@ class LLPoolLayer(BaseLayer):
             vec.RegisterScale(vec.Scale * m.ColumnCount)
             return self.Factory.GetMatrix([vec], EMatrixFormat.ColumnMajor, CopyVectors=False)
         maps, K = len(self.biasVectors), m.ColumnCount
-        batched = (hasattr(m, "MulManySparse") and all(c.IsEncrypted and c.Format == EVectorFormat.dense for c in m.leVectors)
+        batched = (hasattr(m, "leVectors") and all(c.IsEncrypted and c.Format == EVectorFormat.dense for c in m.leVectors)
                    and all(a.encData.count == 1 for c in m.leVectors for a in c.eVectors) and all(any(w) for w in self.weightInts))
         if batched:
             # the `maps` (Mul + Add) pairs as ONE scalar GEMM with dense bias plaintexts per plaintext prime, planned once
@@ -697,7 +694,7 @@ class LLPackedDenseLayer(BaseLayer):
             raise Exception("Expecting only one column")
         env = self.Factory.AllocateComputationEnv()
         vector, res = m.GetColumn(0), []
-        if self.WeightsMatrix._can_batch_rows(vector):
+        if getattr(self.WeightsMatrix, "_can_batch_rows", lambda v: False)(vector):
             # all packed rows at once: one MultiplyPlain / rotate-and-add launch chain per plaintext prime
             res = self.WeightsMatrix.RowsDotProduct(vector, env, length=self.PackingShift, bias=self.BiasMatrix)
         else:

@@ -166,3 +166,20 @@ def test_reference_kats_with_the_device_client():
     data = np.array([[0, 0, 1, 0, 0, 2], [0, 0, 3, 0, 0, 4], [0, 0, 5, 0, 0, 6]], dtype=float).T
     mm = F.GetEncryptedMatrix(data, EMatrixFormat.ColumnMajor, 10)
     assert list(mm.Interleave(-1, env).Decrypt(env)) == [5, 3, 1, 6, 4, 2]
+
+
+def test_basic_example_on_the_default_encrypted_factory():
+    """BASELINE config 0 as the reference ships it (`Basic Example/Program.cs:18`: `new EncryptedSealBfvFactory()`, N = 4096,
+    five plaintext primes): the same three results as on RawFactory (tests/test_raw_operations.py::test_basic_example)."""
+    import importlib.util
+    import os
+    from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
+    from cryptonets_amd.raw import RawFactory
+    spec = importlib.util.spec_from_file_location("basic_example", os.path.join(os.path.dirname(__file__), "..", "examples", "basic_example.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    enc = mod.run(EncryptedSealBfvFactory())
+    raw = mod.run(RawFactory(4096))
+    assert enc["norm_squared"][0] == raw["norm_squared"][0] == 14.0
+    assert enc["sum"][0] == raw["sum"][0] == 6.0
+    assert enc["elementwise"][:3] == raw["elementwise"] == [-1.0, 10.0, -12.0]

@@ -5,13 +5,17 @@ import pytest
 
 from oracle_backend import make_factory
 from cryptonets_amd.hewrapper import EMatrixFormat, EVectorFormat
+from cryptonets_amd.raw import RawFactory
 from cryptonets_amd.layers import EncryptLayer, FakeLayer, InputLayer, LLDenseLayer, PoolLayer, SquareActivation
 
-BACKENDS = [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)]
+# "raw": the reference's own set-up for these tests (LayersTest.cs:56,87,157 run on Defaults.RawFactory)
+BACKENDS = [pytest.param("raw"), pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)]
 _f = {}
 
 
 def factory(backend, **kw):
+    if backend == "raw":
+        return RawFactory(kw.get("n", 8192))
     key = (backend, tuple(sorted(kw.items())))
     if key not in _f:
         _f[key] = make_factory(backend, **kw)

@@ -121,6 +121,29 @@ def test_lola_dense_single_image(tmp_path):
     assert [int(x) for x in got] == exp
 
 
+def test_lola_mnist_on_the_raw_factory(tmp_path):
+    """The reference's `Encrypt = false` switch (`LoLaCryptonets.cs:208`, `:124`): the same layer graphs on RawFactory.  Plain doubles
+    (no modular wrap, 53-bit mantissa), so the logits equal the exact integer model to double precision."""
+    from cryptonets_amd.raw import RawFactory
+    img = image()
+    net = lola(RawFactory(8192), img)
+    net.PrepareNetwork()
+    out = net.GetNext()
+    exp = np.array(int_logits(img), dtype=float)
+    got = np.array(out.GetColumn(0).DecryptFullPrecision(None), dtype=float)
+    assert got.shape == (10,) and np.allclose(got, exp, rtol=1e-12, atol=0) and int(np.argmax(got)) == int(np.argmax(exp))
+    img = image(5)
+    tsv = tmp_path / "one_image.tsv"
+    tsv.write_text("7\t784\t" + "\t".join("%d:%d" % (i, int(img[i])) for i in np.nonzero(img)[0]) + "\n")
+    reader, net = lola_dense(RawFactory(16384), str(tsv))
+    net.PrepareNetwork()
+    out = net.GetNext()
+    exp = np.array(int_logits(img), dtype=float)
+    got = np.array(out.GetColumn(0).DecryptFullPrecision(None), dtype=float)
+    assert list(reader.Labels) == [7]
+    assert got.shape == (10,) and np.allclose(got, exp, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("backend", [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)])
 def test_small_lola_single_image(backend):
     """SmallLoLa (`LoLaCryptonets.cs:280-329`, BASELINE config 4b): N = 8192, dbc 40 / 40 (two digits per limb), plaintext primes
