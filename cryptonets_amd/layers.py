@@ -20,6 +20,12 @@ class RawData(RawMatrix):
         super().__init__(np.asarray(m, dtype=np.float64), scale, EMatrixFormat.ColumnMajor, Defaults.RawFactory.BlockSize)
 
 
+def _sync_factory(Factory):
+    """device work is asynchronous: wait for the streams of the factory's contexts before reading a clock (no-op on RawFactory)"""
+    for e in getattr(Factory.AllocateComputationEnv(), "Environments", ()):
+        e.ctx.sync()
+
+
 class BaseLayer:
     """NeuralNetworks/BaseLayer.cs: pull-based chaining (GetNext :23-49), scale bookkeeping."""
 
@@ -52,11 +58,22 @@ class BaseLayer:
     def Apply(self, m):
         raise NotImplementedError
 
+    Verbose = False
+
     def GetNext(self):
         if not self.layerPrepared:
             self.Prepare()
         m = self.Source.GetNext()
-        res = self.Apply(m)
+        if m is None:                                            # a single-record reader at end of file
+            return None
+        if not self.Verbose:
+            res = self.Apply(m)
+        else:                                                    # BaseLayer.cs:30-43: per-layer wall time and width
+            import time
+            start = time.perf_counter()
+            res = self.Apply(m)
+            _sync_factory(self.Factory)
+            print("Layer %s computed in %.6f seconds layer width (%d,%d)" % (type(self).__name__, time.perf_counter() - start, m.RowCount, m.ColumnCount))
         if res is not m:
             m.Dispose()
         return res
@@ -298,22 +315,77 @@ class FakeLayer(BaseLayer):
 # Pure callers of the IVector / IMatrix surface (component 15): one image packed into a few ciphertexts,
 # dense layers as plaintext-row x ciphertext dot products with rotate-and-sum.
 
-class LLConvReader(BaseLayer):
-    """NeuralNetworks/LLConvReader.cs:96-158: im2col of ONE image into a [corners x offsets] matrix (padding = 0)."""
+def _parse_record(line, SparseFormat, LabelColumn, NormalizationFactor, normalize_dense):
+    """One TSV record of the reference's readers -> (label, features).  Sparse: `label <TAB> dim <TAB> index:value ...`; dense:
+    one value per column, the label in `LabelColumn` (int.MaxValue when LabelColumn is beyond the columns)."""
+    f = line.rstrip("\r\n").split("\t")
+    if SparseFormat:
+        features = np.zeros(int(f[1]))
+        for item in f[2:]:
+            c, v = item.split(":")
+            features[int(c)] = float(v) * NormalizationFactor
+        return int(f[0]), features
+    if LabelColumn >= len(f):
+        label, features = 2 ** 31 - 1, np.array([float(x) for x in f])
+    else:
+        label, features = int(f[LabelColumn]), np.array([float(x) for k, x in enumerate(f) if k != LabelColumn])
+    return label, (features * NormalizationFactor if normalize_dense else features)
 
-    def __init__(self, Features=None, Scale=1.0, NormalizationFactor=1.0, InputShape=None, KernelShape=None, Stride=None, Padding=None,
-                 Upperpadding=None, Lowerpadding=None, Factory=None):
+
+class LLConvReader(BaseLayer):
+    """NeuralNetworks/LLConvReader.cs: im2col of ONE record into a [corners x offsets] matrix (padding = 0, :139-147).  The record is
+    the next line of `FileName` (formats as BatchReader, values times NormalizationFactor, :100-137) unless `Features` was set - a
+    feature vector set by hand is taken as it is and used for one GetNext (:49-60,150).  None at end of file."""
+
+    def __init__(self, FileName=None, Features=None, Scale=1.0, NormalizationFactor=1.0, InputShape=None, KernelShape=None, Stride=None,
+                 Padding=None, Upperpadding=None, Lowerpadding=None, SparseFormat=True, LabelColumn=0, Factory=None):
         super().__init__(None, Factory)
-        self.Features, self.Scale, self.NormalizationFactor = Features, Scale, NormalizationFactor
+        self.Scale, self.NormalizationFactor, self.SparseFormat, self.LabelColumn = Scale, NormalizationFactor, SparseFormat, LabelColumn
         self.engine = ConvolutionEngine(InputShape, KernelShape, Stride, Padding, Upperpadding, Lowerpadding)
+        self.Labels, self._sr, self._dim, self._features = None, None, -1, None
+        if FileName is not None:
+            self.FileName = FileName
+        self.Features = Features
+
+    @property
+    def FileName(self):
+        return self._file_name
+
+    @FileName.setter
+    def FileName(self, value):
+        self._file_name = value
+        if self._sr is not None:
+            self._sr.close()
+        self._sr = open(value, "r")
+        self._dim = -1
+
+    @property
+    def Features(self):
+        return self._features
+
+    @Features.setter
+    def Features(self, value):
+        self._features = None if value is None else np.asarray(value, dtype=np.float64)
+        if self._features is not None:
+            self._dim = self._features.size
 
     def PrepareNetwork(self):
         self.Prepare()
 
+    def Apply(self, m):
+        return self.GetNext()
+
     def GetNext(self):
-        f = np.asarray(self.Features, dtype=np.float64) * self.NormalizationFactor
+        if self._features is None:
+            line = self._sr.readline() if self._sr is not None else ""
+            if line == "":
+                return None
+            label, self._features = _parse_record(line, self.SparseFormat, self.LabelColumn, self.NormalizationFactor, True)
+            self.Labels = np.array([label], dtype=np.int64)
+            self._dim = self._features.size
         g = self.engine.gather_table()
-        mat = np.where(g >= 0, f[np.maximum(g, 0)], 0.0)
+        mat = np.where(g >= 0, self._features[np.maximum(g, 0)], 0.0)
+        self._features = None
         return RawData(mat, self.Scale)
 
     def GetOutputScale(self):
@@ -321,6 +393,11 @@ class LLConvReader(BaseLayer):
 
     def OutputDimension(self):
         return len(self.engine.Corners)
+
+    def Dispose(self):
+        if self._sr is not None:
+            self._sr.close()
+            self._sr = None
 
 
 class LLSingleLineReader(BaseLayer):
@@ -541,11 +618,7 @@ class TimingLayer(BaseLayer):
     def Apply(self, m):
         import time
         if self.StopCounters or self.StartCounters:
-            try:
-                for e in self.Factory.AllocateComputationEnv().Environments:
-                    e.ctx.sync()
-            except AttributeError:
-                pass
+            _sync_factory(self.Factory)
         now = time.perf_counter()
         for c in self.StartCounters:
             TimingLayer.StartTime[c] = now

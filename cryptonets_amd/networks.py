@@ -1,0 +1,163 @@
+"""The reference's application networks as layer graphs (`CryptoNets/CryptoNets.cs:14-75`, `LowLatencyCryptoNets/LoLaCryptonets.cs:
+118-329`): the callers of the hot path, one builder per network plus the two evaluation loops.  A builder takes the factory (an
+`EncryptedSealBfvFactory` - or a `RawFactory`, the reference's `Encrypt = false`), the reader layer and the model arrays (the
+reference compiles them in as `Weights.cs` / `SmallModel.cs`; here they are passed in - `tests/golden/*.npz` holds them as data).
+The factory parameters each network was designed for are in `FACTORY_PARAMETERS`.
+"""
+import numpy as np
+
+from .hewrapper import EVectorFormat
+from .layers import (BatchReader, EncryptLayer, LLConvReader, LLDenseLayer, LLDuplicateLayer, LLInterleavedDenseLayer, LLInterleaveLayer,
+                     LLPackedDenseLayer, LLPoolLayer, LLPreConvLayer, LLSingleLineReader, LLVectorizeLayer, PoolLayer, SquareActivation,
+                     TimingLayer)
+
+# plaintext primes, N, decomposition bit counts, coefficient primes taken: CryptoNets.cs:17; LoLaCryptonets.cs:123,208,285
+FACTORY_PARAMETERS = {
+    "CryptoNets": dict(primes=(549764251649, 549764284417), n=8192),
+    "LoLa": dict(primes=(557057, 638977, 737281, 786433), n=8192),
+    "LoLaDense": dict(primes=(34359771137, 34360754177), n=16384, DecompositionBitCount=60, GaloisDecompositionBitCount=60, SmallModulusCount=7),
+    "LoLaSmall": dict(primes=(2277377, 2424833), n=8192, DecompositionBitCount=40, GaloisDecompositionBitCount=40, SmallModulusCount=3),
+}
+MNIST_CONV = dict(InputShape=[28, 28], KernelShape=[5, 5], Upperpadding=[1, 1], Stride=[2, 2])
+
+
+def Transpose(weights, inputShapeSize, outputMaps):
+    """CryptoNets.cs:112-123: [input][map] -> [map][input]"""
+    w = np.asarray(weights, dtype=np.float64)
+    return w[:inputShapeSize * outputMaps].reshape(inputShapeSize, outputMaps).T.reshape(-1).copy()
+
+
+def mnist_reader(FileName, batchSize, Factory=None):
+    return BatchReader(FileName=FileName, SparseFormat=True, MaxSlots=batchSize, NormalizationFactor=1.0 / 256.0, Scale=16.0, Factory=Factory)
+
+
+def CryptoNets(Factory, reader, w, weightscale=32, timing=True):
+    """CryptoNets.cs:19-75: conv 5x5 stride 2 (5 maps) -> square -> dense 845->100 -> square -> dense 100->10, one sample per slot."""
+    enc = EncryptLayer(Source=reader, Factory=Factory)
+    src = TimingLayer(Source=enc, StartCounters=["Batch-Time"]) if timing else enc
+    c1 = PoolLayer(Source=src, MapCount=[5, 1], WeightsScale=weightscale, Weights=w["Weights_0"], **MNIST_CONV)
+    a2 = SquareActivation(Source=c1)
+    d3 = PoolLayer(Source=a2, InputShape=[845], KernelShape=[845], Stride=[1000], MapCount=[100], Weights=Transpose(w["Weights_1"], 845, 100),
+                   Bias=w["Biases_2"], WeightsScale=weightscale * weightscale)
+    a4 = SquareActivation(Source=d3)
+    d5 = PoolLayer(Source=a4, InputShape=[100], KernelShape=[100], Stride=[1000], MapCount=[10], Weights=w["Weights_3"], Bias=w["Biases_3"],
+                   WeightsScale=weightscale)
+    return TimingLayer(Source=d5, StopCounters=["Batch-Time"]) if timing else d5
+
+
+def LoLa(Factory, reader, w, weightscale=32):
+    """LoLaCryptonets.cs:203-278: the reader does the im2col; 8-fold packed dense layer, interleave, interleaved dense layer."""
+    enc = EncryptLayer(Source=reader, Factory=Factory)
+    c1 = LLPoolLayer(Source=enc, MapCount=[5, 1], WeightsScale=weightscale, Weights=w["Weights_0"], **MNIST_CONV)
+    v2 = LLVectorizeLayer(Source=c1)
+    a3 = SquareActivation(Source=v2)
+    d4 = LLDuplicateLayer(Source=a3, Count=8)
+    d5 = LLPackedDenseLayer(Source=d4, Weights=Transpose(w["Weights_1"], 845, 100), Bias=w["Biases_2"], WeightsScale=weightscale * weightscale,
+                            PackingCount=d4.Count, PackingShift=1024)
+    sel = [1023 + i * 1024 for i in range(int(d4.Count))]
+    i6 = LLInterleaveLayer(Source=d5, Shift=-1, SelectedIndices=sel)
+    a7 = SquareActivation(Source=i6)
+    return LLInterleavedDenseLayer(Source=a7, Weights=w["Weights_3"], Bias=w["Biases_3"], WeightsScale=weightscale, Shift=-1, SelectedIndices=sel)
+
+
+def LoLaDense(Factory, reader, w, weightscale=32):
+    """LoLaCryptonets.cs:118-199: ONE packed ciphertext in; the im2col is done homomorphically (LLPreConvLayer), 16-fold packing."""
+    enc = EncryptLayer(Source=reader, Factory=Factory)
+    pre = LLPreConvLayer(Source=enc, UseAxisForBlocks=[True, True], **MNIST_CONV)
+    c2 = LLPoolLayer(Source=pre, MapCount=[5, 1], WeightsScale=weightscale, Weights=w["Weights_0"], HotIndices=pre.HotIndices, **MNIST_CONV)
+    v3 = LLVectorizeLayer(Source=c2)
+    a4 = SquareActivation(Source=v3)
+    d5 = LLDuplicateLayer(Source=a4, Count=16)
+    d6 = LLPackedDenseLayer(Source=d5, Weights=pre.RearrangeWeights(Transpose(w["Weights_1"], 845, 100)), Bias=w["Biases_2"],
+                            WeightsScale=weightscale * weightscale, PackingCount=d5.Count, PackingShift=1024)
+    a7 = SquareActivation(Source=d6)
+    sel = [1023 + i * 1024 for i in range(int(d5.Count))]
+    i8 = LLInterleaveLayer(Source=a7, Shift=-1, SelectedIndices=sel)
+    return LLInterleavedDenseLayer(Source=i8, Weights=w["Weights_3"], Bias=w["Biases_3"], WeightsScale=weightscale, Shift=-1, SelectedIndices=sel)
+
+
+def SmallLoLa(Factory, reader, w, weightscale=64):
+    """LoLaCryptonets.cs:280-329 (model: SmallModel.cs): conv -> vectorize -> square -> dense 845->10 on the packed vector."""
+    enc = EncryptLayer(Source=reader, Factory=Factory)
+    c1 = LLPoolLayer(Source=enc, MapCount=[5, 1], WeightsScale=weightscale, Weights=w["Weights_0"], **MNIST_CONV)
+    v2 = LLVectorizeLayer(Source=c1)
+    a3 = SquareActivation(Source=v2)
+    return LLDenseLayer(Source=a3, Bias=w["Biases_1"], Weights=w["Weights_1"], WeightsScale=weightscale, InputFormat=EVectorFormat.dense)
+
+
+def lola_reader(name, FileName=None, Factory=None):
+    """the input layer each LoLa variant reads MNIST with (LoLaCryptonets.cs:131-137,212-223,294-305)"""
+    if name == "LoLaDense":
+        return LLSingleLineReader(FileName=FileName, SparseFormat=True, NormalizationFactor=1.0 / 256.0, Scale=16.0, Factory=Factory)
+    return LLConvReader(FileName=FileName, SparseFormat=True, NormalizationFactor=1.0 / 256.0, Scale=16.0, Factory=Factory, **MNIST_CONV)
+
+
+LOLA_NETWORKS = {"LoLa": LoLa, "LoLaDense": LoLaDense, "LoLaSmall": SmallLoLa}
+
+
+def _chain(network):
+    p = network
+    while p is not None:
+        yield p
+        p = p.Source
+
+
+def evaluate_batches(network, Factory, reader, numberOfRecords, report=print):
+    """CryptoNets.cs:80-109: batches until `numberOfRecords` samples are scored; prediction = arg max of the decrypted row.
+    Returns (errors, count)."""
+    network.PrepareNetwork()
+    count = errs = 0
+    while count < numberOfRecords:
+        try:
+            m = network.GetNext()
+        except Exception as e:                                   # BatchReader at end of file
+            if "end of file" in str(e):
+                break
+            raise
+        env = Factory.AllocateComputationEnv()
+        try:
+            decrypted = np.asarray(m.Decrypt(env))
+            rows = min(decrypted.shape[0], len(reader.Labels))
+            pred = np.argmax(decrypted[:rows], axis=1)               # first maximum, like the strict '>' scan (:94-97)
+            errs += int(np.sum(pred != np.asarray(reader.Labels[:rows])))
+            count += rows
+            if report is not None:
+                report("errs %d/%d accuracy %.3f%%" % (errs, count, 100 - 100.0 * errs / count))
+                report("Batch size %d %s" % (rows, TimingLayer.GetStats()))
+        finally:
+            Factory.FreeComputationEnv(env)
+            m.Dispose()
+    return errs, count
+
+
+def evaluate_single(network, Factory, records, verbose=False, report=print):
+    """LoLaCryptonets.cs:64-115: "Prediction-Time" brackets everything after the EncryptLayer; one record per GetNext.
+    Returns (errors, count)."""
+    layers = list(_chain(network))
+    reader = layers[-1]
+    first = next(p for p in layers if isinstance(p.Source, EncryptLayer))
+    start = TimingLayer(Source=first.Source, StartCounters=["Prediction-Time"])
+    first.Source = start
+    network = TimingLayer(Source=network, StopCounters=["Prediction-Time"])
+    for p in _chain(network):
+        p.Factory = Factory
+        p.Verbose = verbose
+    network.PrepareNetwork()
+    errs = count = 0
+    for i in range(records):
+        m = network.GetNext()
+        if m is None:
+            break
+        env = Factory.AllocateComputationEnv()
+        try:
+            dec = np.asarray(m.Decrypt(env))[:, 0]
+            pred = int(np.argmax(dec[:10]))
+            label = int(reader.Labels[0])
+            errs += int(pred != label)
+            count += 1
+            if report is not None:
+                report("errs %d/%d accuracy %.3f%% %s prediction %d label %d" % (errs, count, 100 - 100.0 * errs / count, TimingLayer.GetStats(), pred, label))
+        finally:
+            Factory.FreeComputationEnv(env)
+            m.Dispose()
+    return errs, count

@@ -20,18 +20,11 @@ def weights():
 
 
 def build_network(Factory, images):
-    w0, w1, b2, w3, b3 = weights()
-    w1t = np.zeros_like(w1)                                       # CryptoNets.Transpose (CryptoNets.cs:112-123)
-    for i in range(845):
-        w1t[i + 845 * np.arange(100)] = w1[100 * i + np.arange(100)]
+    from cryptonets_amd import networks
     reader = InputLayer(images, Scale=16.0, NormalizationFactor=1.0 / 256.0, Factory=Factory)
-    enc = EncryptLayer(Source=reader)
-    conv = PoolLayer(Source=enc, InputShape=[28, 28], KernelShape=[5, 5], Upperpadding=[1, 1], Stride=[2, 2], MapCount=[5, 1], WeightsScale=32, Weights=w0)
-    a2 = SquareActivation(Source=conv)
-    d3 = PoolLayer(Source=a2, InputShape=[845], KernelShape=[845], Stride=[1000], MapCount=[100], Weights=w1t, Bias=b2, WeightsScale=32 * 32)
-    a4 = SquareActivation(Source=d3)
-    d5 = PoolLayer(Source=a4, InputShape=[100], KernelShape=[100], Stride=[1000], MapCount=[10], Weights=w3, Bias=b3, WeightsScale=32)
-    return d5, (conv, d3, d5)
+    net = networks.CryptoNets(Factory, reader, np.load(GOLD), timing=False)          # CryptoNets.cs:19-75
+    pools = [p for p in networks._chain(net) if isinstance(p, PoolLayer)][::-1]
+    return net, tuple(pools)
 
 
 def synthetic_images(count, seed=1):

@@ -55,7 +55,7 @@ def test_lola_cifar_shapes_end_to_end(limbs):
     w2 = np.rint(rng.normal(0, 0.05, 10 * 5488) * 512) / 512
     b2 = np.rint(rng.normal(0, 0.05, 10) * 512) / 512
     conv = dict(InputShape=[3, 32, 32], KernelShape=[3, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
-    reader = LLConvReader(Features=img, Scale=8.0, NormalizationFactor=1.0 / 256.0, Factory=Factory, **conv)
+    reader = LLConvReader(Features=img / 256.0, Scale=8.0, Factory=Factory, **conv)
     enc = EncryptLayer(Source=reader)
     c1 = LLPoolLayer(Source=enc, MapCount=[83, 1, 1], WeightsScale=256.0, Weights=w0, Bias=b0, **conv)
     v2 = LLVectorizeLayer(Source=c1)

@@ -20,7 +20,7 @@ w0 = np.rint(rng.normal(0, 0.05, 83 * 192) * 256) / 256; b0 = np.rint(rng.normal
 w1 = np.rint(rng.normal(0, 0.02, 112 * 8300) * 512) / 512; b1 = np.rint(rng.normal(0, 0.05, 112) * 512) / 512
 w2 = np.rint(rng.normal(0, 0.05, 10 * 5488) * 512) / 512; b2 = np.rint(rng.normal(0, 0.05, 10) * 512) / 512
 conv = dict(InputShape=[3, 32, 32], KernelShape=[3, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
-reader = LLConvReader(Features=img, Scale=8.0, NormalizationFactor=1.0 / 256.0, Factory=Factory, **conv)
+reader = LLConvReader(Features=img / 256.0, Scale=8.0, Factory=Factory, **conv)
 enc = EncryptLayer(Source=reader)
 c1 = LLPoolLayer(Source=enc, MapCount=[83, 1, 1], WeightsScale=256.0, Weights=w0, Bias=b0, **conv)
 v2 = LLVectorizeLayer(Source=c1); a3 = SquareActivation(Source=v2)
@@ -33,6 +33,7 @@ def sync():
     for e in env.Environments: e.ctx.sync()
 layers = [c1, v2, a3, d4, a5, d6]
 for rep in range(3):
+    reader.Features = img / 256.0
     m = enc.GetNext(); sync()
     times = []; t_all = time.perf_counter()
     for L in layers:

@@ -24,6 +24,7 @@ def sync():
     for e in env.Environments:
         e.ctx.sync()
 for rep in range(3):
+    layers[0].Features = img / 256.0                      # a hand-set record is used for ONE GetNext (LLConvReader.cs:150)
     m = layers[0].GetNext()
     t0 = time.perf_counter(); m = layers[1].Apply(m); sync(); t_enc = time.perf_counter() - t0
     for e in env.Environments:
