@@ -81,16 +81,14 @@ class ConvolutionEngine:
         return np.array([bias[i] for i in range(self.maps) for _ in self.Corners])
 
     def GetDenseWeights(self, weights):
-        rows = self.maps * len(self.Corners)
-        cols = int(np.prod(self.InputShape))
-        ksz = int(np.prod(self.KernelShape))
-        mat = np.zeros((rows, cols))
-        for m in range(self.maps):
-            for i, c in enumerate(self.Corners):
-                for o in self.Offsets:
-                    l = self.Location(c, o, self.InputShape)
-                    if l < 0:
-                        continue
-                    k = self.Location(None, o, self.KernelShape)
-                    mat[m * len(self.Corners) + i, l] = weights[k + m * ksz]
+        """the convolution unrolled into a [maps x corners, inputs] matrix, row major (ConvolutionEngine.cs:117-144)"""
+        w = np.asarray(weights, dtype=np.float64)
+        g = self.gather_table()                                      # [corners, offsets] -> input index or -1
+        ksz, corners = int(np.prod(self.KernelShape)), len(self.Corners)
+        kidx = np.array([self.Location(None, o, self.KernelShape) for o in self.Offsets])
+        mat = np.zeros((self.maps * corners, int(np.prod(self.InputShape))))
+        for i in range(corners):
+            ok = g[i] >= 0
+            rows = np.arange(self.maps) * corners + i
+            mat[rows[:, None], g[i][ok][None, :]] = w[kidx[ok][None, :] + (np.arange(self.maps) * ksz)[:, None]]
         return mat.reshape(-1)

@@ -11,13 +11,16 @@ from .layers import (BatchReader, EncryptLayer, LLConvReader, LLDenseLayer, LLDu
                      LLPackedDenseLayer, LLPoolLayer, LLPreConvLayer, LLSingleLineReader, LLVectorizeLayer, PoolLayer, SquareActivation,
                      TimingLayer)
 
-# plaintext primes, N, decomposition bit counts, coefficient primes taken: CryptoNets.cs:17; LoLaCryptonets.cs:123,208,285
+# plaintext primes, N, decomposition bit counts, coefficient primes taken: CryptoNets.cs:17; LoLaCryptonets.cs:123,208,285;
+# LolaCifarCryptoNet.cs:35
 FACTORY_PARAMETERS = {
     "CryptoNets": dict(primes=(549764251649, 549764284417), n=8192),
     "LoLa": dict(primes=(557057, 638977, 737281, 786433), n=8192),
     "LoLaDense": dict(primes=(34359771137, 34360754177), n=16384, DecompositionBitCount=60, GaloisDecompositionBitCount=60, SmallModulusCount=7),
     "LoLaSmall": dict(primes=(2277377, 2424833), n=8192, DecompositionBitCount=40, GaloisDecompositionBitCount=40, SmallModulusCount=3),
+    "LoLaCifar": dict(primes=(957181001729, 957181034497), n=16384, DecompositionBitCount=60, GaloisDecompositionBitCount=60, SmallModulusCount=8),
 }
+CIFAR_CONV = dict(InputShape=[3, 32, 32], KernelShape=[3, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
 MNIST_CONV = dict(InputShape=[28, 28], KernelShape=[5, 5], Upperpadding=[1, 1], Stride=[2, 2])
 
 
@@ -85,6 +88,28 @@ def SmallLoLa(Factory, reader, w, weightscale=64):
     return LLDenseLayer(Source=a3, Bias=w["Biases_1"], Weights=w["Weights_1"], WeightsScale=weightscale, InputFormat=EVectorFormat.dense)
 
 
+def cifar_reader(FileName=None, Factory=None):
+    """LolaCifarCryptoNet.cs:43-55: dense TSV records (label in column 0, 3072 pixel values), im2col for the 8x8 stride-2 convolution"""
+    return LLConvReader(FileName=FileName, SparseFormat=False, NormalizationFactor=1.0 / 256.0, Scale=8.0, Factory=Factory, **CIFAR_CONV)
+
+
+def LoLaCifar(Factory, reader, Weights, Biases, timing=True):
+    """LolaCifarCryptoNet.cs:58-131.  `Weights` / `Biases`: the three arrays of `WeightsReader("CifarWeight.csv", "CifarBias.csv")`:
+    conv1 83 x (3x8x8) + 83, conv2 112 x (83x10x10) + 112 (unrolled into a 5488 x 16268 dense layer), dense 10 x 5488 + 10."""
+    from .convolution import ConvolutionEngine
+    enc = EncryptLayer(Source=reader, Factory=Factory)
+    src = TimingLayer(Source=enc, StartCounters=["Inference-Time"]) if timing else enc
+    c1 = LLPoolLayer(Source=src, MapCount=[83, 1, 1], WeightsScale=256.0, Weights=Weights[0], Bias=Biases[0], **CIFAR_CONV)
+    v2 = LLVectorizeLayer(Source=c1)
+    a3 = SquareActivation(Source=v2)
+    eng = ConvolutionEngine([83, 14, 14], [83, 10, 10], [83, 2, 2], Upperpadding=[0, 4, 4], Lowerpadding=[0, 4, 4], MapCount=[112, 1, 1])
+    d4 = LLDenseLayer(Source=a3, WeightsScale=512.0, Weights=eng.GetDenseWeights(Weights[1]), Bias=eng.GetDenseBias(Biases[1]),
+                      InputFormat=EVectorFormat.dense, ForceDenseFormat=True)
+    a5 = SquareActivation(Source=d4)
+    d6 = LLDenseLayer(Source=a5, Weights=Weights[2], Bias=Biases[2], WeightsScale=512.0, InputFormat=EVectorFormat.dense)
+    return TimingLayer(Source=d6, StopCounters=["Inference-Time"]) if timing else d6
+
+
 def lola_reader(name, FileName=None, Factory=None):
     """the input layer each LoLa variant reads MNIST with (LoLaCryptonets.cs:131-137,212-223,294-305)"""
     if name == "LoLaDense":
@@ -135,10 +160,11 @@ def evaluate_single(network, Factory, records, verbose=False, report=print):
     Returns (errors, count)."""
     layers = list(_chain(network))
     reader = layers[-1]
-    first = next(p for p in layers if isinstance(p.Source, EncryptLayer))
-    start = TimingLayer(Source=first.Source, StartCounters=["Prediction-Time"])
-    first.Source = start
-    network = TimingLayer(Source=network, StopCounters=["Prediction-Time"])
+    if not any(isinstance(p, TimingLayer) for p in layers):      # the CIFAR graph brings its own "Inference-Time" brackets
+        first = next(p for p in layers if isinstance(p.Source, EncryptLayer))
+        start = TimingLayer(Source=first.Source, StartCounters=["Prediction-Time"])
+        first.Source = start
+        network = TimingLayer(Source=network, StopCounters=["Prediction-Time"])
     for p in _chain(network):
         p.Factory = Factory
         p.Verbose = verbose

@@ -58,3 +58,16 @@ def test_cryptonets_program_encrypted_scores_like_raw():
     raw = run("cryptonets.py", "--synthetic", "300", "--raw")
     pick = lambda s: re.findall(r"errs (\d+)/300 accuracy", s)[-1]
     assert pick(enc) == pick(raw)
+
+
+def test_lola_cifar_program_raw():
+    out = run("lola_cifar.py", "--synthetic", "1")
+    assert len(predictions(out)) == 1 and "Inference-Time" in out and "Max computed value 2^" in out
+
+
+@pytest.mark.gpu
+def test_lola_cifar_program_encrypted_predicts_like_raw():
+    """synthetic model of the reference's shapes (CifarWeight.csv is a missing blob): the encrypted prediction is the plaintext one"""
+    enc = predictions(run("lola_cifar.py", "-e", "--limbs", "9", "--synthetic", "1"))
+    raw = predictions(run("lola_cifar.py", "--synthetic", "1"))
+    assert len(enc) == 1 and enc == raw

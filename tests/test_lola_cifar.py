@@ -14,8 +14,7 @@ import numpy as np
 import pytest
 
 from cryptonets_amd.convolution import ConvolutionEngine
-from cryptonets_amd.hewrapper import EVectorFormat
-from cryptonets_amd.layers import EncryptLayer, LLConvReader, LLDenseLayer, LLPoolLayer, LLVectorizeLayer, SquareActivation
+from cryptonets_amd import networks
 
 PRIMES = (957181001729, 957181034497)
 
@@ -24,20 +23,6 @@ def mulmod(a, b, p):
     b = np.asarray(b, dtype=np.uint64)
     hi = (a * (b >> np.uint64(20))) % p
     return (hi * np.uint64(1 << 20) + a * (b & np.uint64(0xFFFFF))) % p
-
-
-def dense_weights(eng, w):
-    """ConvolutionEngine.GetDenseWeights vectorised (ConvolutionEngine.cs:117-144)"""
-    g = eng.gather_table()                                         # [corners, offsets] -> input index or -1
-    ksz = int(np.prod(eng.KernelShape))
-    kidx = np.array([eng.Location(None, o, eng.KernelShape) for o in eng.Offsets])
-    rows, cols = eng.maps * len(eng.Corners), int(np.prod(eng.InputShape))
-    mat = np.zeros((rows, cols))
-    for i in range(len(eng.Corners)):
-        ok = g[i] >= 0
-        for m in range(eng.maps):
-            mat[m * len(eng.Corners) + i, g[i][ok]] = w[kidx[ok] + m * ksz]
-    return mat
 
 
 @pytest.mark.gpu
@@ -54,18 +39,14 @@ def test_lola_cifar_shapes_end_to_end(limbs):
     b1 = np.rint(rng.normal(0, 0.05, 112) * 512) / 512
     w2 = np.rint(rng.normal(0, 0.05, 10 * 5488) * 512) / 512
     b2 = np.rint(rng.normal(0, 0.05, 10) * 512) / 512
-    conv = dict(InputShape=[3, 32, 32], KernelShape=[3, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
-    reader = LLConvReader(Features=img / 256.0, Scale=8.0, Factory=Factory, **conv)
-    enc = EncryptLayer(Source=reader)
-    c1 = LLPoolLayer(Source=enc, MapCount=[83, 1, 1], WeightsScale=256.0, Weights=w0, Bias=b0, **conv)
-    v2 = LLVectorizeLayer(Source=c1)
-    a3 = SquareActivation(Source=v2)
+    reader = networks.cifar_reader(Factory=Factory)
+    reader.Features = img / 256.0
+    d6 = networks.LoLaCifar(Factory, reader, [w0, w1, w2], [b0, b1, b2], timing=False)          # LolaCifarCryptoNet.cs:58-131
+    a5 = d6.Source
+    d4 = a5.Source
+    c1 = d4.Source.Source.Source
     eng = ConvolutionEngine([83, 14, 14], [83, 10, 10], [83, 2, 2], Upperpadding=[0, 4, 4], Lowerpadding=[0, 4, 4], MapCount=[112, 1, 1])
-    W1 = dense_weights(eng, w1)
-    assert W1.shape == (5488, 16268)
-    d4 = LLDenseLayer(Source=a3, WeightsScale=512.0, Weights=W1.reshape(-1), Bias=eng.GetDenseBias(b1), InputFormat=EVectorFormat.dense, ForceDenseFormat=True)
-    a5 = SquareActivation(Source=d4)
-    d6 = LLDenseLayer(Source=a5, Weights=w2, Bias=b2, WeightsScale=512.0, InputFormat=EVectorFormat.dense)
+    W1 = eng.GetDenseWeights(w1).reshape(5488, 16268)
     d6.PrepareNetwork()
     out4 = d4.GetNext()                                             # encrypt ... big dense layer
     out = None
