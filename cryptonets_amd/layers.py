@@ -20,9 +20,14 @@ class RawData(RawMatrix):
         super().__init__(np.asarray(m, dtype=np.float64), scale, EMatrixFormat.ColumnMajor, Defaults.RawFactory.BlockSize)
 
 
-def _sync_factory(Factory):
-    """device work is asynchronous: wait for the streams of the factory's contexts before reading a clock (no-op on RawFactory)"""
-    for e in getattr(Factory.AllocateComputationEnv(), "Environments", ()):
+def _sync_factory(layer):
+    """device work is asynchronous: wait for the streams of the layer's factory before reading a clock (nothing to wait for on a
+    RawFactory or on a chain without a factory)"""
+    try:
+        env = layer.Factory.AllocateComputationEnv()
+    except AttributeError:
+        return
+    for e in getattr(env, "Environments", ()):
         e.ctx.sync()
 
 
@@ -72,7 +77,7 @@ class BaseLayer:
             import time
             start = time.perf_counter()
             res = self.Apply(m)
-            _sync_factory(self.Factory)
+            _sync_factory(self)
             print("Layer %s computed in %.6f seconds layer width (%d,%d)" % (type(self).__name__, time.perf_counter() - start, m.RowCount, m.ColumnCount))
         if res is not m:
             m.Dispose()
@@ -618,7 +623,7 @@ class TimingLayer(BaseLayer):
     def Apply(self, m):
         import time
         if self.StopCounters or self.StartCounters:
-            _sync_factory(self.Factory)
+            _sync_factory(self)
         now = time.perf_counter()
         for c in self.StartCounters:
             TimingLayer.StartTime[c] = now
