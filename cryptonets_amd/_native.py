@@ -105,6 +105,7 @@ SIGNATURES = {
     "cn_get_key": (C.c_int, [_CTX, C.c_int, C.c_uint64, U64P, C.c_size_t]),
     "cn_encrypt": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32, _u32, C.c_uint64]),
     "cn_decrypt": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32]),
+    "cn_noise_poly": (C.c_int, [_CTX, _H, _u32, _u32, C.POINTER(C.c_uint64)]),
     "cn_ntt_forward": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
     "cn_ntt_inverse": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
     "cn_ct_ntt": (C.c_int, [_CTX, _H, _u32, _u32, C.c_int]),
@@ -378,6 +379,32 @@ class Context:
 
     def decrypt(self, ct, ci, count, pt_out, pi):
         self._chk(self.L.cn_decrypt(self._h, ct, ci, count, pt_out, pi))
+
+    def noise_poly(self, ct, ci=0, count=1):
+        """residues of t*(c0 + c1 s + c2 s^2) mod q_j, uint64 [count, k, n] (needs the secret key)"""
+        out = np.empty((count, self.k, self.n), dtype=np.uint64)
+        self._chk(self.L.cn_noise_poly(self._h, ct, ci, count, _p64(out)))
+        return out
+
+    def invariant_noise_budget(self, ct, ci=0, count=1, exact_bits=False):
+        """Decryptor.InvariantNoiseBudget (what CryptoTracker.TestBudget reads, CryptoTracker.cs:41-52) of `count` ciphertexts:
+        log2(q) - log2(|| t (c0 + c1 s + c2 s^2) mod q ||_inf, centred) - 1, in bits (float); with `exact_bits` SEAL's integer
+        max(0, bitcount(q) - bitcount(norm) - 1).  The limbs are composed on the host with Python integers: a debugging probe."""
+        import math
+        w = self.noise_poly(ct, ci, count)
+        Q = 1
+        for qj in self.q:
+            Q *= qj
+        coef = [(Q // qj) * pow((Q // qj) % qj, -1, qj) for qj in self.q]
+        out = []
+        for c in range(count):
+            x = sum(w[c, j].astype(object) * coef[j] for j in range(self.k)) % Q
+            norm = max(int(v) if 2 * int(v) <= Q else Q - int(v) for v in x)
+            if exact_bits:
+                out.append(max(0, Q.bit_length() - norm.bit_length() - 1))
+            else:
+                out.append(math.log2(Q) - (math.log2(norm) if norm else 0.0) - 1.0)
+        return out
 
     # ---- raw transforms / timing / stats
     def ct_ntt(self, h, first, count, inverse=False):

@@ -34,6 +34,10 @@ class DeviceClient(ClientCrypto):
         finally:
             self.ctx.free(pt)
 
+    def noise_budget(self, ct_handle, first=0, count=1):
+        """Decryptor.InvariantNoiseBudget of `count` ciphertexts (integer bits, like SEAL): what CryptoTracker probes"""
+        return self.ctx.invariant_noise_budget(ct_handle, first, count, exact_bits=True)
+
     # ClientCrypto interface on host arrays
     def encrypt(self, plain):
         pt, ct = self.ctx.pt_alloc(1), self.ctx.ct_alloc(1)

@@ -1258,16 +1258,12 @@ extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_st
 template <int K> static void launch_dec_scale(cn_ctx *c, const uint64_t *c0, size_t stride, const uint64_t *acc, uint64_t *plain, uint32_t cnt) {
     hipLaunchKernelGGL(k_decrypt_scale<K>, dim3(cnt * c->chunks), dim3(c->bs), 0, c->stream, c0, stride, acc, plain, c->dc, c->chunks);
 }
-// Decryptor.Decrypt (AtomicSealBfvVector.cs:1042,1085): m = round(t (c0 + c1 s + c2 s^2) / q) mod t
-extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi) {
-    LOCK; GETCT(I, ct, 0); GETPT(P, pt_out);
-    if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
-    if (!ctx->hc.inv_g_t) return fail(CN_ERR_ARG, "device decryption needs a prime plain modulus");
-    if (!range_ok(I, ci, count) || !range_ok(P, pi, count)) return fail(CN_ERR_ARG, "index out of range");
-    if (!count) return 0;
+// acc[ct][j] <- c1 s (+ c2 s^2) in coefficient form: the part of the decryption phase that needs the secret key
+static int decrypt_phase(cn_ctx *ctx, Buffer *I, uint32_t ci, uint32_t count, uint64_t *&acc) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
     CHECK(ensure_scratch(ctx, al((size_t)count * kn * 8) * 3 + al(kn * 8)));
-    uint64_t *acc = salloc<uint64_t>(ctx, (size_t)count * kn), *tmp = salloc<uint64_t>(ctx, (size_t)count * kn), *sp = salloc<uint64_t>(ctx, kn);
+    acc = salloc<uint64_t>(ctx, (size_t)count * kn);
+    uint64_t *tmp = salloc<uint64_t>(ctx, (size_t)count * kn), *sp = salloc<uint64_t>(ctx, kn);
     const uint64_t *base = I->d + ci * I->item_words;
     HIPCHK(hipMemcpy2DAsync(acc, kn * 8, base + kn, I->item_words * 8, kn * 8, count, hipMemcpyDeviceToDevice, ctx->stream));
     CHECK(run_ntt(ctx, acc, count * k, 0, k, 0));
@@ -1279,10 +1275,34 @@ extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count
         hipLaunchKernelGGL(k_mul_limbs_bcast, dim3(count * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, tmp, sp, acc, acc, ctx->dc, ctx->chunks);
     }
     HIPCHK(hipGetLastError()); launch_count(ctx, 2);
-    CHECK(run_ntt(ctx, acc, count * k, 0, k, 1));
-    DISPATCH_K2(launch_dec_scale, ctx, base, I->item_words, acc, P->d + (size_t)pi * n, count);
+    return run_ntt(ctx, acc, count * k, 0, k, 1);
+}
+// Decryptor.Decrypt (AtomicSealBfvVector.cs:1042,1085): m = round(t (c0 + c1 s + c2 s^2) / q) mod t
+extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi) {
+    LOCK; GETCT(I, ct, 0); GETPT(P, pt_out);
+    if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
+    if (!ctx->hc.inv_g_t) return fail(CN_ERR_ARG, "device decryption needs a prime plain modulus");
+    if (!range_ok(I, ci, count) || !range_ok(P, pi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    uint64_t *acc = nullptr;
+    CHECK(decrypt_phase(ctx, I, ci, count, acc));
+    DISPATCH_K2(launch_dec_scale, ctx, I->d + ci * I->item_words, I->item_words, acc, P->d + (size_t)pi * ctx->hc.n, count);
     HIPCHK(hipGetLastError()); launch_count(ctx);
     for (uint32_t c = 0; c < count; c++) P->pt_zero[pi + c] = 0;      // unknown: treated as non-zero
+    return 0;
+}
+// Decryptor.InvariantNoiseBudget (CryptoTracker.cs:41-52): the residues of t (c0 + c1 s + c2 s^2) mod q, [count][k][N] to the host
+extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, uint64_t *host) {
+    LOCK; GETCT(I, ct, 0);
+    if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
+    if (!host || !range_ok(I, ci, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (!count) return 0;
+    uint64_t *acc = nullptr;
+    CHECK(decrypt_phase(ctx, I, ci, count, acc));
+    hipLaunchKernelGGL(k_noise_poly, dim3(count * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, I->d + ci * I->item_words, (size_t)I->item_words, acc, ctx->dc, ctx->chunks);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    HIPCHK(hipMemcpyAsync(host, acc, (size_t)count * ctx->hc.k * ctx->hc.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

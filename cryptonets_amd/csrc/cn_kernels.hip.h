@@ -1139,6 +1139,13 @@ __global__ void k_mul_limbs_bcast(const uint64_t *a, const uint64_t *b, const ui
     uint64_t v = mulmod(a[x], b[(size_t)j * C->n + i], qm);
     o[x] = add ? addmod(v, add[x], qm.q) : v;
 }
+// noise probe: acc[ct][j] <- t * (c0[ct][j] + acc[ct][j]) mod q_j  (the polynomial whose centred norm InvariantNoiseBudget measures)
+__global__ void k_noise_poly(const uint64_t *__restrict__ c0, size_t ct_stride, uint64_t *__restrict__ acc, const DevConsts *__restrict__ C, uint32_t chunks) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t j = limb % C->k, ct = limb / C->k; const DMod qm = C->q[j];
+    const size_t x = (size_t)limb * C->n + i;
+    acc[x] = mulmod(addmod(c0[(size_t)ct * ct_stride + (size_t)j * C->n + i], acc[x], qm.q), C->t.q % qm.q, qm);
+}
 // encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t *__restrict__ u, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pt,

@@ -10,6 +10,7 @@ import numpy as np
 from .convolution import ConvolutionEngine
 from .hewrapper import EMatrixFormat, EVectorFormat
 from .raw import Defaults, RawMatrix
+from .cryptotracker import CryptoTracker
 
 
 class RawData(RawMatrix):
@@ -79,6 +80,7 @@ class BaseLayer:
             res = self.Apply(m)
             _sync_factory(self)
             print("Layer %s computed in %.6f seconds layer width (%d,%d)" % (type(self).__name__, time.perf_counter() - start, m.RowCount, m.ColumnCount))
+            CryptoTracker.TestBudget(res.GetColumn(0), self.Factory)                 # BaseLayer.cs:37 (a no-op unless budget tests are on)
         if res is not m:
             m.Dispose()
         return res

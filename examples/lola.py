@@ -24,6 +24,7 @@ def main():
     ap.add_argument("-n", "--network", required=True, choices=sorted(networks.LOLA_NETWORKS))
     ap.add_argument("-e", "--encrypt", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--budget", action="store_true", help="with -e -v: probe the invariant noise budget after every layer (CryptoTracker)")
     ap.add_argument("--file", default="MNIST-28x28-test.txt")
     ap.add_argument("--synthetic", type=int, default=0, metavar="RECORDS")
     ap.add_argument("--records", type=int, default=10000)
@@ -46,8 +47,13 @@ def main():
     weights = np.load(GOLDEN + ("/small_model_weights.npz" if a.network == "LoLaSmall" else "/cryptonets_weights.npz"))
     reader = networks.lola_reader(a.network, a.file)
     network = networks.LOLA_NETWORKS[a.network](Factory, reader, weights)
+    if a.budget:
+        from cryptonets_amd.cryptotracker import CryptoTracker
+        CryptoTracker.EnableBudgetTests()
     errs, count = networks.evaluate_single(network, Factory, a.records, verbose=a.verbose)
     print("errs %d/%d accuracy %.3f%%" % (errs, count, 100 - 100.0 * errs / max(count, 1)))
+    if a.budget and a.encrypt:
+        print("Minimal noise budget seen %d bits" % CryptoTracker.MinBudgetSoFar)
     if a.verbose and not a.encrypt:
         from cryptonets_amd.raw import RawMatrix
         print("Maximal value used %s (%.2f bits)" % (RawMatrix.Max, math.log2(RawMatrix.Max)))

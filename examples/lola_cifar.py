@@ -38,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-e", "--encrypt", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--budget", action="store_true", help="with -e -v: probe the invariant noise budget after every layer (CryptoTracker)")
     ap.add_argument("--file", default="cifar-test.tsv")
     ap.add_argument("--weights", default=None)
     ap.add_argument("--biases", default=None)
@@ -66,8 +67,13 @@ def main():
     reader = networks.cifar_reader(a.file)
     network = networks.LoLaCifar(Factory, reader, W, B)
     print("Preparing")
+    if a.budget:
+        from cryptonets_amd.cryptotracker import CryptoTracker
+        CryptoTracker.EnableBudgetTests()
     errs, count = networks.evaluate_single(network, Factory, a.records, verbose=a.verbose)
     print("errs %d/%d accuracy %.3f%%" % (errs, count, 100 - 100.0 * errs / max(count, 1)))
+    if a.budget and a.encrypt:
+        print("Minimal noise budget seen %d bits" % CryptoTracker.MinBudgetSoFar)
     if not a.encrypt:
         from cryptonets_amd.raw import RawMatrix
         print("Max computed value 2^%.2f" % np.log2(RawMatrix.Max))

@@ -160,6 +160,10 @@ int cn_get_key(cn_ctx *ctx, int which /*0 relin,1 galois,2 public,3 secret*/, ui
 int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed);
 /* Decryptor.Decrypt of size-2 or size-3 ciphertexts into dense plaintexts */
 int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi);
+/* Decryptor.InvariantNoiseBudget as CryptoTracker.TestBudget probes it (HE Wrapper/CryptoTracker.cs:41-52, BaseLayer.cs:37): writes the
+ * residues of t*(c0 + c1 s + c2 s^2) mod q_j, [count][k][N], to `host`; the caller composes the limbs (CRT) and takes
+ * budget = log2(q) - log2(centred infinity norm) - 1.  Needs the secret key (client-side context); synchronises. */
+int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, uint64_t *host);
 
 /* ---- raw transforms (kernel benchmarks / parity tests of the NTT itself) --------------- */
 /* in-place negacyclic NTT over `limbs` limbs of N words at a device pointer; limb i uses modulus

@@ -31,6 +31,24 @@ class OracleClient:
     def decrypt(self, ct):
         return self.o.decrypt(np.ascontiguousarray(ct, dtype=np.uint64))
 
+    def noise_poly(self, ct):
+        """t * (c0 + c1 s + c2 s^2) mod q_j, [k, n]: the polynomial whose centred norm Decryptor.InvariantNoiseBudget measures"""
+        o = self.o
+        x = o.dot_with_secret(np.ascontiguousarray(ct, dtype=np.uint64)).reshape(o.k, o.n)
+        return np.stack([np.array([(int(v) * o.t) % int(o.q[j]) for v in x[j]], dtype=np.uint64) for j in range(o.k)])
+
+    def noise_budget_words(self, ct):
+        """SEAL's integer budget: max(0, bitcount(q) - bitcount(norm) - 1)"""
+        o = self.o
+        w = self.noise_poly(ct)
+        Q = 1
+        for qj in o.q:
+            Q *= int(qj)
+        coef = [(Q // int(qj)) * pow((Q // int(qj)) % int(qj), -1, int(qj)) for qj in o.q]
+        x = sum(w[j].astype(object) * coef[j] for j in range(o.k)) % Q
+        norm = max(int(v) if 2 * int(v) <= Q else Q - int(v) for v in x)
+        return max(0, Q.bit_length() - norm.bit_length() - 1)
+
 
 class OracleBackend:
     """Same method names as cryptonets_amd._native.Context, computing with the oracle on numpy arrays."""
