@@ -77,3 +77,39 @@ class CryptoTracker:
         else:
             last = dec.size if showAll else min(3, dec.size)
             print("%s size %d\t%s\t||\t%.4f\t%.4f" % (name, dec.size, "\t".join("%.4f" % v for v in dec[:last]), float(dec.min()), float(dec.max())))
+
+
+class OperationsCount:
+    """`OperationsCount` (HE Wrapper/AtomicSealBfvVector.cs:208-294): how many evaluator operations of each kind ran.  The counters
+    live in libcnhip, one set per context (`cn_stats_get`, same names; plus the limb transforms and kernel launches behind them);
+    this class sums them over the plaintext primes of a factory, per prime like the reference's per-evaluator-call counting."""
+    Totals = {}
+
+    @staticmethod
+    def _contexts(factory):
+        return [e.ctx for e in getattr(factory.AllocateComputationEnv(), "Environments", ()) if hasattr(e.ctx, "stats")]
+
+    @classmethod
+    def Counts(cls, factory, reset=False):
+        out = {}
+        for ctx in cls._contexts(factory):
+            for k, v in ctx.stats(reset=reset).items():
+                out[k] = out.get(k, 0) + v
+        return out
+
+    @classmethod
+    def Reset(cls, factory):
+        for k, v in cls.Counts(factory, reset=True).items():          # :254-270: fold into the totals, then zero
+            cls.Totals[k] = cls.Totals.get(k, 0) + v
+
+    @classmethod
+    def Print(cls, factory):
+        print("Operations:")
+        for k, v in cls.Counts(factory).items():
+            print("\t%s\t%d" % (k, v))
+
+    @classmethod
+    def PrintTotals(cls, factory):
+        print("Operations (total):")
+        for k, v in cls.Counts(factory).items():
+            print("\t%s\t%d" % (k, v + cls.Totals.get(k, 0)))

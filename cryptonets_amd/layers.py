@@ -10,7 +10,7 @@ import numpy as np
 from .convolution import ConvolutionEngine
 from .hewrapper import EMatrixFormat, EVectorFormat
 from .raw import Defaults, RawMatrix
-from .cryptotracker import CryptoTracker
+from .cryptotracker import CryptoTracker, OperationsCount
 
 
 class RawData(RawMatrix):
@@ -76,11 +76,14 @@ class BaseLayer:
             res = self.Apply(m)
         else:                                                    # BaseLayer.cs:30-43: per-layer wall time and width
             import time
+            OperationsCount.Reset(self.Factory)
             start = time.perf_counter()
             res = self.Apply(m)
             _sync_factory(self)
             print("Layer %s computed in %.6f seconds layer width (%d,%d)" % (type(self).__name__, time.perf_counter() - start, m.RowCount, m.ColumnCount))
             CryptoTracker.TestBudget(res.GetColumn(0), self.Factory)                 # BaseLayer.cs:37 (a no-op unless budget tests are on)
+            if OperationsCount._contexts(self.Factory):
+                OperationsCount.Print(self.Factory)                                  # BaseLayer.cs:39
         if res is not m:
             m.Dispose()
         return res

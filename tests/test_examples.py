@@ -71,3 +71,11 @@ def test_lola_cifar_program_encrypted_predicts_like_raw():
     enc = predictions(run("lola_cifar.py", "-e", "--limbs", "9", "--synthetic", "1"))
     raw = predictions(run("lola_cifar.py", "--synthetic", "1"))
     assert len(enc) == 1 and enc == raw
+
+
+@pytest.mark.gpu
+def test_verbose_run_reports_operations_and_budget():
+    """-v prints the per-layer OperationsCount (BaseLayer.cs:39), --budget the CryptoTracker watermark (BaseLayer.cs:37)"""
+    out = run("lola.py", "-n", "LoLa", "-e", "-v", "--budget", "--synthetic", "1")
+    assert "Operations:" in out and re.search(r"\tRotation\t[1-9]", out) and re.search(r"\tRelinarization\t[1-9]", out)
+    assert re.search(r"Minimal noise budget seen [1-9]\d* bits", out) and "Warning: Current minimal budget" in out
