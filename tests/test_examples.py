@@ -79,3 +79,46 @@ def test_verbose_run_reports_operations_and_budget():
     out = run("lola.py", "-n", "LoLa", "-e", "-v", "--budget", "--synthetic", "1")
     assert "Operations:" in out and re.search(r"\tRotation\t[1-9]", out) and re.search(r"\tRelinarization\t[1-9]", out)
     assert re.search(r"Minimal noise budget seen [1-9]\d* bits", out) and "Warning: Current minimal budget" in out
+
+
+def test_data_preprocess_formats(tmp_path):
+    """`DataPreprocess/GetMNIST.cs:37-81`, `GetCIFAR.cs:16-29`: the written records, read back by the reader layers"""
+    import gzip
+    import importlib.util
+    import io
+    import tarfile
+    import numpy as np
+    from cryptonets_amd.layers import BatchReader
+    from cryptonets_amd import networks
+    spec = importlib.util.spec_from_file_location("data_preprocess", os.path.join(EX, "data_preprocess.py"))
+    dp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dp)
+    r = np.random.default_rng(2)
+    assert dp.mnist(str(tmp_path)) is None and dp.cifar(str(tmp_path)) is None        # files absent: a hint, nothing written
+    imgs = np.where(r.random((5, 784)) < 0.8, 0, r.integers(1, 256, size=(5, 784))).astype(np.uint8)
+    labs = r.integers(0, 10, size=5).astype(np.uint8)
+    with gzip.open(tmp_path / "t10k-images-idx3-ubyte.gz", "wb") as f:
+        f.write(bytes([0, 0, 8, 3]) + (5).to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + imgs.tobytes())
+    with gzip.open(tmp_path / "t10k-labels-idx1-ubyte.gz", "wb") as f:
+        f.write(bytes([0, 0, 8, 1]) + (5).to_bytes(4, "big") + labs.tobytes())
+    path = dp.mnist(str(tmp_path))
+    first = open(path).readline().rstrip("\n").split("\t")
+    assert first[0] == str(labs[0]) and first[1] == "784" and len(first) == 2 + np.count_nonzero(imgs[0])
+    rd = BatchReader(FileName=path, SparseFormat=True, MaxSlots=8)
+    m = rd.GetNext()
+    assert list(rd.Labels) == list(labs) and np.array_equal(m.Data, imgs.astype(float))
+    rec = np.concatenate([r.integers(0, 10, size=(3, 1)), r.integers(0, 256, size=(3, 3072))], axis=1).astype(np.uint8)
+    with tarfile.open(tmp_path / "cifar-10-binary.tar.gz", "w:gz") as tar:
+        info = tarfile.TarInfo("cifar-10-batches-bin/test_batch.bin")
+        info.size = rec.size
+        tar.addfile(info, io.BytesIO(rec.tobytes()))
+    path = dp.cifar(str(tmp_path))
+    rows = [ln.rstrip("\n").split("\t") for ln in open(path)]
+    assert len(rows) == 3 and all(len(x) == 3073 for x in rows)
+    for i in range(3):
+        assert int(rows[i][0]) == rec[i, 0]
+        for (c, y, x) in [(0, 0, 0), (1, 5, 9), (2, 31, 30), (0, 17, 3)]:
+            assert int(rows[i][1 + (c * 32 + y) * 32 + x]) == rec[i, 1 + y + 32 * (x + 32 * c)]        # GetCIFAR.cs:24-27
+    reader = networks.cifar_reader(path)
+    m = reader.GetNext()
+    assert list(reader.Labels) == [rec[0, 0]] and m.RowCount == 196 and m.ColumnCount == 192
