@@ -11,16 +11,18 @@ from .layers import (BatchReader, EncryptLayer, LLConvReader, LLDenseLayer, LLDu
                      LLPackedDenseLayer, LLPoolLayer, LLPreConvLayer, LLSingleLineReader, LLVectorizeLayer, PoolLayer, SquareActivation,
                      TimingLayer)
 
-# plaintext primes, N, decomposition bit counts, coefficient primes taken: CryptoNets.cs:17; LoLaCryptonets.cs:123,208,285;
+# plaintext primes, N, decomposition bit counts, coefficient primes taken: CryptoNets.cs:17; LoLaCryptonets.cs:123,208,285,338;
 # LolaCifarCryptoNet.cs:35
 FACTORY_PARAMETERS = {
     "CryptoNets": dict(primes=(549764251649, 549764284417), n=8192),
     "LoLa": dict(primes=(557057, 638977, 737281, 786433), n=8192),
     "LoLaDense": dict(primes=(34359771137, 34360754177), n=16384, DecompositionBitCount=60, GaloisDecompositionBitCount=60, SmallModulusCount=7),
     "LoLaSmall": dict(primes=(2277377, 2424833), n=8192, DecompositionBitCount=40, GaloisDecompositionBitCount=40, SmallModulusCount=3),
+    "LoLaLarge": dict(primes=(2148728833, 2148794369, 2149810177), n=16384, DecompositionBitCount=60, GaloisDecompositionBitCount=60, SmallModulusCount=7),
     "LoLaCifar": dict(primes=(957181001729, 957181034497), n=16384, DecompositionBitCount=60, GaloisDecompositionBitCount=60, SmallModulusCount=8),
 }
 CIFAR_CONV = dict(InputShape=[3, 32, 32], KernelShape=[3, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
+LARGE_CONV = dict(InputShape=[1, 28, 28], KernelShape=[1, 8, 8], Upperpadding=[0, 1, 1], Lowerpadding=[0, 1, 1], Stride=[1000, 2, 2])
 MNIST_CONV = dict(InputShape=[28, 28], KernelShape=[5, 5], Upperpadding=[1, 1], Stride=[2, 2])
 
 
@@ -88,6 +90,23 @@ def SmallLoLa(Factory, reader, w, weightscale=64):
     return LLDenseLayer(Source=a3, Bias=w["Biases_1"], Weights=w["Weights_1"], WeightsScale=weightscale, InputFormat=EVectorFormat.dense)
 
 
+def LargeLoLa(Factory, reader, Weights, Biases):
+    """LoLaCryptonets.cs:332-409.  `Weights` / `Biases`: the arrays of `WeightsReader("MnistLargeWeight.csv", "MnistLargeBias.csv")`:
+    conv1 83 x (8x8) + 83 (the file stores the conv1 weights times 256), conv2 163 x (83x6x6) + 163 unrolled into a 2608 x 11952 dense
+    layer, dense 10 x 2608 + 10."""
+    from .convolution import ConvolutionEngine
+    enc = EncryptLayer(Source=reader, Factory=Factory)
+    c1 = LLPoolLayer(Source=enc, MapCount=[83, 1, 1], WeightsScale=4096, Weights=np.asarray(Weights[0], dtype=np.float64) / 256, Bias=Biases[0],
+                     **LARGE_CONV)
+    v2 = LLVectorizeLayer(Source=c1)
+    a3 = SquareActivation(Source=v2)
+    eng = ConvolutionEngine([83, 12, 12], [83, 6, 6], [83, 2, 2], Padding=[False, False, False], MapCount=[163, 1, 1])
+    d4 = LLDenseLayer(Source=a3, WeightsScale=64, Weights=eng.GetDenseWeights(Weights[1]), Bias=eng.GetDenseBias(Biases[1]),
+                      InputFormat=EVectorFormat.dense, ForceDenseFormat=True)
+    a5 = SquareActivation(Source=d4)
+    return LLDenseLayer(Source=a5, Weights=Weights[2], Bias=Biases[2], WeightsScale=512, InputFormat=EVectorFormat.dense)
+
+
 def cifar_reader(FileName=None, Factory=None):
     """LolaCifarCryptoNet.cs:43-55: dense TSV records (label in column 0, 3072 pixel values), im2col for the 8x8 stride-2 convolution"""
     return LLConvReader(FileName=FileName, SparseFormat=False, NormalizationFactor=1.0 / 256.0, Scale=8.0, Factory=Factory, **CIFAR_CONV)
@@ -112,6 +131,8 @@ def LoLaCifar(Factory, reader, Weights, Biases, timing=True):
 
 def lola_reader(name, FileName=None, Factory=None):
     """the input layer each LoLa variant reads MNIST with (LoLaCryptonets.cs:131-137,212-223,294-305)"""
+    if name == "LoLaLarge":                                      # :346-357: pixels are NOT normalised here
+        return LLConvReader(FileName=FileName, SparseFormat=True, NormalizationFactor=1.0, Scale=16.0, Factory=Factory, **LARGE_CONV)
     if name == "LoLaDense":
         return LLSingleLineReader(FileName=FileName, SparseFormat=True, NormalizationFactor=1.0 / 256.0, Scale=16.0, Factory=Factory)
     return LLConvReader(FileName=FileName, SparseFormat=True, NormalizationFactor=1.0 / 256.0, Scale=16.0, Factory=Factory, **MNIST_CONV)

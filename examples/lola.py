@@ -4,7 +4,8 @@
     python examples/lola.py -n LoLaSmall -e --synthetic 20                   # synthetic records (timing; labels are random)
     python examples/lola.py -n LoLaDense --synthetic 5                       # without -e: RawFactory, prints the largest value used
 
-Networks: LoLa, LoLaDense, LoLaSmall (LoLaLarge needs MnistLargeWeight.csv, which the reference does not ship).  The coefficient
+Networks: LoLa, LoLaDense, LoLaSmall, LoLaLarge (its MnistLargeWeight.csv is not shipped by the reference: pass --weights /
+--biases, or a random model of the same shapes is used).  The coefficient
 modulus of LoLaDense / LoLaSmall is one prime longer than the reference's (`--limbs`): with the reference's count the noise budget
 is exhausted before the last layer (LoLa sections).
 """
@@ -21,7 +22,9 @@ from cryptonets_amd import networks
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("-n", "--network", required=True, choices=sorted(networks.LOLA_NETWORKS))
+    ap.add_argument("-n", "--network", required=True, choices=sorted(networks.LOLA_NETWORKS) + ["LoLaLarge"])
+    ap.add_argument("--weights", default=None, help="LoLaLarge: MnistLargeWeight.csv (not shipped by the reference; default: a random model of its shapes)")
+    ap.add_argument("--biases", default=None, help="LoLaLarge: MnistLargeBias.csv")
     ap.add_argument("-e", "--encrypt", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("--budget", action="store_true", help="with -e -v: probe the invariant noise budget after every layer (CryptoTracker)")
@@ -33,20 +36,32 @@ def main():
     if a.synthetic:
         a.file, a.records = synthetic_mnist_file(tempfile.mktemp(suffix=".tsv"), a.synthetic), a.synthetic
     parms = dict(networks.FACTORY_PARAMETERS[a.network])
-    print({"LoLa": "LoLa mode", "LoLaDense": "LoLa-Dense mode", "LoLaSmall": "Small LoLa mode"}[a.network])
+    print({"LoLa": "LoLa mode", "LoLaDense": "LoLa-Dense mode", "LoLaSmall": "Small LoLa mode", "LoLaLarge": "Large LoLa mode"}[a.network])
     start = time.time()
     if a.encrypt:
         from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
         if "SmallModulusCount" in parms:
-            parms["SmallModulusCount"] = a.limbs if a.limbs else parms["SmallModulusCount"] + 1
+            parms["SmallModulusCount"] = a.limbs if a.limbs else parms["SmallModulusCount"] + (a.network != "LoLaLarge")
         Factory = EncryptedSealBfvFactory(**parms)
     else:
         from cryptonets_amd.raw import RawFactory
         Factory = RawFactory(parms["n"])
     print("Generating keys in %.2f seconds" % (time.time() - start))
-    weights = np.load(GOLDEN + ("/small_model_weights.npz" if a.network == "LoLaSmall" else "/cryptonets_weights.npz"))
     reader = networks.lola_reader(a.network, a.file)
-    network = networks.LOLA_NETWORKS[a.network](Factory, reader, weights)
+    if a.network == "LoLaLarge":
+        if a.weights:
+            from cryptonets_amd.layers import WeightsReader
+            wr = WeightsReader(a.weights, a.biases)
+            W, B = wr.Weights, wr.Biases
+        else:
+            r = np.random.default_rng(7)                         # small and sparse, so that the logits stay below the 93-bit plaintext modulus
+            pick = lambda n, p, s: r.choice([-1.0, 0.0, 1.0], size=n, p=[p / 2, 1 - p, p / 2]) / s
+            W = [np.rint(r.normal(0, 0.01, 83 * 64) * 4096) / 16, pick(163 * 83 * 36, 0.01, 64), pick(10 * 2608, 0.02, 512)]
+            B = [np.rint(r.normal(0, 0.05, 83) * 4096) / 4096, pick(163, 0.5, 64), pick(10, 0.5, 512)]
+        network = networks.LargeLoLa(Factory, reader, W, B)
+    else:
+        weights = np.load(GOLDEN + ("/small_model_weights.npz" if a.network == "LoLaSmall" else "/cryptonets_weights.npz"))
+        network = networks.LOLA_NETWORKS[a.network](Factory, reader, weights)
     if a.budget:
         from cryptonets_amd.cryptotracker import CryptoTracker
         CryptoTracker.EnableBudgetTests()

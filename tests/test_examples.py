@@ -31,7 +31,7 @@ def test_cryptonets_program_raw():
     assert re.search(r"errs \d+/48 accuracy", out) and out.count("Batch size") == 2          # 32 + 16 records
 
 
-@pytest.mark.parametrize("net", ["LoLa", "LoLaDense", "LoLaSmall"])
+@pytest.mark.parametrize("net", ["LoLa", "LoLaDense", "LoLaSmall", "LoLaLarge"])
 def test_lola_program_raw(net):
     out = run("lola.py", "-n", net, "--synthetic", "3", "-v")
     assert len(predictions(out)) == 3 and "Maximal value used" in out and "Layer LLPoolLayer computed in" in out
@@ -44,9 +44,9 @@ def test_basic_example_program_encrypted():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("net", ["LoLa", "LoLaSmall", "LoLaDense"])
+@pytest.mark.parametrize("net", ["LoLa", "LoLaSmall", "LoLaDense", "LoLaLarge"])
 def test_lola_program_encrypted_predicts_like_raw(net):
-    n = "2" if net == "LoLaDense" else "4"
+    n = "2" if net in ("LoLaDense", "LoLaLarge") else "4"
     enc = predictions(run("lola.py", "-n", net, "-e", "--synthetic", n))
     raw = predictions(run("lola.py", "-n", net, "--synthetic", n))
     assert len(enc) == int(n) and enc == raw
