@@ -6,7 +6,7 @@
 
 Networks: LoLa, LoLaDense, LoLaSmall, LoLaLarge (its MnistLargeWeight.csv is not shipped by the reference: pass --weights /
 --biases, or a random model of the same shapes is used).  The coefficient
-modulus of LoLaDense / LoLaSmall is one prime longer than the reference's (`--limbs`): with the reference's count the noise budget
+modulus of LoLaDense / LoLaSmall / LoLaLarge is one prime longer than the reference's (`--limbs`): with the reference's count the noise budget
 is exhausted before the last layer (LoLa sections).
 """
 import argparse
@@ -41,7 +41,7 @@ def main():
     if a.encrypt:
         from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
         if "SmallModulusCount" in parms:
-            parms["SmallModulusCount"] = a.limbs if a.limbs else parms["SmallModulusCount"] + (a.network != "LoLaLarge")
+            parms["SmallModulusCount"] = a.limbs if a.limbs else parms["SmallModulusCount"] + 1
         Factory = EncryptedSealBfvFactory(**parms)
     else:
         from cryptonets_amd.raw import RawFactory
