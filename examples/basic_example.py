@@ -12,20 +12,22 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from cryptonets_amd.hewrapper import EVectorFormat        # noqa: E402
+from cryptonets_amd.utils import ProcessInEnv             # noqa: E402
 
 
 def run(Factory):
     v = np.array([1.0, 2.0, 3.0])
     z = np.array([-1.0, 5.0, -4.0])
-    env = Factory.AllocateComputationEnv()                   # Utils.ProcessInEnv (Utils.cs:26-44)
-    try:
+    out = {}
+
+    def compute(env):                                        # Program.cs:35-47
         ciphertext = Factory.GetEncryptedVector(v, EVectorFormat.dense, 1)
-        norm = ciphertext.DotProduct(ciphertext, env).Decrypt(env)
-        total = ciphertext.SumAllSlots(env).Decrypt(env)
+        out["norm"] = ciphertext.DotProduct(ciphertext, env).Decrypt(env)
+        out["total"] = ciphertext.SumAllSlots(env).Decrypt(env)
         z_ciphertext = Factory.GetEncryptedVector(z, EVectorFormat.dense, 1)
-        prod = ciphertext.PointwiseMultiply(z_ciphertext, env).Decrypt(env)
-    finally:
-        Factory.FreeComputationEnv(env)
+        out["prod"] = ciphertext.PointwiseMultiply(z_ciphertext, env).Decrypt(env)
+    ProcessInEnv(compute, Factory)
+    norm, total, prod = out["norm"], out["total"], out["prod"]
     return {"norm_squared": [float(x) for x in norm], "sum": [float(x) for x in total], "elementwise": [float(x) for x in prod]}
 
 
