@@ -188,3 +188,20 @@ def synthetic_images(count, seed=1):
     """MNIST-like sparsity: a pixel is 0 with probability 0.81, else uniform in 1..255"""
     r = np.random.default_rng(seed)
     return np.where(r.random((count, 784)) < 0.81, 0, r.integers(1, 256, size=(count, 784))).astype(float)
+
+
+def int_logits(w, image, input_scale=16.0):
+    """Exact integer model of the CryptoNets / LoLa MNIST network for ONE image (Python integers, no modulus): the wrapper's rounding
+    of inputs (`round(pixel / 256 * scale)`), weights and biases, then conv -> square -> dense -> square -> dense.  What a decryption
+    must equal modulo the product of the plaintext primes.  `w`: the arrays of CryptoNets/Weights.cs."""
+    L = layer_tables(w["Weights_0"], w["Weights_1"], w["Biases_2"], w["Weights_3"], w["Biases_3"])
+    act = [int(v) for v in np.rint(np.asarray(image, dtype=np.float64) / 256.0 * input_scale)]
+    for li, T in enumerate(L):
+        out = [T["bias"][o] + sum(T["W"][o][k] * act[idx] for k, idx in enumerate(T["idx"][o]) if idx >= 0) for o in range(len(T["W"]))]
+        act = [v * v for v in out] if li < 2 else out
+    return act
+
+
+def centred(values, M):
+    """representatives in (-M/2, M/2] (what DecryptFullPrecision returns for signed vectors)"""
+    return [((v % M) - M) if (v % M) * 2 > M else (v % M) for v in values]

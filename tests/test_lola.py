@@ -25,13 +25,7 @@ def lola(Factory, image):
 def int_logits(image):
     """exact integer model (same rounding as the wrapper: round(v*scale))"""
     from cryptonets_amd import cryptonets_mnist as cm
-    w = np.load(GOLD)
-    L = cm.layer_tables(w["Weights_0"], w["Weights_1"], w["Biases_2"], w["Weights_3"], w["Biases_3"])
-    act = [int(v) for v in np.rint(np.asarray(image) / 256.0 * 16.0)]
-    for li, T in enumerate(L):
-        out = [T["bias"][o] + sum(T["W"][o][k] * act[idx] for k, idx in enumerate(T["idx"][o]) if idx >= 0) for o in range(len(T["W"]))]
-        act = [v * v for v in out] if li < 2 else out
-    return act
+    return cm.int_logits(np.load(GOLD), image)
 
 
 def image(seed=3):
