@@ -703,6 +703,14 @@ template <int RN> struct KsMac<ArF64T<RN>> {
     static DEV void settle(double (&a)[16], const ArCtx<ArF64> &A) { ArF64::renorm(a, A.m); }
     static DEV double sum(double acc, double x, const DMod &) { return __dadd_rn(acc, x); }
 };
+#ifndef KS_SGPR_A
+#define KS_SGPR_A 1         // FP64 key switch: the first-pass roots of the output limb live in SGPRs for all digits (ArPassA)
+#endif
+template <class FW0, bool ON> struct KsPassA { typedef FW0 P; };
+template <class FW0> struct KsPassA<FW0, true> { typedef ArPassA<FW0> P; };
+#ifndef KS_PRE_SYNC
+#define KS_PRE_SYNC 1       // the "image is free again" barrier of a digit sits behind the next digit's first pass (ntt_forward_regs<.., PRE>)
+#endif
 #ifndef KS_MAC_FENCE
 #define KS_MAC_FENCE 0      // FP64 path: letting the scheduler interleave key loads with the MACs measured 11-14 % faster (same VGPRs)
 #endif
@@ -732,7 +740,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
     // TWL: forward twiddles from an LDS copy of the table (FP64 policies, N <= 8192, enough digits per workgroup to pay for staging it)
-    typedef typename std::conditional<TWL, typename KsFwd<AR, L>::P, AR>::type FW;
+    typedef typename std::conditional<TWL, typename KsFwd<AR, L>::P, AR>::type FW0;
+    typedef typename KsPassA<FW0, KS_SGPR_A && std::is_same<T, double>::value>::P FW;
     typename FW::Tw fwt;
     if constexpr (TWL) {
         static_assert(KsFwd<AR, L>::lds, "LDS twiddles need an FP64 policy and N <= 8192");
@@ -740,7 +749,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
         stage_table(tws, A.fw.w, n, tid, NttPlan<L>::NT);
         fwt.w = (const __attribute__((address_space(3))) double *)tws;
         __syncthreads();
-    } else fwt = A.fw;
+    } else static_cast<typename FW0::Tw &>(fwt) = A.fw;
+    if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwt, A.fw.w);
     const T *kp = reinterpret_cast<const T *>(key_);
     uint32_t terms = 0;
     for (uint32_t l = 0; l < k; l++) {
@@ -766,7 +776,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
                 v[r] = A.load(t);                  // F64: the first recentring of the transform reduces digits >= q_j
             }
             if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }     // digits below q_j need no recentring (uniform branch)
-            ntt_forward_regs<FW, L>(v, s, fwt, A.m, tl);
+            ntt_forward_regs<FW, L, KS_PRE_SYNC != 0>(v, s, fwt, A.m, tl);
             const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -778,9 +788,13 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
                 KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
             }
             if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
-            __syncthreads();                      // LDS of this transform is reused by the next one
+            // LDS of this transform is reused by the next one.  KS_PRE_SYNC: that barrier is inside the next forward transform; the
+            // inverse transforms below start with block-local traffic (every wave in its own blocks) or, without NTT_TAIL_LOCAL /
+            // for D = 2, still need it here.
+            if (!KS_PRE_SYNC) __syncthreads();
         }
     }
+    if (KS_PRE_SYNC && !ntt_tail_local<L>()) __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < 2; p++) {
         T v[16];
@@ -826,7 +840,11 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
     typedef const NTT_GLOBAL double *GP;
     // (an LDS copy of the half's table, as in k_keyswitch_rr, was measured: -30 % - with one digit per limb a workgroup runs only
     // k = 8 transforms, too few to pay for staging 64 KiB)
-    const typename AR::Tw fwh = {(GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2)}, ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
+    typedef typename KsPassA<AR, KS_SGPR_A != 0>::P FW;
+    typename FW::Tw fwh;
+    fwh.w = (GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2);
+    if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwh, fwh.w);
+    const typename AR::Tw ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
     const int dbc = galois ? C->gdbc : C->dbc;
     const uint64_t mask = (1ull << dbc) - 1;
     const size_t kn = (size_t)k * n;
@@ -851,7 +869,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
                 v[r] = h ? Y : X;
             }
             AR::renorm(v, A.m);
-            ntt_forward_regs<AR, L>(v, s, fwh, A.m, tl);
+            ntt_forward_regs<FW, L, KS_PRE_SYNC != 0>(v, s, fwh, A.m, tl);
             const T *k0 = kp + (size_t)j * n + (size_t)h * n2, *k1 = k0 + kn;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -862,9 +880,10 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
                 KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
             }
             if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
-            __syncthreads();
+            if (!KS_PRE_SYNC) __syncthreads();
         }
     }
+    if (KS_PRE_SYNC && !ntt_tail_local<L>()) __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < 2; p++) {
         T v[16];
@@ -997,7 +1016,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
             v[r] = A.load(t);
         }
         if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
-        ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tl);
+        ntt_forward_regs<AR, L, KS_PRE_SYNC != 0>(v, s, A.fw, A.m, tl);
         const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -1008,7 +1027,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
             KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
         }
         if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
-        __syncthreads();
+        if (!KS_PRE_SYNC) __syncthreads();         // otherwise inside the next forward transform; nothing else uses the image
     }
     KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A);        // partials leave recentred: k of them are summed without a check
     T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * k + l) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;

@@ -21,6 +21,9 @@
 #ifndef NTT_STAGE_FENCE
 #define NTT_STAGE_FENCE 0
 #endif
+#ifndef NTT_TAIL_LOCAL
+#define NTT_TAIL_LOCAL 1      // D = 1: the last pass stays inside the half-wave that owns a 512-coefficient block (see tail_index)
+#endif
 
 NTT_DEV uint32_t lds_pos(uint32_t e) { return e + 2u * (e >> 5); }
 __host__ __device__ inline uint32_t ntt_lds_words(uint32_t n) { return n + 2u * (n >> 5); }
@@ -122,6 +125,39 @@ template <int RN> struct ArF64LdsT : ArF64T<RN> {
     }
 };
 
+// First-pass twiddles in SGPRs.  In the first pass (stages 0..SA-1) every thread of the workgroup uses the SAME roots - stage u, block
+// blk: roots[2^u + blk], 2^SA - 1 <= 15 values per modulus (pass_hi is 0 there: g*NT + tid < 2^(L-SA)).  A kernel that pushes many
+// transforms of one modulus through a workgroup loads them once (ntt_load_pass_a) and the butterflies take them as scalar operands:
+// no LDS / L2 read and no VGPRs for a quarter of the butterflies.  BASE = ArF64T<RN> or ArF64LdsT<RN>.
+NTT_DEV double ntt_uniform(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+template <class BASE> struct ArPassA : BASE {
+    typedef typename BASE::T T;
+    typedef typename BASE::Mod Mod;
+    struct Tw : BASE::Tw { double wa[16]; };
+    static constexpr bool passA = true;
+    static NTT_DEV void fwdA(T &X, T &Y, const Tw &t, int ti, const Mod &m) {
+        const double p = BASE::mulmod(Y, t.wa[ti], m);
+        Y = __dadd_rn(X, -p);
+        X = __dadd_rn(X, p);
+    }
+    static NTT_DEV void invA(T &U, T &V, const Tw &t, int ti, const Mod &m) {
+        const double s = __dadd_rn(U, V), d = __dadd_rn(U, -V);
+        U = s;
+        V = BASE::mulmod(d, t.wa[ti], m);
+    }
+};
+template <class AR, class = void> struct HasPassA { static constexpr bool value = false; };
+template <class AR> struct HasPassA<AR, decltype((void)AR::passA)> { static constexpr bool value = true; };
+// wa[1 .. 2^SA) <- table[1 .. 2^SA) of a GLOBAL root table (uniform addresses), forced into SGPRs
+template <int SA, class TW> NTT_DEV void ntt_load_pass_a(TW &t, const NTT_GLOBAL double *table) {
+#pragma unroll
+    for (int i = 1; i < (1 << SA); i++) t.wa[i] = ntt_uniform(table[i]);
+}
+
 template <int L> struct NttPlan {
     static constexpr int D = (L == 14) ? 2 : 1;      // stages of the last (adjacent-coefficient) pass
     static constexpr int SA = L - 8 - D;             // stages of the first pass (1..4)
@@ -149,14 +185,15 @@ template <class AR, int L, int S, int S0> NTT_DEV void fwd_stages(typename AR::T
         const int half = 1 << (S - 1 - u);
 #pragma unroll
         for (int g = 0; g < (16 >> S); g++) {
-            const uint32_t hi = pass_hi<L, S, S0>(tid, g);
+            const uint32_t hi = S0 == 0 ? 0u : pass_hi<L, S, S0>(tid, g);          // first pass: g*NT + tid < 2^(L-S), same roots for all threads
 #pragma unroll
             for (int blk = 0; blk < (1 << u); blk++) {
                 const uint32_t ti = (1u << (S0 + u)) + ((hi << u) | (uint32_t)blk);
 #pragma unroll
                 for (int j = 0; j < half; j++) {
                     const int a = (g << S) + blk * 2 * half + j;
-                    AR::fwd(x[a], x[a + half], tw, ti, m);
+                    if constexpr (S0 == 0 && HasPassA<AR>::value) AR::fwdA(x[a], x[a + half], tw, (1 << u) + blk, m);
+                    else AR::fwd(x[a], x[a + half], tw, ti, m);
                 }
             }
         }
@@ -169,14 +206,15 @@ template <class AR, int L, int S, int S0> NTT_DEV void inv_stages(typename AR::T
         const int half = 1 << (S - 1 - u);
 #pragma unroll
         for (int g = 0; g < (16 >> S); g++) {
-            const uint32_t hi = pass_hi<L, S, S0>(tid, g);
+            const uint32_t hi = S0 == 0 ? 0u : pass_hi<L, S, S0>(tid, g);          // first pass: g*NT + tid < 2^(L-S), same roots for all threads
 #pragma unroll
             for (int blk = 0; blk < (1 << u); blk++) {
                 const uint32_t ti = (1u << (S0 + u)) + ((hi << u) | (uint32_t)blk);
 #pragma unroll
                 for (int j = 0; j < half; j++) {
                     const int a = (g << S) + blk * 2 * half + j;
-                    AR::inv(x[a], x[a + half], tw, ti, m);
+                    if constexpr (S0 == 0 && HasPassA<AR>::value) AR::invA(x[a], x[a + half], tw, (1 << u) + blk, m);
+                    else AR::inv(x[a], x[a + half], tw, ti, m);
                 }
             }
         }
@@ -190,9 +228,17 @@ template <class T, int L, int S, int S0> NTT_DEV void lds_get(T (&x)[16], const 
 #pragma unroll
     for (int r = 0; r < 16; r++) x[r] = s[lds_pos(pass_index<L, S, S0>(tid, r))];
 }
-// last pass layout: register r holds coefficient  (c << D) + (r & (2^D - 1)),  c = tid + NT * (r >> D)
+// last pass layout.  D = 2 (and NTT_TAIL_LOCAL = 0): register r holds coefficient  (c << D) + (r & (2^D - 1)),  c = tid + NT * (r >> D)
+// - consecutive lanes own consecutive 16 B across the whole limb, which needs a workgroup exchange.
+// D = 1, NTT_TAIL_LOCAL: after pass C the 2^9-coefficient block b = tid >> 5 is held by the 32 threads 32b..32b+31 (half a wave), and
+// the last stage only pairs neighbours - so thread u = tid & 31 takes the pairs u + 32*(r >> 1) OF ITS OWN BLOCK: coefficient
+// 512 b + 2 (u + 32 (r >> 1)) + (r & 1).  A half-wave still covers 512 contiguous bytes per register pair (global stores / key loads
+// stay fully coalesced, the LDS image is read as conflict-free ds_read_b128), and the exchange C -> tail needs no workgroup barrier.
+template <int L> constexpr bool ntt_tail_local() { return NTT_TAIL_LOCAL && NttPlan<L>::D == 1; }
 template <int L> NTT_DEV uint32_t tail_index(uint32_t tid, int r) {
     constexpr int D = NttPlan<L>::D, NT = NttPlan<L>::NT;
+    if (ntt_tail_local<L>())
+        return ((tid >> 5) << 9) + (((tid & 31u) + 32u * (uint32_t)(r >> 1)) << 1) + (uint32_t)(r & 1);
     return ((tid + (uint32_t)NT * (uint32_t)(r >> D)) << D) + (uint32_t)(r & ((1 << D) - 1));
 }
 template <class T, int L> NTT_DEV void lds_put_tail(const T (&x)[16], T *s, uint32_t tid) {
@@ -254,10 +300,14 @@ NTT_DEV void ntt_wave_sync() {
 }
 // Forward transform.  In: x[r] = coefficient pass_index<L,SA,0>(tid,r) (canonical).  Out: x[r] = value at bit-reversed
 // position tail_index<L>(tid,r), lazy (U64: [0,4q); F64: |x| <= 4.5q).  `s` = LDS scratch of ntt_lds_words(N) elements.
-template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
+// PRE: a kernel that pushes one transform after another through the same image (key switch) passes PRE = true instead of ending
+// every iteration with a barrier: the barrier "everybody has finished reading the previous image" then sits AFTER the first pass'
+// arithmetic, where stragglers have 256 FP64 instructions of slack, and the barrier behind the put finds the waves already aligned.
+template <class AR, int L, bool PRE = false> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m, uint32_t tid) {
     typedef typename AR::T T;
     constexpr int SA = NttPlan<L>::SA;
     fwd_stages<AR, L, SA, 0>(x, tw, m, tid);
+    if (PRE) __syncthreads();
     lds_put<T, L, SA, 0>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA>(x, s, tid);
@@ -269,7 +319,7 @@ template <class AR, int L> NTT_DEV void ntt_forward_regs(typename AR::T (&x)[16]
     AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     lds_put<T, L, 4, SA + 4>(x, s, tid);
-    __syncthreads();
+    if (ntt_tail_local<L>()) ntt_wave_sync(); else __syncthreads();       // pass C -> tail: block-local as well (tail_index)
     lds_get_tail<T, L>(x, s, tid);
     AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_tail<AR, L>(x, tw, m, tid);
@@ -282,7 +332,7 @@ template <class AR, int L> NTT_DEV void ntt_inverse_regs(typename AR::T (&x)[16]
     AR::template renorm_at<RS_INV_START>(x, m);
     inv_tail<AR, L>(x, tw, m, tid);
     lds_put_tail<T, L>(x, s, tid);
-    __syncthreads();
+    if (ntt_tail_local<L>()) ntt_wave_sync(); else __syncthreads();       // tail -> pass C: block-local (tail_index)
     lds_get<T, L, 4, SA + 4>(x, s, tid);
     AR::template renorm_at<RS_INV_C>(x, m);
     inv_stages<AR, L, 4, SA + 4>(x, tw, m, tid);

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cryptonets_amd._native import Context
 
-for n, k, cts in ((8192, 5, 845), (8192, 2, 845), (16384, 8, 200), (4096, 3, 845)):
+CONFIGS = ((8192, 5, 845), (8192, 2, 845), (16384, 8, 200), (4096, 3, 845))
+for n, k, cts in (CONFIGS[:1] if os.environ.get("NTT_PROBE_ONLY") else CONFIGS):
     q = None
     g = Context(n, 549764251649 if n >= 8192 else 40961, q=None if k in (3, 5) else ([0x7fffffd8001, 0x7fffffc8001] if k == 2 else
                 [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001, 0x1ffffffea0001, 0x1ffffffe88001]))
