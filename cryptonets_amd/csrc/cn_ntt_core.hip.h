@@ -5,7 +5,9 @@
 // D = 1, or 2 for N = 16384):  pass A reads its operands straight from global memory (stride N/2^SA between a thread's
 // operands, consecutive lanes -> consecutive addresses: coalesced), passes B and C exchange through LDS, and pass D works
 // on 2^D adjacent coefficients per thread so the results leave as 16 B/lane fully coalesced stores.  Three LDS exchanges
-// and three barriers per transform instead of log2(N) of each.  The inverse transform mirrors the same passes.
+// per transform instead of log2(N), and only the first one (the transpose behind pass A) needs a workgroup barrier: after
+// pass A the transform falls apart into 512-coefficient blocks that one half-wave owns through passes B, C and (D = 1) the
+// last pass, so those exchanges are ordered by the wave's own LDS queue.  The inverse transform mirrors the same passes.
 //
 // LDS image: coefficient e lives at P(e) = e + 2*(e >> 5) (two u64 of padding per 32): every exchange pattern below is then
 // bank-conflict free for ds_read/write_b64 (half-wave groups) and ds_read/write_b128.
