@@ -125,7 +125,8 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
 static void launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }
 
 template <int L, class AR> static void launch_ntt_rr(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
-    hipLaunchKernelGGL((k_ntt_rr<L, AR>), dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod, inverse);
+    if (inverse) hipLaunchKernelGGL((k_ntt_rr<L, AR, true>), dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod);
+    else hipLaunchKernelGGL((k_ntt_rr<L, AR, false>), dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod);
 }
 template <class AR> static bool launch_ntt_by_size(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
     switch (c->hc.logn) {
@@ -173,7 +174,7 @@ template <class K> static int big_lds(K kern, size_t bytes) {
 // dynamic LDS of the fused key switch with LDS-resident forward twiddles: exchange image + table
 template <int L> static size_t ks_twl_lds() { return ((size_t)ntt_lds_words(1u << L) + (1u << L)) * 8; }
 template <int L, class AR> static int big_lds_policy(size_t bytes) {      // every register-radix kernel of one (size, arithmetic policy)
-    CHECK(big_lds(k_ntt_rr<L, AR>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
+    CHECK(big_lds(k_ntt_rr<L, AR, false>, bytes)); CHECK(big_lds(k_ntt_rr<L, AR, true>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
     if constexpr (KsFwd<AR, L>::lds) CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>()));
     CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
     return 0;

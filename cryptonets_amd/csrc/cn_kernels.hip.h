@@ -588,8 +588,8 @@ template <int RN> struct ArCtx<ArF64T<RN>> {
     DEV uint64_t scaled(double v) const { return ArF64::to_u64(ArF64::mulmod(v, ni, m), m); }
 };
 
-template <int L, class AR>
-__global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
+template <int L, class AR, bool inverse>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
