@@ -86,7 +86,7 @@ def main():
     from cryptonets_amd import cryptonets_mnist as cm
     from cryptonets_amd.distributed import broadcast_words, max_over_ranks
 
-    layers = cm.layer_tables(*cm.synthetic_weights(1))
+    layers = cm.layer_tables(*cm.synthetic_weights(1), conv_tile=int(os.environ.get("BENCH_CONV_TILE", "1")))    # gather-list tiling: same outputs
     images = cm.synthetic_images(cm.N, seed=1000 + rank)            # this rank's batch (independent batches per GPU)
     x_int = np.rint(images * cm.NORMALIZATION * cm.INPUT_SCALE).astype(np.int64)
     dev = torch.device("cuda", local)

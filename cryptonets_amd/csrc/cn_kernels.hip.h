@@ -226,6 +226,29 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
 // exact double (< 2^(LW+20)), and up to 2^(52-LW-20) such terms accumulate exactly in one v_fma_f64 per limb - two half-rate
 // FMAs per MAC instead of a 64x64->128-bit integer multiply-add (~12 half-rate instructions).  The signed weight is the same
 // for every limb j, so the table is k times smaller as well.  Folded back with one 128-bit Barrett reduction per `lazy` terms.
+// Weights through the vector memory path (MT = 20): a wave-uniform weight as a scalar operand means s_load, and scalar loads return
+// out of order - the only possible wait is lgkmcnt(0), and ~70 free SGPRs hold less than two terms of 20 weights, so every other term
+// exposed an L2 round trip (the 135 KB weight tile of a block never fits the 16 KB scalar cache).  Instead lanes 0..15 of every
+// row of 16 load 16 consecutive table entries (5 coalesced 8 B loads per 4 terms, in-order vmcnt, requested two steps ahead) and
+// the FMA takes its weight through DPP: v_fmac_f64_dpp ... row_newbcast:i reads src0 from lane i of the own row - the one DPP
+// control gfx90a+ allows on FP64 instructions, at no extra issue slot.  (Through __builtin_amdgcn_update_dpp the compiler emits a
+// separate v_mov_b64_dpp per weight, +50 % FP64-rate instructions - hence inline assembly; "s_nop 1" covers the 2 wait states a
+// DPP read needs after a VALU write of its source, in case the register allocator put a copy right in front.)
+#ifndef GEMM_DPP_W
+#define GEMM_DPP_W 1
+#endif
+template <int LANE> DEV void fmac_bcast(double &acc, double w, double x) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x), "n"(LANE));
+}
+DEV void fmac_bcast_lane(int lane, double &acc, double w, double x) {          // `lane` is a constant after unrolling
+    switch (lane) {
+    case 0: fmac_bcast<0>(acc, w, x); break;   case 1: fmac_bcast<1>(acc, w, x); break;   case 2: fmac_bcast<2>(acc, w, x); break;   case 3: fmac_bcast<3>(acc, w, x); break;
+    case 4: fmac_bcast<4>(acc, w, x); break;   case 5: fmac_bcast<5>(acc, w, x); break;   case 6: fmac_bcast<6>(acc, w, x); break;   case 7: fmac_bcast<7>(acc, w, x); break;
+    case 8: fmac_bcast<8>(acc, w, x); break;   case 9: fmac_bcast<9>(acc, w, x); break;   case 10: fmac_bcast<10>(acc, w, x); break; case 11: fmac_bcast<11>(acc, w, x); break;
+    case 12: fmac_bcast<12>(acc, w, x); break; case 13: fmac_bcast<13>(acc, w, x); break; case 14: fmac_bcast<14>(acc, w, x); break; default: fmac_bcast<15>(acc, w, x); break;
+    }
+}
+// (178 VGPRs = 2 waves per SIMD.  Forcing 168 VGPRs for 3 waves costs 4 spilled registers and measured 16.3 vs 15.3 ms per batch.)
 template <int MT, int NL, int LW>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const int32_t *__restrict__ idx, const double *__restrict__ Wd,
                                                          const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ bias, const int32_t *__restrict__ bias_idx,
@@ -293,15 +316,48 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             }
         }
     };
+    constexpr bool DPPW = GEMM_DPP_W && MT == 20 && PF == 4;
+    constexpr int WV = DPPW ? PF * MT / 16 : 1;                    // 4 terms x 20 weights = 5 registers of 16 lanes
+    auto wfetch = [&](double (&wv)[WV], uint32_t kk) {             // rows min(kk, K + 4) .. + 3: inside the 8 spare (zero) rows of the table
+        const double *wp = gw + (size_t)min(kk, K + 4) * MT + (threadIdx.x & 15);
+#pragma unroll
+        for (int v = 0; v < WV; v++) wv[v] = wp[16 * v];
+    };
+    auto terms_dpp = [&](const uint64_t (&x)[PF], double (&wv)[WV]) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            double xl[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x[p] >> (l * LW)) & ((1ull << LW) - 1));
+            asm volatile("s_nop 1");
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int f = p * MT + m;
+#pragma unroll
+                for (int l = 0; l < NL; l++) fmac_bcast_lane(f & 15, acc[l][m], wv[(f >> 4) % WV], xl[l]);
+            }
+        }
+    };
     for (uint32_t k0 = 0; k0 < K; k0 += lazy) {
         const uint32_t k1 = min(K, k0 + lazy);
         uint64_t xa[PF], xb[PF];
-        fetch(xa, k0, k1);
-        for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
-            fetch(xb, kk + PF, k1);
-            terms(xa, kk);
-            fetch(xa, kk + 2 * PF, k1);
-            terms(xb, kk + PF);
+        if constexpr (DPPW) {
+            double wa[WV], wb[WV];
+            fetch(xa, k0, k1); wfetch(wa, k0);
+            for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
+                fetch(xb, kk + PF, k1); wfetch(wb, kk + PF);
+                terms_dpp(xa, wa);
+                fetch(xa, kk + 2 * PF, k1); wfetch(wa, kk + 2 * PF);
+                terms_dpp(xb, wb);
+            }
+        } else {
+            fetch(xa, k0, k1);
+            for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
+                fetch(xb, kk + PF, k1);
+                terms(xa, kk);
+                fetch(xa, kk + 2 * PF, k1);
+                terms(xb, kk + PF);
+            }
         }
         fold();
     }
