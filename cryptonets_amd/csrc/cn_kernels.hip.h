@@ -759,6 +759,9 @@ template <int RN> struct KsMac<ArF64T<RN>> {
     static DEV void settle(double (&a)[16], const ArCtx<ArF64> &A) { ArF64::renorm(a, A.m); }
     static DEV double sum(double acc, double x, const DMod &) { return __dadd_rn(acc, x); }
 };
+// (Measured, not kept: using the N*8 bytes of LDS behind the image for a key prefetch instead of the twiddle table - every wave requests
+// the first key component of a digit with global_load_lds_dwordx4 at the start of the digit (global -> LDS without registers, read
+// back as ds_read_b128).  Bit-exact, -2 % in the stand-alone loop of tools/ubench_ks.hip, but +4 % in this kernel: 3.78 vs 3.62 ms.)
 #ifndef KS_SGPR_A
 #define KS_SGPR_A 1         // FP64 key switch: the first-pass roots of the output limb live in SGPRs for all digits (ArPassA)
 #endif

@@ -9,7 +9,7 @@
 #include <cstdint>
 #include <vector>
 #include "cn_ntt_core.hip.h"
-enum { F_KEYS = 1, F_LDS = 2, F_MATH = 4, F_MAC = 8, F_BAR = 16, F_TWL = 32, F_RAW = 64, F_DB = 128 };   // F_DB: two LDS images, one barrier per digit
+enum { F_KEYS = 1, F_LDS = 2, F_MATH = 4, F_MAC = 8, F_BAR = 16, F_TWL = 32, F_RAW = 64, F_DB = 128, F_KLDS = 256 };   // F_KLDS: first key component of a digit prefetched into LDS with global_load_lds (no registers)   // F_DB: two LDS images, one barrier per digit
 typedef ArF64T<0> AR;
 constexpr int L = 13;
 constexpr uint32_t N = 1u << L;
@@ -66,14 +66,23 @@ __global__ void __launch_bounds__(512, 1) k_ks(const uint64_t *__restrict__ targ
             double v[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) v[r] = AR::from_u64((raw[r] >> sh) & 1023);
-            fwd_flagged<F, FW>(v, (F & F_DB) ? s + ((l * 5 + d) & 1) * ntt_lds_words(N) : s, fwt, m, tl);
             const double *k0 = kp + (size_t)j * N, *k1 = kp + kn + (size_t)j * N;
+            double *kbuf = s + ntt_lds_words(N) + ((tid >> 6) * 8) * 128;            // this wave's 8 KiB: [pair j][lane] 16 B
+            if constexpr ((F & F_KLDS) != 0) {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(k0 + tail_index<L>(tl, 2 * jj)),
+                                                     (__attribute__((address_space(3))) void *)(kbuf + jj * 128), 16, 0, 0);
+            }
+            fwd_flagged<F, FW>(v, (F & F_DB) ? s + ((l * 5 + d) & 1) * ntt_lds_words(N) : s, fwt, m, tl);
+            if constexpr ((F & F_KLDS) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const uint32_t pos = tail_index<L>(tl, r);
                 struct alignas(16) P2 { double a, b; };
                 P2 a, b;
-                if (F & F_KEYS) { a = *reinterpret_cast<const P2 *>(k0 + pos); b = *reinterpret_cast<const P2 *>(k1 + pos); }
+                if (F & F_KLDS) { a = *reinterpret_cast<const P2 *>(kbuf + (r >> 1) * 128 + (tl & 63) * 2); b = *reinterpret_cast<const P2 *>(k1 + pos); }
+                else if (F & F_KEYS) { a = *reinterpret_cast<const P2 *>(k0 + pos); b = *reinterpret_cast<const P2 *>(k1 + pos); }
                 else { a = P2{q - 3.0 - r, 12345.0 + pos}; b = P2{q - 5.0 - r, 54321.0 + pos}; }
                 if (F & F_MAC) {
                     acc0[r] = __dadd_rn(acc0[r], AR::mulmod(v[r], a.a, m)); acc0[r + 1] = __dadd_rn(acc0[r + 1], AR::mulmod(v[r + 1], a.b, m));
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(512, 1) k_ks(const uint64_t *__restrict__ targ
     }
 }
 template <int F> void run(const char *what, const uint64_t *tgt, const double *key, uint64_t *out, const double *tw, int cts) {
-    const size_t lds = ((size_t)ntt_lds_words(N) * ((F & F_DB) ? 2 : 1) + ((F & F_TWL) ? N : 0)) * 8;
+    const size_t lds = ((size_t)ntt_lds_words(N) * ((F & F_DB) ? 2 : 1) + ((F & (F_TWL | F_KLDS)) ? N : 0)) * 8;
     hipFuncSetAttribute((const void *)k_ks<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const double q = 8796092792833.0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -131,6 +140,7 @@ int main() {
     run<127 - F_TWL + F_DB>("two LDS images (one barrier per digit), twiddles from L2", tgt, key, out, tw, cts);
     run<127 - F_TWL + F_DB - F_KEYS>("two LDS images, twiddles from L2, no key loads", tgt, key, out, tw, cts);
     run<127 - F_TWL - F_BAR>("no barriers, twiddles from L2", tgt, key, out, tw, cts);
+    run<127 - F_TWL + F_KLDS>("first key component prefetched into LDS, twiddles from L2", tgt, key, out, tw, cts);
     run<127 - F_KEYS>("no key loads", tgt, key, out, tw, cts);
     run<127 - F_BAR>("no barriers in the digit loop", tgt, key, out, tw, cts);
     run<127 - F_LDS>("no LDS exchanges", tgt, key, out, tw, cts);
