@@ -576,3 +576,35 @@ def test_small_scratch_and_no_pool(rng, monkeypatch):
         g.free(x)
     assert g.live_handles() == 0
     g.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c3"])
+def test_scalar_gemm_wide_output_tiles(name, rng):
+    """Dense-layer shape: MANY outputs share one gather list, which selects the 20-outputs-per-thread FP64 kernel whose weights travel
+    through vector registers and are broadcast inside the FMA (DPP row_newbcast).  37 outputs = one full and one ragged tile, K = 13
+    and 1100 (not multiples of the 4-term / 8-term pipeline steps; beyond one exact-accumulation window on the 2x22-bit path), padded
+    taps, extreme weights, bias, and a second group with its own gather list."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    n_in = 9
+    vals, cts = enc_batch(o, rng, n_in)
+    h = up(g, cts)
+    wmax = min(2 ** 20 - 1, (o.t - 1) // 2)
+    for K in (13, 1100 if name == "tiny" else 45):
+        O1, O2 = 37, 21
+        row1, row2 = rng.integers(0, n_in, size=K, dtype=np.int32), rng.integers(0, n_in, size=K, dtype=np.int32)
+        row1[3], row2[0], row2[K - 1] = -1, -1, -1
+        idx = np.concatenate([np.tile(row1, (O1, 1)), np.tile(row2, (O2, 1))]).astype(np.int32)
+        Ws = rng.integers(-wmax, wmax + 1, size=(O1 + O2, K))
+        Ws[0, 0], Ws[1, 1], Ws[2, 1:], Ws[2, 0] = wmax, -wmax, 0, 1          # (an all-zero row is an error: AddMany of nothing)
+        W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
+        bias_vals = rng.integers(0, o.t, size=3, dtype=np.uint64)
+        bias_plain = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in bias_vals])
+        bh = g.pt_alloc(3)
+        g.pt_upload(bh, 0, bias_plain)
+        bias_idx = rng.integers(0, 3, size=O1 + O2).astype(np.int32)
+        out = g.ct_alloc(O1 + O2)
+        g.scalar_gemm(h, W, out, 0, idx=idx, bias_pt=bh, bias_idx=bias_idx)
+        exp = o.add_plain_batch(o.scalar_gemm(cts, W, idx), bias_plain[bias_idx])
+        assert np.array_equal(g.ct_download(out, 0, O1 + O2), exp), (name, K)
+        g.free(out); g.free(bh)
+    g.free(h)

@@ -17,14 +17,12 @@ fa = sum(F["k_addsub"]) / len(F["k_addsub"]); wa = sum(W["k_addsub"]) / len(W["k
 res["k_addsub"] = {"FETCH_SIZE": fa, "WRITE_SIZE": wa, "true_read": add_read_kib, "true_write": add_write_kib,
                    "fetch_correction": add_read_kib / fa, "write_correction": add_write_kib / wa}
 for name in F:
-    if "k_ntt" in name:
-        v, w = F[name], W[name]
-        half = len(v) // 2
-        for tag, sl in (("forward", slice(0, half)), ("inverse", slice(half, None))):
-            f_ = sum(v[sl]) / len(v[sl]); w_ = sum(w[sl]) / len(w[sl])
-            corr = f_ * res["k_addsub"]["fetch_correction"] + w_ * res["k_addsub"]["write_correction"]
-            res["%s %s" % (name, tag)] = {"FETCH_SIZE": f_, "WRITE_SIZE": w_, "hbm_traffic_corrected_KiB": corr,
-                                          "hbm_traffic_corrected_bytes": corr * 1024, "algorithmic_bytes": cts * 10 * n * 16,
-                                          "traffic_over_algorithmic": corr * 1024 / (cts * 10 * n * 16)}
+    if "k_ntt" in name:                                # one instantiation per direction: k_ntt_rr<L, AR, false|true>
+        tag = "inverse" if name.rstrip(" >").endswith("true") else "forward"
+        f_ = sum(F[name]) / len(F[name]); w_ = sum(W[name]) / len(W[name])
+        corr = f_ * res["k_addsub"]["fetch_correction"] + w_ * res["k_addsub"]["write_correction"]
+        res["%s %s" % (name, tag)] = {"FETCH_SIZE": f_, "WRITE_SIZE": w_, "hbm_traffic_corrected_KiB": corr,
+                                      "hbm_traffic_corrected_bytes": corr * 1024, "algorithmic_bytes": cts * 10 * n * 16,
+                                      "traffic_over_algorithmic": corr * 1024 / (cts * 10 * n * 16)}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
