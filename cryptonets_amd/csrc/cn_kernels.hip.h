@@ -761,7 +761,9 @@ template <int RN> struct KsMac<ArF64T<RN>> {
 };
 // (Measured, not kept: using the N*8 bytes of LDS behind the image for a key prefetch instead of the twiddle table - every wave requests
 // the first key component of a digit with global_load_lds_dwordx4 at the start of the digit (global -> LDS without registers, read
-// back as ds_read_b128).  Bit-exact, -2 % in the stand-alone loop of tools/ubench_ks.hip, but +4 % in this kernel: 3.78 vs 3.62 ms.)
+// back as ds_read_b128).  Bit-exact, -2 % in the stand-alone loop of tools/ubench_ks.hip, but +4 % in this kernel: 3.78 vs 3.62 ms.
+// Likewise s_setprio 3 / 0 for the two waves a SIMD holds, so that their memory waits stop coinciding: -7 % in the stand-alone loop,
+// no change here (3.65 vs 3.66 ms) and +30 % on the 100-ciphertext launch.)
 #ifndef KS_SGPR_A
 #define KS_SGPR_A 1         // FP64 key switch: the first-pass roots of the output limb live in SGPRs for all digits (ArPassA)
 #endif

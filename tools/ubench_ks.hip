@@ -9,7 +9,7 @@
 #include <cstdint>
 #include <vector>
 #include "cn_ntt_core.hip.h"
-enum { F_KEYS = 1, F_LDS = 2, F_MATH = 4, F_MAC = 8, F_BAR = 16, F_TWL = 32, F_RAW = 64, F_DB = 128, F_KLDS = 256 };   // F_KLDS: first key component of a digit prefetched into LDS with global_load_lds (no registers)   // F_DB: two LDS images, one barrier per digit
+enum { F_KEYS = 1, F_LDS = 2, F_MATH = 4, F_MAC = 8, F_BAR = 16, F_TWL = 32, F_RAW = 64, F_DB = 128, F_KLDS = 256, F_PRIO = 512 };   // F_KLDS: first key component of a digit prefetched into LDS with global_load_lds (no registers)   // F_DB: two LDS images, one barrier per digit
 typedef ArF64T<0> AR;
 constexpr int L = 13;
 constexpr uint32_t N = 1u << L;
@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(512, 1) k_ks(const uint64_t *__restrict__ targ
     extern __shared__ __align__(16) unsigned char smem[];
     double *s = reinterpret_cast<double *>(smem);
     const uint32_t k = 5, tid = threadIdx.x, ct = blockIdx.x / k, j = blockIdx.x % k;
+    if constexpr ((F & F_PRIO) != 0) { if (tid < 256) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }   // one wave of every SIMD runs ahead
     const AR::Mod m = {q, qinv};
     const size_t kn = (size_t)k * N;
     typedef typename std::conditional<(F & F_TWL) != 0, ArF64LdsT<0>, AR>::type FW0;
@@ -136,6 +137,7 @@ int main() {
     hipMemcpy(key, kk.data(), kk.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(tw, kk.data(), 5 * 2 * N * 8, hipMemcpyHostToDevice);
     run<127>("full (keys, LDS, math, MAC, barriers, LDS twiddles, source loads)", tgt, key, out, tw, cts);
+    run<127 + F_PRIO>("full, waves 0-3 at priority 3, waves 4-7 at priority 0", tgt, key, out, tw, cts);
     run<127 - F_TWL>("full, twiddles from L2 instead of LDS", tgt, key, out, tw, cts);
     run<127 - F_TWL + F_DB>("two LDS images (one barrier per digit), twiddles from L2", tgt, key, out, tw, cts);
     run<127 - F_TWL + F_DB - F_KEYS>("two LDS images, twiddles from L2, no key loads", tgt, key, out, tw, cts);
