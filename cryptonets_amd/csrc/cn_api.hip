@@ -66,6 +66,7 @@ struct cn_ctx {
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
+    bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
 };
 
 // ---------------------------------------------------------------- helpers
@@ -177,6 +178,7 @@ template <int L, class AR> static int big_lds_policy(size_t bytes) {      // eve
     CHECK(big_lds(k_ntt_rr<L, AR, false>, bytes)); CHECK(big_lds(k_ntt_rr<L, AR, true>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
     if constexpr (KsFwd<AR, L>::lds) CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>()));
     CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
+    if constexpr (std::is_same<typename AR::T, double>::value) CHECK(big_lds(k_square_fused<L, AR>, bytes));
     return 0;
 }
 template <int EPT> static int set_ks_attr(size_t bytes) {
@@ -229,6 +231,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
+    if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (n == 4096) {                       // N = 4096: image + LDS twiddle table of the fused FP64 key switch = 66.5 KiB
         CHECK(big_lds(k_keyswitch_rr<12, ArF64, 1, true>, ks_twl_lds<12>())); CHECK(big_lds(k_keyswitch_rr<12, ArF64L, 1, true>, ks_twl_lds<12>()));
@@ -268,6 +271,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
+    if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
@@ -774,6 +778,35 @@ static bool run_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uin
     if (ok) { launch_count(c); c->st.ntt_inverse_limbs += (uint64_t)cnt * 3 * Lm; }
     return ok;
 }
+// squaring: forward transforms, tensor and inverse transforms of one (ciphertext, limb) in ONE kernel (FP64 policies)
+template <int L, class AR> static void launch_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
+    hipLaunchKernelGGL((k_square_fused<L, AR>), dim3(cnt * Lm), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, A, astride, D, c->dc, base_off, Lm);
+}
+template <class AR> static bool square_fused_by_size(cn_ctx *c, const uint64_t *A, size_t astride, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
+    switch (c->hc.logn) {
+        case 10: launch_square_fused<10, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
+        case 11: launch_square_fused<11, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
+        case 12: launch_square_fused<12, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
+        case 13: launch_square_fused<13, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
+        case 14: launch_square_fused<14, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
+        default: return false;
+    }
+}
+static bool square_fused_ok(cn_ctx *c, uint32_t base_off, uint32_t Lm, bool &light) {
+    if (!c->sq_fused || c->legacy_ntt || !c->use_f64 || c->hc.logn < 10 || c->hc.logn > 14) return false;
+    light = true;
+    for (uint32_t m = base_off; m < base_off + Lm; m++) {
+        if (!c->hc.f64ok[m]) return false;
+        uint64_t q = m < c->hc.k ? c->hc.q[m].q : c->hc.bsk[m - c->hc.k].q;
+        if (q >> 44) light = false;
+    }
+    return true;
+}
+static void run_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm, bool light) {
+    if (light) square_fused_by_size<ArF64L>(c, A, astride, D, cnt, base_off, Lm); else square_fused_by_size<ArF64>(c, A, astride, D, cnt, base_off, Lm);
+    launch_count(c);
+    c->st.ntt_forward_limbs += (uint64_t)cnt * 2 * Lm; c->st.ntt_inverse_limbs += (uint64_t)cnt * 3 * Lm;
+}
 static size_t mul_scratch_per_ct(cn_ctx *c, bool square) {
     size_t n = c->hc.n, k = c->hc.k, kb = c->hc.kb;
     size_t w = (square ? 1 : 2) * 2 * (k + kb) * n + 3 * (k + kb) * n;
@@ -783,14 +816,21 @@ static size_t mul_scratch_per_ct(cn_ctx *c, bool square) {
 static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const uint64_t *b, uint32_t bstride, uint64_t *out3, uint32_t cnt) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, kb = ctx->hc.kb;
     const bool square = (a == b && astride == bstride);
-    uint64_t *aq = salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n), *ab = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n);
+    // squarings on the FP64 path: one fused kernel per base does forward transforms, tensor and inverse transforms; its q side reads the
+    // input ciphertexts in place, so k_behz_extend only has to produce the Bsk limbs
+    bool lq = false, lb = false;
+    const bool fused = square && ctx->hc.behz_f64 && square_fused_ok(ctx, 0, k, lq) && square_fused_ok(ctx, k, kb, lb);
+    uint64_t *aq = fused ? nullptr : salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n), *ab = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n);
     uint64_t *bq = aq, *bb = ab;
     if (!square) { bq = salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n); bb = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n); }
     uint64_t *dq = salloc<uint64_t>(ctx, (size_t)cnt * 3 * k * n), *db = salloc<uint64_t>(ctx, (size_t)cnt * 3 * kb * n);
-    if (!aq || !ab || !bq || !bb || !dq || !db) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply");
+    if ((!fused && !aq) || !ab || (!square && (!bq || !bb)) || !dq || !db) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply");
     DISPATCH_K(launch_extend, ctx, a, astride, aq, ab, cnt);
     if (!square) { DISPATCH_K(launch_extend, ctx, b, bstride, bq, bb, cnt); }
     HIPCHK(hipGetLastError()); launch_count(ctx, square ? 1 : 2);
+    if (fused) {
+        run_square_fused(ctx, a, (size_t)astride * 2 * k * n, dq, cnt, 0, k, lq); run_square_fused(ctx, ab, (size_t)2 * kb * n, db, cnt, k, kb, lb);
+    } else {
     CHECK(run_ntt(ctx, aq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, ab, cnt * 2 * kb, k, kb, 0));
     if (!square) { CHECK(run_ntt(ctx, bq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, bb, cnt * 2 * kb, k, kb, 0)); }
     if (!run_intt_tensor(ctx, aq, bq, dq, cnt, 0, k) || !run_intt_tensor(ctx, ab, bb, db, cnt, k, kb)) {
@@ -798,6 +838,7 @@ static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const u
         hipLaunchKernelGGL(k_tensor, dim3(cnt * kb * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ab, bb, db, ctx->dc, ctx->chunks, kb, k);
         HIPCHK(hipGetLastError()); launch_count(ctx, 2);
         CHECK(run_ntt(ctx, dq, cnt * 3 * k, 0, k, 1)); CHECK(run_ntt(ctx, db, cnt * 3 * kb, k, kb, 1));
+    }
     }
     HIPCHK(hipGetLastError());
     DISPATCH_K(launch_floor, ctx, dq, db, out3, cnt);

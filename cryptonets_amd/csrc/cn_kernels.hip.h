@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_behz_extend_f64(const uint64_t *__restr
 #pragma unroll
     for (int j = 0; j < K; j++) {
         const uint64_t v = x[(size_t)j * n];
-        oq[(size_t)j * n] = v;
+        if (aq) oq[(size_t)j * n] = v;             // aq == nullptr: the fused squaring kernel reads the q limbs from the ciphertext itself
         const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
         y[j] = bz_canon(BzF::mulmod(BzF::from_u64(v), C->bd.mt_inv_qhat_q[j], mq), mq);       // canonical: feeds the mod-m~ sum
         mt += (uint32_t)__double_as_longlong(__dadd_rn(y[j], 4503599627370496.0)) * (uint32_t)C->qhat_mt[j];   // low 32 bits of y (exact integer < 2^49)
@@ -728,6 +728,81 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *
     uint64_t *o = D + ((size_t)ct * 3 + p) * Ln + (size_t)l * n;
 #pragma unroll
     for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(tid, r)] = A.scaled(v[r]);
+}
+
+// BEHZ steps 2-4 of a SQUARING in one kernel (FP64 policies): block = (ciphertext, limb) of the q or the Bsk base.  The operand polys
+// a0, a1 arrive in COEFFICIENT form (k_behz_extend's output) and the tensor (a0^2, 2 a0 a1, a1^2) leaves in coefficient form:
+//     step 0:  A0 = NTT(a0) -> parked in d1's place;               d0 = INTT(A0^2)
+//     step 1:  A1 = NTT(a1) -> parked in d2's place;  A0 back;     d1 = INTT(2 A0 A1)   (overwrites the parked A0)
+//     step 2:  A1 back;                                            d2 = INTT(A1^2)      (overwrites the parked A1)
+// Two forward and three inverse transforms like the separate launches, but every step needs only the 16 coefficients of ONE polynomial
+// per thread (126 VGPRs, two resident workgroups per CU) - keeping A0 and A1 in registers for the cross term would cost 64 more VGPRs
+// and a workgroup per CU.  The parked values are the thread's own doubles at its own 16 B/lane positions (stored and re-read by the
+// same thread: program order), 64 KiB per polynomial that is overwritten by the result a few microseconds later, i.e. while it still
+// sits in L2.  Against the separate launches (forward transforms in place 2R + 2W, tensor + inverse 4R + 3W per limb) HBM sees 2R + 3W.
+// The inverse transform's workgroup barrier orders "everybody has re-read its parked words" before any result word is stored over them.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64_t *__restrict__ A_, size_t a_stride, uint64_t *__restrict__ D,
+                                                                    const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm) {
+    // 4 waves per SIMD: two 512-thread workgroups per CU.  a_stride: words between the operands of consecutive ciphertexts (the q side
+    // reads the input ciphertexts in place, the Bsk side k_behz_extend's array)
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value, "FP64 policies only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l = blockIdx.x % Lm, ct = blockIdx.x / Lm, mod = base_off + l;
+    const ArCtx<AR> A(C, mod);
+    const size_t Ln = (size_t)Lm * n;
+    const uint64_t *a0 = A_ + (size_t)ct * a_stride + (size_t)l * n, *a1 = a0 + Ln;
+    uint64_t *d0 = D + (size_t)ct * 3 * Ln + (size_t)l * n, *d1 = d0 + Ln, *d2 = d1 + Ln;
+    struct alignas(16) P2 { T a, b; };
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));                             // one transform's address math / twiddles live at a time
+        T v[16];
+        if (step < 2) {
+            const uint64_t *x = step ? a1 : a0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tl, r)]);
+            ntt_forward_regs<AR, L, true>(v, s, A.fw, A.m, tl);  // PRE: the image of the previous inverse transform is free
+            AR::renorm(v, A.m);                                  // lazy transform output (up to 28 q) -> |x| <= q/2
+            T *park = reinterpret_cast<T *>(step ? d2 : d1);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) *reinterpret_cast<P2 *>(park + tail_index<L>(tl, r)) = P2{v[r], v[r + 1]};
+            if (step == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = AR::mulmod(v[r], v[r], A.m);
+            } else {
+                const T *pa0 = reinterpret_cast<const T *>(d1);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const P2 w = *reinterpret_cast<const P2 *>(pa0 + tail_index<L>(tl, r));
+                    v[r] = AR::mulmod(__dadd_rn(w.a, w.a), v[r], A.m); v[r + 1] = AR::mulmod(__dadd_rn(w.b, w.b), v[r + 1], A.m);
+                }
+            }
+            if (!ntt_tail_local<L>()) __syncthreads();           // (block-local tail: the inverse starts inside the wave's own blocks)
+        } else {
+            const T *pa1 = reinterpret_cast<const T *>(d2);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const P2 w = *reinterpret_cast<const P2 *>(pa1 + tail_index<L>(tl, r));
+                v[r] = AR::mulmod(w.a, w.a, A.m); v[r + 1] = AR::mulmod(w.b, w.b, A.m);
+            }
+            __syncthreads();                                     // no forward transform in this step: the previous inverse's image is free
+        }
+        uint32_t ti = tid;
+        asm volatile("" : "+v"(ti));                             // the inverse transform's address math starts here, not before the forward one
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, ti);
+        uint64_t *o = step == 0 ? d0 : (step == 1 ? d1 : d2);
+        uint32_t to = tid;
+        asm volatile("" : "+v"(to));
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(to, r)] = A.scaled(v[r]);
+    }
 }
 
 // Key switching on the register-radix core: block = (ciphertext, output limb j).  For every (source limb l, digit d) the
