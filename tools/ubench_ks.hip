@@ -2,7 +2,10 @@
 // output limbs, 25 digits each, LDS twiddle table, SGPR first-pass roots, 2 inverse transforms) with pieces switched off - timing only.
 // (Measured and dropped from this file: 256-thread workgroups whose threads play two "virtual threads" of the 512-thread layout one
 // after the other, so that two INDEPENDENT workgroups share a CU - 234 VGPRs, every load is followed by its own s_waitcnt: 5.7 ms
-// against 3.0 ms.  The accumulators of 32 coefficients per thread do not leave the scheduler any registers.)
+// against 3.0 ms.  The accumulators of 32 coefficients per thread do not leave the scheduler any registers.  Likewise the 512-thread
+// layout with the accumulators parked in the output's place (read-modify-write through L2 per digit) and the source words re-read per
+// digit, which fits 128 VGPRs and two workgroups per CU: 6.4 ms.  Differences below ~8 % between variants of this file are run-to-run
+// noise (clock / power state): the same kernel measures 2.9-3.1 ms.)
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I cryptonets_amd/csrc tools/ubench_ks.hip -o tools/ubench_ks
 #include <hip/hip_runtime.h>
 #include <cstdio>
