@@ -53,6 +53,12 @@ def cpu_baseline(cores, budget_s=20.0):
                       "(%.1f s per batch)" % (4 * ns, ns, ns, 2 * ns, total)}
 
 
+def _conv_tile():
+    """BENCH_CONV_TILE=2 or 1x2: outputs of neighbouring positions share a gather list (same outputs; developer A/B switch)."""
+    v = os.environ.get("BENCH_CONV_TILE", "1")
+    return tuple(int(x) for x in v.split("x")) if "x" in v else int(v)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +92,7 @@ def main():
     from cryptonets_amd import cryptonets_mnist as cm
     from cryptonets_amd.distributed import broadcast_words, max_over_ranks
 
-    layers = cm.layer_tables(*cm.synthetic_weights(1), conv_tile=int(os.environ.get("BENCH_CONV_TILE", "1")))    # gather-list tiling: same outputs
+    layers = cm.layer_tables(*cm.synthetic_weights(1), conv_tile=_conv_tile())    # gather-list tiling: same outputs
     images = cm.synthetic_images(cm.N, seed=1000 + rank)            # this rank's batch (independent batches per GPU)
     x_int = np.rint(images * cm.NORMALIZATION * cm.INPUT_SCALE).astype(np.int64)
     dev = torch.device("cuda", local)

@@ -32,7 +32,8 @@ def _corner_tiles(eng, gather, tile):
     input ciphertext of the block once for tile^2 * maps outputs: 5x5 windows at stride 2 overlap 3/5 per axis, a 2x2 block
     reads 49 pixels instead of 4 x 25.  Same sums, same ciphertext words - only fewer passes over HBM."""
     coords = [sorted(set(c[d] for c in eng.Corners)) for d in range(len(eng.Corners[0]))]
-    key = [tuple(coords[d].index(c[d]) // tile for d in range(len(c))) for c in eng.Corners]
+    tiles = (tile,) * len(coords) if isinstance(tile, int) else tuple(tile)           # per-axis block shape, e.g. (1, 2)
+    key = [tuple(coords[d].index(c[d]) // tiles[d] for d in range(len(c))) for c in eng.Corners]
     names = {k: i for i, k in enumerate(sorted(set(key)))}
     tile_of = [names[k] for k in key]
     unions = [sorted({int(g) for c, t in enumerate(tile_of) if t == i for g in gather[c] if g >= 0}) for i in range(len(names))]
