@@ -25,6 +25,10 @@ PARAMS = {
     "c4": dict(n=8192, t=557057, q=None, dbc=10, gdbc=20),
     # small ring for exhaustive/edge cases
     "tiny": dict(n=1024, t=12289, q=[0xffffee001, 0xffffc4001, 0x1ffffe0001], dbc=10, gdbc=20),
+    # LoLa-Dense shapes: N=16384 with 7 of the CIFAR primes (LoLaCryptonets.cs:118-199 takes SmallModulusCount 7): k+1 primes below 2^49
+    # are a valid BEHZ auxiliary base here, so the N=16384 multiplications run on the FP64 kernels (the k=8 set keeps SEAL's 61-bit base)
+    "n16k7": dict(n=16384, t=957181001729, q=[0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001,
+                                               0x1ffffffee8001, 0x1ffffffea0001], dbc=60, gdbc=60),
     # BASELINE config 5 shapes: LoLa-CIFAR N=16384, k=8, dbc 60/60 (LolaCifarCryptoNet.cs:35)
     "c5": dict(n=16384, t=957181001729, q=[0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001,
                                             0x1ffffffee8001, 0x1ffffffea0001, 0x1ffffffe88001], dbc=60, gdbc=60),

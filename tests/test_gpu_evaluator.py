@@ -193,6 +193,33 @@ def test_multiply_relinearize(name, rng):
         g.free(x)
 
 
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c3", "n16k7"])
+def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
+    """SquareActivation path: forward transforms + tensor + inverse transforms of a squaring run as ONE kernel per base (NTT-form operands
+    parked in the output's place, q side read from the ciphertext in place); cn_set_option("sq_fused", 0) selects the separate launches.
+    Same words from both and from the oracle, also at an input offset / stride, and the inputs are left untouched."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    cnt = 5
+    vals, cts = enc_batch(o, rng, cnt)
+    h = up(g, cts)
+    out3, out2 = g.ct_alloc(cnt, 3), g.ct_alloc(cnt)
+    exp3 = [o.multiply(c, c) for c in cts]
+    got = {}
+    for fused in (1, 0):
+        g.set_option("sq_fused", fused)
+        g.multiply(h, 1, h, 1, out3, 1, cnt - 1)                 # squares of ciphertexts 1.. (offset into the array)
+        got[fused] = g.ct_download(out3, 1, cnt - 1, size=3)
+        for i in range(cnt - 1):
+            assert np.array_equal(got[fused][i], exp3[i + 1]), (name, fused, i)
+        g.mul_relin(h, 0, h, 0, out2, 0, cnt)
+        assert np.array_equal(g.ct_download(out2, 0, cnt), o.mul_relin_batch(cts, cts)), (name, fused)
+    g.set_option("sq_fused", 1)
+    assert np.array_equal(got[0], got[1])
+    assert np.array_equal(g.ct_download(h, 0, cnt), cts)         # operands intact (the q side is read in place)
+    for x in (h, out3, out2):
+        g.free(x)
+
+
 @pytest.mark.parametrize("name", ["tiny", "default4096", "c4"])
 def test_rotations(name, rng):
     """HOT LOOP C: Galois automorphism + key switch, direct keys and NAF-decomposed steps, column swap."""
