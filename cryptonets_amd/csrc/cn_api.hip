@@ -66,6 +66,7 @@ struct cn_ctx {
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
+    bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
 };
 
@@ -179,6 +180,7 @@ template <int L, class AR> static int big_lds_policy(size_t bytes) {      // eve
     if constexpr (KsFwd<AR, L>::lds) CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>()));
     CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
     if constexpr (std::is_same<typename AR::T, double>::value) CHECK(big_lds(k_square_fused<L, AR>, bytes));
+    CHECK(big_lds(k_lift_ntt<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_fused<L, AR>, bytes));
     return 0;
 }
 template <int EPT> static int set_ks_attr(size_t bytes) {
@@ -231,7 +233,8 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
-    if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;          // A/B switch of the fused squaring kernel
+    if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
+    if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (n == 4096) {                       // N = 4096: image + LDS twiddle table of the fused FP64 key switch = 66.5 KiB
         CHECK(big_lds(k_keyswitch_rr<12, ArF64, 1, true>, ks_twl_lds<12>())); CHECK(big_lds(k_keyswitch_rr<12, ArF64L, 1, true>, ks_twl_lds<12>()));
@@ -272,6 +275,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
+    if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
@@ -507,12 +511,58 @@ extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
     return 0;
 }
 // out[c] = a[c * (a_bcast ? 0 : 1)] * pt[c * pstride]; a_bcast: ONE ciphertext against `count` plaintexts (row-dot batches)
+// Dense MultiplyPlain in two launches (k_lift_ntt, k_mul_plain_fused); ranges / zero plaintexts were checked by the caller
+template <int L, class AR> static void launch_mul_plain_fused(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride,
+                                                              uint32_t pstride, uint64_t *out, uint32_t count, uint32_t polys) {
+    const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
+    hipLaunchKernelGGL((k_lift_ntt<L, AR>), dim3(npt * c->hc.k), dim3(NttPlan<L>::NT), lds, c->stream, pt, pitch, lift, c->dc);
+    hipLaunchKernelGGL((k_mul_plain_fused<L, AR>), dim3(count * polys * c->hc.k), dim3(NttPlan<L>::NT), lds, c->stream, src, sstride, lift, pstride, out, c->dc, polys);
+}
+template <class AR> static void mul_plain_fused_by_size(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride,
+                                                        uint32_t pstride, uint64_t *out, uint32_t count, uint32_t polys) {
+    switch (c->hc.logn) {
+        case 10: launch_mul_plain_fused<10, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
+        case 11: launch_mul_plain_fused<11, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
+        case 12: launch_mul_plain_fused<12, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
+        case 13: launch_mul_plain_fused<13, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
+        default: launch_mul_plain_fused<14, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
+    }
+}
+static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
+    uint64_t *o = O->d + oi * O->item_words;
+    const uint64_t *src = A->d + ai * A->item_words;
+    // one input ciphertext broadcast over the outputs: it must survive until the last block has read it
+    const bool alias = a_bcast && src >= o && src < o + (size_t)count * A->item_words;
+    CHECK(ensure_scratch(ctx, al((size_t)npt * k * n * 8) + (alias ? al(A->item_words * 8) : 0)));
+    uint64_t *lift = salloc<uint64_t>(ctx, (size_t)npt * k * n);
+    if (alias) {
+        uint64_t *keep = salloc<uint64_t>(ctx, A->item_words);
+        if (!keep) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply_plain");
+        HIPCHK(hipMemcpyAsync(keep, src, A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        src = keep;
+    }
+    if (!lift) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply_plain");
+    bool f64 = ctx->use_f64, light = true;
+    for (uint32_t m = 0; m < k; m++) { f64 = f64 && ctx->hc.f64ok[m]; if (ctx->hc.q[m].q >> 44) light = false; }
+    const uint64_t *pt = P->d + (size_t)pi * n;
+    const size_t sstride = a_bcast ? 0 : A->item_words;
+    const uint32_t pitch = pstride ? pstride : 1u, ps = pstride ? 1u : 0u;
+    if (f64 && light) mul_plain_fused_by_size<ArF64L>(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
+    else if (f64) mul_plain_fused_by_size<ArF64>(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
+    else mul_plain_fused_by_size<ArU64>(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
+    HIPCHK(hipGetLastError()); launch_count(ctx, 2);
+    ctx->st.ntt_forward_limbs += (uint64_t)npt * k + (uint64_t)count * A->size * k; ctx->st.ntt_inverse_limbs += (uint64_t)count * A->size * k;
+    ctx->st.PlainMultiplication += count;
+    return 0;
+}
 static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(A, ai, a_bcast ? 1 : count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1))
         return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
     for (uint32_t c = 0; c < npt; c++) if (P->pt_zero[pi + c * pstride]) return fail(CN_ERR_ZERO, "plain cannot be zero");
+    if (ctx->mp_fused && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) return mul_plain_fused(ctx, A, ai, a_bcast, P, pi, pstride, O, oi, count);
     CHECK(ensure_scratch(ctx, al((size_t)npt * k * n * 8)));
     uint64_t *lift = salloc<uint64_t>(ctx, (size_t)npt * k * n);
     // lift every referenced plaintext into the k limbs (one launch), NTT them

@@ -692,6 +692,71 @@ template <int RN> struct TensorOps<ArF64T<RN>> {
     DEV double mul(double a, double b, const ArCtx<ArF64T<RN>> &A) const { return ArF64T<RN>::mulmod(a, b, A.m); }
     DEV double add(double a, double b) const { return __dadd_rn(a, b); }
 };
+// Dense MultiplyPlain on the register-radix core, two launches instead of six (lift, transform, copy, transform, dyadic, transform):
+//   k_lift_ntt:        block = (plaintext, limb j): coefficients mod t -> fast plain lift into q_j -> forward transform -> NTT form
+//   k_mul_plain_fused: block = (ciphertext, poly, limb j): forward transform, pointwise product with the plaintext's NTT form (read at
+//                      the positions the thread holds, 16 B/lane), inverse transform, N^-1, store.  The product never exists in HBM in
+//                      NTT form: read ct limb + plaintext limb, write ct limb (3 limb transfers instead of 9).  src_stride = 0
+//                      broadcasts ONE input ciphertext over all plaintexts (the row-dot batches of the LoLa dense layers: 5488 rows at
+//                      CIFAR shapes, previously 5488 device-to-device copies per call).
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_lift_ntt(const uint64_t *__restrict__ pt, uint32_t pitch, uint64_t *__restrict__ lifted, const DevConsts *__restrict__ C) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, k = C->k, j = blockIdx.x % k, pi = blockIdx.x / k;
+    const ArCtx<AR> A(C, j);
+    const uint64_t *x = pt + (size_t)pi * pitch * n, th = C->t_half, inc = C->lift_inc[j];
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const uint64_t m = x[pass_index<L, SA, 0>(tid, r)]; v[r] = A.load(m >= th ? m + inc : m); }
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    uint64_t *o = lifted + (size_t)blockIdx.x * n;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        ulonglong2 w; w.x = A.canon(v[r]); w.y = A.canon(v[r + 1]);
+        *reinterpret_cast<ulonglong2 *>(o + tail_index<L>(tid, r)) = w;
+    }
+}
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_fused(const uint64_t *src, size_t src_stride, const uint64_t *__restrict__ ptn, uint32_t pstride,
+                                                                    uint64_t *out, const DevConsts *__restrict__ C, uint32_t polys) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, k = C->k, j = blockIdx.x % k, cp = blockIdx.x / k, ct = cp / polys, p = cp % polys;
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t *x = src + (size_t)ct * src_stride + ((size_t)p * k + j) * n;
+    const uint64_t *w = ptn + ((size_t)ct * pstride * k + j) * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tid, r)]);
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    uint32_t tm = tid;
+    asm volatile("" : "+v"(tm));
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(w + tail_index<L>(tm, r));
+        if constexpr (std::is_same<T, double>::value) {                   // lazy transform output x canonical plaintext word: exact (see KsMac)
+            v[r] = ops.mul(v[r], A.load(y.x), A); v[r + 1] = ops.mul(v[r + 1], A.load(y.y), A);
+        } else {
+            v[r] = ops.mul(A.canon(v[r]), y.x, A); v[r + 1] = ops.mul(A.canon(v[r + 1]), y.y, A);
+        }
+    }
+    if (!ntt_tail_local<L>()) __syncthreads();                            // (block-local tail: the inverse starts inside the wave's own blocks)
+    uint32_t ti = tid;
+    asm volatile("" : "+v"(ti));
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, ti);
+    uint64_t *o = out + ((size_t)cp * k + j) * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(ti, r)] = A.scaled(v[r]);
+}
+
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *__restrict__ A_, const uint64_t *__restrict__ B_, uint64_t *__restrict__ D,
                                                                 const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm) {
