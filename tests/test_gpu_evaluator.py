@@ -220,6 +220,54 @@ def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
         g.free(x)
 
 
+@pytest.mark.parametrize("name", ["tiny", "c4", "n16k7"])
+def test_multiply_plain_fused_kernels_are_the_separate_launches(name, rng):
+    """Dense MultiplyPlain: k_lift_ntt + k_mul_plain_fused (default) against the six separate launches (cn_set_option("mp_fused", 0)) and
+    the oracle - one plaintext per ciphertext, one plaintext shared by all, in place, size-3 ciphertexts, and the broadcast form of
+    cn_rowdot_batch (ONE input ciphertext against many rows)."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    cnt = 3
+    vals, cts = enc_batch(o, rng, cnt)
+    pts = np.stack([o.encode(rng.integers(0, o.t, size=o.n, dtype=np.uint64)) for _ in range(cnt)])
+    ph = g.pt_alloc(cnt)
+    g.pt_upload(ph, 0, pts)
+    exp = [o.multiply_plain(cts[i], pts[i]) for i in range(cnt)]
+    exp_shared = [o.multiply_plain(cts[i], pts[1]) for i in range(cnt)]
+    for fused in (1, 0):
+        g.set_option("mp_fused", fused)
+        h, out = up(g, cts), g.ct_alloc(cnt)
+        g.mul_plain(h, 0, ph, 0, out, 0, cnt)
+        assert np.array_equal(g.ct_download(out, 0, cnt), exp), (name, fused)
+        g.mul_plain(h, 0, ph, 1, out, 0, cnt, pt_stride=0)
+        assert np.array_equal(g.ct_download(out, 0, cnt), exp_shared), (name, fused, "shared plaintext")
+        g.mul_plain(h, 1, ph, 0, h, 1, 2)                                       # in place, at an offset
+        assert np.array_equal(g.ct_download(h, 0, cnt), [cts[0], o.multiply_plain(cts[1], pts[0]), o.multiply_plain(cts[2], pts[1])]), (name, fused)
+        g.ct_upload(h, 0, cts)
+        # size-3 ciphertext x plaintext (the reference never relinearises before a MultiplyPlain in PointwiseMultiply chains)
+        h3 = g.ct_alloc(1, 3)
+        g.multiply(h, 0, h, 1, h3, 0, 1)
+        g.mul_plain(h3, 0, ph, 2, h3, 0, 1)
+        assert np.array_equal(g.ct_download(h3, 0, 1, size=3)[0], o.multiply_plain(o.multiply(cts[0], cts[1]), pts[2])), (name, fused)
+        # broadcast: rows of a dense layer against ONE vector (no device copies of the vector in the fused form)
+        length = 8
+        from cryptonets_amd._native import CnError
+        with pytest.raises(CnError):
+            g.rowdot_batch(h, 0, ph, 0, cnt, length, h, 0)                      # the API refuses to overwrite the vector
+        g.rowdot_batch(h, 0, ph, 0, cnt, length, out, 0)
+        got = g.ct_download(out, 0, cnt)
+        assert np.array_equal(g.ct_download(h, 0, 1)[0], cts[0])
+        for r in range(cnt):
+            c, sh = o.multiply_plain(cts[0], pts[r]), 1
+            while sh < length:                                                 # SumAllSlots(length): RotateRows(-2^s) + Add
+                c = o.add(c, o.rotate_rows(c, -sh))
+                sh *= 2
+            assert np.array_equal(got[r], c), (name, fused, r)
+        for x in (h, out, h3):
+            g.free(x)
+    g.set_option("mp_fused", 1)
+    g.free(ph)
+
+
 @pytest.mark.parametrize("name", ["tiny", "default4096", "c4"])
 def test_rotations(name, rng):
     """HOT LOOP C: Galois automorphism + key switch, direct keys and NAF-decomposed steps, column swap."""
