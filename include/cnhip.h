@@ -55,7 +55,10 @@ int cn_sync(cn_ctx *ctx);
  * "ks_wide" = -1 (default: automatic by batch size) / 0 fused one-launch kernel / 1 two launches with one workgroup per digit
  * (1-6 ciphertexts: single-image latency) / 2 two launches with one workgroup per source limb (7-32 ciphertexts);
  * "ks_tight" = 1 the 128-VGPR fused variant; "ks_split14" = 1 (default) runs the N = 16384 key switch as two 8192-point
- * halves per limb (no register spills), 0 = the fused 1024-thread kernel.  All variants produce identical words. */
+ * halves per limb (no register spills), 0 = the fused 1024-thread kernel; "sq_fused" = 1 (default) runs the transforms and the tensor
+ * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
+ * MultiplyPlain as two launches (lift + transform of the plaintexts; transform, product, inverse transform of the ciphertext limbs),
+ * 0 = six.  All variants produce identical words. */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
