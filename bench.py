@@ -182,6 +182,29 @@ def main():
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "ms_per_launch": round(ms, 4), "bytes_per_launch": alg_bytes}
 
+    # ---- the kernel that takes the largest share of the batch (a third): the fused key switch of the first squaring layer, timed the same
+    # way.  It is bound by FP64 issue, not by HBM: the ISA of the digit loop holds 1104 FP64 instructions per thread and digit (transform
+    # + 2 x 16 multiply-accumulates), the two inverse transforms 1064 each, and the pipe issues one FP64 wave-instruction per 2.15 ns per
+    # SIMD whatever the occupancy (profiles/r01_ubench_mulmod.txt); tools/ubench_ks.hip measures the arithmetic alone at the same 2.1 ms.
+    key_switch = None
+    if rank == 0:
+        cts = 845
+        t3, t2 = g.ct_alloc(cts, 3), g.ct_alloc(cts)
+        g.multiply(chans[0].h1, 0, chans[0].h1, 0, t3, 0, cts)           # the products the layer relinearises
+        g.relinearize(t3, 0, t2, 0, cts); g.sync()
+        g.time_begin()
+        for _ in range(5):
+            g.relinearize(t3, 0, t2, 0, cts)
+        ks_ms = g.time_end() / 5
+        g.free(t3); g.free(t2)
+        digits = sum(-(-int(q).bit_length() // 10) for q in g.q)          # base-2^10 digits of every source limb
+        fp64_per_thread = digits * 1104 + 2 * 1064
+        floor_ms = cts * g.k * 8 * fp64_per_thread / 1024 * 2.15e-6     # wave-instructions per SIMD x 2.15 ns
+        key_switch = {"kernel": "k_keyswitch_rr (845 ciphertexts x %d output limbs, %d digit transforms each)" % (g.k, digits),
+                      "share_of_batch": round(2 * ks_ms / (1e3 * dt / args.steps), 3), "bound": "fp64 issue", "ms_per_launch": round(ks_ms, 3),
+                      "fp64_issue_floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ks_ms, 3),
+                      "ns_per_limb_transform": round(ks_ms * 1e6 / (cts * g.k * (digits + 2)), 1)}
+
     if rank == 0:
         images = 8192 * args.steps * world
         out = {"metric": "encrypted images/sec (CryptoNets-MNIST, N=8192)", "value": round(images / dt, 1), "unit": "images/s",
@@ -195,7 +218,7 @@ def main():
                           "arithmetic": "exact modular integers over 43-49-bit RNS primes (results are u64 words, bit-identical to the integer "
                                         "oracle); products evaluated with error-free FP64 instruction sequences where the modulus is below 2^49, "
                                         "64-bit integer instructions otherwise"},
-               "roofline": roofline}
+               "roofline": roofline, "key_switch": key_switch}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
