@@ -823,7 +823,6 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64
     const size_t Ln = (size_t)Lm * n;
     const uint64_t *a0 = A_ + (size_t)ct * a_stride + (size_t)l * n, *a1 = a0 + Ln;
     uint64_t *d0 = D + (size_t)ct * 3 * Ln + (size_t)l * n, *d1 = d0 + Ln, *d2 = d1 + Ln;
-    struct alignas(16) P2 { T a, b; };
 #pragma unroll 1
     for (int step = 0; step < 3; step++) {
         uint32_t tl = tid;
@@ -835,27 +834,30 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64
             for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tl, r)]);
             ntt_forward_regs<AR, L, true>(v, s, A.fw, A.m, tl);  // PRE: the image of the previous inverse transform is free
             AR::renorm(v, A.m);                                  // lazy transform output (up to 28 q) -> |x| <= q/2
-            T *park = reinterpret_cast<T *>(step ? d2 : d1);
+            uint64_t *park = step ? d2 : d1;                     // bit patterns of the doubles: every access to D stays a u64 access
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) *reinterpret_cast<P2 *>(park + tail_index<L>(tl, r)) = P2{v[r], v[r + 1]};
+            for (int r = 0; r < 16; r += 2) {
+                ulonglong2 w; w.x = (uint64_t)__double_as_longlong(v[r]); w.y = (uint64_t)__double_as_longlong(v[r + 1]);
+                *reinterpret_cast<ulonglong2 *>(park + tail_index<L>(tl, r)) = w;
+            }
             if (step == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = AR::mulmod(v[r], v[r], A.m);
             } else {
-                const T *pa0 = reinterpret_cast<const T *>(d1);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const P2 w = *reinterpret_cast<const P2 *>(pa0 + tail_index<L>(tl, r));
-                    v[r] = AR::mulmod(__dadd_rn(w.a, w.a), v[r], A.m); v[r + 1] = AR::mulmod(__dadd_rn(w.b, w.b), v[r + 1], A.m);
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(d1 + tail_index<L>(tl, r));
+                    const T wa = __longlong_as_double((long long)w.x), wb = __longlong_as_double((long long)w.y);
+                    v[r] = AR::mulmod(__dadd_rn(wa, wa), v[r], A.m); v[r + 1] = AR::mulmod(__dadd_rn(wb, wb), v[r + 1], A.m);
                 }
             }
             if (!ntt_tail_local<L>()) __syncthreads();           // (block-local tail: the inverse starts inside the wave's own blocks)
         } else {
-            const T *pa1 = reinterpret_cast<const T *>(d2);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const P2 w = *reinterpret_cast<const P2 *>(pa1 + tail_index<L>(tl, r));
-                v[r] = AR::mulmod(w.a, w.a, A.m); v[r + 1] = AR::mulmod(w.b, w.b, A.m);
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(d2 + tail_index<L>(tl, r));
+                const T wa = __longlong_as_double((long long)w.x), wb = __longlong_as_double((long long)w.y);
+                v[r] = AR::mulmod(wa, wa, A.m); v[r + 1] = AR::mulmod(wb, wb, A.m);
             }
             __syncthreads();                                     // no forward transform in this step: the previous inverse's image is free
         }
