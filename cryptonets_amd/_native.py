@@ -89,6 +89,9 @@ SIGNATURES = {
     "cn_scalar_gemm": (C.c_int, [_CTX, _H, I32P, U64P, _u32, _u32, _H, I32P, _H, _u32]),
     "cn_gemm_plan_create": (C.c_int, [_CTX, I32P, U64P, _u32, _u32, _H, I32P, C.POINTER(_H)]),
     "cn_gemm_plan_apply": (C.c_int, [_CTX, _H, _H, _H, _u32]),
+    "cn_graph_begin": (C.c_int, [_CTX]),
+    "cn_graph_end": (C.c_int, [_CTX, C.POINTER(_H)]),
+    "cn_graph_launch": (C.c_int, [_CTX, _H]),
     "cn_multiply": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
     "cn_relinearize": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
     "cn_mul_relin": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32, _u32, _H, _u32, _u32]),
@@ -423,6 +426,18 @@ class Context:
 
     def stream(self):
         return self.L.cn_stream(self._h)
+
+    # ---- captured sequences (HIP graphs): see include/cnhip.h
+    def graph_begin(self):
+        self._chk(self.L.cn_graph_begin(self._h))
+
+    def graph_end(self):
+        h = _H()
+        self._chk(self.L.cn_graph_end(self._h, C.byref(h)))
+        return h.value
+
+    def graph_launch(self, graph):
+        self._chk(self.L.cn_graph_launch(self._h, graph))
 
     def time_begin(self):
         self._chk(self.L.cn_event_time_begin(self._h))

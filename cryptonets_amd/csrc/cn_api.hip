@@ -24,9 +24,18 @@ static int fail(int code, const char *fmt, ...) {
 #define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 struct GemmPlan;
+// A captured operation sequence (cn_graph_begin / cn_graph_end): the instantiated HIP graph, the host blocks its upload nodes read at
+// every launch, and the device arrays that were handed out while it was recorded and are not owned by a live handle - they stay
+// reserved for the graph (its kernels carry their addresses), out of the pool, until the graph is freed.
+struct CapturedGraph {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    std::vector<std::unique_ptr<char[]>> staged;
+    std::vector<std::pair<uint64_t *, size_t>> reserved;
+};
 struct Buffer {
-    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array, 2 = scalar GEMM plan
+    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array, 2 = scalar GEMM plan, 3 = captured graph
     std::shared_ptr<GemmPlan> plan;
+    std::shared_ptr<CapturedGraph> cg;
     uint32_t count, size;     // size = polys per ciphertext
     uint64_t *d;
     size_t item_words;
@@ -66,6 +75,10 @@ struct cn_ctx {
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
+    bool capturing = false;   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
+    std::vector<std::unique_ptr<char[]>> cap_staged;                 // host blocks of the upload nodes recorded so far
+    std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
+    int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
 };
@@ -73,11 +86,13 @@ struct cn_ctx {
 // ---------------------------------------------------------------- helpers
 static void pool_flush(cn_ctx *ctx);
 static int free_gemm_plan(cn_ctx *ctx, Buffer &b);
+static int free_graph(cn_ctx *ctx, Buffer &b);
 static int use(cn_ctx *c) { HIPCHK(hipSetDevice(c->device)); return 0; }
 
 static int ensure_scratch(cn_ctx *c, size_t bytes) {
     c->soff = 0;
     if (bytes <= c->scap) return 0;
+    if (c->capturing || c->graphs_alive) return fail(CN_ERR_ARG, "the scratch arena would have to grow while a graph is recorded / alive: run the sequence once before cn_graph_begin");
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->scratch) HIPCHK(hipFree(c->scratch));
     c->scratch = nullptr; c->scap = 0;
@@ -102,6 +117,12 @@ template <class T> static T *salloc(cn_ctx *c, size_t count) {
 template <class T> static int upload_tmp(cn_ctx *c, const T *host, size_t count, T **dev) {
     *dev = salloc<T>(c, count);
     if (!*dev) return fail(CN_ERR_HIP, "internal: scratch exhausted");
+    if (c->capturing) {                                        // the upload becomes a graph node that reads the host block at EVERY launch
+        c->cap_staged.emplace_back(new char[count * sizeof(T)]);
+        memcpy(c->cap_staged.back().get(), host, count * sizeof(T));
+        HIPCHK(hipMemcpyAsync(*dev, c->cap_staged.back().get(), count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
     if (!c->staged.empty() && hipStreamQuery(c->stream) == hipSuccess) c->staged.clear();
     (void)hipGetLastError();                                   // hipStreamQuery reports hipErrorNotReady through the sticky error as well
     c->staged.emplace_back(new char[count * sizeof(T)]);
@@ -257,7 +278,11 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->bufs) { if (kv.second.kind == 2) (void)free_gemm_plan(ctx, kv.second); else (void)hipFree(kv.second.d); }
+    for (auto &kv : ctx->bufs) {
+        if (kv.second.kind == 2) (void)free_gemm_plan(ctx, kv.second);
+        else if (kv.second.kind == 3) { (void)free_graph(ctx, kv.second); }
+        else (void)hipFree(kv.second.d);
+    }
     pool_flush(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
@@ -280,7 +305,8 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     return fail(CN_ERR_ARG, "unknown option %s", name);
 }
-extern "C" int cn_sync(cn_ctx *ctx) { LOCK; HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; }
+#define NOT_CAPTURING(what) do { if (ctx->capturing) return fail(CN_ERR_ARG, what " is not possible while a graph is recorded (cn_graph_begin .. cn_graph_end)"); } while (0)
+extern "C" int cn_sync(cn_ctx *ctx) { LOCK; NOT_CAPTURING("cn_sync"); HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; }
 extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
 extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ? ctx->hc.gk_tot : ctx->hc.rl_tot) * ctx->ctw2; }
 
@@ -333,8 +359,10 @@ static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
     auto it = ctx->pool.find(bytes);
     if (it != ctx->pool.end() && !it->second.empty()) {
         *out = it->second.back(); it->second.pop_back(); ctx->pool_bytes -= bytes;
+        if (ctx->capturing) ctx->cap_allocs.emplace_back(*out, bytes);
         return 0;
     }
+    if (ctx->capturing) return fail(CN_ERR_ARG, "a new device array would have to be allocated while a graph is recorded: run the sequence once before cn_graph_begin");
     if (hipMalloc((void **)out, bytes) != hipSuccess) {          // out of memory: give the cached arrays back and retry once
         (void)hipGetLastError();
         pool_flush(ctx);
@@ -343,7 +371,7 @@ static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
     return 0;
 }
 static int dev_release(cn_ctx *ctx, uint64_t *p, size_t bytes) {
-    if (ctx->pool_bytes + bytes <= ctx->pool_max) { ctx->pool[bytes].push_back(p); ctx->pool_bytes += bytes; return 0; }
+    if (ctx->pool_bytes + bytes <= ctx->pool_max || ctx->capturing) { ctx->pool[bytes].push_back(p); ctx->pool_bytes += bytes; return 0; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(p));
     return 0;
@@ -367,28 +395,88 @@ extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
     LOCK;
     auto it = ctx->bufs.find(h);
     if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    if (it->second.kind == 2) CHECK(free_gemm_plan(ctx, it->second));
+    if (it->second.kind == 2) { NOT_CAPTURING("releasing a GEMM plan"); CHECK(free_gemm_plan(ctx, it->second)); }
+    else if (it->second.kind == 3) { NOT_CAPTURING("releasing a graph"); CHECK(free_graph(ctx, it->second)); }
     else CHECK(dev_release(ctx, it->second.d, it->second.item_words * 8 * it->second.count));
     ctx->bufs.erase(it);
     return 0;
 }
+// ---- captured sequences: the launch-bound chains of small kernels of a single-image inference (LoLa: ~235 launches per plaintext
+// prime) are recorded once on the context stream and replayed with one hipGraphLaunch - no per-launch host work, dependent kernels
+// back to back on the device.  Recording rules: the same sequence must have run once before (so that every temporary comes out of
+// the handle pool and the scratch arenas have their size), nothing may synchronise (cn_sync, uploads / downloads of handles, key
+// changes) between begin and end, and the handles created while recording must stay alive as long as the graph is launched - the
+// kernels carry their addresses.  New inputs go INTO the handles the recorded sequence read (cn_copy / cn_encrypt on them).
+static int free_graph(cn_ctx *ctx, Buffer &b) {
+    if (!b.cg) return 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (b.cg->exec) (void)hipGraphExecDestroy(b.cg->exec);
+    if (b.cg->graph) (void)hipGraphDestroy(b.cg->graph);
+    for (auto &r : b.cg->reserved) { ctx->pool[r.second].push_back(r.first); ctx->pool_bytes += r.second; }
+    b.cg.reset();
+    ctx->graphs_alive--;
+    return 0;
+}
+extern "C" int cn_graph_begin(cn_ctx *ctx) {
+    LOCK; NOT_CAPTURING("cn_graph_begin");
+    ctx->cap_staged.clear(); ctx->cap_allocs.clear();
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    return 0;
+}
+extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) {
+    LOCK;
+    if (!ctx->capturing) return fail(CN_ERR_ARG, "cn_graph_end without cn_graph_begin");
+    ctx->capturing = false;
+    std::shared_ptr<CapturedGraph> g = std::make_shared<CapturedGraph>();
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
+    if (e != hipSuccess || !g->graph) { (void)hipGetLastError(); ctx->cap_staged.clear(); ctx->cap_allocs.clear(); return fail(CN_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(g->graph); ctx->cap_staged.clear(); ctx->cap_allocs.clear(); return fail(CN_ERR_HIP, "graph instantiation failed: %s", hipGetErrorString(e)); }
+    g->staged = std::move(ctx->cap_staged); ctx->cap_staged.clear();
+    // arrays handed out while recording that are back in the pool now (temporaries): reserve them for the graph
+    for (auto &a : ctx->cap_allocs) {
+        auto it = ctx->pool.find(a.second);
+        if (it == ctx->pool.end()) continue;
+        auto pos = std::find(it->second.begin(), it->second.end(), a.first);
+        if (pos == it->second.end()) continue;                  // owned by a live handle (an output of the sequence)
+        it->second.erase(pos); ctx->pool_bytes -= a.second;
+        g->reserved.push_back(a);
+    }
+    ctx->cap_allocs.clear();
+    if (!graph) return fail(CN_ERR_ARG, "null argument");
+    Buffer b; b.kind = 3; b.count = 0; b.size = 0; b.d = nullptr; b.item_words = 0; b.cg = g;
+    cn_handle h = ctx->next_handle++;
+    ctx->bufs[h] = std::move(b);
+    ctx->graphs_alive++;
+    *graph = h;
+    return 0;
+}
+extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) {
+    LOCK; NOT_CAPTURING("cn_graph_launch");
+    Buffer *b = getbuf(ctx, graph, 3);
+    if (!b || !b->cg) return fail(CN_ERR_ARG, "invalid graph handle");
+    HIPCHK(hipGraphLaunch(b->cg->exec, ctx->stream));
+    ctx->st.kernel_launches += 1;
+    return 0;
+}
 extern "C" int cn_live_handles(cn_ctx *ctx) { std::lock_guard<std::mutex> lk(ctx->mu); return (int)ctx->bufs.size(); }
 extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
-    LOCK; GETCT(b, h, 0);
+    LOCK; NOT_CAPTURING("cn_ct_upload"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(b->d + first * b->item_words, host, count * b->item_words * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 extern "C" int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) {
-    LOCK; GETCT(b, h, 0);
+    LOCK; NOT_CAPTURING("cn_ct_download"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(host, b->d + first * b->item_words, count * b->item_words * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
-    LOCK; GETPT(b, h);
+    LOCK; NOT_CAPTURING("cn_pt_upload"); GETPT(b, h);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     const uint32_t n = ctx->hc.n; const uint64_t t = ctx->hc.t.q;
     for (uint32_t p = 0; p < count; p++) {
@@ -401,7 +489,7 @@ extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t c
     return 0;
 }
 extern "C" int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) {
-    LOCK; GETPT(b, h);
+    LOCK; NOT_CAPTURING("cn_pt_download"); GETPT(b, h);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(host, b->d + (size_t)first * ctx->hc.n, (size_t)count * ctx->hc.n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -409,7 +497,7 @@ extern "C" int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t
 }
 // BatchEncoder.Encode: slot values -> plaintext coefficients (scatter by the index map, INTT mod t on the device)
 extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi) {
-    LOCK; GETPT(b, pt);
+    LOCK; NOT_CAPTURING("cn_encode"); GETPT(b, pt);
     if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
     const uint32_t n = ctx->hc.n;
     if (pi >= b->count || nvalues > n || (nvalues && !values)) return fail(CN_ERR_ARG, "bad encode arguments");
@@ -429,7 +517,7 @@ extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, 
 }
 // BatchEncoder.Decode: plaintext coefficients -> N slot values
 extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values) {
-    LOCK; GETPT(b, pt);
+    LOCK; NOT_CAPTURING("cn_decode"); GETPT(b, pt);
     if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
     const uint32_t n = ctx->hc.n;
     if (pi >= b->count || !values) return fail(CN_ERR_ARG, "bad decode arguments");
@@ -764,7 +852,7 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
 // Plan once, apply per inference: the weight tiles and gather tables stay in HBM (cn_free releases the plan).
 extern "C" int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt, const int32_t *bias_idx,
                                    cn_handle *plan) {
-    LOCK;
+    LOCK; NOT_CAPTURING("cn_gemm_plan_create");
     if (!plan) return fail(CN_ERR_ARG, "null argument");
     Buffer *BP = bias_pt ? getbuf(ctx, bias_pt, 1) : nullptr;
     std::shared_ptr<GemmPlan> P = std::make_shared<GemmPlan>();
@@ -958,6 +1046,7 @@ template <class AR> static bool launch_ks_by_size(cn_ctx *c, const KsArgs &a) {
 }
 static int ensure_ks_part(cn_ctx *ctx, size_t need) {
     if (need <= ctx->ks_part_cap) return 0;
+    if (ctx->capturing || ctx->graphs_alive) return fail(CN_ERR_ARG, "the key-switch arena would have to grow while a graph is recorded / alive: run the sequence once before cn_graph_begin");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->ks_part) HIPCHK(hipFree(ctx->ks_part));
     ctx->ks_part = nullptr; ctx->ks_part_cap = 0;
@@ -1214,7 +1303,7 @@ extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t coun
 extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); }
 // which: 0 relin, 1 galois(elt), 2 public, 3 secret.  Exports u64 residues (FP64-form keys are converted back).
 extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, size_t count) {
-    LOCK;
+    LOCK; NOT_CAPTURING("cn_get_key");
     const uint64_t *src = nullptr; size_t words = 0; bool f64 = false;
     if (which == 0) { src = ctx->rlk.d; words = cn_key_words(ctx, 0); f64 = ctx->rlk.f64; }
     else if (which == 1) { auto it = ctx->gk.find(elt); if (it != ctx->gk.end()) { src = it->second.d; f64 = it->second.f64; } words = cn_key_words(ctx, 1); }
@@ -1266,7 +1355,7 @@ static int adopt_ksk(cn_ctx *ctx, KsKey &slot, uint64_t *dev, size_t words) {   
 // KeyGenerator (AtomicSealBfvVector.cs:62-74,163-173 runs it inside SEAL): secret, public, relinearisation and the default Galois
 // key set (2N-1, 3^(2^i), 3^(-2^i)) generated on the device from a Philox stream.
 extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
-    LOCK;
+    LOCK; NOT_CAPTURING("cn_keygen");
     const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
     if (!ctx->sk) HIPCHK(hipMalloc((void **)&ctx->sk, kn * 8));
     if (!ctx->pk) HIPCHK(hipMalloc((void **)&ctx->pk, 2 * kn * 8));
@@ -1385,7 +1474,7 @@ extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count
 }
 // Decryptor.InvariantNoiseBudget (CryptoTracker.cs:41-52): the residues of t (c0 + c1 s + c2 s^2) mod q, [count][k][N] to the host
 extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, uint64_t *host) {
-    LOCK; GETCT(I, ct, 0);
+    LOCK; NOT_CAPTURING("cn_noise_poly"); GETCT(I, ct, 0);
     if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
     if (!host || !range_ok(I, ci, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
@@ -1411,7 +1500,7 @@ extern "C" int cn_ct_ntt(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t coun
     return raw_ntt(ctx, B->d + first * B->item_words, count * B->size * ctx->hc.k, 0, inverse);
 }
 extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse, int iters, float *ms) {
-    LOCK;
+    LOCK; NOT_CAPTURING("cn_ntt_time");
     if (iters < 1 || !ms) return fail(CN_ERR_ARG, "bad arguments");
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++) CHECK(raw_ntt(ctx, p, limbs, base, inverse));
@@ -1423,7 +1512,7 @@ extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int i
 }
 extern "C" int cn_event_time_begin(cn_ctx *ctx) { LOCK; HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return 0; }
 extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) {
-    LOCK;
+    LOCK; NOT_CAPTURING("cn_event_time_end");
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream)); HIPCHK(hipEventSynchronize(ctx->ev1));
     HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return 0;

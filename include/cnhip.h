@@ -121,6 +121,17 @@ int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint
                         const int32_t *bias_idx, cn_handle *plan);
 int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi);
 
+/* Captured sequences (HIP graphs) for the launch-bound chains of a single-image inference (LoLa: ~235 small launches per plaintext
+ * prime, the reference's LowLatencyCryptoNets loop LoLaCryptonets.cs:236-278): every library call between cn_graph_begin and
+ * cn_graph_end is RECORDED on the context stream instead of executed; cn_graph_launch replays the whole sequence with one launch.
+ * Rules: run the same sequence once before recording (temporaries then come out of the handle pool, the arenas have their size);
+ * nothing that synchronises (cn_sync, uploads / downloads, key changes) between begin and end; handles created while recording stay
+ * alive as long as the graph is launched (its kernels carry their addresses); new inputs are written INTO the handles the recorded
+ * sequence read (cn_copy, cn_encrypt).  Release with cn_free. */
+int cn_graph_begin(cn_ctx *ctx);
+int cn_graph_end(cn_ctx *ctx, cn_handle *graph);
+int cn_graph_launch(cn_ctx *ctx, cn_handle graph);
+
 /* ---- non-linear ops ------------------------------------------------------------------ */
 /* Evaluator.Multiply (BEHZ), size2 x size2 -> size3 (AtomicSealBfvVector.cs:461,546,786,839,1457) */
 int cn_multiply(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out3, uint32_t oi, uint32_t count);

@@ -683,3 +683,61 @@ def test_scalar_gemm_wide_output_tiles(name, rng):
         assert np.array_equal(g.ct_download(out, 0, O1 + O2), exp), (name, K)
         g.free(out); g.free(bh)
     g.free(h)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_captured_sequence_replays_on_new_inputs(name, rng):
+    """cn_graph_begin / cn_graph_end / cn_graph_launch: a recorded chain (one-shot scalar GEMM with its table upload, squaring +
+    relinearisation, rotation, AddMany, temporaries from the handle pool) replayed with ONE launch gives the eager words - on the inputs
+    it was recorded with and on new ones written into the same handle.  Synchronising calls are refused while recording."""
+    from cryptonets_amd._native import CnError
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    vals, cts = enc_batch(o, rng, 4)
+    vals2, cts2 = enc_batch(o, rng, 4)
+    W = (rng.integers(-50, 51, size=(3, 4)) % o.t).astype(np.uint64)
+    W[:, 0] = np.maximum(W[:, 0], 1)
+    h, out = up(g, cts), g.ct_alloc(1)
+
+    def sequence():
+        t1, t2 = g.ct_alloc(3), g.ct_alloc(3)
+        g.scalar_gemm(h, W, t1, 0)
+        g.mul_relin(t1, 0, t1, 0, t2, 0, 3)
+        g.rotate_rows(t2, 0, -3, t1, 0, 3)
+        g.add_many(t1, [0, 1, 2], out, 0)
+        g.free(t1); g.free(t2)
+
+    def expected(c):
+        e = o.mul_relin_batch(o.scalar_gemm(c, W), o.scalar_gemm(c, W))
+        e = [o.rotate_rows(x, -3) for x in e]
+        return o.add(o.add(e[0], e[1]), e[2])
+
+    sequence()                                                   # eager (also warms the pool and the arenas)
+    assert np.array_equal(g.ct_download(out, 0, 1)[0], expected(cts))
+    live = g.live_handles()
+    g.graph_begin()
+    with pytest.raises(CnError):
+        g.sync()                                                 # refused, the recording goes on
+    with pytest.raises(CnError):
+        g.ct_download(out, 0, 1)
+    sequence()
+    graph = g.graph_end()
+    assert g.live_handles() == live + 1
+    for c in (cts2, cts, cts2):
+        g.ct_upload(h, 0, c)
+        g.ct_upload(out, 0, cts[:1])                             # stale content must be overwritten by the replay
+        g.graph_launch(graph)
+        assert np.array_equal(g.ct_download(out, 0, 1)[0], expected(c))
+    # eager work between launches may use the pool; the graph's temporaries are reserved
+    tmp = [g.ct_alloc(3) for _ in range(3)]
+    for x in tmp:
+        g.ct_upload(x, 0, cts[:3])
+    g.graph_launch(graph)
+    assert np.array_equal(g.ct_download(out, 0, 1)[0], expected(cts2))
+    for x in tmp:
+        assert np.array_equal(g.ct_download(x, 0, 3), cts[:3])
+        g.free(x)
+    g.free(graph)
+    with pytest.raises(CnError):
+        g.graph_launch(graph)
+    for x in (h, out):
+        g.free(x)
