@@ -362,7 +362,8 @@ static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
         if (ctx->capturing) ctx->cap_allocs.emplace_back(*out, bytes);
         return 0;
     }
-    if (ctx->capturing) return fail(CN_ERR_ARG, "a new device array would have to be allocated while a graph is recorded: run the sequence once before cn_graph_begin");
+    if (ctx->capturing) return fail(CN_ERR_ARG, "a new device array (%zu bytes) would have to be allocated while a graph is recorded: run the sequence once before cn_graph_begin "
+                                    "(handle pool: %zu bytes in %zu sizes)", bytes, ctx->pool_bytes, ctx->pool.size());
     if (hipMalloc((void **)out, bytes) != hipSuccess) {          // out of memory: give the cached arrays back and retry once
         (void)hipGetLastError();
         pool_flush(ctx);

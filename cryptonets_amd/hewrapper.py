@@ -166,6 +166,22 @@ class AtomicSealBfvEncryptedEnvironment:
         self.ctx.encode(np.asarray(values, dtype=np.uint64), v.h, 0)
         return v
 
+    def mask_plain(self, kind, count):
+        """Selection masks of the packing ops (ones over the first `count` slots: Interleave's row-boundary split,
+        AtomicSealBfvVector.cs:628-688; a single one in slot `count`: ForceOutputInColumn, :936-945), encoded once per environment and
+        kept in HBM: the reference re-encodes them on every call; here that would also put a host upload + synchronisation into the
+        middle of an inference (and a recorded evaluation could not contain it).  The caller must NOT release the view."""
+        cache = self.__dict__.setdefault("_mask_plains", {})
+        key = (kind, int(count))
+        if key not in cache:
+            if kind == "ones":
+                vals = np.ones(count, dtype=np.uint64)
+            else:
+                vals = np.zeros(count + 1, dtype=np.uint64)
+                vals[count] = 1
+            cache[key] = self.encode(vals)
+        return cache[key]
+
 
 class AtomicSealBfvEncryptedVector:
     """A vector under ONE plaintext modulus: ceil(Dim/N) ciphertexts (dense) or Dim ciphertexts holding one constant
@@ -297,7 +313,8 @@ class AtomicSealBfvEncryptedVector:
         self.Scale = scale
 
     def Dispose(self):
-        for v in (self.encData, self.plainDense):
+        cached = self.__dict__.pop("_sparse_as_dense", None)
+        for v in (self.encData, self.plainDense, cached[1] if cached else None):
             if v is not None:
                 v.release()
         self.encData = self.plainDense = self.plainSparse = None
@@ -377,7 +394,7 @@ class AtomicSealBfvEncryptedVector:
         half = blockSize // 2
 
         def ones_mask(count):
-            return env.encode(np.ones(count, dtype=np.uint64))
+            return env.mask_plain("ones", count)
 
         for k, src in enumerate(vecs):
             thisShift = shift * k
@@ -403,7 +420,6 @@ class AtomicSealBfvEncryptedVector:
                     p = ones_mask(upperPartSize)
                     ctx.mul_plain(work.h, v, p.h, 0, work.h, v, 1)
                     ctx.sub(work.h, v2, work.h, v, work.h, v2, 1)
-                    p.release()
                     upper[startBlock].append(v2)
                     lower[endBlock].append(v)
             else:
@@ -414,7 +430,6 @@ class AtomicSealBfvEncryptedVector:
                     p = ones_mask(upperPartSize)
                     ctx.mul_plain(work.h, v, p.h, 0, work.h, v, 1)
                     ctx.sub(work.h, v2, work.h, v, work.h, v2, 1)
-                    p.release()
                     upper[startBlock].append(v)
                     lower[startBlock].append(v2)
                 else:
@@ -442,7 +457,12 @@ class AtomicSealBfvEncryptedVector:
         outputBlocks = 1
         if shift > 0:
             outputBlocks = int(math.ceil(vecs[0].Dim * len(vecs) / float(blockSize)))
-        enc = AtomicSealBfvEncryptedVector._Inteleave([v.encData.sub(0) for v in vecs], shift, outputBlocks, env)
+        subs = [v.encData.sub(0) for v in vecs]
+        try:
+            enc = AtomicSealBfvEncryptedVector._Inteleave(subs, shift, outputBlocks, env)
+        finally:
+            for sv in subs:                              # (these views used to stay alive: every Interleave / Stack kept its inputs' arrays)
+                sv.release()
         return AtomicSealBfvEncryptedVector._new(encData=enc, Dim=vecs[0].Dim, Scale=vecs[0].Scale, IsSigned=vecs[0].IsSigned,
                                                  Format=EVectorFormat.dense)
 
@@ -590,12 +610,8 @@ class AtomicSealBfvEncryptedVector:
         if length >= slots // 2:
             length = slots // 2
         if ForceOutputInColumn is not None:
-            col = ForceOutputInColumn
-            mask = np.zeros(col + 1, dtype=np.uint64)
-            mask[col] = 1
-            p = env.encode(mask)
+            p = env.mask_plain("slot", ForceOutputInColumn)
             ctx.mul_plain(work.h, 0, p.h, 0, work.h, 0, 1)
-            p.release()
             length = 1
         res = _Buf(ctx, "ct", 1).view()
         ctx.copy(work.h, 0, res.h, 0, 1)
@@ -674,11 +690,19 @@ class AtomicSealBfvEncryptedVector:
         """Plaintexts as device polynomials: dense plaintexts as they are; sparse ones as constant polynomials."""
         if self.plainDense is not None:
             return self.plainDense, False
-        pv = _Buf(env.ctx, "pt", len(self.plainSparse)).view()
-        polys = np.zeros((len(self.plainSparse), env.ctx.n), dtype=np.uint64)
-        polys[:, 0] = np.array(self.plainSparse, dtype=np.uint64)
-        env.ctx.pt_upload(pv.h, 0, polys)
-        return pv, True
+        # sparse plaintexts (biases) are constants of the network: their polynomial form is uploaded once and kept with the vector - no
+        # host upload + synchronisation in the middle of every inference (a recorded evaluation could not contain one either)
+        key = tuple(int(x) for x in self.plainSparse)
+        cached = self.__dict__.get("_sparse_as_dense")
+        if cached is None or cached[0] != key or not cached[1].live:
+            if cached is not None:
+                cached[1].release()
+            pv = _Buf(env.ctx, "pt", len(self.plainSparse)).view()
+            polys = np.zeros((len(self.plainSparse), env.ctx.n), dtype=np.uint64)
+            polys[:, 0] = np.array(self.plainSparse, dtype=np.uint64)
+            env.ctx.pt_upload(pv.h, 0, polys)
+            self._sparse_as_dense = cached = (key, pv)
+        return cached[1], False
 
     # -- decryption (client side) -------------------------------------------------------------------------------
     def _decrypt_ints(self, env):
@@ -1342,6 +1366,49 @@ class EncryptedSealBfvMatrix:
 
 
 # ------------------------------------------------------------------------------------------------ factory
+class CapturedEvaluation:
+    """A recorded evaluation (one HIP graph per plaintext-prime context, `cn_graph_begin/end/launch`): the launch-bound chain of a
+    single-image inference - LoLa issues ~235 small launches per prime (`LoLaCryptonets.cs:236-278`) - replayed with one launch per
+    prime.  `fn(inputs)` is the evaluation (layer `Apply` chain) on encrypted matrices; it must have run once before on data of the same
+    shapes (temporaries then come out of the handle pools).  `run(new_inputs)` writes the new ciphertext words into the buffers the
+    recording read, launches the graphs and returns the matrix the recording produced (same object every time: decrypt or copy it
+    before the next run).  Everything the recording created stays alive until `Dispose`."""
+
+    def __init__(self, env, fn, inputs):
+        self.env, self.inputs = env, list(inputs)
+        ctxs = [e.ctx for e in env.Environments]
+        import gc
+        gc.collect()                                  # temporaries of the rehearsal that only the collector frees go back to the pools first
+        for c in ctxs:
+            c.graph_begin()
+        try:
+            self.result = fn(*self.inputs)
+        finally:
+            self.graphs = [c.graph_end() for c in ctxs]
+
+    @staticmethod
+    def _views(m):
+        return [[a.encData for a in v.eVectors] for v in m.leVectors]
+
+    def run(self, *new_inputs):
+        for dst, src in zip(self.inputs, new_inputs):
+            if src is dst:
+                continue
+            for dv, sv in zip(self._views(dst), self._views(src)):
+                for e, d, s_ in zip(self.env.Environments, dv, sv):
+                    if d.count != s_.count:
+                        raise Exception("a captured evaluation takes inputs of the shapes it was recorded with")
+                    e.ctx.copy(s_.h, s_.first, d.h, d.first, d.count)
+        for e, g in zip(self.env.Environments, self.graphs):
+            e.ctx.graph_launch(g)
+        return self.result
+
+    def Dispose(self):
+        for e, g in zip(self.env.Environments, self.graphs):
+            e.ctx.free(g)
+        self.graphs = []
+
+
 class EncryptedSealBfvFactory:
     """IFactory.cs:240-410.  `client_factory(t, n, q, dbc, gdbc)` builds the client-side SEAL objects for one plaintext
     prime; the device contexts are libcnhip contexts (`context_factory` is only overridden by the CPU test harness)."""
