@@ -50,6 +50,55 @@ def test_lola_mnist_single_image(backend):
     assert dec.shape == (10, 1)
 
 
+@pytest.mark.gpu
+def test_lola_mnist_recorded_evaluation_on_new_images():
+    """The evaluation recorded once (`CapturedEvaluation`: one HIP graph per plaintext prime, cn_graph_begin/end/launch) and replayed
+    on freshly encrypted images gives the exact integer logits of THOSE images - and running inferences does not grow the number
+    of live device arrays (Interleave / Stack used to keep their inputs alive)."""
+    from cryptonets_amd.hewrapper import CapturedEvaluation
+    Factory = make_factory("gpu", primes=PRIMES, n=8192, galois=True)
+    env = Factory.AllocateComputationEnv()
+    imgs = [image(3), image(4), image(5)]
+    net = lola(Factory, imgs[0])
+    net.PrepareNetwork()
+    layers = list(networks._chain(net))[::-1]                    # reader, encrypt, conv, ...
+    reader, encrypt = layers[0], layers[1]
+    M = env.bigFactor
+
+    def centred(v):
+        return [((x % M) - M) if (x % M) * 2 > M else (x % M) for x in v]
+
+    def encrypted(img):
+        reader.Features = np.asarray(img) / 256.0
+        return encrypt.Apply(reader.GetNext())
+
+    def evaluate(x, keep):
+        for L in layers[2:]:
+            y = L.Apply(x)
+            if y is not x and x is not keep:
+                x.Dispose()
+            x = y
+        return x
+
+    first = encrypted(imgs[0])
+    live = []
+    for _ in range(2):                                           # rehearsal (also the leak check)
+        r = evaluate(first, first)
+        assert [int(v) for v in r.GetColumn(0).DecryptFullPrecision(env)] == centred(int_logits(imgs[0]))
+        r.Dispose()
+        import gc
+        gc.collect()
+        live.append([e.ctx.live_handles() for e in env.Environments])
+    assert live[0] == live[1]
+    cap = CapturedEvaluation(env, lambda x: evaluate(x, first), [first])
+    for img in (imgs[1], imgs[2], imgs[0]):
+        fresh = encrypted(img)
+        out = cap.run(fresh)
+        assert [int(v) for v in out.GetColumn(0).DecryptFullPrecision(env)] == centred(int_logits(img))
+        fresh.Dispose()
+    cap.Dispose()
+
+
 def lola_dense(Factory, tsv_path):
     """LoLa-Dense (`LowLatencyCryptoNets/LoLaCryptonets.cs:118-199`): the image arrives as ONE packed ciphertext; the im2col of the
     convolution is done homomorphically by LLPreConvLayer (masks + Permute), the rest is the LoLa pipeline with 16-fold packing."""
