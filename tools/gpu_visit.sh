@@ -15,7 +15,7 @@ python tools/summarize_trace.py $KT > $OUT/trace_summary.txt 2>&1
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/prof -name "*kernel_trace.csv" -delete
 head -16 $OUT/trace_summary.txt
-timeout 600 python tools/lola_latency.py > $OUT/lola.txt 2>&1
-tail -5 $OUT/lola.txt | cut -c1-300
+timeout 600 python tools/lola_latency.py LoLa --graph > $OUT/lola.txt 2>&1
+tail -9 $OUT/lola.txt | cut -c1-300
 timeout 900 python tools/cifar_latency.py > $OUT/cifar.txt 2>&1
 tail -4 $OUT/cifar.txt | cut -c1-300
