@@ -362,8 +362,14 @@ static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
         if (ctx->capturing) ctx->cap_allocs.emplace_back(*out, bytes);
         return 0;
     }
-    if (ctx->capturing) return fail(CN_ERR_ARG, "a new device array (%zu bytes) would have to be allocated while a graph is recorded: run the sequence once before cn_graph_begin "
-                                    "(handle pool: %zu bytes in %zu sizes)", bytes, ctx->pool_bytes, ctx->pool.size());
+    if (ctx->capturing) {                                       // relaxed capture mode permits hipMalloc (it does not touch the recording stream);
+        if (hipMalloc((void **)out, bytes) != hipSuccess) {     // flushing the pool would synchronise, so no retry here
+            (void)hipGetLastError();
+            return fail(CN_ERR_HIP, "out of device memory while a graph is recorded (%zu bytes)", bytes);
+        }
+        ctx->cap_allocs.emplace_back(*out, bytes);
+        return 0;
+    }
     if (hipMalloc((void **)out, bytes) != hipSuccess) {          // out of memory: give the cached arrays back and retry once
         (void)hipGetLastError();
         pool_flush(ctx);

@@ -176,6 +176,77 @@ def evaluate_batches(network, Factory, reader, numberOfRecords, report=print):
     return errs, count
 
 
+def evaluate_single_recorded(network, Factory, records, report=print):
+    """The loop of `evaluate_single` with the evaluation RECORDED: the first record runs layer by layer (rehearsal), the layers after the
+    EncryptLayer are then recorded once as one HIP graph per plaintext prime (`hewrapper.CapturedEvaluation`) and every further record
+    is encrypted, copied into the recorded input and evaluated with one launch per prime.  "Prediction-Time" covers the same window
+    as the reference's brackets (after encryption .. before decryption).  Encrypted GPU factory only.  Returns (errors, count)."""
+    import time
+    from .hewrapper import CapturedEvaluation
+    layers = list(_chain(network))[::-1]                          # reader first
+    reader = layers[0]
+    k = next(i for i, p in enumerate(layers) if isinstance(p, EncryptLayer))
+    enc, tail = layers[k], layers[k + 1:]
+    if any(isinstance(p, TimingLayer) for p in layers):
+        raise Exception("a recorded evaluation cannot contain TimingLayers (they synchronise)")
+    for p in layers:
+        p.Factory = Factory
+    network.PrepareNetwork()
+    env = Factory.AllocateComputationEnv()
+
+    def sync():
+        for e in env.Environments:
+            e.ctx.sync()
+
+    def run_tail(x, keep):
+        for L in tail:
+            y = L.Apply(x)
+            if y is not x and x is not keep:
+                x.Dispose()
+            x = y
+        return x
+    errs = count = 0
+    cap = first = None
+    try:
+        for i in range(records):
+            m = enc.GetNext()
+            if m is None:
+                break
+            sync()
+            t0 = time.perf_counter()
+            if cap is None:
+                first = m
+                out = run_tail(first, first)
+                if i == 0 and records > 1:                        # rehearsed once: record it for the remaining records
+                    sync(); dt = time.perf_counter() - t0
+                    score = np.asarray(out.Decrypt(env))[:, 0]
+                    out.Dispose()
+                    cap = CapturedEvaluation(env, lambda x: run_tail(x, first), [first])
+                else:
+                    sync(); dt = time.perf_counter() - t0
+                    score = np.asarray(out.Decrypt(env))[:, 0]
+                    out.Dispose()
+            else:
+                out = cap.run(m)
+                sync(); dt = time.perf_counter() - t0
+                score = np.asarray(out.Decrypt(env))[:, 0]
+                m.Dispose()
+            pred, label = int(np.argmax(score[:10])), int(reader.Labels[0])
+            errs += int(pred != label)
+            count += 1
+            if report is not None:
+                report("errs %d/%d accuracy %.3f%% Prediction-Time %.2f ms%s prediction %d label %d"
+                       % (errs, count, 100 - 100.0 * errs / count, 1e3 * dt, " (recorded)" if cap is not None and i > 0 else "", pred, label))
+    finally:
+        if cap is not None:
+            cap.result.Dispose()
+            cap.Dispose()
+        if first is not None:
+            first.Dispose()
+        Factory.FreeComputationEnv(env)
+    return errs, count
+
+
 def evaluate_single(network, Factory, records, verbose=False, report=print):
     """LoLaCryptonets.cs:64-115: "Prediction-Time" brackets everything after the EncryptLayer; one record per GetNext.
     Returns (errors, count)."""

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--biases", default=None, help="LoLaLarge: MnistLargeBias.csv")
     ap.add_argument("-e", "--encrypt", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="with -e: record the evaluation once (one HIP graph per plaintext prime) and replay it for every further record")
     ap.add_argument("--budget", action="store_true", help="with -e -v: probe the invariant noise budget after every layer (CryptoTracker)")
     ap.add_argument("--file", default="MNIST-28x28-test.txt")
     ap.add_argument("--synthetic", type=int, default=0, metavar="RECORDS")
@@ -65,7 +66,10 @@ def main():
     if a.budget:
         from cryptonets_amd.cryptotracker import CryptoTracker
         CryptoTracker.EnableBudgetTests()
-    errs, count = networks.evaluate_single(network, Factory, a.records, verbose=a.verbose)
+    if a.graph and a.encrypt:
+        errs, count = networks.evaluate_single_recorded(network, Factory, a.records)
+    else:
+        errs, count = networks.evaluate_single(network, Factory, a.records, verbose=a.verbose)
     print("errs %d/%d accuracy %.3f%%" % (errs, count, 100 - 100.0 * errs / max(count, 1)))
     if a.budget and a.encrypt:
         print("Minimal noise budget seen %d bits" % CryptoTracker.MinBudgetSoFar)

@@ -124,7 +124,7 @@ int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out,
 /* Captured sequences (HIP graphs) for the launch-bound chains of a single-image inference (LoLa: ~235 small launches per plaintext
  * prime, the reference's LowLatencyCryptoNets loop LoLaCryptonets.cs:236-278): every library call between cn_graph_begin and
  * cn_graph_end is RECORDED on the context stream instead of executed; cn_graph_launch replays the whole sequence with one launch.
- * Rules: run the same sequence once before recording (temporaries then come out of the handle pool, the arenas have their size);
+ * Rules: run the same sequence once before recording (the scratch arenas then have their size; temporaries come out of the handle pool);
  * nothing that synchronises (cn_sync, uploads / downloads, key changes) between begin and end; handles created while recording stay
  * alive as long as the graph is launched (its kernels carry their addresses); new inputs are written INTO the handles the recorded
  * sequence read (cn_copy, cn_encrypt).  Release with cn_free. */

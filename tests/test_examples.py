@@ -60,6 +60,14 @@ def test_cryptonets_program_encrypted_scores_like_raw():
     assert pick(enc) == pick(raw)
 
 
+@pytest.mark.gpu
+def test_lola_program_recorded_evaluation_predicts_like_raw():
+    """`--graph`: the first record rehearses, the rest replay the recorded evaluation - same predictions as the plaintext factory"""
+    enc = run("lola.py", "-n", "LoLa", "-e", "--graph", "--synthetic", "4")
+    raw = run("lola.py", "-n", "LoLa", "--synthetic", "4")
+    assert len(predictions(enc)) == 4 and predictions(enc) == predictions(raw) and enc.count("(recorded)") == 3
+
+
 def test_lola_cifar_program_raw():
     out = run("lola_cifar.py", "--synthetic", "1")
     assert len(predictions(out)) == 1 and "Inference-Time" in out and "Max computed value 2^" in out
