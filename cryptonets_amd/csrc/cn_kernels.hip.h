@@ -803,8 +803,10 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *
 // Two forward and three inverse transforms like the separate launches, but every step needs only the 16 coefficients of ONE polynomial
 // per thread (126 VGPRs, two resident workgroups per CU) - keeping A0 and A1 in registers for the cross term would cost 64 more VGPRs
 // and a workgroup per CU.  The parked values are the thread's own doubles at its own 16 B/lane positions (stored and re-read by the
-// same thread: program order), 64 KiB per polynomial that is overwritten by the result a few microseconds later, i.e. while it still
-// sits in L2.  Against the separate launches (forward transforms in place 2R + 2W, tensor + inverse 4R + 3W per limb) HBM sees 2R + 3W.
+// same thread: program order), 64 KiB per polynomial that is overwritten by the result a few microseconds later.  Measured HBM traffic
+// (profiles/r01_pmc_square_fused.txt): the parked limbs ARE written back before they are overwritten (5 limbs written per block, not 3)
+// and part of their re-reads comes from HBM (3.2-4.4 limbs read) - against 2R + 2W (forward transforms in place) + 4R + 3W (tensor +
+// inverse transforms) of the separate launches.
 // The inverse transform's workgroup barrier orders "everybody has re-read its parked words" before any result word is stored over them.
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64_t *__restrict__ A_, size_t a_stride, uint64_t *__restrict__ D,
