@@ -117,3 +117,20 @@ def test_oracle_against_bigint_models(n, t, q, dbc, gdbc):
             X += int(x[j, i]) * Qj * pow(Qj, -1, q[j])
         X %= Q
         assert ((X * t * 2 + Q) // (2 * Q)) % t == int(d[i])
+
+
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c3"])
+def test_oracle_words_match_the_committed_digests(name):
+    """Regression pin: SHA-256 of the oracle's words (keys, fresh encryption under a seeded stream, every evaluator op) for seeded inputs
+    equal tests/golden/oracle_digests.json (written by tests/golden/make_oracle_digests.py).  A drift of the oracle - and with it of the
+    words the HIP path is held to - shows up here on the CPU.  (Not SEAL known answers: ciphertext-word parity with SEAL 3.2 stays unpinned.)"""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_digests", os.path.join(here, "make_oracle_digests.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "oracle_digests.json")))[name]
+    got = mod.digests(name)
+    assert got == want, sorted(k for k in want if got.get(k) != want[k])
