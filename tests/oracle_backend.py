@@ -59,6 +59,7 @@ class OracleBackend:
         self.ctw = oracle.ctw
         self.dbc, self.gdbc = oracle.dbc, oracle.gdbc
         self.bufs, self.next = {}, 1
+        self._recording, self._graphs, self._parked, self._depth = None, {}, set(), 0
 
     # keys (cn_get_key / cn_has_galois_key)
     def get_key(self, which, elt=0):
@@ -85,10 +86,46 @@ class OracleBackend:
         return h
 
     def free(self, h):
+        if h in self._graphs:
+            for g in self._graphs.pop(h)[1]:
+                self.bufs.pop(g, None)
+            return
+        if self._recording is not None:                 # arrays freed while recording stay reserved for the graph (cn_graph_end)
+            self._recording[1].append(h)
+            self._parked.add(h)
+            return
         del self.bufs[h]
+        self._parked.discard(h)
 
     def live_handles(self):
-        return len(self.bufs)
+        return len(self.bufs) - len(self._parked) + len(self._graphs)
+
+    # ---- emulation of cn_graph_begin / cn_graph_end / cn_graph_launch for the CPU suite: the compute calls made while recording are
+    # logged (and executed), a launch re-executes them on the same handles - what the HIP graph does with the same device addresses.
+    # Uploads / downloads / synchronisation are refused while recording, like the library does.
+    _REPLAYED = ("copy", "add", "sub", "add_many", "add_plain", "mul_plain", "mul_scalar", "scalar_gemm", "gemm_apply", "mul_relin", "multiply",
+                 "relinearize", "rotate_rows", "rotate_rows_add", "rotate_columns", "rotate_columns_add", "sum_slots", "rowdot_batch")
+    _REFUSED = ("sync", "ct_upload", "ct_download", "pt_upload", "pt_download", "encode", "decode", "set_relin_key", "set_galois_key")
+
+    def graph_begin(self):
+        if self._recording is not None:
+            raise RuntimeError("cn_graph_begin is not possible while a graph is recorded")
+        self._recording = ([], [])
+        self.__class__ = _RecordingBackend
+
+    def graph_end(self):
+        calls, parked = self._recording
+        self._recording = None
+        self.__class__ = OracleBackend
+        h = self.next
+        self.next += 1
+        self._graphs[h] = (calls, parked)
+        return h
+
+    def graph_launch(self, graph):
+        for name, args, kw in self._graphs[graph][0]:
+            getattr(OracleBackend, name)(self, *args, **kw)
+
 
     def ct_upload(self, h, first, data):
         d = np.asarray(data, dtype=np.uint64).reshape(-1, self.bufs[h].shape[1])
@@ -193,6 +230,36 @@ class OracleBackend:
     def rotate_columns(self, src, ii, out, oi, count=1):
         for i in range(count):
             self.bufs[out][oi + i] = self.o.rotate_columns(self.bufs[src][ii + i])
+
+
+class _RecordingBackend(OracleBackend):
+    """OracleBackend while a graph is recorded (graph_begin swaps the instance's class, graph_end swaps it back): compute calls are
+    logged and executed, synchronising calls are refused.  Kept off the normal class - attribute interception is slow."""
+
+    def __getattribute__(self, name):
+        attr = object.__getattribute__(self, name)
+        if name.startswith("_") or not callable(attr):
+            return attr
+        rec = object.__getattribute__(self, "_recording")
+        if rec is None:
+            return attr
+        if name in OracleBackend._REFUSED:
+            def refused(*a, **k):
+                raise RuntimeError("%s is not possible while a graph is recorded" % name)
+            return refused
+        if name in OracleBackend._REPLAYED:
+            def logged(*a, **k):
+                if object.__getattribute__(self, "_depth"):     # a compound call (rowdot_batch, sum_slots) is logged once, not its parts
+                    return attr(*a, **k)
+                rec[0].append((name, tuple(np.array(x, copy=True) if isinstance(x, (np.ndarray, list)) else x for x in a),
+                               {kk: (np.array(v, copy=True) if isinstance(v, (np.ndarray, list)) else v) for kk, v in k.items()}))
+                self._depth = 1
+                try:
+                    return attr(*a, **k)
+                finally:
+                    self._depth = 0
+            return logged
+        return attr
 
 
 class OracleHarness:
