@@ -28,29 +28,55 @@ def uniform_ct_words(rng, q, n, count, polys=2):
     return out.reshape(count, -1)
 
 
-def cpu_baseline(cores, budget_s=20.0):
-    """Time the CPU oracle (port of the SEAL 3.2 path the reference runs) on a bounded sample of the same
-    workload and extrapolate to one 8192-image batch over both plaintext primes."""
+def _omp_threads(n):
+    """OpenMP team size of the oracle library for the parallel regions that follow (omp_set_num_threads of the loaded runtime)"""
+    import ctypes
+    for name in ("libgomp.so.1", "libomp.so", "libiomp5.so"):
+        try:
+            ctypes.CDLL(name).omp_set_num_threads(int(n))
+            return True
+        except OSError:
+            continue
+    return False
+
+
+def _cpu_sample(o, layers, p, ns):
+    """seconds per 8192-image batch and plaintext prime, extrapolated from ns-sized samples of every layer (the layers' own weight rows)"""
+    from cryptonets_amd import cryptonets_mnist as cm
+    rng = np.random.default_rng(7)
+    cts = uniform_ct_words(rng, o.q, o.n, 64)
+    W = [cm.residues(L["W"], p) for L in layers]
+    rows = lambda Wl, cnt: np.ascontiguousarray(Wl[np.arange(cnt) % Wl.shape[0]])
+    t0 = time.perf_counter(); o.scalar_gemm(cts[:25], rows(W[0], 4 * ns)); t_conv = (time.perf_counter() - t0) / (4 * ns)
+    big = np.tile(cts, (14, 1))[:845]
+    t0 = time.perf_counter(); o.scalar_gemm(big, rows(W[1], ns)); t_d3 = (time.perf_counter() - t0) / ns
+    t0 = time.perf_counter(); o.scalar_gemm(big[:100], rows(W[2], ns)); t_d5 = (time.perf_counter() - t0) / ns
+    sq = np.tile(cts, (max(1, (2 * ns + 63) // 64), 1))[:2 * ns]
+    t0 = time.perf_counter(); o.mul_relin_batch(sq, sq); t_sq = (time.perf_counter() - t0) / (2 * ns)
+    return 845 * t_conv + 945 * t_sq + 100 * t_d3 + 10 * t_d5
+
+
+def cpu_baseline(cores, layers):
+    """Time the CPU oracle (port of the SEAL 3.2 path the reference runs) on a bounded sample of the same workload - the same weight
+    rows the GPU run used - and extrapolate to one 8192-image batch over both plaintext primes: on all host cores (OpenMP over
+    ciphertexts, mirroring ParallelProcessInEnv) and on ONE thread (SURVEY 8d asks for both)."""
     from oracle.cno import Oracle
     from cryptonets_amd import cryptonets_mnist as cm
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    o = Oracle(cm.N, cm.PLAIN_PRIMES[0], dbc=10, gdbc=20)
+    p = cm.PLAIN_PRIMES[0]
+    o = Oracle(cm.N, p, dbc=10, gdbc=20)
     o.keygen(1, galois=False)
-    rng = np.random.default_rng(7)
+    single = None
+    if _omp_threads(1):
+        t1 = 2 * _cpu_sample(o, layers, p, 2)
+        single = {"value": round(8192.0 / t1, 2), "unit": "images/s", "cores": 1, "seconds_per_batch": round(t1, 1)}
+        _omp_threads(cores)
     ns = max(8, cores)                                # sample sizes that keep every core busy
-    cts = uniform_ct_words(rng, o.q, o.n, 64)
-    t0 = time.perf_counter(); o.scalar_gemm(cts[:25], rng.integers(1, 1 << 20, size=(4 * ns, 25), dtype=np.uint64)); t_conv = (time.perf_counter() - t0) / (4 * ns)
-    big = np.tile(cts, (14, 1))[:845]
-    t0 = time.perf_counter(); o.scalar_gemm(big, rng.integers(1, 1 << 20, size=(ns, 845), dtype=np.uint64)); t_d3 = (time.perf_counter() - t0) / ns
-    t0 = time.perf_counter(); o.scalar_gemm(big[:100], rng.integers(1, 1 << 20, size=(ns, 100), dtype=np.uint64)); t_d5 = (time.perf_counter() - t0) / ns
-    sq = np.tile(cts, (max(1, (2 * ns + 63) // 64), 1))[:2 * ns]
-    t0 = time.perf_counter(); o.mul_relin_batch(sq, sq); t_sq = (time.perf_counter() - t0) / (2 * ns)
-    per_prime = 845 * t_conv + 945 * t_sq + 100 * t_d3 + 10 * t_d5
-    total = 2 * per_prime
-    return {"value": 8192.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
+    total = 2 * _cpu_sample(o, layers, p, ns)
+    return {"value": 8192.0 / total, "unit": "images/s", "cores": cores, "kind": "port", "single_thread": single,
             "sample": "oracle (C restatement of SEAL 3.2 BFV, OpenMP) timed on %d conv outputs, %d dense-845 outputs, %d dense-100 "
-                      "outputs, %d square+relinearize ciphertexts of the N=8192 k=5 workload, extrapolated to 845/100/10/945 x 2 primes "
-                      "(%.1f s per batch)" % (4 * ns, ns, ns, 2 * ns, total)}
+                      "outputs, %d square+relinearize ciphertexts of the N=8192 k=5 workload with the run's own weight rows, extrapolated to "
+                      "845/100/10/945 x 2 primes (%.1f s per batch); single_thread: the same on one thread from 8/2/2/4 items" % (4 * ns, ns, ns, 2 * ns, total)}
 
 
 def _conv_tile():
@@ -65,6 +91,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", choices=("trained", "synthetic"), default="trained",
+                    help="trained: the reference's CryptoNets/Weights.cs (shipped as package data); synthetic: random-init weights of the same shapes")
+    ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
+    ap.add_argument("--caller-threads", type=int, default=8)
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
     args = ap.parse_args()
 
@@ -92,7 +122,8 @@ def main():
     from cryptonets_amd import cryptonets_mnist as cm
     from cryptonets_amd.distributed import broadcast_words, max_over_ranks
 
-    layers = cm.layer_tables(*cm.synthetic_weights(1), conv_tile=_conv_tile())    # gather-list tiling: same outputs
+    weights = cm.reference_weights() if args.weights == "trained" else cm.synthetic_weights(1)
+    layers = cm.layer_tables(*weights, conv_tile=_conv_tile())      # gather-list tiling: same outputs
     images = cm.synthetic_images(cm.N, seed=1000 + rank)            # this rank's batch (independent batches per GPU)
     x_int = np.rint(images * cm.NORMALIZATION * cm.INPUT_SCALE).astype(np.int64)
     dev = torch.device("cuda", local)
@@ -174,7 +205,8 @@ def main():
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     traffic = None                                        # HBM bytes per launch from the committed PMC passes (same launch geometry)
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt_hbm_traffic.json")))
+        import glob
+        prof = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ntt_hbm_traffic.json")))[-1]))    # the latest round's PMC passes
         traffic = [v["hbm_traffic_corrected_bytes"] for kname, v in prof.items() if "k_ntt" in kname and "forward" in kname][0]
     except Exception:
         pass
@@ -197,30 +229,56 @@ def main():
             g.relinearize(t3, 0, t2, 0, cts)
         ks_ms = g.time_end() / 5
         g.free(t3); g.free(t2)
-        digits = sum(-(-int(q).bit_length() // 10) for q in g.q)          # base-2^10 digits of every source limb
-        fp64_per_thread = digits * 1104 + 2 * 1064
-        floor_ms = cts * g.k * 8 * fp64_per_thread / 1024 * 2.15e-6     # wave-instructions per SIMD x 2.15 ns
+        per_limb = [-(-int(q).bit_length() // 10) for q in g.q]           # base-2^10 digits of every source limb
+        digits = sum(per_limb)
         key_switch = {"kernel": "k_keyswitch_rr (845 ciphertexts x %d output limbs, %d digit transforms each)" % (g.k, digits),
                       "share_of_batch": round(2 * ks_ms / (1e3 * dt / args.steps), 3), "bound": "fp64 issue", "ms_per_launch": round(ks_ms, 3),
-                      "fp64_issue_floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ks_ms, 3),
                       "ns_per_limb_transform": round(ks_ms * 1e6 / (cts * g.k * (digits + 2)), 1)}
+        try:        # FP64 instructions per thread from the disassembly of the BUILT kernel (tools/ks_isa_counts.py), priced at the measured
+                    # issue rate of one FP64 wave-instruction per 2.15 ns per SIMD (profiles/r01_ubench_mulmod.txt)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ks_isa_counts
+            fp64_per_thread, isa = ks_isa_counts.fp64_per_thread(g.k, per_limb)
+            floor_ms = cts * g.k * 8 * fp64_per_thread / 1024 * 2.15e-6   # 8 waves per workgroup, 4 SIMDs x 256 CUs
+            key_switch.update({"fp64_per_thread": fp64_per_thread, "fp64_digit_loop": isa["fp64_digit_loop"], "fp64_tail_loop": isa["fp64_tail_loop"],
+                               "fp64_issue_floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ks_ms, 3)})
+        except Exception as ex:                                            # no disassembler / unrecognised code shape: no floor rather than a stale one
+            key_switch.update({"fp64_issue_floor_ms": None, "frac": None, "isa_error": str(ex)[:200]})
+
+    # ---- the reference's UNCHANGED caller: one evaluator call per ciphertext from `caller-threads` threads (tools/replay_reference_calls.cpp),
+    # merged by libcnhip's deferred submission; same inputs, its final words must equal the batched run's
+    unchanged = None
+    if rank == 0 and world == 1 and not args.no_unchanged_caller:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import replay_reference_calls as rp
+            ref_words = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
+            ums, uwords = rp.measure(chans, layers, args.caller_threads, max(2, min(args.steps, 5)), warmup=1)
+            unchanged = {"value": round(8192e3 / ums, 1), "unit": "images/s", "ms_per_step": round(ums, 2), "threads": args.caller_threads,
+                         "frac_of_batched": round((1e3 * dt / args.steps) / ums, 3),
+                         "words_identical_to_batched": bool(all(np.array_equal(a, b) for a, b in zip(uwords, ref_words))),
+                         "pattern": "PoolLayer.Apply: per (map, corner) cn_scalar_dot + cn_add_plain + cn_free; SquareActivation: per column "
+                                    "cn_mul_relin(count 1); every ciphertext its own handle; 2 x 2855 calls per batch; cn_set_option(defer, 1)"}
+        except Exception as ex:
+            unchanged = {"error": str(ex)[:300]}
 
     if rank == 0:
         images = 8192 * args.steps * world
         out = {"metric": "encrypted images/sec (CryptoNets-MNIST, N=8192)", "value": round(images / dt, 1), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+               "data": "synthetic images" + (", the reference's trained weights (CryptoNets/Weights.cs)" if args.weights == "trained" else ", synthetic weights"),
                "verified_against_integer_model": verified,
                "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
-                                      "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM",
+                                      "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; weights: " + args.weights,
                           "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world,
                           "arithmetic": "exact modular integers over 43-49-bit RNS primes (results are u64 words, bit-identical to the integer "
                                         "oracle); products evaluated with error-free FP64 instruction sequences where the modulus is below 2^49, "
                                         "64-bit integer instructions otherwise"},
-               "roofline": roofline, "key_switch": key_switch}
+               "roofline": roofline, "key_switch": key_switch, "unchanged_caller": unchanged}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1, layers)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

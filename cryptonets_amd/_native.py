@@ -12,9 +12,12 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "lib", "libcnhip.so")
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("cn_api.hip", "cn_tables.cpp")]
-HEADERS = [os.path.join(_PKG, "csrc", f) for f in ("cn_kernels.hip.h", "cn_ntt_core.hip.h", "cn_internal.h")] + [
-    os.path.join(_ROOT, "include", "cnhip.h")]
+CSRC = os.path.join(_PKG, "csrc")
+# one translation unit per kernel family: hipcc compiles them in parallel (the register-radix kernels alone are ~180 instantiations)
+SOURCES = [os.path.join(CSRC, f) for f in (
+    "cn_api.hip", "cn_host.cpp", "cn_tables.cpp", "cn_l_gemm.hip", "cn_l_behz.hip",
+    "cn_l_rr_u64.hip", "cn_l_rr_f64.hip", "cn_l_rr_f64l.hip", "cn_l_ks_u64.hip", "cn_l_ks_f64.hip", "cn_l_ks_f64l.hip")]
+OBJ_DIR = os.path.join(_PKG, "lib", "obj")
 
 U64P = C.POINTER(C.c_uint64)
 I32P = C.POINTER(C.c_int32)
@@ -34,19 +37,46 @@ class CnStats(C.Structure):
         "ntt_forward_limbs", "ntt_inverse_limbs", "kernel_launches")]
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    deps = SOURCES + HEADERS
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+def _deps(path, seen=None):
+    """`path` and every header it includes (transitively, quoted includes only)"""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        _deps(os.path.normpath(os.path.join(os.path.dirname(path), inc)), seen)
+    return seen
+
+
+def build(force=False, verbose=False, defines=(), out=None):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU): the translation units are compiled in
+    parallel into lib/obj/ (only those whose sources changed), then linked.  `defines` / `out`: A/B builds of tools/ (-D switches,
+    another library name - their objects go to a directory of their own)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib_path = out or LIB_PATH
+    obj_dir = OBJ_DIR if out is None else os.path.splitext(out)[0] + "_obj"
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
-           *SOURCES, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", *["-D" + d for d in defines]]
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        newest = max(os.path.getmtime(d) for d in _deps(src))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
+    objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
+    if not jobs and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for o in objs):
+        return lib_path
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "-shared", "--offload-arch=gfx950", *objs, "-o", lib_path])
+    return lib_path
 
 
 # every exported symbol of include/cnhip.h: name -> (restype, argtypes)
@@ -87,6 +117,7 @@ SIGNATURES = {
     "cn_mul_plain": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32, _H, _u32, _u32]),
     "cn_mul_scalar": (C.c_int, [_CTX, _H, _u32, U64P, _u32, _H, _u32, _u32]),
     "cn_scalar_gemm": (C.c_int, [_CTX, _H, I32P, U64P, _u32, _u32, _H, I32P, _H, _u32]),
+    "cn_scalar_dot": (C.c_int, [_CTX, C.POINTER(_H), U32P, U64P, _u32, _H, _u32]),
     "cn_gemm_plan_create": (C.c_int, [_CTX, I32P, U64P, _u32, _u32, _H, I32P, C.POINTER(_H)]),
     "cn_gemm_plan_apply": (C.c_int, [_CTX, _H, _H, _H, _u32]),
     "cn_graph_begin": (C.c_int, [_CTX]),
@@ -102,6 +133,7 @@ SIGNATURES = {
     "cn_rotate_columns_add": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
     "cn_sum_slots": (C.c_int, [_CTX, _H, _u32, _u32, _u32]),
     "cn_rowdot_batch": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32, _u32, _H, _u32]),
+    "cn_set_rng_salt": (C.c_int, [_CTX, C.c_uint64]),
     "cn_keygen": (C.c_int, [_CTX, C.c_uint64, C.c_int]),
     "cn_set_public_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
     "cn_set_secret_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
@@ -140,7 +172,8 @@ def lib():
 
 
 def _p64(a):
-    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "expected contiguous uint64 array"
+    if a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("expected contiguous uint64 array")
     return a.ctypes.data_as(U64P)
 
 
@@ -227,6 +260,11 @@ class Context:
     def ct_upload(self, h, first, data):
         d = np.ascontiguousarray(data, dtype=np.uint64)
         count = d.shape[0] if d.ndim > 1 else 1
+        _, nbytes = self.device_ptr(h)                     # the library reads count * item words from the host pointer: check the row width here
+        row = d.size // count if count else 0
+        if count == 0 or d.size != count * row or row % (self.k * self.n) or row // (self.k * self.n) not in (2, 3) \
+                or nbytes % (row * 8) or first + count > nbytes // (row * 8):
+            raise ValueError("ct_upload: data of shape %s does not fit the ciphertexts of this handle" % (d.shape,))
         self._chk(self.L.cn_ct_upload(self._h, h, first, count, _p64(d)))
 
     def ct_download(self, h, first, count, size=2):
@@ -296,14 +334,26 @@ class Context:
         ip = None
         if idx is not None:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
-            assert idx.shape == (O, K)
+            if idx.shape != (O, K):
+                raise ValueError("gather table must have the shape of the weight matrix")
             ip = idx.ctypes.data_as(I32P)
         bp = None
         if bias_pt:
             bias_idx = np.ascontiguousarray(bias_idx, dtype=np.int32)
-            assert bias_idx.shape == (O,)
+            if bias_idx.shape != (O,):
+                raise ValueError("one bias index per output expected")
             bp = bias_idx.ctypes.data_as(I32P)
         self._chk(self.L.cn_scalar_gemm(self._h, src, ip, _p64(W), O, K, bias_pt, bp, out, oi))
+
+    def scalar_dot(self, handles, indices, weights, out, oi):
+        """out[oi] = sum_k weights[k] * handles[k][indices[k]]: one output of DenseMatrixBySparseVectorMultiply whose input ciphertexts
+        are separate arrays (handle 0 = padded tap)"""
+        hs = np.ascontiguousarray(handles, dtype=np.uint64)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        w = np.ascontiguousarray(weights, dtype=np.uint64)
+        if not (hs.shape == ix.shape == w.shape) or hs.ndim != 1:
+            raise ValueError("scalar_dot: handles, indices and weights must be 1-d arrays of one length")
+        self._chk(self.L.cn_scalar_dot(self._h, hs.ctypes.data_as(C.POINTER(_H)), ix.ctypes.data_as(U32P), _p64(w), hs.size, out, oi))
 
     def gemm_plan(self, W, idx=None, bias_pt=0, bias_idx=None):
         """plan a scalar GEMM once (weights and gather tables stay in HBM); returns a handle for gemm_apply / free"""
@@ -312,12 +362,14 @@ class Context:
         ip = None
         if idx is not None:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
-            assert idx.shape == (O, K)
+            if idx.shape != (O, K):
+                raise ValueError("gather table must have the shape of the weight matrix")
             ip = idx.ctypes.data_as(I32P)
         bp = None
         if bias_pt:
             bias_idx = np.ascontiguousarray(bias_idx, dtype=np.int32)
-            assert bias_idx.shape == (O,)
+            if bias_idx.shape != (O,):
+                raise ValueError("one bias index per output expected")
             bp = bias_idx.ctypes.data_as(I32P)
         h = _H()
         self._chk(self.L.cn_gemm_plan_create(self._h, ip, _p64(W), O, K, bias_pt, bp, C.byref(h)))
@@ -360,6 +412,9 @@ class Context:
         self._chk(self.L.cn_rotate_columns(self._h, src, ii, out, oi, count))
 
     # ---- client side on the device
+    def set_rng_salt(self, salt):
+        self._chk(self.L.cn_set_rng_salt(self._h, salt))
+
     def keygen(self, seed, galois=True):
         self._chk(self.L.cn_keygen(self._h, seed, int(galois)))
 

@@ -102,6 +102,15 @@ def layer_tables(weights0, weights1, biases2, weights3, biases3, conv_tile=1):
     return layers
 
 
+def reference_weights():
+    """The reference's TRAINED CryptoNets-MNIST weights (`CryptoNets/Weights.cs:8-978`), shipped as package data
+    (`data/cryptonets_weights.npz`, extracted by tests/golden/make_cryptonets_weights.py): (Weights_0, Weights_1, Biases_2, Weights_3,
+    Biases_3) in the order layer_tables takes them."""
+    import os
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cryptonets_weights.npz"))
+    return tuple(w[k] for k in ("Weights_0", "Weights_1", "Biases_2", "Weights_3", "Biases_3"))
+
+
 def synthetic_weights(seed=1):
     """Random-init weights of the CryptoNets-MNIST architecture (the trained ones live in the reference repo)."""
     r = np.random.default_rng(seed)

@@ -1,89 +1,49 @@
 // libcnhip.so host runtime: contexts, device buffers, launch logic behind the C ABI of include/cnhip.h.
 // The compute path is HIP-only: there is no CPU fallback; every entry point fails with CN_ERR_NODEV /
 // CN_ERR_HIP when no gfx950 device is usable.
-#include "../../include/cnhip.h"
-#include "cn_kernels.hip.h"
+#include "cn_runtime.h"
+#include "cn_k_elem.hip.h"
 #include <algorithm>
-#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <unordered_map>
-#include <vector>
 
-static thread_local char g_err[512] = "";
-static int fail(int code, const char *fmt, ...) {
-    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
-    return code;
-}
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(CN_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
-#define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
-
-struct GemmPlan;
-// A captured operation sequence (cn_graph_begin / cn_graph_end): the instantiated HIP graph, the host blocks its upload nodes read at
-// every launch, and the device arrays that were handed out while it was recorded and are not owned by a live handle - they stay
-// reserved for the graph (its kernels carry their addresses), out of the pool, until the graph is freed.
-struct CapturedGraph {
-    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-    std::vector<std::unique_ptr<char[]>> staged;
-    std::vector<std::pair<uint64_t *, size_t>> reserved;
-};
-struct Buffer {
-    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array, 2 = scalar GEMM plan, 3 = captured graph
-    std::shared_ptr<GemmPlan> plan;
-    std::shared_ptr<CapturedGraph> cg;
-    uint32_t count, size;     // size = polys per ciphertext
-    uint64_t *d;
-    size_t item_words;
-    std::vector<uint8_t> pt_zero;   // per plaintext: all coefficients zero?
-};
-struct KsKey { uint64_t *d; bool owned; bool f64; };   // f64: words converted to doubles for the FP64 key-switch kernel
-
-struct cn_ctx {
-    int device;
-    hipStream_t stream;
-    DevConsts hc;             // host copy
-    DevConsts *dc;            // device copy
-    uint64_t *tw;
-    std::mutex mu;
-    std::unordered_map<cn_handle, Buffer> bufs;
-    cn_handle next_handle = 1;
-    KsKey rlk{nullptr, false, false};
-    double *twd = nullptr, *twdh = nullptr;
-    bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
-    std::map<uint64_t, KsKey> gk;
-    uint64_t *sk = nullptr, *pk = nullptr;   // client-side keys (NTT form) when the data owner's GPU runs keygen/encrypt/decrypt
-    uint64_t rng_item = 0;                    // running polynomial counter of the Philox streams
-    char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
-    std::vector<std::unique_ptr<char[]>> staged;   // host blocks of in-flight upload_tmp copies
-    cn_stats st{};
-    hipEvent_t ev0, ev1;
-    uint32_t bs, chunks;      // element-wise geometry
-    std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
-    size_t ctw2;              // words of a size-2 ciphertext
-    bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
-    // freed ciphertext / plaintext arrays are kept per size and handed out again: every op of a context is ordered on its
-    // stream, so reuse needs no synchronisation, while hipFree / hipMalloc cost ~60 / ~25 us and a device-wide sync each
-    // (a LoLa inference allocates and frees ~300 temporaries per plaintext prime)
-    std::unordered_map<size_t, std::vector<uint64_t *>> pool;
-    size_t pool_bytes = 0, pool_max;
-    bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
-    int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
-    void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
-    bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
-    bool capturing = false;   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
-    std::vector<std::unique_ptr<char[]>> cap_staged;                 // host blocks of the upload nodes recorded so far
-    std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
-    int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
-    bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
-    bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
-};
+#define fail cn_fail
+static const RrOps *const rr_ops[3] = {&cn_rr_u64, &cn_rr_f64, &cn_rr_f64l};
+static const KsOps *const ks_ops[3] = {&cn_ks_u64, &cn_ks_f64, &cn_ks_f64l};
 
 // ---------------------------------------------------------------- helpers
+// deferred submission of per-ciphertext calls (second half of this file)
+static DeferQueue *cn_defer_new();
+static void cn_defer_delete(DeferQueue *q);
+static int cn_defer_flush(cn_ctx *ctx);
+static bool cn_defer_pending(cn_ctx *ctx);
+enum { DOP_GEMM1 = 0, DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN, DOP_MULRELIN, DOP_TYPES };
+struct DOp {
+    int type; int32_t level;
+    uint64_t *out;                 // output ciphertext (size 2)
+    const uint64_t *a, *b;         // operands (ADD/SUB/MULRELIN: ciphertexts; ADDPLAIN/SUBPLAIN: b = plaintext polynomial)
+    uint32_t K; size_t terms;      // GEMM1: K (address, weight) pairs from DeferQueue::addr / ::wt [terms ..)
+    const uint64_t *bias;          // GEMM1: plaintext polynomial added to the result (an AddPlain folded in at flush time), or null
+};
+struct DeferQueue {
+    std::vector<DOp> ops;
+    std::vector<uint64_t> addr, wt;
+    struct Haz { int32_t w = -1, r = -1, wop = -1; uint32_t readers = 0; };   // level of the last writer / deepest reader since / index of the writing op / readers since
+    std::unordered_map<const uint64_t *, Haz> haz;
+    int32_t maxlevel = -1;
+    std::vector<std::pair<uint64_t *, size_t>> frees;      // arrays released by the caller while calls were pending: back to the pool after the flush
+};
+// Small arrays (a per-ciphertext caller allocates every Ciphertext on its own: thousands of 640 KiB arrays per layer) are carved out of
+// slabs - one hipMalloc per SLAB_PIECES arrays, neighbours in the address space - and only ever travel between the handles and the pool;
+// the slabs themselves are released with the context.
+static const size_t SLAB_MAX_ITEM = 8u << 20, SLAB_BYTES = 64u << 20;
+struct Slab { char *base; size_t bytes; };
+static std::vector<Slab> &slabs_of(cn_ctx *ctx) { return *reinterpret_cast<std::vector<Slab> *>(ctx->slabs); }
+static bool in_slab(cn_ctx *ctx, const void *p) {
+    for (const Slab &s : slabs_of(ctx)) if ((const char *)p >= s.base && (const char *)p < s.base + s.bytes) return true;
+    return false;
+}
 static void pool_flush(cn_ctx *ctx);
 static int free_gemm_plan(cn_ctx *ctx, Buffer &b);
 static int free_graph(cn_ctx *ctx, Buffer &b);
@@ -143,25 +103,13 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
 #define GETCT(var, h, sz) Buffer *var = getbuf(ctx, h, 0); if (!var) return fail(CN_ERR_ARG, "invalid ciphertext handle " #h); \
     if ((sz) && var->size != (uint32_t)(sz)) return fail(CN_ERR_ARG, "ciphertext size mismatch for " #h)
 #define GETPT(var, h) Buffer *var = getbuf(ctx, h, 1); if (!var) return fail(CN_ERR_ARG, "invalid plaintext handle " #h)
-#define LOCK std::lock_guard<std::mutex> lk_(ctx->mu); CHECK(use(ctx))
+// every entry point takes the context lock; all but the deferrable ones (cn_defer.hip) first drain the queue of deferred calls
+#define LOCK_ONLY std::lock_guard<CnMutex> lk_(ctx->mu); CHECK(use(ctx))
+#define LOCK LOCK_ONLY; CHECK(cn_defer_flush(ctx))
 
-static void launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }
+#define launch_count cn_launch_count
 
-template <int L, class AR> static void launch_ntt_rr(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
-    if (inverse) hipLaunchKernelGGL((k_ntt_rr<L, AR, true>), dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod);
-    else hipLaunchKernelGGL((k_ntt_rr<L, AR, false>), dim3(limbs), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, data, c->dc, base_off, nmod);
-}
-template <class AR> static bool launch_ntt_by_size(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
-    switch (c->hc.logn) {
-        case 10: launch_ntt_rr<10, AR>(c, data, limbs, base_off, nmod, inverse); return true;
-        case 11: launch_ntt_rr<11, AR>(c, data, limbs, base_off, nmod, inverse); return true;
-        case 12: launch_ntt_rr<12, AR>(c, data, limbs, base_off, nmod, inverse); return true;
-        case 13: launch_ntt_rr<13, AR>(c, data, limbs, base_off, nmod, inverse); return true;
-        case 14: launch_ntt_rr<14, AR>(c, data, limbs, base_off, nmod, inverse); return true;
-        default: return false;
-    }
-}
-static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
+int cn_run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse) {
     if (!limbs) return 0;
     uint32_t n = c->hc.n;
     bool f64 = c->use_f64;
@@ -171,9 +119,7 @@ static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off,
         uint64_t q = m < c->hc.k ? c->hc.q[m].q : (m < c->hc.k + c->hc.kb ? c->hc.bsk[m - c->hc.k].q : c->hc.t.q);
         if (q >> 44) light = false;
     }
-    bool done = !c->legacy_ntt && (light ? launch_ntt_by_size<ArF64L>(c, data, limbs, base_off, nmod, inverse)
-                                   : f64 ? launch_ntt_by_size<ArF64>(c, data, limbs, base_off, nmod, inverse)
-                                         : launch_ntt_by_size<ArU64>(c, data, limbs, base_off, nmod, inverse));
+    bool done = !c->legacy_ntt && rr_ops[light ? POL_F64L : (f64 ? POL_F64 : POL_U64)]->ntt(c, data, limbs, base_off, nmod, inverse);
     if (!done) {
         uint32_t nt = std::min<uint32_t>(512, n / 2);
         hipLaunchKernelGGL(k_ntt, dim3(limbs), dim3(nt), (size_t)n * 8, c->stream, data, c->dc, base_off, nmod, inverse);
@@ -186,22 +132,11 @@ static int run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off,
 
 // ---------------------------------------------------------------- misc API
 extern "C" int cn_version(void) { return 100; }
-extern "C" const char *cn_last_error(void) { return g_err; }
 extern "C" int cn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int cn_default_coeff_modulus(uint32_t n, uint64_t *q) { return cn_default_coeff_modulus_impl(n, q); }
 
 template <class K> static int big_lds(K kern, size_t bytes) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
-}
-// dynamic LDS of the fused key switch with LDS-resident forward twiddles: exchange image + table
-template <int L> static size_t ks_twl_lds() { return ((size_t)ntt_lds_words(1u << L) + (1u << L)) * 8; }
-template <int L, class AR> static int big_lds_policy(size_t bytes) {      // every register-radix kernel of one (size, arithmetic policy)
-    CHECK(big_lds(k_ntt_rr<L, AR, false>, bytes)); CHECK(big_lds(k_ntt_rr<L, AR, true>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
-    if constexpr (KsFwd<AR, L>::lds) CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>()));
-    CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
-    if constexpr (std::is_same<typename AR::T, double>::value) CHECK(big_lds(k_square_fused<L, AR>, bytes));
-    CHECK(big_lds(k_lift_ntt<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_fused<L, AR>, bytes));
     return 0;
 }
 template <int EPT> static int set_ks_attr(size_t bytes) {
@@ -257,20 +192,13 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
-    if (n == 4096) {                       // N = 4096: image + LDS twiddle table of the fused FP64 key switch = 66.5 KiB
-        CHECK(big_lds(k_keyswitch_rr<12, ArF64, 1, true>, ks_twl_lds<12>())); CHECK(big_lds(k_keyswitch_rr<12, ArF64L, 1, true>, ks_twl_lds<12>()));
-    }
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
         CHECK(big_lds(k_ntt, lds)); CHECK(big_lds(k_galois_lds, (size_t)n * 8));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
-        CHECK((big_lds_policy<13, ArU64>(lds))); CHECK((big_lds_policy<14, ArU64>(lds)));
-        CHECK((big_lds_policy<13, ArF64>(lds))); CHECK((big_lds_policy<14, ArF64>(lds)));
-        CHECK((big_lds_policy<13, ArF64L>(lds))); CHECK((big_lds_policy<14, ArF64L>(lds)));
-        CHECK(big_lds(k_encrypt_tail<13, ArU64>, lds)); CHECK(big_lds(k_encrypt_tail<14, ArU64>, lds));
-        CHECK(big_lds(k_encrypt_tail<13, ArF64>, lds)); CHECK(big_lds(k_encrypt_tail<14, ArF64>, lds));
-        CHECK(big_lds(k_keyswitch_split14<ArF64>, (size_t)ntt_lds_words(8192) * 8)); CHECK(big_lds(k_keyswitch_split14<ArF64L>, (size_t)ntt_lds_words(8192) * 8));
-        CHECK(big_lds(k_keyswitch_rr<13, ArU64, 4>, lds)); CHECK(big_lds(k_keyswitch_rr<13, ArF64, 4>, lds)); CHECK(big_lds(k_keyswitch_rr<13, ArF64L, 4>, lds));
     }
+    for (int pol = 0; pol < 3; pol++) { CHECK(rr_ops[pol]->set_attrs(c->hc.logn, lds)); CHECK(ks_ops[pol]->set_attrs(c->hc.logn, lds)); }
+    c->dq = cn_defer_new();
+    c->slabs = new std::vector<Slab>();
     *out = c;
     return 0;
 }
@@ -281,15 +209,18 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     for (auto &kv : ctx->bufs) {
         if (kv.second.kind == 2) (void)free_gemm_plan(ctx, kv.second);
         else if (kv.second.kind == 3) { (void)free_graph(ctx, kv.second); }
-        else (void)hipFree(kv.second.d);
+        else if (!in_slab(ctx, kv.second.d)) (void)hipFree(kv.second.d);
     }
     pool_flush(ctx);
+    for (const Slab &sl : slabs_of(ctx)) (void)hipFree(sl.base);
+    delete &slabs_of(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
     (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
+    cn_defer_delete(ctx->dq);
     delete ctx;
     return 0;
 }
@@ -303,6 +234,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
+    if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     return fail(CN_ERR_ARG, "unknown option %s", name);
 }
 #define NOT_CAPTURING(what) do { if (ctx->capturing) return fail(CN_ERR_ARG, what " is not possible while a graph is recorded (cn_graph_begin .. cn_graph_end)"); } while (0)
@@ -331,14 +263,14 @@ static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count
     return 0;
 }
 extern "C" int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_dev) {
-    LOCK; return set_key(ctx, ctx->rlk, words, count, cn_key_words(ctx, 0), is_dev);
+    LOCK; NOT_CAPTURING("cn_set_relin_key"); return set_key(ctx, ctx->rlk, words, count, cn_key_words(ctx, 0), is_dev);
 }
 extern "C" int cn_set_galois_key(cn_ctx *ctx, uint64_t elt, const uint64_t *words, size_t count, int is_dev) {
-    LOCK;
+    LOCK; NOT_CAPTURING("cn_set_galois_key");
     if (!(elt & 1) || elt >= 2ull * ctx->hc.n) return fail(CN_ERR_ARG, "invalid Galois element");
     return set_key(ctx, ctx->gk[elt], words, count, cn_key_words(ctx, 1), is_dev);
 }
-extern "C" int cn_has_galois_key(cn_ctx *ctx, uint64_t elt) { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
+extern "C" int cn_has_galois_key(cn_ctx *ctx, uint64_t elt) { std::lock_guard<CnMutex> lk(ctx->mu); auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
 extern "C" uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps) {
     uint64_t n = ctx->hc.n, m = 2 * n;
     if (steps == 0) return m - 1;
@@ -352,8 +284,11 @@ extern "C" uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps) {
 // ---------------------------------------------------------------- buffers
 static void pool_flush(cn_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->pool) for (uint64_t *p : kv.second) (void)hipFree(p);
-    ctx->pool.clear(); ctx->pool_bytes = 0;
+    for (auto &kv : ctx->pool) {
+        std::vector<uint64_t *> keep;
+        for (uint64_t *p : kv.second) { if (in_slab(ctx, p)) keep.push_back(p); else { (void)hipFree(p); ctx->pool_bytes -= kv.first; } }
+        kv.second.swap(keep);
+    }
 }
 static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
     auto it = ctx->pool.find(bytes);
@@ -370,6 +305,19 @@ static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
         ctx->cap_allocs.emplace_back(*out, bytes);
         return 0;
     }
+    if (bytes <= SLAB_MAX_ITEM && bytes % 256 == 0) {            // a slab of neighbours: one goes to the caller, the rest into the pool
+        const size_t pieces = std::min<size_t>(64, std::max<size_t>(4, SLAB_BYTES / bytes));
+        char *base = nullptr;
+        if (hipMalloc((void **)&base, pieces * bytes) == hipSuccess) {
+            slabs_of(ctx).push_back({base, pieces * bytes});
+            std::vector<uint64_t *> &pl = ctx->pool[bytes];
+            for (size_t i = pieces; i-- > 1;) pl.push_back((uint64_t *)(base + i * bytes));
+            ctx->pool_bytes += (pieces - 1) * bytes;
+            *out = (uint64_t *)base;
+            return 0;
+        }
+        (void)hipGetLastError();
+    }
     if (hipMalloc((void **)out, bytes) != hipSuccess) {          // out of memory: give the cached arrays back and retry once
         (void)hipGetLastError();
         pool_flush(ctx);
@@ -378,7 +326,7 @@ static int dev_alloc(cn_ctx *ctx, size_t bytes, uint64_t **out) {
     return 0;
 }
 static int dev_release(cn_ctx *ctx, uint64_t *p, size_t bytes) {
-    if (ctx->pool_bytes + bytes <= ctx->pool_max || ctx->capturing) { ctx->pool[bytes].push_back(p); ctx->pool_bytes += bytes; return 0; }
+    if (ctx->pool_bytes + bytes <= ctx->pool_max || ctx->capturing || in_slab(ctx, p)) { ctx->pool[bytes].push_back(p); ctx->pool_bytes += bytes; return 0; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(p));
     return 0;
@@ -395,15 +343,16 @@ static int alloc_buf(cn_ctx *ctx, int kind, uint32_t count, uint32_t size, cn_ha
     return 0;
 }
 extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) {
-    LOCK; if (size < 2 || size > 3) return fail(CN_ERR_ARG, "ciphertext size must be 2 or 3"); return alloc_buf(ctx, 0, count, size, out);
+    LOCK_ONLY; if (size < 2 || size > 3) return fail(CN_ERR_ARG, "ciphertext size must be 2 or 3"); return alloc_buf(ctx, 0, count, size, out);
 }
-extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { LOCK; return alloc_buf(ctx, 1, count, 1, out); }
+extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { LOCK_ONLY; return alloc_buf(ctx, 1, count, 1, out); }
 extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
-    LOCK;
+    LOCK_ONLY;
     auto it = ctx->bufs.find(h);
     if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    if (it->second.kind == 2) { NOT_CAPTURING("releasing a GEMM plan"); CHECK(free_gemm_plan(ctx, it->second)); }
-    else if (it->second.kind == 3) { NOT_CAPTURING("releasing a graph"); CHECK(free_graph(ctx, it->second)); }
+    if (it->second.kind == 2) { NOT_CAPTURING("releasing a GEMM plan"); CHECK(cn_defer_flush(ctx)); CHECK(free_gemm_plan(ctx, it->second)); }
+    else if (it->second.kind == 3) { NOT_CAPTURING("releasing a graph"); CHECK(cn_defer_flush(ctx)); CHECK(free_graph(ctx, it->second)); }
+    else if (cn_defer_pending(ctx)) ctx->dq->frees.emplace_back(it->second.d, it->second.item_words * 8 * it->second.count);   // queued calls may still read it
     else CHECK(dev_release(ctx, it->second.d, it->second.item_words * 8 * it->second.count));
     ctx->bufs.erase(it);
     return 0;
@@ -438,6 +387,10 @@ extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) {
     std::shared_ptr<CapturedGraph> g = std::make_shared<CapturedGraph>();
     hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
     if (e != hipSuccess || !g->graph) { (void)hipGetLastError(); ctx->cap_staged.clear(); ctx->cap_allocs.clear(); return fail(CN_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e)); }
+    if (!graph) {                                              // nowhere to put the handle: drop the recording (nothing was reserved yet)
+        (void)hipGraphDestroy(g->graph); ctx->cap_staged.clear(); ctx->cap_allocs.clear();
+        return fail(CN_ERR_ARG, "null argument");
+    }
     e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(g->graph); ctx->cap_staged.clear(); ctx->cap_allocs.clear(); return fail(CN_ERR_HIP, "graph instantiation failed: %s", hipGetErrorString(e)); }
     g->staged = std::move(ctx->cap_staged); ctx->cap_staged.clear();
@@ -451,7 +404,6 @@ extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) {
         g->reserved.push_back(a);
     }
     ctx->cap_allocs.clear();
-    if (!graph) return fail(CN_ERR_ARG, "null argument");
     Buffer b; b.kind = 3; b.count = 0; b.size = 0; b.d = nullptr; b.item_words = 0; b.cg = g;
     cn_handle h = ctx->next_handle++;
     ctx->bufs[h] = std::move(b);
@@ -467,7 +419,7 @@ extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) {
     ctx->st.kernel_launches += 1;
     return 0;
 }
-extern "C" int cn_live_handles(cn_ctx *ctx) { std::lock_guard<std::mutex> lk(ctx->mu); return (int)ctx->bufs.size(); }
+extern "C" int cn_live_handles(cn_ctx *ctx) { std::lock_guard<CnMutex> lk(ctx->mu); return (int)ctx->bufs.size(); }
 extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
     LOCK; NOT_CAPTURING("cn_ct_upload"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -518,7 +470,7 @@ extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, 
     uint64_t *d = b->d + (size_t)pi * n;
     HIPCHK(hipMemcpyAsync(d, tmp.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    CHECK(run_ntt(ctx, d, 1, ctx->hc.k + ctx->hc.kb, 1, 1));
+    CHECK(cn_run_ntt(ctx, d, 1, ctx->hc.k + ctx->hc.kb, 1, 1));
     b->pt_zero[pi] = zero;
     return 0;
 }
@@ -531,7 +483,7 @@ extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *value
     CHECK(ensure_scratch(ctx, al((size_t)n * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, n);
     HIPCHK(hipMemcpyAsync(tmp, b->d + (size_t)pi * n, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    CHECK(run_ntt(ctx, tmp, 1, ctx->hc.k + ctx->hc.kb, 1, 0));
+    CHECK(cn_run_ntt(ctx, tmp, 1, ctx->hc.k + ctx->hc.kb, 1, 0));
     std::vector<uint64_t> host(n);
     HIPCHK(hipMemcpyAsync(host.data(), tmp, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -550,7 +502,7 @@ extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle ds
     return 0;
 }
 extern "C" int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<CnMutex> lk(ctx->mu);
     auto it = ctx->bufs.find(h);
     if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
     if (ptr) *ptr = it->second.d;
@@ -571,11 +523,19 @@ static int addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t b
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;
 }
+static bool deferring(cn_ctx *ctx);
+static int defer_addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op);
+static int defer_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count);
+static int defer_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out, uint32_t oi, uint32_t count);
 extern "C" int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 0)); ctx->st.Addition += count; return 0;
+    LOCK_ONLY;
+    if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, 0); if (rc <= 0) return rc; }      // > 0: not deferrable (size-3 operands)
+    CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 0)); ctx->st.Addition += count; return 0;
 }
 extern "C" int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 1)); ctx->st.Subtraction += count; return 0;
+    LOCK_ONLY;
+    if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, 1); if (rc <= 0) return rc; }
+    CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 1)); ctx->st.Subtraction += count; return 0;
 }
 extern "C" int cn_negate(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
     LOCK; return addsub(ctx, a, ai, a, ai, out, oi, count, 2);
@@ -595,7 +555,10 @@ extern "C" int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint3
     return 0;
 }
 extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    LOCK_ONLY;
+    if (deferring(ctx)) { int rc = defer_add_plain(ctx, a, ai, pt, pi, subtract, out, oi, count); if (rc <= 0) return rc; }
+    CHECK(cn_defer_flush(ctx));
+    GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
     if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     uint32_t limbs = count * A->size * ctx->hc.k;
@@ -607,22 +570,6 @@ extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
 }
 // out[c] = a[c * (a_bcast ? 0 : 1)] * pt[c * pstride]; a_bcast: ONE ciphertext against `count` plaintexts (row-dot batches)
 // Dense MultiplyPlain in two launches (k_lift_ntt, k_mul_plain_fused); ranges / zero plaintexts were checked by the caller
-template <int L, class AR> static void launch_mul_plain_fused(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride,
-                                                              uint32_t pstride, uint64_t *out, uint32_t count, uint32_t polys) {
-    const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
-    hipLaunchKernelGGL((k_lift_ntt<L, AR>), dim3(npt * c->hc.k), dim3(NttPlan<L>::NT), lds, c->stream, pt, pitch, lift, c->dc);
-    hipLaunchKernelGGL((k_mul_plain_fused<L, AR>), dim3(count * polys * c->hc.k), dim3(NttPlan<L>::NT), lds, c->stream, src, sstride, lift, pstride, out, c->dc, polys);
-}
-template <class AR> static void mul_plain_fused_by_size(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride,
-                                                        uint32_t pstride, uint64_t *out, uint32_t count, uint32_t polys) {
-    switch (c->hc.logn) {
-        case 10: launch_mul_plain_fused<10, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
-        case 11: launch_mul_plain_fused<11, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
-        case 12: launch_mul_plain_fused<12, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
-        case 13: launch_mul_plain_fused<13, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
-        default: launch_mul_plain_fused<14, AR>(c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys); break;
-    }
-}
 static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
     uint64_t *o = O->d + oi * O->item_words;
@@ -643,9 +590,7 @@ static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Bu
     const uint64_t *pt = P->d + (size_t)pi * n;
     const size_t sstride = a_bcast ? 0 : A->item_words;
     const uint32_t pitch = pstride ? pstride : 1u, ps = pstride ? 1u : 0u;
-    if (f64 && light) mul_plain_fused_by_size<ArF64L>(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
-    else if (f64) mul_plain_fused_by_size<ArF64>(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
-    else mul_plain_fused_by_size<ArU64>(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
+    rr_ops[f64 && light ? POL_F64L : (f64 ? POL_F64 : POL_U64)]->mul_plain_fused(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
     HIPCHK(hipGetLastError()); launch_count(ctx, 2);
     ctx->st.ntt_forward_limbs += (uint64_t)npt * k + (uint64_t)count * A->size * k; ctx->st.ntt_inverse_limbs += (uint64_t)count * A->size * k;
     ctx->st.PlainMultiplication += count;
@@ -655,6 +600,8 @@ static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buf
     if (!range_ok(A, ai, a_bcast ? 1 : count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1))
         return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
+    if (A == O && !a_bcast && ai != oi && ai < oi + count && oi < ai + count)          // block c writes out[c] while another block still reads in[c']
+        return fail(CN_ERR_ARG, "multiply_plain: input and output ranges overlap partially (use the same range or disjoint ranges)");
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
     for (uint32_t c = 0; c < npt; c++) if (P->pt_zero[pi + c * pstride]) return fail(CN_ERR_ZERO, "plain cannot be zero");
     if (ctx->mp_fused && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) return mul_plain_fused(ctx, A, ai, a_bcast, P, pi, pstride, O, oi, count);
@@ -663,7 +610,7 @@ static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buf
     // lift every referenced plaintext into the k limbs (one launch), NTT them
     hipLaunchKernelGGL(k_lift_plain, dim3(npt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, P->d + (size_t)pi * n, lift, ctx->dc, ctx->chunks, pstride ? pstride : 1u);
     HIPCHK(hipGetLastError()); launch_count(ctx);
-    CHECK(run_ntt(ctx, lift, npt * k, 0, k, 0));
+    CHECK(cn_run_ntt(ctx, lift, npt * k, 0, k, 0));
     uint64_t *o = O->d + oi * O->item_words;
     const uint64_t *src = A->d + ai * A->item_words;
     if (a_bcast) {
@@ -671,10 +618,10 @@ static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buf
             if (o + c * A->item_words != src) HIPCHK(hipMemcpyAsync(o + c * A->item_words, src, A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     } else if (o != src) HIPCHK(hipMemcpyAsync(o, src, count * A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     uint32_t limbs = count * A->size * k;
-    CHECK(run_ntt(ctx, o, limbs, 0, k, 0));
+    CHECK(cn_run_ntt(ctx, o, limbs, 0, k, 0));
     hipLaunchKernelGGL(k_dyadic_pt, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, o, lift, pstride ? 1u : 0u, ctx->dc, ctx->chunks, A->size);
     HIPCHK(hipGetLastError()); launch_count(ctx);
-    CHECK(run_ntt(ctx, o, limbs, 0, k, 1));
+    CHECK(cn_run_ntt(ctx, o, limbs, 0, k, 1));
     ctx->st.PlainMultiplication += count;
     return 0;
 }
@@ -706,14 +653,54 @@ extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64
 }
 
 // HOT LOOP A
-template <int MT>
-static void launch_gemm(cn_ctx *ctx, const uint64_t *in, const int32_t *idx, const uint64_t *Wl, const int32_t *oidx, const uint64_t *bias,
-                        const int32_t *bidx, uint64_t *out, uint32_t G, uint32_t M, uint32_t K, uint32_t lazy, uint32_t Kp, uint32_t obase) {
-    uint32_t mtiles = (M + MT - 1) / MT;
-    size_t blocks = (size_t)ctx->chunks * 2 * ctx->hc.k * mtiles * G;
-    hipLaunchKernelGGL(k_scalar_gemm<MT>, dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, in, idx, Wl, oidx, bias, bidx, out, ctx->dc,
-                       ctx->chunks, G, M, K, mtiles, lazy, Kp, obase);
+// weight tiles of a planned GEMM in kernel layout; row(g, m): the K weights (residues mod t) of member m of group g, or null
+template <class ROW> static void pack_gemm_weights(cn_ctx *ctx, uint32_t G, uint32_t M, uint32_t K, bool small, ROW row, uint32_t &MT, std::vector<char> &wbytes) {
+    const uint32_t k = ctx->hc.k; const uint64_t t = ctx->hc.t.q;
+    if (small) {
+        const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
+        std::vector<double> hWd((size_t)G * mtf * K * MTf + 8 * MTf, 0.0);   // [g][mtile][kk][m], zero padded; + 8 rows: the kernel's software
+                                                                               // pipeline reads (and multiplies by 0) up to 7 terms past a block
+        for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+            const uint64_t *wr = row(g, m);
+            if (!wr) continue;
+            double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
+            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
+        }
+        MT = MTf;
+        wbytes.assign((const char *)hWd.data(), (const char *)(hWd.data() + hWd.size()));
+    } else {
+        const uint32_t MTi = M >= 8 ? 10 : (M >= 3 ? 5 : 1), mti = (M + MTi - 1) / MTi;
+        std::vector<uint64_t> hW((size_t)k * G * mti * K * MTi, 0);         // [j][g][mtile][kk][m], zero padded
+        for (uint32_t j = 0; j < k; j++) for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+            const uint64_t *wr = row(g, m);
+            if (!wr) continue;
+            uint64_t *dst = &hW[((((size_t)j * G + g) * mti + m / MTi) * K) * MTi + m % MTi];
+            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
+        }
+        MT = MTi;
+        wbytes.assign((const char *)hW.data(), (const char *)(hW.data() + hW.size()));
+    }
 }
+// small signed weights (|w| < 2^20 after centring mod t - every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
+static bool gemm_weights_small(cn_ctx *ctx, const uint64_t *W, size_t count) {
+    for (size_t x = 0; x < count; x++) {
+        const uint64_t w = W[x], a = w >= ctx->hc.t_half ? ctx->hc.t.q - w : w;
+        if (a >> 20) return false;
+    }
+    return true;
+}
+struct GemmArith { bool small, two; uint32_t lazy; };
+static GemmArith gemm_arith(cn_ctx *ctx, bool weights_small) {
+    uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+    const int bits = 64 - __builtin_clzll(qmax);
+    GemmArith g;
+    g.small = weights_small && ctx->use_f64 && bits <= 49;       // the kernel folds its limb sums with exact-FP64 modular arithmetic (q < 2^49.4)
+    g.two = bits <= 44;                                          // 2 limbs of 22 bits, else 3 limbs of 17 bits
+    if (g.small) g.lazy = g.two ? 1024u : 32768u;                // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
+    else g.lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));   // products of two values < q_max in 128 bits
+    return g;
+}
+
 // A scalar GEMM is planned once per (gather table, weight matrix): validation, grouping of the outputs that share a gather list,
 // weight tiles in the kernel's layout.  A plan can live in HBM (cn_gemm_plan_create: the weights of a layer are uploaded once, every
 // inference only launches) or in the per-call scratch (cn_scalar_gemm).
@@ -734,7 +721,7 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
                            GemmPlan &P) {
     if (!O || !K || !W) return fail(CN_ERR_ARG, "empty scalar GEMM");
     if (bias_pt && (!BP || !bias_idx)) return fail(CN_ERR_ARG, "invalid bias plaintext handle");
-    const uint32_t k = ctx->hc.k; const uint64_t t = ctx->hc.t.q;
+    const uint64_t t = ctx->hc.t.q;
     // validate + default gather (identity) + reference semantics: zero weights are skipped, all-zero row is an error
     std::vector<int32_t> gidx((size_t)O * K);
     for (uint32_t o = 0; o < O; o++) {
@@ -770,43 +757,13 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
         }
     }
     for (size_t x = 0; x < member.size(); x++) if (member[x] != NONE) { hoidx[x] = (int32_t)member[x]; if (BP) hbidx[x] = bias_idx[member[x]]; }   // relative to the output base
-    // small signed weights (every PoolLayer weight round(w*scale) is): exact-FP64 limb-split kernel
-    uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
-    const int bits = 64 - __builtin_clzll(qmax);
-    bool small = ctx->use_f64 && bits <= 49;                     // the kernel folds its limb sums with exact-FP64 modular arithmetic (q < 2^49.4)
-    for (size_t x = 0; x < (size_t)O * K && small; x++) {
-        uint64_t w = W[x], a = w >= ctx->hc.t_half ? t - w : w;
-        if (a >> 20) small = false;
-    }
+    const GemmArith ar = gemm_arith(ctx, gemm_weights_small(ctx, W, (size_t)O * K));
+    const bool small = ar.small;
     P.O = O; P.K = K; P.Kp = Kp; P.G = G; P.M = M; P.small = small; P.has_bias = BP != nullptr; P.bias_pt = bias_pt; P.bias_count = BP ? BP->count : 0;
+    P.two = ar.two; P.lazy = ar.lazy;
     std::vector<char> wbytes;
-    if (small) {
-        const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
-        std::vector<double> hWd((size_t)G * mtf * K * MTf + 8 * MTf, 0.0);   // [g][mtile][kk][m], zero padded; + 8 rows: the kernel's software
-                                                                               // pipeline reads (and multiplies by 0) up to 7 terms past a block
-        for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
-            if (member[(size_t)g * M + m] == NONE) continue;
-            const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
-            double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
-            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
-        }
-        P.MT = MTf; P.two = bits <= 44;                     // 2 limbs of 22 bits, else 3 limbs of 17 bits
-        P.lazy = P.two ? 1024u : 32768u;                     // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
-        wbytes.assign((const char *)hWd.data(), (const char *)(hWd.data() + hWd.size()));
-    } else {
-        const uint32_t MTi = M >= 8 ? 10 : (M >= 3 ? 5 : 1), mti = (M + MTi - 1) / MTi;
-        std::vector<uint64_t> hW((size_t)k * G * mti * K * MTi, 0);         // [j][g][mtile][kk][m], zero padded
-        for (uint32_t j = 0; j < k; j++) for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
-            if (member[(size_t)g * M + m] == NONE) continue;
-            const uint64_t *wr = W + (size_t)member[(size_t)g * M + m] * K;
-            uint64_t *dst = &hW[((((size_t)j * G + g) * mti + m / MTi) * K) * MTi + m % MTi];
-            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
-        }
-        P.MT = MTi;
-        // lazy-reduction interval: K' products of two values < q_max fit in 128 bits
-        P.lazy = (2 * bits >= 127) ? 1u : (uint32_t)std::min<uint64_t>(1u << 20, 1ull << (127 - 2 * bits));
-        wbytes.assign((const char *)hW.data(), (const char *)(hW.data() + hW.size()));
-    }
+    pack_gemm_weights(ctx, G, M, K, small, [&](uint32_t g, uint32_t m) -> const uint64_t * {
+        return member[(size_t)g * M + m] == NONE ? nullptr : W + (size_t)member[(size_t)g * M + m] * K; }, P.MT, wbytes);
     P.off_oidx = al(hidx.size() * 4); P.off_bidx = P.off_oidx + al(hoidx.size() * 4); P.off_w = P.off_bidx + al(hbidx.size() * 4);
     P.host.assign(P.off_w + al(wbytes.size()), 0);
     memcpy(P.host.data(), hidx.data(), hidx.size() * 4);
@@ -826,22 +783,9 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
         if (!BP || BP->count < P.bias_count) return fail(CN_ERR_ARG, "invalid bias plaintext handle");
         bias = BP->d;
     }
-    const int32_t *didx = (const int32_t *)tables, *doidx = (const int32_t *)(tables + P.off_oidx), *dbidx = (const int32_t *)(tables + P.off_bidx);
-    const uint32_t k = ctx->hc.k, G = P.G, M = P.M, K = P.K, Kp = P.Kp, lazy = P.lazy;
-    if (P.small) {
-        const double *dWd = (const double *)(tables + P.off_w);
-#define GEMM_F64(MT_) do { uint32_t mtiles = (M + MT_ - 1) / MT_; size_t blocks = (size_t)ctx->chunks * 2 * k * mtiles * G; \
-        if (P.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 2, 22>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp, oi); \
-        else hipLaunchKernelGGL((k_scalar_gemm_f64<MT_, 3, 17>), dim3((uint32_t)blocks), dim3(ctx->bs), 0, ctx->stream, I->d, didx, dWd, doidx, bias, dbidx, OB->d, ctx->dc, ctx->chunks, G, M, K, mtiles, lazy, Kp, oi); } while (0)
-        if (P.MT == 20) GEMM_F64(20); else if (P.MT == 10) GEMM_F64(10); else if (P.MT == 5) GEMM_F64(5); else GEMM_F64(1);
-#undef GEMM_F64
-    } else {
-        const uint64_t *dW = (const uint64_t *)(tables + P.off_w);
-        if (P.MT == 10) launch_gemm<10>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp, oi);
-        else if (P.MT == 5) launch_gemm<5>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp, oi);
-        else launch_gemm<1>(ctx, I->d, didx, dW, doidx, bias, dbidx, OB->d, G, M, K, lazy, Kp, oi);
-    }
-    HIPCHK(hipGetLastError()); launch_count(ctx);
+    GemmLaunch gl{P.small, P.two, false, P.MT, I->d, tables, tables + P.off_w, tables + P.off_oidx, bias, tables + P.off_bidx, OB->d,
+                  P.G, P.M, P.K, P.lazy, P.Kp, oi};
+    CHECK(cn_l_gemm(ctx, gl));
     ctx->st.PlainMultiplication += P.nnz; ctx->st.Addition += P.nnz - P.O;
     if (P.has_bias) ctx->st.PlainAddition += P.O;
     return 0;
@@ -881,34 +825,7 @@ extern "C" int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_
 }
 
 // ---------------------------------------------------------------- BEHZ multiply / key switching
-template <int K> static void launch_extend(cn_ctx *c, const uint64_t *src, uint32_t stride, uint64_t *aq, uint64_t *ab, uint32_t cnt) {
-    if (c->hc.behz_f64 && c->use_f64) hipLaunchKernelGGL(k_behz_extend_f64<K>, dim3(cnt * 2 * c->chunks), dim3(c->bs), 0, c->stream, src, stride, aq, ab, c->dc, c->chunks);
-    else hipLaunchKernelGGL(k_behz_extend<K>, dim3(cnt * 2 * c->chunks), dim3(c->bs), 0, c->stream, src, stride, aq, ab, c->dc, c->chunks);
-}
-template <int K> static void launch_floor(cn_ctx *c, const uint64_t *dq, const uint64_t *db, uint64_t *out, uint32_t cnt) {
-    if (c->hc.behz_f64 && c->use_f64) hipLaunchKernelGGL(k_behz_floor_f64<K>, dim3(cnt * 3 * c->chunks), dim3(c->bs), 0, c->stream, dq, db, out, c->dc, c->chunks);
-    else hipLaunchKernelGGL(k_behz_floor<K>, dim3(cnt * 3 * c->chunks), dim3(c->bs), 0, c->stream, dq, db, out, c->dc, c->chunks);
-}
-#define DISPATCH_K(fn, ...) switch (ctx->hc.k) { \
-    case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; \
-    case 4: fn<4>(__VA_ARGS__); break; case 5: fn<5>(__VA_ARGS__); break; case 6: fn<6>(__VA_ARGS__); break; \
-    case 7: fn<7>(__VA_ARGS__); break; case 8: fn<8>(__VA_ARGS__); break; case 9: fn<9>(__VA_ARGS__); break; \
-    default: return fail(CN_ERR_ARG, "ciphertext multiply supports at most 9 coefficient moduli"); }
-
 // tensor product fused into the inverse transform (register-radix sizes only); returns false when the caller must fall back
-template <int L, class AR> static void launch_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
-    hipLaunchKernelGGL((k_intt_tensor<L, AR>), dim3(cnt * 3 * Lm), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, A, B, D, c->dc, base_off, Lm);
-}
-template <class AR> static bool intt_tensor_by_size(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
-    switch (c->hc.logn) {
-        case 10: launch_intt_tensor<10, AR>(c, A, B, D, cnt, base_off, Lm); return true;
-        case 11: launch_intt_tensor<11, AR>(c, A, B, D, cnt, base_off, Lm); return true;
-        case 12: launch_intt_tensor<12, AR>(c, A, B, D, cnt, base_off, Lm); return true;
-        case 13: launch_intt_tensor<13, AR>(c, A, B, D, cnt, base_off, Lm); return true;
-        case 14: launch_intt_tensor<14, AR>(c, A, B, D, cnt, base_off, Lm); return true;
-        default: return false;
-    }
-}
 static bool run_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
     if (c->legacy_ntt || c->hc.logn < 10 || c->hc.logn > 14) return false;
     bool f64 = c->use_f64, light = true;
@@ -917,26 +834,11 @@ static bool run_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uin
         uint64_t q = m < c->hc.k ? c->hc.q[m].q : c->hc.bsk[m - c->hc.k].q;
         if (q >> 44) light = false;
     }
-    bool ok = (f64 && light) ? intt_tensor_by_size<ArF64L>(c, A, B, D, cnt, base_off, Lm)
-              : f64         ? intt_tensor_by_size<ArF64>(c, A, B, D, cnt, base_off, Lm)
-                            : intt_tensor_by_size<ArU64>(c, A, B, D, cnt, base_off, Lm);
+    bool ok = rr_ops[f64 && light ? POL_F64L : (f64 ? POL_F64 : POL_U64)]->intt_tensor(c, A, B, D, cnt, base_off, Lm);
     if (ok) { launch_count(c); c->st.ntt_inverse_limbs += (uint64_t)cnt * 3 * Lm; }
     return ok;
 }
 // squaring: forward transforms, tensor and inverse transforms of one (ciphertext, limb) in ONE kernel (FP64 policies)
-template <int L, class AR> static void launch_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
-    hipLaunchKernelGGL((k_square_fused<L, AR>), dim3(cnt * Lm), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, A, astride, D, c->dc, base_off, Lm);
-}
-template <class AR> static bool square_fused_by_size(cn_ctx *c, const uint64_t *A, size_t astride, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
-    switch (c->hc.logn) {
-        case 10: launch_square_fused<10, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
-        case 11: launch_square_fused<11, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
-        case 12: launch_square_fused<12, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
-        case 13: launch_square_fused<13, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
-        case 14: launch_square_fused<14, AR>(c, A, astride, D, cnt, base_off, Lm); return true;
-        default: return false;
-    }
-}
 static bool square_fused_ok(cn_ctx *c, uint32_t base_off, uint32_t Lm, bool &light) {
     if (!c->sq_fused || c->legacy_ntt || !c->use_f64 || c->hc.logn < 10 || c->hc.logn > 14) return false;
     light = true;
@@ -947,8 +849,8 @@ static bool square_fused_ok(cn_ctx *c, uint32_t base_off, uint32_t Lm, bool &lig
     }
     return true;
 }
-static void run_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm, bool light) {
-    if (light) square_fused_by_size<ArF64L>(c, A, astride, D, cnt, base_off, Lm); else square_fused_by_size<ArF64>(c, A, astride, D, cnt, base_off, Lm);
+static void run_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm, bool light) {
+    rr_ops[light ? POL_F64L : POL_F64]->square_fused(c, A, astride, atab, D, cnt, base_off, Lm);
     launch_count(c);
     c->st.ntt_forward_limbs += (uint64_t)cnt * 2 * Lm; c->st.ntt_inverse_limbs += (uint64_t)cnt * 3 * Lm;
 }
@@ -957,10 +859,12 @@ static size_t mul_scratch_per_ct(cn_ctx *c, bool square) {
     size_t w = (square ? 1 : 2) * 2 * (k + kb) * n + 3 * (k + kb) * n;
     return al(w * 8) + 1024;
 }
-// a, b: pointers to first operand ciphertext (size 2); out3: [cnt][3][k][N]; scratch must be ensured by caller
-static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const uint64_t *b, uint32_t bstride, uint64_t *out3, uint32_t cnt) {
+// a, b: pointers to first operand ciphertext (size 2); out3: [cnt][3][k][N]; scratch must be ensured by caller.  atab / btab: one
+// operand address per ciphertext instead of a + ct*astride*ctw (deferred per-ciphertext calls; atab == btab: squarings)
+static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const uint64_t *b, uint32_t bstride, uint64_t *out3, uint32_t cnt,
+                       const uint64_t *const *atab = nullptr, const uint64_t *const *btab = nullptr) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, kb = ctx->hc.kb;
-    const bool square = (a == b && astride == bstride);
+    const bool square = atab ? atab == btab : (a == b && astride == bstride);
     // squarings on the FP64 path: one fused kernel per base does forward transforms, tensor and inverse transforms; its q side reads the
     // input ciphertexts in place, so k_behz_extend only has to produce the Bsk limbs
     bool lq = false, lb = false;
@@ -970,86 +874,28 @@ static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const u
     if (!square) { bq = salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n); bb = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n); }
     uint64_t *dq = salloc<uint64_t>(ctx, (size_t)cnt * 3 * k * n), *db = salloc<uint64_t>(ctx, (size_t)cnt * 3 * kb * n);
     if ((!fused && !aq) || !ab || (!square && (!bq || !bb)) || !dq || !db) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply");
-    DISPATCH_K(launch_extend, ctx, a, astride, aq, ab, cnt);
-    if (!square) { DISPATCH_K(launch_extend, ctx, b, bstride, bq, bb, cnt); }
-    HIPCHK(hipGetLastError()); launch_count(ctx, square ? 1 : 2);
+    CHECK(cn_l_behz_extend(ctx, a, astride, atab, aq, ab, cnt));
+    if (!square) CHECK(cn_l_behz_extend(ctx, b, bstride, btab, bq, bb, cnt));
     if (fused) {
-        run_square_fused(ctx, a, (size_t)astride * 2 * k * n, dq, cnt, 0, k, lq); run_square_fused(ctx, ab, (size_t)2 * kb * n, db, cnt, k, kb, lb);
+        run_square_fused(ctx, a, (size_t)astride * 2 * k * n, atab, dq, cnt, 0, k, lq); run_square_fused(ctx, ab, (size_t)2 * kb * n, nullptr, db, cnt, k, kb, lb);
     } else {
-    CHECK(run_ntt(ctx, aq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, ab, cnt * 2 * kb, k, kb, 0));
-    if (!square) { CHECK(run_ntt(ctx, bq, cnt * 2 * k, 0, k, 0)); CHECK(run_ntt(ctx, bb, cnt * 2 * kb, k, kb, 0)); }
+    CHECK(cn_run_ntt(ctx, aq, cnt * 2 * k, 0, k, 0)); CHECK(cn_run_ntt(ctx, ab, cnt * 2 * kb, k, kb, 0));
+    if (!square) { CHECK(cn_run_ntt(ctx, bq, cnt * 2 * k, 0, k, 0)); CHECK(cn_run_ntt(ctx, bb, cnt * 2 * kb, k, kb, 0)); }
     if (!run_intt_tensor(ctx, aq, bq, dq, cnt, 0, k) || !run_intt_tensor(ctx, ab, bb, db, cnt, k, kb)) {
         hipLaunchKernelGGL(k_tensor, dim3(cnt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, aq, bq, dq, ctx->dc, ctx->chunks, k, 0u);
         hipLaunchKernelGGL(k_tensor, dim3(cnt * kb * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ab, bb, db, ctx->dc, ctx->chunks, kb, k);
         HIPCHK(hipGetLastError()); launch_count(ctx, 2);
-        CHECK(run_ntt(ctx, dq, cnt * 3 * k, 0, k, 1)); CHECK(run_ntt(ctx, db, cnt * 3 * kb, k, kb, 1));
+        CHECK(cn_run_ntt(ctx, dq, cnt * 3 * k, 0, k, 1)); CHECK(cn_run_ntt(ctx, db, cnt * 3 * kb, k, kb, 1));
     }
     }
     HIPCHK(hipGetLastError());
-    DISPATCH_K(launch_floor, ctx, dq, db, out3, cnt);
-    HIPCHK(hipGetLastError()); launch_count(ctx);
+    CHECK(cn_l_behz_floor(ctx, dq, db, out3, cnt));
     ctx->st.Multiplication += cnt;
     return 0;
 }
-// One key switch of `cnt` ciphertexts: out[ct] = (add0[ct], add1[ct]) + KeySwitch(target[ct]) (+ extra[ct] - the fused accumulator of
-// the cn_*_add entry points).  target / add0 / add1 / extra are strided per ciphertext (in words), out is dense size-2.
-struct KsArgs {
-    const uint64_t *target; size_t tstride;
-    const uint64_t *add0, *add1; size_t astride;
-    const uint64_t *key; uint64_t *out; uint32_t cnt; int galois;
-    const uint64_t *extra; size_t xstride;
-    uint32_t accmax;          // FP64 accumulators: terms between recentrings
-    int mode;                 // 0 fused, 1 two launches / workgroup per digit, 2 two launches / workgroup per source limb
-};
 template <int EPT> static void launch_ks_legacy(cn_ctx *c, uint32_t nt, const KsArgs &a) {
     hipLaunchKernelGGL(k_keyswitch<EPT>, dim3(a.cnt * c->hc.k), dim3(nt), (size_t)c->hc.n * 8, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride, a.key,
-                       a.out, c->dc, a.galois);
-}
-// the LDS copy of the twiddle table pays once a workgroup runs enough digit transforms of its modulus
-static const uint32_t KS_TWL_MIN_DIGITS = 12;
-template <int L, class AR, int MINW = 1> static void launch_ks_fused(cn_ctx *c, const KsArgs &a) {
-    const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot;
-    if constexpr (KsFwd<AR, L>::lds && MINW == 1) {
-        if (tot >= KS_TWL_MIN_DIGITS) {
-            const size_t lds = ks_twl_lds<L>();
-            hipLaunchKernelGGL((k_keyswitch_rr<L, AR, 1, true>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, a.add0, a.add1,
-                               a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((k_keyswitch_rr<L, AR, MINW>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, a.target, a.tstride,
-                       a.add0, a.add1, a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride);
-}
-template <int L, class AR> static void launch_ks_two_phase(cn_ctx *c, const KsArgs &a) {
-    const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;
-    const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
-    if (a.mode == 2) {              // one partial per (ct, source limb): k*k workgroups per ciphertext, k partials to sum
-        hipLaunchKernelGGL((k_ks_limb_mac<L, AR>), dim3(a.cnt * k * k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, (const void *)a.key, c->ks_part,
-                           c->dc, a.galois, a.accmax);
-        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(a.cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, a.add0, a.add1, a.astride,
-                           a.out, c->dc, k, 0xffffffffu, a.extra, a.xstride);
-    } else {                        // one partial per (ct, digit)
-        hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(a.cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, (const void *)a.key, c->ks_part,
-                           c->dc, a.galois, tot);
-        hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(a.cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, a.add0, a.add1, a.astride,
-                           a.out, c->dc, tot, a.accmax, a.extra, a.xstride);
-    }
-    launch_count(c);
-}
-template <int L, class AR> static void launch_ks_rr(cn_ctx *c, const KsArgs &a) {
-    if (a.mode) { launch_ks_two_phase<L, AR>(c, a); return; }
-    if constexpr (L == 13) { if (c->ks_tight) { launch_ks_fused<L, AR, 4>(c, a); return; } }      // 128-VGPR variant (A/B only)
-    launch_ks_fused<L, AR>(c, a);
-}
-template <class AR> static bool launch_ks_by_size(cn_ctx *c, const KsArgs &a) {
-    switch (c->hc.logn) {
-        case 10: launch_ks_rr<10, AR>(c, a); return true;
-        case 11: launch_ks_rr<11, AR>(c, a); return true;
-        case 12: launch_ks_rr<12, AR>(c, a); return true;
-        case 13: launch_ks_rr<13, AR>(c, a); return true;
-        case 14: launch_ks_rr<14, AR>(c, a); return true;
-        default: return false;
-    }
+                       a.out, c->dc, a.galois, a.out_tab);
 }
 static int ensure_ks_part(cn_ctx *ctx, size_t need) {
     if (need <= ctx->ks_part_cap) return 0;
@@ -1065,13 +911,14 @@ static int ensure_ks_part(cn_ctx *ctx, size_t need) {
 // every source limb does; above that the fused kernel fills the chip by itself.
 static const uint32_t KS_DIGIT_MAX_BLOCKS = 32, KS_WIDE_MAX_BLOCKS = 160;
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
-                        const KsKey &key, uint64_t *out, uint32_t cnt, int galois, const uint64_t *extra = nullptr, size_t xstride = 0) {
+                        const KsKey &key, uint64_t *out, uint32_t cnt, int galois, const uint64_t *extra = nullptr, size_t xstride = 0,
+                        uint64_t *const *out_tab = nullptr) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
     KsArgs a{target, tstride, add0, add1, astride, key.d, out, cnt, galois, extra, xstride,
              key.f64 ? (bits >= 50 ? 1u : (1u << std::min(10, 50 - bits))) : 0xffffffffu,     // lazy FP64 accumulators: |term| <= 2.1 q, sum below 2^52
-             0};
+             0, out_tab};
     const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;                // register-radix kernels available
     if (rr && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * k <= KS_WIDE_MAX_BLOCKS))) {
         // N = 16384: 1024-thread workgroups cannot hold two accumulator sets without spilling -> per-digit only
@@ -1081,20 +928,16 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     }
     if (a.mode == 0 && rr && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14) {   // N = 16384 as two 8192-point halves per limb
         CHECK(ensure_ks_part(ctx, (size_t)cnt * ctx->ctw2 * 8));
-        const size_t lds = (size_t)ntt_lds_words(8192) * 8;
-        if (bits <= 44) hipLaunchKernelGGL((k_keyswitch_split14<ArF64L>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
-                                           (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, a.accmax);
-        else hipLaunchKernelGGL((k_keyswitch_split14<ArF64>), dim3(cnt * k * 2), dim3(NttPlan<13>::NT), lds, ctx->stream, target, tstride,
-                                (const void *)key.d, (uint64_t *)ctx->ks_part, ctx->dc, galois, a.accmax);
+        ks_ops[bits <= 44 ? POL_F64L : POL_F64]->split14(ctx, a);
         hipLaunchKernelGGL(k_ks_combine14, dim3(cnt * 2 * k * (n / 512)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ks_part, add0, add1, astride, out, ctx->dc,
-                           extra, xstride);
+                           extra, xstride, out_tab);
         launch_count(ctx);
     } else {
         bool done = false;
         if (key.f64) {
-            done = rr && (bits <= 44 ? launch_ks_by_size<ArF64L>(ctx, a) : launch_ks_by_size<ArF64>(ctx, a));
+            done = rr && ks_ops[bits <= 44 ? POL_F64L : POL_F64]->launch(ctx, a);
             if (!done) return fail(CN_ERR_ARG, "internal: FP64 key without FP64 kernel");
-        } else if (rr) done = launch_ks_by_size<ArU64>(ctx, a);
+        } else if (rr) done = ks_ops[POL_U64]->launch(ctx, a);
         if (!done) {                          // radix-2 LDS fallback (N < 1024, legacy_ntt): no fused accumulator -> one element-wise add behind it
             const uint32_t nt = std::min<uint32_t>(1024, n);
             switch (n / nt) {
@@ -1106,7 +949,7 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
                 default: return fail(CN_ERR_ARG, "unsupported poly modulus degree for key switching");
             }
             if (extra) {
-                if (xstride != ctx->ctw2) return fail(CN_ERR_ARG, "internal: accumulator stride");
+                if (xstride != ctx->ctw2 || out_tab) return fail(CN_ERR_ARG, "internal: accumulator stride");
                 hipLaunchKernelGGL(k_addsub, dim3(cnt * 2 * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, out, extra, out, ctx->dc, ctx->chunks, 0);
                 launch_count(ctx);
             }
@@ -1148,7 +991,10 @@ extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle
 }
 extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out,
                             uint32_t oi, uint32_t count) {
-    LOCK; GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out, 2);
+    LOCK_ONLY;
+    if (deferring(ctx)) return defer_mul_relin(ctx, a, ai, astride, b, bi, bstride, out, oi, count);
+    CHECK(cn_defer_flush(ctx));
+    GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out, 2);
     if (!range_ok(A, ai, astride ? count : 1, astride ? astride : 1) || !range_ok(B, bi, bstride ? count : 1, bstride ? bstride : 1) || !range_ok(O, oi, count))
         return fail(CN_ERR_ARG, "index out of range");
     if (!ctx->rlk.d) return fail(CN_ERR_NOKEY, "relinearization keys not set");
@@ -1306,8 +1152,8 @@ static int set_plain_key(cn_ctx *ctx, uint64_t **slot, const uint64_t *words, si
     HIPCHK(hipMemcpy(*slot, words, expect * 8, hipMemcpyHostToDevice));
     return 0;
 }
-extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2); }
-extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); }
+extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; NOT_CAPTURING("cn_set_public_key"); return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2); }
+extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; NOT_CAPTURING("cn_set_secret_key"); return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); }
 // which: 0 relin, 1 galois(elt), 2 public, 3 secret.  Exports u64 residues (FP64-form keys are converted back).
 extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, size_t count) {
     LOCK; NOT_CAPTURING("cn_get_key");
@@ -1324,7 +1170,7 @@ extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, 
     return 0;
 }
 static int sample_poly(cn_ctx *ctx, uint64_t *dst, uint32_t polys, int kind, uint64_t seed, uint64_t stream) {
-    hipLaunchKernelGGL(k_sample, dim3(polys * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, dst, ctx->dc, ctx->chunks, kind, seed, stream, ctx->rng_item);
+    hipLaunchKernelGGL(k_sample, dim3(polys * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, dst, ctx->dc, ctx->chunks, kind, seed, stream, ctx->rng_item, ctx->rng_salt);
     HIPCHK(hipGetLastError()); launch_count(ctx);
     ctx->rng_item += polys;
     return 0;
@@ -1338,7 +1184,7 @@ static int gen_ksk(cn_ctx *ctx, const uint64_t *snew, int dbc, const uint32_t *d
         for (uint32_t d = 0; d < dig[l]; d++, p += 2 * kn) {
             CHECK(sample_poly(ctx, p + kn, 1, 2, seed, 3));                 // a: uniform, directly in the NTT domain
             CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
-            CHECK(run_ntt(ctx, e, k, 0, k, 0));
+            CHECK(cn_run_ntt(ctx, e, k, 0, k, 0));
             hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, p + kn, e, ctx->sk, snew, (uint64_t)f, (int)l, p, ctx->dc, ctx->chunks);
             HIPCHK(hipGetLastError()); launch_count(ctx);
             f = (f << dbc) % ql;
@@ -1359,6 +1205,8 @@ static int adopt_ksk(cn_ctx *ctx, KsKey &slot, uint64_t *dev, size_t words) {   
     }
     return 0;
 }
+// second 64 bits of sampler key material: XOR-ed into the counter word of every Philox block keygen / encrypt draw from now on
+extern "C" int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt) { LOCK; ctx->rng_salt = salt; return 0; }
 // KeyGenerator (AtomicSealBfvVector.cs:62-74,163-173 runs it inside SEAL): secret, public, relinearisation and the default Galois
 // key set (2N-1, 3^(2^i), 3^(-2^i)) generated on the device from a Philox stream.
 extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
@@ -1370,11 +1218,11 @@ extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
     uint64_t *e = salloc<uint64_t>(ctx, kn), *snew = salloc<uint64_t>(ctx, kn), *tmp = salloc<uint64_t>(ctx, kn);
     ctx->rng_item = 0;
     CHECK(sample_poly(ctx, ctx->sk, 1, 0, seed, 0));
-    CHECK(run_ntt(ctx, ctx->sk, k, 0, k, 0));
+    CHECK(cn_run_ntt(ctx, ctx->sk, k, 0, k, 0));
     // public key (-(a s + e), a)
     CHECK(sample_poly(ctx, ctx->pk + kn, 1, 2, seed, 3));
     CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
-    CHECK(run_ntt(ctx, e, k, 0, k, 0));
+    CHECK(cn_run_ntt(ctx, e, k, 0, k, 0));
     hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->pk + kn, e, ctx->sk, ctx->sk, 0ull, -1, ctx->pk, ctx->dc, ctx->chunks);
     HIPCHK(hipGetLastError());
     // relinearisation key: target s^2
@@ -1392,10 +1240,10 @@ extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
         size_t gw = cn_key_words(ctx, 1);
         for (uint64_t elt : elts) {
             HIPCHK(hipMemcpyAsync(tmp, ctx->sk, kn * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            CHECK(run_ntt(ctx, tmp, k, 0, k, 1));
+            CHECK(cn_run_ntt(ctx, tmp, k, 0, k, 1));
             hipLaunchKernelGGL(k_galois, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, tmp, snew, ctx->dc, ctx->chunks, elt);
             HIPCHK(hipGetLastError());
-            CHECK(run_ntt(ctx, snew, k, 0, k, 0));
+            CHECK(cn_run_ntt(ctx, snew, k, 0, k, 0));
             uint64_t *gk; HIPCHK(hipMalloc((void **)&gk, gw * 8));
             CHECK(gen_ksk(ctx, snew, ctx->hc.gdbc, ctx->hc.gk_dig, ctx->hc.gk_tot, seed, gk, e));
             CHECK(adopt_ksk(ctx, ctx->gk[elt], gk, gw));
@@ -1404,22 +1252,9 @@ extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
-template <int L, class AR> static void launch_enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0) {
-    hipLaunchKernelGGL((k_encrypt_tail<L, AR>), dim3(cnt * 2 * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, u, c->pk, pt, pts, out, c->dc, seed, item0);
-}
-template <class AR> static bool enc_tail_by_size(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0) {
-    switch (c->hc.logn) {
-        case 10: launch_enc_tail<10, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
-        case 11: launch_enc_tail<11, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
-        case 12: launch_enc_tail<12, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
-        case 13: launch_enc_tail<13, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
-        case 14: launch_enc_tail<14, AR>(c, u, pt, pts, out, cnt, seed, item0); return true;
-        default: return false;
-    }
-}
 // Encryptor.Encrypt (AtomicSealBfvVector.cs:1211,1227): (pk0 u + e1 + Delta m [+ r_t(q)], pk1 u + e2); pt = 0 encrypts zero
 extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) {
-    LOCK; GETCT(O, out, 2);
+    LOCK; NOT_CAPTURING("cn_encrypt (a replayed graph would reuse its randomness)"); GETCT(O, out, 2);
     if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
     if (!range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
@@ -1431,10 +1266,9 @@ extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_st
     uint64_t *u = salloc<uint64_t>(ctx, (size_t)count * kn);
     const uint64_t item0 = ctx->rng_item;
     CHECK(sample_poly(ctx, u, count, 0, seed, 0));
-    CHECK(run_ntt(ctx, u, count * k, 0, k, 0));
+    CHECK(cn_run_ntt(ctx, u, count * k, 0, k, 0));
     bool f64 = ctx->use_f64 && ctx->hc.q_f64;
-    bool ok = f64 ? enc_tail_by_size<ArF64>(ctx, u, ptd, pt_stride ? n : 0, O->d + oi * O->item_words, count, seed, item0)
-                  : enc_tail_by_size<ArU64>(ctx, u, ptd, pt_stride ? n : 0, O->d + oi * O->item_words, count, seed, item0);
+    bool ok = rr_ops[f64 ? POL_F64 : POL_U64]->enc_tail(ctx, u, ptd, pt_stride ? n : 0, O->d + oi * O->item_words, count, seed, item0);
     if (!ok) return fail(CN_ERR_ARG, "unsupported size");
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;
@@ -1454,16 +1288,16 @@ static int decrypt_phase(cn_ctx *ctx, Buffer *I, uint32_t ci, uint32_t count, ui
     uint64_t *tmp = salloc<uint64_t>(ctx, (size_t)count * kn), *sp = salloc<uint64_t>(ctx, kn);
     const uint64_t *base = I->d + ci * I->item_words;
     HIPCHK(hipMemcpy2DAsync(acc, kn * 8, base + kn, I->item_words * 8, kn * 8, count, hipMemcpyDeviceToDevice, ctx->stream));
-    CHECK(run_ntt(ctx, acc, count * k, 0, k, 0));
+    CHECK(cn_run_ntt(ctx, acc, count * k, 0, k, 0));
     hipLaunchKernelGGL(k_mul_limbs_bcast, dim3(count * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, acc, ctx->sk, (const uint64_t *)nullptr, acc, ctx->dc, ctx->chunks);
     if (I->size == 3) {
         hipLaunchKernelGGL(k_mul_limbs, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->sk, ctx->sk, sp, ctx->dc, ctx->chunks);
         HIPCHK(hipMemcpy2DAsync(tmp, kn * 8, base + 2 * kn, I->item_words * 8, kn * 8, count, hipMemcpyDeviceToDevice, ctx->stream));
-        CHECK(run_ntt(ctx, tmp, count * k, 0, k, 0));
+        CHECK(cn_run_ntt(ctx, tmp, count * k, 0, k, 0));
         hipLaunchKernelGGL(k_mul_limbs_bcast, dim3(count * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, tmp, sp, acc, acc, ctx->dc, ctx->chunks);
     }
     HIPCHK(hipGetLastError()); launch_count(ctx, 2);
-    return run_ntt(ctx, acc, count * k, 0, k, 1);
+    return cn_run_ntt(ctx, acc, count * k, 0, k, 1);
 }
 // Decryptor.Decrypt (AtomicSealBfvVector.cs:1042,1085): m = round(t (c0 + c1 s + c2 s^2) / q) mod t
 extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi) {
@@ -1494,10 +1328,306 @@ extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t co
     return 0;
 }
 
+
+// ---------------------------------------------------------------- deferred submission of per-ciphertext calls
+// The reference's layers call the evaluator one ciphertext at a time from Defaults.ThreadCount threads: PoolLayer.Apply issues one
+// DenseMatrixBySparseVectorMultiply + Add per (map, corner) (NeuralNetworks/PoolLayer.cs:113-121,182,214), ElementWiseMultiply one
+// Multiply + Relinearize per column (HE Wrapper/EncryptedSealBfvMatrix.cs:140-154), each through Utils.ParallelProcessInEnv
+// (HE Wrapper/Utils.cs:46-88).  With cn_set_option("defer", 1) such calls are not launched one by one: they are QUEUED with the device
+// addresses of their operands, ordered by a dependency level (read-after-write, write-after-read and write-after-write hazards on whole
+// ciphertexts), and flushed as a handful of batched launches - all pending calls of one level and one kind become ONE launch of the
+// same kernels the batched entry points use, reading their operands through address tables.  A flush happens when a call arrives
+// whose level is deeper than anything queued (the previous layer is then complete: its callers had to wait for it), when the queue is
+// full, and before every entry point that is not deferrable (cn_sync, downloads, rotations, key changes ...).  Results are the same
+// words as the immediate calls - every operation is exact modular arithmetic, batching changes no value.  Errors of a flush (HIP
+// failures) surface at the call that triggered it; argument errors are still reported by the call that made them.
+static const size_t DEFER_FLUSH_MIN = 64, DEFER_MAX_OPS = 32768;
+static DeferQueue *cn_defer_new() { return new DeferQueue(); }
+static void cn_defer_delete(DeferQueue *q) { delete q; }
+static bool cn_defer_pending(cn_ctx *ctx) { return ctx->dq && !ctx->dq->ops.empty(); }
+
+static int32_t defer_level(DeferQueue *q, const uint64_t *const *ins, uint32_t nin, const uint64_t *out) {
+    int32_t lv = 0;
+    for (uint32_t i = 0; i < nin; i++) {
+        if (!ins[i]) continue;
+        auto it = q->haz.find(ins[i]);
+        if (it != q->haz.end()) lv = std::max(lv, it->second.w + 1);
+    }
+    auto it = q->haz.find(out);
+    if (it != q->haz.end()) lv = std::max(lv, std::max(it->second.w, it->second.r) + 1);
+    return lv;
+}
+// queue one operation; ins: the ciphertexts it reads
+static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t nin) {
+    DeferQueue *q = ctx->dq;
+    int32_t lv = defer_level(q, ins, nin, op.out);
+    if ((lv > q->maxlevel && q->ops.size() >= DEFER_FLUSH_MIN) || q->ops.size() >= DEFER_MAX_OPS) {
+        // a deeper level opens: everything queued so far is complete (whoever produced this call's inputs has returned) - launch it
+        // now, so that the device works on the previous layer while the callers queue the next one
+        std::vector<uint64_t> ta, tw;
+        if (op.type == DOP_GEMM1) {                     // the terms of this call sit at the end of the term arrays: keep them over the flush
+            ta.assign(q->addr.begin() + op.terms, q->addr.end()); tw.assign(q->wt.begin() + op.terms, q->wt.end());
+            q->addr.resize(op.terms); q->wt.resize(op.terms);
+        }
+        CHECK(cn_defer_flush(ctx));
+        if (op.type == DOP_GEMM1) { op.terms = 0; q->addr = ta; q->wt = tw; }
+        lv = 0;
+    }
+    op.level = lv;
+    const int32_t me = (int32_t)q->ops.size();
+    for (uint32_t i = 0; i < nin; i++) {
+        if (!ins[i]) continue;
+        DeferQueue::Haz &h = q->haz[ins[i]];
+        h.r = std::max(h.r, lv); h.readers++;
+    }
+    DeferQueue::Haz &ho = q->haz[op.out];
+    ho.w = lv; ho.r = -1; ho.wop = me; ho.readers = 0;
+    q->maxlevel = std::max(q->maxlevel, lv);
+    q->ops.push_back(op);
+    return 0;
+}
+
+// element-wise kernels over address tables: entry c = {a, b, out} (b: second ciphertext or plaintext polynomial)
+struct Tab3 { const uint64_t *a, *b; uint64_t *out; };
+__global__ void k_addsub_tab(const Tab3 *__restrict__ tab, const DevConsts *__restrict__ C, uint32_t chunks, int op) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t per = 2 * C->k, ct = limb / per, l = limb % per;
+    const Tab3 t = tab[ct];
+    const uint64_t q = C->q[l % C->k].q; const size_t o = (size_t)l * C->n + i;
+    const uint64_t x = t.a[o];
+    t.out[o] = op == 0 ? addmod(x, t.b[o], q) : submod(x, t.b[o], q);
+}
+__global__ void k_add_plain_tab(const Tab3 *__restrict__ tab, const DevConsts *__restrict__ C, uint32_t chunks, int subtract) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, per = 2 * k, ct = limb / per, l = limb % per, j = l % k;
+    const Tab3 t = tab[ct];
+    const size_t o = (size_t)l * C->n + i;
+    uint64_t x = t.a[o];
+    if (l < k) {
+        const uint64_t s = scale_plain(C, t.b[i], j), q = C->q[j].q;
+        x = subtract ? submod(x, s, q) : addmod(x, s, q);
+    }
+    t.out[o] = x;
+}
+
+// all queued DenseMatrixBySparseVectorMultiply calls of one level with K terms each: ONE scalar GEMM over address tables
+static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> &ops, uint32_t K) {
+    // group the outputs that gather the same inputs (PoolLayer: every map of one corner shares its patch; a dense layer: one group)
+    std::map<std::vector<uint64_t>, std::vector<const DOp *>> groups;
+    for (const DOp *op : ops) groups[std::vector<uint64_t>(q->addr.begin() + op->terms, q->addr.begin() + op->terms + K)].push_back(op);
+    const uint32_t G = (uint32_t)groups.size();
+    uint32_t M = 0;
+    for (auto &g : groups) M = std::max<uint32_t>(M, (uint32_t)g.second.size());
+    const uint32_t Kp = ((K + 7) & ~7u) + 8;
+    std::vector<uint64_t> hidx((size_t)G * Kp, 0), hoidx((size_t)G * M, 0), hbidx((size_t)G * M, 0);
+    std::vector<const DOp *> member((size_t)G * M, nullptr);
+    bool any_bias = false;
+    const uint64_t *fallback = nullptr;
+    {
+        uint32_t g = 0;
+        for (auto &kv : groups) {
+            memcpy(&hidx[(size_t)g * Kp], kv.first.data(), (size_t)K * 8);
+            for (uint32_t m = 0; m < kv.second.size(); m++) {
+                const DOp *op = kv.second[m];
+                member[(size_t)g * M + m] = op; hoidx[(size_t)g * M + m] = (uint64_t)op->out; hbidx[(size_t)g * M + m] = (uint64_t)op->bias;
+                any_bias = any_bias || op->bias;
+            }
+            for (uint64_t a : kv.first) if (a && !fallback) fallback = (const uint64_t *)a;
+            g++;
+        }
+    }
+    bool wsmall = true;
+    for (const DOp *op : ops) wsmall = wsmall && gemm_weights_small(ctx, &q->wt[op->terms], K);
+    const GemmArith ar = gemm_arith(ctx, wsmall);
+    const bool small = ar.small, two = ar.two; const uint32_t lazy = ar.lazy; uint32_t MT = 1;
+    std::vector<char> wbytes;
+    pack_gemm_weights(ctx, G, M, K, small, [&](uint32_t g, uint32_t m) -> const uint64_t * { const DOp *op = member[(size_t)g * M + m]; return op ? &q->wt[op->terms] : nullptr; },
+                      MT, wbytes);
+    const size_t off_oidx = al(hidx.size() * 8), off_bidx = off_oidx + al(hoidx.size() * 8), off_w = off_bidx + al(hbidx.size() * 8);
+    std::vector<char> host(off_w + al(wbytes.size()), 0);
+    memcpy(host.data(), hidx.data(), hidx.size() * 8);
+    memcpy(host.data() + off_oidx, hoidx.data(), hoidx.size() * 8);
+    memcpy(host.data() + off_bidx, hbidx.data(), hbidx.size() * 8);
+    memcpy(host.data() + off_w, wbytes.data(), wbytes.size());
+    CHECK(ensure_scratch(ctx, al(host.size())));
+    char *tables; CHECK(upload_tmp(ctx, host.data(), host.size(), &tables));
+    GemmLaunch gl{small, two, true, MT, fallback, tables, tables + off_w, tables + off_oidx, nullptr, any_bias ? tables + off_bidx : nullptr, nullptr,
+                  G, M, K, lazy, Kp, 0};
+    return cn_l_gemm(ctx, gl);
+}
+static int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, int type) {
+    std::vector<Tab3> tab(ops.size());
+    for (size_t i = 0; i < ops.size(); i++) tab[i] = {ops[i]->a, ops[i]->b, ops[i]->out};
+    CHECK(ensure_scratch(ctx, al(tab.size() * sizeof(Tab3))));
+    Tab3 *dt; CHECK(upload_tmp(ctx, tab.data(), tab.size(), &dt));
+    const uint32_t limbs = (uint32_t)ops.size() * 2 * ctx->hc.k;
+    if (type == DOP_ADD || type == DOP_SUB) hipLaunchKernelGGL(k_addsub_tab, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, dt, ctx->dc, ctx->chunks, type == DOP_SUB);
+    else hipLaunchKernelGGL(k_add_plain_tab, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, dt, ctx->dc, ctx->chunks, type == DOP_SUBPLAIN);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    return 0;
+}
+static uint32_t chunk_for(cn_ctx *ctx, size_t per_ct, uint32_t count);
+// all queued Multiply + Relinearize calls of one level: the batched BEHZ pipeline + ONE key switch, operands and results through tables
+static int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all) {
+    const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
+    for (int sq = 1; sq >= 0; sq--) {                    // squarings (SquareActivation) take the fused kernel; general products the separate launches
+        std::vector<const DOp *> ops;
+        for (const DOp *op : all) if ((op->a == op->b) == (sq == 1)) ops.push_back(op);
+        if (ops.empty()) continue;
+        const size_t per = mul_scratch_per_ct(ctx, sq == 1) + al(3 * kn * 8) + 3 * 8 + 64;
+        const uint32_t ch = chunk_for(ctx, per, (uint32_t)ops.size());
+        for (uint32_t s0 = 0; s0 < ops.size(); s0 += ch) {
+            const uint32_t c = std::min<uint32_t>(ch, (uint32_t)ops.size() - s0);
+            CHECK(ensure_scratch(ctx, per * c + 3 * al((size_t)c * 8) + 8192));
+            std::vector<const uint64_t *> ha(c), hb(c); std::vector<uint64_t *> ho(c);
+            for (uint32_t i = 0; i < c; i++) { ha[i] = ops[s0 + i]->a; hb[i] = ops[s0 + i]->b; ho[i] = ops[s0 + i]->out; }
+            const uint64_t **da, **db = nullptr; uint64_t **dout;
+            CHECK(upload_tmp(ctx, ha.data(), c, &da));
+            if (!sq) CHECK(upload_tmp(ctx, hb.data(), c, &db));
+            CHECK(upload_tmp(ctx, ho.data(), c, &dout));
+            uint64_t *t3 = salloc<uint64_t>(ctx, (size_t)c * 3 * kn);
+            if (!t3) return fail(CN_ERR_HIP, "internal: scratch exhausted in deferred multiply");
+            CHECK(do_multiply(ctx, nullptr, 1, nullptr, 1, t3, c, da, sq ? da : db));
+            CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk, nullptr, c, 0, nullptr, 0, dout));
+        }
+    }
+    return 0;
+}
+
+static int cn_defer_flush(cn_ctx *ctx) {
+    DeferQueue *q = ctx->dq;
+    if (!q) return 0;
+    int rc = 0;
+    if (!q->ops.empty()) {
+        std::vector<DOp> &ops = q->ops;
+        // ---- an AddPlain that only adds the bias to a DenseMatrixBySparseVectorMultiply result the caller has already released
+        // (PoolLayer.cs:184-186: `using (conv = ConvolveOnce(..)) res[k] = conv.Add(bias)`) is folded into the GEMM's epilogue - the GEMM
+        // then runs at the AddPlain's level and writes its output: safe when nothing else reads the intermediate and no later call
+        // overwrites the GEMM's inputs
+        std::vector<uint8_t> dead(ops.size(), 0);
+        {
+            std::unordered_map<const uint64_t *, int> freed;
+            for (auto &f : q->frees) freed[f.first] = 1;
+            for (size_t x = 0; x < ops.size(); x++) {
+                DOp &X = ops[x];
+                if (X.type != DOP_ADDPLAIN || X.a == X.out) continue;
+                auto hi = q->haz.find(X.a);
+                if (hi == q->haz.end() || hi->second.wop < 0 || hi->second.readers != 1 || !freed.count(X.a)) continue;
+                DOp &Gm = ops[hi->second.wop];
+                if (Gm.type != DOP_GEMM1 || Gm.bias || Gm.out != X.a || dead[hi->second.wop]) continue;
+                bool ok = true;
+                for (uint32_t kk = 0; kk < Gm.K && ok; kk++) {
+                    const uint64_t *in = (const uint64_t *)q->addr[Gm.terms + kk];
+                    if (!in) continue;
+                    auto h2 = q->haz.find(in);
+                    if (h2 != q->haz.end() && h2->second.wop > hi->second.wop) ok = false;
+                }
+                if (!ok) continue;
+                Gm.out = X.out; Gm.bias = X.b; Gm.level = X.level;
+                dead[x] = 1;
+            }
+        }
+        // ---- launches: level by level, one batched launch per kind (and per term count for the GEMMs)
+        const int32_t levels = q->maxlevel + 1;
+        for (int32_t lv = 0; lv < levels && !rc; lv++) {
+            std::vector<const DOp *> by_type[DOP_TYPES];
+            for (size_t x = 0; x < ops.size(); x++) if (!dead[x] && ops[x].level == lv) by_type[ops[x].type].push_back(&ops[x]);
+            if (!by_type[DOP_GEMM1].empty()) {
+                std::map<uint32_t, std::vector<const DOp *>> byK;
+                for (const DOp *op : by_type[DOP_GEMM1]) byK[op->K].push_back(op);
+                for (auto &kv : byK) if (!rc) rc = flush_gemm_group(ctx, q, kv.second, kv.first);
+            }
+            for (int t : {DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN}) if (!rc && !by_type[t].empty()) rc = flush_elementwise_group(ctx, by_type[t], t);
+            if (!rc && !by_type[DOP_MULRELIN].empty()) rc = flush_mulrelin_group(ctx, by_type[DOP_MULRELIN]);
+        }
+    }
+    q->ops.clear(); q->addr.clear(); q->wt.clear(); q->haz.clear(); q->maxlevel = -1;
+    for (auto &f : q->frees) { int r2 = dev_release(ctx, f.first, f.second); if (!rc) rc = r2; }
+    q->frees.clear();
+    return rc;
+}
+// true when the call is to be queued rather than launched (the caller holds the lock)
+static bool deferring(cn_ctx *ctx) { return ctx->defer && !ctx->capturing; }
+
+/* DenseMatrixBySparseVectorMultiply for ONE output block whose K input ciphertexts are separate objects (see include/cnhip.h) */
+extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi) {
+    LOCK_ONLY; GETCT(O, out, 2);
+    if (!K || !in || !w) return fail(CN_ERR_ARG, "empty scalar product");
+    if (oi >= O->count) return fail(CN_ERR_ARG, "index out of range");
+    DeferQueue *q = ctx->dq;
+    const size_t t0 = q->addr.size();
+    std::vector<const uint64_t *> ins(K, nullptr);
+    bool any = false;
+    uint64_t *o = O->d + (size_t)oi * O->item_words;
+    uint64_t nnz = 0;
+    for (uint32_t kk = 0; kk < K; kk++) {
+        const uint64_t wk = w[kk];
+        if (wk >= ctx->hc.t.q) { q->addr.resize(t0); q->wt.resize(t0); return fail(CN_ERR_ARG, "weight >= plain modulus"); }
+        uint64_t a = 0;
+        if (in[kk]) {                                        // handle 0: padded tap (PoolLayer.cs:68-80), skipped
+            Buffer *I = getbuf(ctx, in[kk], 0);
+            const uint32_t ii = in_idx ? in_idx[kk] : 0;
+            if (!I || I->size != 2 || ii >= I->count) { q->addr.resize(t0); q->wt.resize(t0); return fail(CN_ERR_ARG, "invalid input ciphertext %u", kk); }
+            const uint64_t *p = I->d + (size_t)ii * I->item_words;
+            if (p == o) { q->addr.resize(t0); q->wt.resize(t0); return fail(CN_ERR_ARG, "scalar product cannot run in place"); }
+            a = (uint64_t)p; ins[kk] = p;                    // (a zero weight keeps its address: outputs that share a patch still share a gather list)
+            if (wk) { any = true; nnz++; }                   // zero weights contribute nothing (AtomicSealBfvVector.cs:468 skips them)
+        }
+        q->addr.push_back(a); q->wt.push_back(a ? wk : 0);
+    }
+    if (!any) { q->addr.resize(t0); q->wt.resize(t0); return fail(CN_ERR_ARG, "output has no non-zero term (AddMany of nothing)"); }
+    DOp op{DOP_GEMM1, 0, o, nullptr, nullptr, K, t0, nullptr};
+    CHECK(defer_push(ctx, op, ins.data(), K));
+    ctx->st.PlainMultiplication += nnz; ctx->st.Addition += nnz - 1;
+    if (!deferring(ctx)) return cn_defer_flush(ctx);
+    return 0;
+}
+
+// ---- the deferrable forms of the per-ciphertext entry points (arguments are checked now, the work is queued)
+static int defer_addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op) {
+    GETCT(A, a, 0); GETCT(O, out, A->size);
+    Buffer *B = getbuf(ctx, b, 0);
+    if (!B || B->size != A->size) return fail(CN_ERR_ARG, "operand sizes do not match");
+    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(B, bi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (A->size != 2) return 1;
+    for (uint32_t c = 0; c < count; c++) {
+        const uint64_t *pa = A->d + (size_t)(ai + c) * A->item_words, *pb = B->d + (size_t)(bi + c) * B->item_words;
+        const uint64_t *ins[2] = {pa, pb};
+        CHECK(defer_push(ctx, DOp{op ? DOP_SUB : DOP_ADD, 0, O->d + (size_t)(oi + c) * O->item_words, pa, pb, 0, 0, nullptr}, ins, 2));
+    }
+    if (op) ctx->st.Subtraction += count; else ctx->st.Addition += count;
+    return 0;
+}
+static int defer_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) {
+    GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (A->size != 2) return 1;
+    for (uint32_t c = 0; c < count; c++) {
+        const uint64_t *pa = A->d + (size_t)(ai + c) * A->item_words;
+        const uint64_t *ins[1] = {pa};
+        CHECK(defer_push(ctx, DOp{subtract ? DOP_SUBPLAIN : DOP_ADDPLAIN, 0, O->d + (size_t)(oi + c) * O->item_words, pa, P->d + (size_t)(pi + c) * ctx->hc.n, 0, 0, nullptr}, ins, 1));
+    }
+    if (subtract) ctx->st.PlainSubtraction += count; else ctx->st.PlainAddition += count;
+    return 0;
+}
+static int defer_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out, uint32_t oi, uint32_t count) {
+    GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out, 2);
+    if (!range_ok(A, ai, astride ? count : 1, astride ? astride : 1) || !range_ok(B, bi, bstride ? count : 1, bstride ? bstride : 1) || !range_ok(O, oi, count))
+        return fail(CN_ERR_ARG, "index out of range");
+    if (!ctx->rlk.d) return fail(CN_ERR_NOKEY, "relinearization keys not set");
+    for (uint32_t c = 0; c < count; c++) {
+        const uint64_t *pa = A->d + ((size_t)ai + (size_t)c * astride) * A->item_words, *pb = B->d + ((size_t)bi + (size_t)c * bstride) * B->item_words;
+        const uint64_t *ins[2] = {pa, pb};
+        CHECK(defer_push(ctx, DOp{DOP_MULRELIN, 0, O->d + (size_t)(oi + c) * O->item_words, pa, pb, 0, 0, nullptr}, ins, 2));
+    }
+    ctx->st.Relinarization += count;          // (Multiplication is counted by the batched multiply at flush time)
+    return 0;
+}
+
 // ---------------------------------------------------------------- raw transforms / timing / stats
 static int raw_ntt(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse) {
     if (base != 0 && base != 1) return fail(CN_ERR_ARG, "base must be 0 (q) or 1 (Bsk)");
-    return run_ntt(ctx, (uint64_t *)p, limbs, base ? ctx->hc.k : 0, base ? ctx->hc.kb : ctx->hc.k, inverse);
+    return cn_run_ntt(ctx, (uint64_t *)p, limbs, base ? ctx->hc.k : 0, base ? ctx->hc.kb : ctx->hc.k, inverse);
 }
 extern "C" int cn_ntt_forward(cn_ctx *ctx, void *p, uint32_t limbs, int base) { LOCK; return raw_ntt(ctx, p, limbs, base, 0); }
 extern "C" int cn_ntt_inverse(cn_ctx *ctx, void *p, uint32_t limbs, int base) { LOCK; return raw_ntt(ctx, p, limbs, base, 1); }
@@ -1525,7 +1655,7 @@ extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) {
     return 0;
 }
 extern "C" int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<CnMutex> lk(ctx->mu);
     if (out) *out = ctx->st;
     if (reset) ctx->st = cn_stats{};
     return 0;

@@ -1,0 +1,243 @@
+// HOT LOOP A: scalar GEMM kernels (AtomicSealBfvVector.cs:434-521).  Included by cn_l_gemm.hip only.
+#pragma once
+#include "cn_dev_common.hip.h"
+
+// ------------------------------------------------------------------ HOT LOOP A: scalar GEMM
+// Workgroup -> (coefficient chunk, limb, output tile mt, group g).  The mtiles output tiles of one (chunk, limb, g) read the SAME
+// input elements; workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles take ids b, b+8, b+16, ...
+// - same XCD, adjacent in time: the K input elements are fetched from HBM once and re-read from that XCD's L2 (dense 845->100:
+// 5 tiles; without this every tile streamed the 528 MB of input ciphertexts again).
+DEV void gemm_block_coords(uint32_t b, uint32_t chunks, uint32_t limbs, uint32_t mtiles, uint32_t G, uint32_t &chunk, uint32_t &limb, uint32_t &mt, uint32_t &g) {
+    const uint32_t D = chunks * limbs * G;
+    uint32_t d;
+    if ((D & 7) == 0) { const uint32_t r = b >> 3; mt = r % mtiles; d = (r / mtiles) * 8 + (b & 7); }
+    else { d = b % D; mt = b / D; }
+    chunk = d % chunks; limb = (d / chunks) % limbs; g = d / (chunks * limbs);
+}
+// Group g gathers K input ciphertexts idx[g][:] once and produces M outputs (register tile MT):
+//   out[out_idx[g][m]] = sum_k Wl[j][g][m][k] * in[idx[g][k]]  (+ scaled bias)   per limb j, coefficient i.
+// Products accumulate lazily in 128 bits; one Barrett reduction per `lazy` terms.
+// ABS: the gather / output / bias tables hold DEVICE ADDRESSES (u64, 0 = padded tap / no output / no bias) instead of indices relative
+// to `in` / `out` / `bias` - the form the deferred per-ciphertext calls arrive in, where every ciphertext is its own array.
+template <bool ABS> struct GemmTab { typedef int32_t T; };
+template <> struct GemmTab<true> { typedef uint64_t T; };
+template <int MT, bool ABS = false>
+__global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const uint64_t *__restrict__ Wl,
+                                                     const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
+                                                     uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase) {
+    typedef typename GemmTab<ABS>::T TT;
+    const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
+    const uint32_t n = C->n, k = C->k, limbs = 2 * k;
+    uint32_t chunk, limb, mt, g;
+    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
+    const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
+    const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
+    const DMod qm = C->q[j];
+    u128 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0;
+    const TT *gi = idx + (size_t)g * Kp;                                                 // row pitch Kp: 16 B aligned, -1 (ABS: 0) beyond K
+    const uint64_t *gw = Wl + (((size_t)j * G + g) * mtiles + mt) * (size_t)K * MT;      // [kk][m]: the MT weights of a term are contiguous
+    const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
+    for (uint32_t k0 = 0; k0 < K; k0 += lazy) {            // reduction between blocks of `lazy` terms (see k_scalar_gemm_f64)
+        const uint32_t k1 = min(K, k0 + lazy);
+        for (uint32_t kk = k0; kk < k1; kk++) {
+            uint64_t x;
+            if constexpr (ABS) { const uint64_t a = gi[kk]; if (!a) continue; x = reinterpret_cast<const uint64_t *>(a)[e]; }
+            else { const int32_t id = gi[kk]; if (id < 0) continue; x = in[(size_t)id * ctw + e]; }
+#pragma unroll
+            for (int m = 0; m < MT; m++) acc[m] += (u128)x * gw[(size_t)kk * MT + m];       // zero-padded beyond mcnt
+        }
+        if (k1 < K) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) acc[m] = bred128(acc[m], qm);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const uint32_t o = g * M + mt * MT + m;
+        if constexpr (ABS) {
+            if ((uint32_t)m < mcnt && out_idx[o]) {
+                uint64_t r = bred128(acc[m], qm);
+                if (bias_idx && bias_idx[o] && limb < k) r = addmod(r, scale_plain(C, reinterpret_cast<const uint64_t *>(bias_idx[o])[i], j), qm.q);
+                reinterpret_cast<uint64_t *>(out_idx[o])[e] = r;
+            }
+        } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {                     // -1: padding member of a smaller group
+            uint64_t r = bred128(acc[m], qm);
+            if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
+        }
+    }
+}
+
+// FP64 variant of the scalar GEMM for SMALL SIGNED weights (|w| < 2^20 after centring mod t - every PoolLayer weight
+// round(w*scale) is): the input residue x < 2^(NL*LW) is split into NL limbs of LW bits, each limb times the weight is an
+// exact double (< 2^(LW+20)), and up to 2^(52-LW-20) such terms accumulate exactly in one v_fma_f64 per limb - two half-rate
+// FMAs per MAC instead of a 64x64->128-bit integer multiply-add (~12 half-rate instructions).  The signed weight is the same
+// for every limb j, so the table is k times smaller as well.  Folded back with one 128-bit Barrett reduction per `lazy` terms.
+// Weights through the vector memory path (MT = 20): a wave-uniform weight as a scalar operand means s_load, and scalar loads return
+// out of order - the only possible wait is lgkmcnt(0), and ~70 free SGPRs hold less than two terms of 20 weights, so every other term
+// exposed an L2 round trip (the 135 KB weight tile of a block never fits the 16 KB scalar cache).  Instead lanes 0..15 of every
+// row of 16 load 16 consecutive table entries (5 coalesced 8 B loads per 4 terms, in-order vmcnt, requested two steps ahead) and
+// the FMA takes its weight through DPP: v_fmac_f64_dpp ... row_newbcast:i reads src0 from lane i of the own row - the one DPP
+// control gfx90a+ allows on FP64 instructions, at no extra issue slot.  (Through __builtin_amdgcn_update_dpp the compiler emits a
+// separate v_mov_b64_dpp per weight, +50 % FP64-rate instructions - hence inline assembly; "s_nop 1" covers the 2 wait states a
+// DPP read needs after a VALU write of its source, in case the register allocator put a copy right in front.)
+#ifndef GEMM_DPP_W
+#define GEMM_DPP_W 1
+#endif
+template <int LANE> DEV void fmac_bcast(double &acc, double w, double x) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x), "n"(LANE));
+}
+DEV void fmac_bcast_lane(int lane, double &acc, double w, double x) {          // `lane` is a constant after unrolling
+    switch (lane) {
+    case 0: fmac_bcast<0>(acc, w, x); break;   case 1: fmac_bcast<1>(acc, w, x); break;   case 2: fmac_bcast<2>(acc, w, x); break;   case 3: fmac_bcast<3>(acc, w, x); break;
+    case 4: fmac_bcast<4>(acc, w, x); break;   case 5: fmac_bcast<5>(acc, w, x); break;   case 6: fmac_bcast<6>(acc, w, x); break;   case 7: fmac_bcast<7>(acc, w, x); break;
+    case 8: fmac_bcast<8>(acc, w, x); break;   case 9: fmac_bcast<9>(acc, w, x); break;   case 10: fmac_bcast<10>(acc, w, x); break; case 11: fmac_bcast<11>(acc, w, x); break;
+    case 12: fmac_bcast<12>(acc, w, x); break; case 13: fmac_bcast<13>(acc, w, x); break; case 14: fmac_bcast<14>(acc, w, x); break; default: fmac_bcast<15>(acc, w, x); break;
+    }
+}
+// (178 VGPRs = 2 waves per SIMD.  Forcing 168 VGPRs for 3 waves costs 4 spilled registers and measured 16.3 vs 15.3 ms per batch.)
+template <int MT, int NL, int LW, bool ABS = false>
+__global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const double *__restrict__ Wd,
+                                                         const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
+                                                         uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase) {
+    typedef typename GemmTab<ABS>::T TT;
+    const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
+    const uint32_t n = C->n, k = C->k, limbs = 2 * k;
+    uint32_t chunk, limb, mt, g;
+    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
+    const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
+    const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
+    const DMod qm = C->q[j];
+    double acc[NL][MT], res[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        res[m] = 0.0;
+#pragma unroll
+        for (int l = 0; l < NL; l++) acc[l][m] = 0.0;
+    }
+    const TT *gi = idx + (size_t)g * Kp;                                                 // row pitch Kp: 16 B aligned, -1 (ABS: 0) beyond K
+    const double *gw = Wd + ((size_t)g * mtiles + mt) * (size_t)K * MT;                  // [kk][m], zero-padded
+    const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
+    // fold: value = sum_l acc[l] * 2^(l*LW) mod q_j, in exact FP64 (q_j < 2^49): Horner with one modular multiply per limb.  (The
+    // 128-bit integer version - double -> int128 conversions and a Barrett reduction per output - cost more instructions than the 25
+    // terms of a convolution window.)
+    const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
+    auto fold = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            double r = acc[NL - 1][m];
+            acc[NL - 1][m] = 0.0;
+#pragma unroll
+            for (int l = NL - 2; l >= 0; l--) { r = __dadd_rn(BzF::mulmod(r, (double)(1u << LW), mq), acc[l][m]); acc[l][m] = 0.0; }
+            res[m] = BzF::center(__dadd_rn(res[m], r), mq);       // |res| <= q/2 between folds, |r| < 2^53 - q
+        }
+    };
+    // blocks of `lazy` terms with the fold BETWEEN the inner loops: a fold test inside the term loop gets if-converted by the
+    // compiler (the whole 128-bit fold executed every iteration under v_cndmask - 30x the instructions of the 2*MT FMAs)
+    // Software pipeline: a term is one dependent scalar load (gather index) + one global load, ~1 us of latency against
+    // 2*MT*NL FMAs.  Two register sets ping-pong: the input elements of the NEXT PF terms are requested before the FMAs of the
+    // current PF terms are issued.  Fetch and compute are branch-free (padded taps and terms past the block read as x = 0 and
+    // multiply whatever weight row follows - the table carries 8 spare rows), so the waits stay exact.
+    constexpr int PF = 4;
+    auto fetch = [&](uint64_t (&x)[PF], uint32_t kk, uint32_t k1) {
+        // ONE 16 B scalar load for the PF gather indices (four dependent s_load_dword + wait chains cost more than the FMAs)
+        if constexpr (ABS) {               // PF addresses: two 16 B scalar loads; a padded tap reads (and discards) the fallback ciphertext `in`
+            const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4), 16));
+            const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4) + 2, 16));
+            const uint64_t ad[PF] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+            for (int p = 0; p < PF; p++) {
+                const bool ok = kk + p < k1 && ad[p] != 0;
+                const uint64_t v = (ad[p] ? reinterpret_cast<const uint64_t *>(ad[p]) : in)[e];
+                x[p] = ok ? v : 0;
+            }
+        } else {
+            const int4 ids = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4), 16));
+            const int32_t id[PF] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+            for (int p = 0; p < PF; p++) {
+                const bool ok = kk + p < k1 && id[p] >= 0;
+                const uint64_t v = in[(size_t)max(id[p], 0) * ctw + e];
+                x[p] = ok ? v : 0;
+            }
+        }
+    };
+    auto terms = [&](const uint64_t (&x)[PF], uint32_t kk) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            double xl[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x[p] >> (l * LW)) & ((1ull << LW) - 1));
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const double w = gw[(size_t)(kk + p) * MT + m];
+#pragma unroll
+                for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
+            }
+        }
+    };
+    constexpr bool DPPW = GEMM_DPP_W && MT == 20 && PF == 4;
+    constexpr int WV = DPPW ? PF * MT / 16 : 1;                    // 4 terms x 20 weights = 5 registers of 16 lanes
+    auto wfetch = [&](double (&wv)[WV], uint32_t kk) {             // rows min(kk, K + 4) .. + 3: inside the 8 spare (zero) rows of the table
+        const double *wp = gw + (size_t)min(kk, K + 4) * MT + (threadIdx.x & 15);
+#pragma unroll
+        for (int v = 0; v < WV; v++) wv[v] = wp[16 * v];
+    };
+    auto terms_dpp = [&](const uint64_t (&x)[PF], double (&wv)[WV]) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            double xl[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x[p] >> (l * LW)) & ((1ull << LW) - 1));
+            asm volatile("s_nop 1");
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int f = p * MT + m;
+#pragma unroll
+                for (int l = 0; l < NL; l++) fmac_bcast_lane(f & 15, acc[l][m], wv[(f >> 4) % WV], xl[l]);
+            }
+        }
+    };
+    for (uint32_t k0 = 0; k0 < K; k0 += lazy) {
+        const uint32_t k1 = min(K, k0 + lazy);
+        uint64_t xa[PF], xb[PF];
+        if constexpr (DPPW) {
+            double wa[WV], wb[WV];
+            fetch(xa, k0, k1); wfetch(wa, k0);
+            for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
+                fetch(xb, kk + PF, k1); wfetch(wb, kk + PF);
+                terms_dpp(xa, wa);
+                fetch(xa, kk + 2 * PF, k1); wfetch(wa, kk + 2 * PF);
+                terms_dpp(xb, wb);
+            }
+        } else {
+            fetch(xa, k0, k1);
+            for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
+                fetch(xb, kk + PF, k1);
+                terms(xa, kk);
+                fetch(xa, kk + 2 * PF, k1);
+                terms(xb, kk + PF);
+            }
+        }
+        fold();
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const uint32_t o = g * M + mt * MT + m;
+        if constexpr (ABS) {
+            if ((uint32_t)m < mcnt && out_idx[o]) {
+                uint64_t r = BzF::to_u64(res[m], mq);
+                if (bias_idx && bias_idx[o] && limb < k) r = addmod(r, scale_plain(C, reinterpret_cast<const uint64_t *>(bias_idx[o])[i], j), qm.q);
+                reinterpret_cast<uint64_t *>(out_idx[o])[e] = r;
+            }
+        } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {
+            uint64_t r = BzF::to_u64(res[m], mq);
+            if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
+        }
+    }
+}

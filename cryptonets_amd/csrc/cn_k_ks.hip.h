@@ -1,0 +1,393 @@
+// HOT LOOP B/C: key switching (relinearisation, Galois) on the register-radix core.  Included by cn_l_ks.inc.h (one translation unit
+// per arithmetic policy).
+#pragma once
+#include "cn_dev_common.hip.h"
+
+// Key switching on the register-radix core: block = (ciphertext, output limb j).  For every (source limb l, digit d) the
+// base-2^dbc digit of the 16 coefficients a thread owns goes through the forward transform in registers/LDS and is
+// multiply-accumulated with the key pair (16 B/lane coalesced key loads) into per-thread accumulators; two inverse transforms
+// finish and the result is added to (add0, add1).  The digit polynomials never exist in HBM.
+// U64 policy: keys are u64 residues, canonical accumulators.  F64 policy: keys were converted to doubles at upload,
+// accumulators are lazy doubles recentred every `accmax` terms.
+// forward-transform policy of the key-switch kernels: FP64 policies read their twiddles from an LDS copy of the table
+// (N <= 8192: image + table = 132 KiB of the 160 KiB; the N = 16384 image alone is 136 KiB)
+template <class AR, int L> struct KsFwd { typedef AR P; static constexpr bool lds = false; };
+template <int RN, int L> struct KsFwd<ArF64T<RN>, L> { typedef typename std::conditional<(L <= 13), ArF64LdsT<RN>, ArF64T<RN>>::type P; static constexpr bool lds = L <= 13; };
+// copy `words` doubles of a global table behind the exchange image (all threads; caller synchronises)
+DEV void stage_table(double *dst, const NTT_GLOBAL double *src, uint32_t words, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid * 2; i < words; i += nthreads * 2) {
+        const double a = src[i], b = src[i + 1];               // adjacent lanes, adjacent pairs: 16 B per lane either way
+        dst[i] = a; dst[i + 1] = b;
+    }
+}
+template <class AR> struct KsMac;
+template <> struct KsMac<ArU64> {
+    static DEV void mac(uint64_t &acc, uint64_t x, uint64_t key, const DMod &qm, const ArCtx<ArU64> &A) { acc = addmod(acc, mulmod(canon4(x, qm.q), key, qm), qm.q); }
+    static DEV void settle(uint64_t (&)[16], const ArCtx<ArU64> &) {}
+    static DEV uint64_t sum(uint64_t acc, uint64_t x, const DMod &qm) { return addmod(acc, x, qm.q); }
+};
+template <int RN> struct KsMac<ArF64T<RN>> {
+    typedef ArF64T<RN> ArF64;
+    static DEV void mac(double &acc, double x, double key, const DMod &, const ArCtx<ArF64> &A) { acc = __dadd_rn(acc, ArF64::mulmod(x, key, A.m)); }
+    static DEV void settle(double (&a)[16], const ArCtx<ArF64> &A) { ArF64::renorm(a, A.m); }
+    static DEV double sum(double acc, double x, const DMod &) { return __dadd_rn(acc, x); }
+};
+// (Measured, not kept: using the N*8 bytes of LDS behind the image for a key prefetch instead of the twiddle table - every wave requests
+// the first key component of a digit with global_load_lds_dwordx4 at the start of the digit (global -> LDS without registers, read
+// back as ds_read_b128).  Bit-exact, -2 % in the stand-alone loop of tools/ubench_ks.hip, but +4 % in this kernel: 3.78 vs 3.62 ms.
+// Likewise s_setprio 3 / 0 for the two waves a SIMD holds, so that their memory waits stop coinciding: -7 % in the stand-alone loop,
+// no change here (3.65 vs 3.66 ms) and +30 % on the 100-ciphertext launch.)
+#ifndef KS_SGPR_A
+#define KS_SGPR_A 1         // FP64 key switch: the first-pass roots of the output limb live in SGPRs for all digits (ArPassA)
+#endif
+template <class FW0, bool ON> struct KsPassA { typedef FW0 P; };
+template <class FW0> struct KsPassA<FW0, true> { typedef ArPassA<FW0> P; };
+#ifndef KS_PRE_SYNC
+#define KS_PRE_SYNC 1       // the "image is free again" barrier of a digit sits behind the next digit's first pass (ntt_forward_regs<.., PRE>)
+#endif
+#ifndef KS_MAC_FENCE
+#define KS_MAC_FENCE 0      // FP64 path: letting the scheduler interleave key loads with the MACs measured 11-14 % faster (same VGPRs)
+#endif
+template <int L, class AR, int MINW = 1, bool TWL = false>
+__global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
+                                                                 const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
+                                                                 uint64_t *out, const DevConsts *__restrict__ C, int galois, uint32_t accmax,
+                                                                 const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    // out_tab: one output address per ciphertext instead of out + ct*2kN (deferred per-ciphertext calls)
+    // (ct, j) with j fastest: the k workgroups of a ciphertext run together and share its source limbs through L2 / MALL.  (A
+    // limb-major order that lets an XCD's workgroups share one key slice in L2 was measured: no gain at N = 8192 - the 15.6 MB of
+    // keys stream from the infinity cache fast enough - and 30 % slower at N = 16384, where the source limbs then come from HBM
+    // once per (limb, half) workgroup.)
+    const uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const ArCtx<AR> A(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    T acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    // TWL: forward twiddles from an LDS copy of the table (FP64 policies, N <= 8192, enough digits per workgroup to pay for staging it)
+    typedef typename std::conditional<TWL, typename KsFwd<AR, L>::P, AR>::type FW0;
+    typedef typename KsPassA<FW0, KS_SGPR_A && std::is_same<T, double>::value>::P FW;
+    typename FW::Tw fwt;
+    if constexpr (TWL) {
+        static_assert(KsFwd<AR, L>::lds, "LDS twiddles need an FP64 policy and N <= 8192");
+        double *tws = reinterpret_cast<double *>(smem) + ntt_lds_words(n);
+        stage_table(tws, A.fw.w, n, tid, NttPlan<L>::NT);
+        fwt.w = (const __attribute__((address_space(3))) double *)tws;
+        __syncthreads();
+    } else static_cast<typename FW0::Tw &>(fwt) = A.fw;
+    if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwt, A.fw.w);
+    const T *kp = reinterpret_cast<const T *>(key_);
+    uint32_t terms = 0;
+    for (uint32_t l = 0; l < k; l++) {
+        const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        uint64_t raw[16];                          // the source words of limb l stay in registers for all of its digits
+        {
+            uint32_t t0 = tid;
+            asm volatile("" : "+v"(t0));
+#pragma unroll
+            for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
+        }
+        for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+            const int sh = dbc * (int)d;
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));           // opaque copy of tid: keeps LDS/twiddle address math and twiddle loads inside the
+                                                   // loop (hoisted as loop invariants they cost >150 VGPRs and spill)
+            T v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint64_t t = (raw[r] >> sh) & mask;
+                if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
+                v[r] = A.load(t);                  // F64: the first recentring of the transform reduces digits >= q_j
+            }
+            if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }     // digits below q_j need no recentring (uniform branch)
+            ntt_forward_regs<FW, L, KS_PRE_SYNC != 0>(v, s, fwt, A.m, tl);
+            const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                if (KS_MAC_FENCE || std::is_same<T, uint64_t>::value) __builtin_amdgcn_sched_barrier(0);   // integer path: bounds live key words
+                const uint32_t pos = tail_index<L>(tl, r);
+                struct alignas(16) P2 { T a, b; };
+                const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+                KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+                KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
+            }
+            if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
+            // LDS of this transform is reused by the next one.  KS_PRE_SYNC: that barrier is inside the next forward transform; the
+            // inverse transforms below start with block-local traffic (every wave in its own blocks) or, without NTT_TAIL_LOCAL /
+            // for D = 2, still need it here.
+            if (!KS_PRE_SYNC) __syncthreads();
+        }
+    }
+    if (KS_PRE_SYNC && !ntt_tail_local<L>()) __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));               // see above: no hoisting / sharing of address math across the two transforms
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
+        const uint64_t *ad = p ? add1 : add0;
+        uint64_t *o = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t e = pass_index<L, SA, 0>(tl, r);
+            uint64_t val = A.scaled(v[r]);
+            if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], q);
+            if (extra) val = addmod(val, extra[(size_t)ct * ex_stride + (size_t)p * kn + (size_t)j * n + e], q);   // fused "+ accumulator" (may alias out)
+            o[e] = val;
+        }
+        __syncthreads();
+    }
+}
+// N = 16384 key switch without spills.  k_keyswitch_rr<14> needs 1024 threads per limb, which caps a thread at 128 VGPRs - the
+// 2 x 16 accumulators + 16 coefficients + twiddles do not fit and go to scratch.  A 2N'-point negacyclic transform is one
+// butterfly stage over (i, i + N') followed by two independent N'-point transforms with re-indexed root tables (DevConsts::twdh),
+// and the key multiply-accumulate is pointwise - so block = (ct, output limb j, half h) runs the N' = 8192 machinery of
+// k_keyswitch_rr<13> (512 threads, 204 VGPRs, no scratch) on its half: stage 0 is folded into the digit load (both inputs of the
+// butterfly are read, one output kept), keys are read at h*N' + position.  The two inverse sub-transforms leave through `half`
+// and k_ks_combine14 applies the last inverse stage (u + v, (u - v) w^-1), the N^-1 scaling and the (c0, c1) addends.
+template <class AR>
+__global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
+                                                                        uint64_t *__restrict__ half, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value, "FP64 policies only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr int L = 13;
+    constexpr uint32_t n2 = 1u << L, n = 2 * n2;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t h = blockIdx.x & 1, j = (blockIdx.x >> 1) % k, ct = blockIdx.x / (2 * k);
+    const DMod qm = C->q[j];
+    const ArCtx<AR> A(C, j);
+    typedef const NTT_GLOBAL double *GP;
+    // (an LDS copy of the half's table, as in k_keyswitch_rr, was measured: -30 % - with one digit per limb a workgroup runs only
+    // k = 8 transforms, too few to pay for staging 64 KiB)
+    typedef typename KsPassA<AR, KS_SGPR_A != 0>::P FW;
+    typename FW::Tw fwh;
+    fwh.w = (GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2);
+    if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwh, fwh.w);
+    const typename AR::Tw ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    T acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const T *kp = reinterpret_cast<const T *>(key_);
+    uint32_t terms = 0;
+    for (uint32_t l = 0; l < k; l++) {
+        const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+            const int sh = dbc * (int)d;
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));           // as in k_keyswitch_rr: keep address math and twiddle loads inside the loop
+            T v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t e = pass_index<L, SA, 0>(tl, r);
+                T X = A.load((src[e] >> sh) & mask), Y = A.load((src[e + n2] >> sh) & mask);
+                AR::fwd(X, Y, A.fw, 1, A.m);        // stage 0 of the 2N'-point transform: (x + w y, x - w y), w = root[1]
+                v[r] = h ? Y : X;
+            }
+            AR::renorm(v, A.m);
+            ntt_forward_regs<FW, L, KS_PRE_SYNC != 0>(v, s, fwh, A.m, tl);
+            const T *k0 = kp + (size_t)j * n + (size_t)h * n2, *k1 = k0 + kn;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t pos = tail_index<L>(tl, r);
+                struct alignas(16) P2 { T a, b; };
+                const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+                KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+                KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
+            }
+            if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
+            if (!KS_PRE_SYNC) __syncthreads();
+        }
+    }
+    if (KS_PRE_SYNC && !ntt_tail_local<L>()) __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        ntt_inverse_regs<AR, L>(v, s, ivh, A.m, tl);
+        uint64_t *o = half + ((size_t)ct * 2 + p) * kn + (size_t)j * n + (size_t)h * n2;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(tl, r)] = A.canon(v[r]);
+        __syncthreads();
+    }
+}
+// Latency variant of the key switch for SMALL batches (LoLa: one image = 1..13 ciphertexts per rotation): the fused kernel above
+// runs count*k workgroups, each pushing all digit transforms through one CU in sequence - 5 busy CUs of 256 at count 1.  Here
+// the digit transforms are spread over the chip and the sum is a second launch:
+//   k_ks_digit_mac : block = (ct, digit g, output limb j): digit -> forward transform -> times the key pair -> partial products
+//                    part[ct][g][2][k][N] (transform order, same 16 B/lane pattern as the key reads)
+//   k_ks_sum_intt  : block = (ct, j, component p): sum of the partials over g -> inverse transform -> (+ add_p) -> out
+// Same residues as the fused kernel (exact arithmetic in both), HBM traffic 2 * tot * 2kN words per ciphertext more.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
+                                                                  void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t tot) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t j = blockIdx.x % k, g = (blockIdx.x / k) % tot, ct = blockIdx.x / (k * tot);
+    uint32_t l = 0, d = g;
+    for (;; l++) { const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l]; if (d < nd) break; d -= nd; }
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const ArCtx<AR> A(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc, sh = dbc * (int)d;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        uint64_t t = (src[pass_index<L, SA, 0>(tid, r)] >> sh) & mask;
+        if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
+        v[r] = A.load(t);
+    }
+    if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    const T *k0 = reinterpret_cast<const T *>(key_) + (size_t)g * 2 * kn + (size_t)j * n, *k1 = k0 + kn;
+    T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * tot + g) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;
+    struct alignas(16) P2 { T a, b; };
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+        P2 x = {0, 0}, y = {0, 0};
+        KsMac<AR>::mac(x.a, v[r], a.a, qm, A); KsMac<AR>::mac(x.b, v[r + 1], a.b, qm, A);
+        KsMac<AR>::mac(y.a, v[r], b.a, qm, A); KsMac<AR>::mac(y.b, v[r + 1], b.b, qm, A);
+        *reinterpret_cast<P2 *>(o0 + pos) = x; *reinterpret_cast<P2 *>(o1 + pos) = y;
+    }
+}
+// Middle ground for batches of ~7-32 ciphertexts: block = (ct, source limb l, output limb j) runs the digits of ONE source limb
+// through the fused loop (accumulators in registers) and leaves one partial pair per (ct, l): k*k workgroups per ciphertext
+// instead of k (fused) or digits*k (k_ks_digit_mac), and k_ks_sum_intt adds k partials instead of all digits.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
+                                                                 void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t j = blockIdx.x % k, l = (blockIdx.x / k) % k, ct = blockIdx.x / (k * k);
+    const DMod qm = C->q[j];
+    const uint64_t q = qm.q;
+    const ArCtx<AR> A(C, j);
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const uint64_t mask = (1ull << dbc) - 1;
+    const size_t kn = (size_t)k * n;
+    uint32_t g0 = 0;                                   // index of the first digit of limb l in the key
+    for (uint32_t i = 0; i < l; i++) g0 += galois ? C->gk_dig[i] : C->rl_dig[i];
+    const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
+    const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    uint64_t raw[16];
+    {
+        uint32_t t0 = tid;
+        asm volatile("" : "+v"(t0));
+#pragma unroll
+        for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
+    }
+    T acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const T *kp = reinterpret_cast<const T *>(key_) + (size_t)g0 * 2 * kn;
+    uint32_t terms = 0;
+    for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
+        const int sh = dbc * (int)d;
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            uint64_t t = (raw[r] >> sh) & mask;
+            if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
+            v[r] = A.load(t);
+        }
+        if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
+        ntt_forward_regs<AR, L, KS_PRE_SYNC != 0>(v, s, A.fw, A.m, tl);
+        const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t pos = tail_index<L>(tl, r);
+            struct alignas(16) P2 { T a, b; };
+            const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+            KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+            KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
+        }
+        if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
+        if (!KS_PRE_SYNC) __syncthreads();         // otherwise inside the next forward transform; nothing else uses the image
+    }
+    KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A);        // partials leave recentred: k of them are summed without a check
+    T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * k + l) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;
+    struct alignas(16) P2 { T a, b; };
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        *reinterpret_cast<P2 *>(o0 + pos) = P2{acc0[r], acc0[r + 1]};
+        *reinterpret_cast<P2 *>(o1 + pos) = P2{acc1[r], acc1[r + 1]};
+    }
+}
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__restrict__ part_, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
+                                                                 size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, uint32_t tot,
+                                                                 uint32_t accmax, const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x;
+    const uint32_t p = blockIdx.x & 1, j = (blockIdx.x >> 1) % k, ct = blockIdx.x / (2 * k);
+    const DMod qm = C->q[j];
+    const ArCtx<AR> A(C, j);
+    const size_t kn = (size_t)k * n;
+    const T *src = reinterpret_cast<const T *>(part_) + ((size_t)ct * tot * 2 + p) * kn + (size_t)j * n;
+    struct alignas(16) P2 { T a, b; };
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = 0;
+    uint32_t terms = 0;
+    for (uint32_t g = 0; g < tot; g++, src += 2 * kn) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const P2 x = *reinterpret_cast<const P2 *>(src + tail_index<L>(tid, r));
+            v[r] = KsMac<AR>::sum(v[r], x.a, qm); v[r + 1] = KsMac<AR>::sum(v[r + 1], x.b, qm);
+        }
+        if (++terms == accmax) { terms = 0; KsMac<AR>::settle(v, A); }
+    }
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    const uint64_t *ad = p ? add1 : add0;
+    uint64_t *o = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(tid, r);
+        uint64_t val = A.scaled(v[r]);
+        if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], qm.q);
+        if (extra) val = addmod(val, extra[(size_t)ct * ex_stride + (size_t)p * kn + (size_t)j * n + e], qm.q);
+        o[e] = val;
+    }
+}

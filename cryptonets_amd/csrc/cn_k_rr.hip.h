@@ -1,0 +1,256 @@
+// Register-radix transform kernels (N = 2^L, L = 10..14): batched NTT, fused dense MultiplyPlain, tensor product fused into the inverse
+// transform, fused squaring, encryption tail.  Included by cn_l_rr.inc.h (one translation unit per arithmetic policy).
+#pragma once
+#include "cn_dev_common.hip.h"
+
+template <int L, class AR, bool inverse>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, mod = base_off + blockIdx.x % nmod;
+    const ArCtx<AR> A(C, mod);
+    uint64_t *x = data + (size_t)blockIdx.x * n;
+    T v[16];
+    if (!inverse) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tid, r)]);
+        ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            ulonglong2 o; o.x = A.canon(v[r]); o.y = A.canon(v[r + 1]);
+            *reinterpret_cast<ulonglong2 *>(x + tail_index<L>(tid, r)) = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            ulonglong2 i2 = *reinterpret_cast<const ulonglong2 *>(x + tail_index<L>(tid, r));
+            v[r] = A.load(i2.x); v[r + 1] = A.load(i2.y);
+        }
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[pass_index<L, SA, 0>(tid, r)] = A.scaled(v[r]);
+    }
+}
+// BEHZ step 2 fused into the inverse transform: block = (ciphertext, output poly p of the tensor product, limb).  The NTT-form
+// operands are read at the positions the inverse transform starts from (16 B/lane), d_p = a0*b0 | a0*b1 + a1*b0 | a1*b1 is formed
+// in registers and transformed back at once - the 3-poly NTT-form tensor never exists in HBM (saves one write + one read of
+// 3(k + k+1) limbs per ciphertext and a kernel).  A, B: [cnt][2][Lm][N]; D: [cnt][3][Lm][N] (coefficient form, canonical).
+// Dense MultiplyPlain on the register-radix core, two launches instead of six (lift, transform, copy, transform, dyadic, transform):
+//   k_lift_ntt:        block = (plaintext, limb j): coefficients mod t -> fast plain lift into q_j -> forward transform -> NTT form
+//   k_mul_plain_fused: block = (ciphertext, poly, limb j): forward transform, pointwise product with the plaintext's NTT form (read at
+//                      the positions the thread holds, 16 B/lane), inverse transform, N^-1, store.  The product never exists in HBM in
+//                      NTT form: read ct limb + plaintext limb, write ct limb (3 limb transfers instead of 9).  src_stride = 0
+//                      broadcasts ONE input ciphertext over all plaintexts (the row-dot batches of the LoLa dense layers: 5488 rows at
+//                      CIFAR shapes, previously 5488 device-to-device copies per call).
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_lift_ntt(const uint64_t *__restrict__ pt, uint32_t pitch, uint64_t *__restrict__ lifted, const DevConsts *__restrict__ C) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, k = C->k, j = blockIdx.x % k, pi = blockIdx.x / k;
+    const ArCtx<AR> A(C, j);
+    const uint64_t *x = pt + (size_t)pi * pitch * n, th = C->t_half, inc = C->lift_inc[j];
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const uint64_t m = x[pass_index<L, SA, 0>(tid, r)]; v[r] = A.load(m >= th ? m + inc : m); }
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    uint64_t *o = lifted + (size_t)blockIdx.x * n;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        ulonglong2 w; w.x = A.canon(v[r]); w.y = A.canon(v[r + 1]);
+        *reinterpret_cast<ulonglong2 *>(o + tail_index<L>(tid, r)) = w;
+    }
+}
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_fused(const uint64_t *src, size_t src_stride, const uint64_t *__restrict__ ptn, uint32_t pstride,
+                                                                    uint64_t *out, const DevConsts *__restrict__ C, uint32_t polys) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, k = C->k, j = blockIdx.x % k, cp = blockIdx.x / k, ct = cp / polys, p = cp % polys;
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t *x = src + (size_t)ct * src_stride + ((size_t)p * k + j) * n;
+    const uint64_t *w = ptn + ((size_t)ct * pstride * k + j) * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tid, r)]);
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    uint32_t tm = tid;
+    asm volatile("" : "+v"(tm));
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(w + tail_index<L>(tm, r));
+        if constexpr (std::is_same<T, double>::value) {                   // lazy transform output x canonical plaintext word: exact (see KsMac)
+            v[r] = ops.mul(v[r], A.load(y.x), A); v[r + 1] = ops.mul(v[r + 1], A.load(y.y), A);
+        } else {
+            v[r] = ops.mul(A.canon(v[r]), y.x, A); v[r + 1] = ops.mul(A.canon(v[r + 1]), y.y, A);
+        }
+    }
+    if (!ntt_tail_local<L>()) __syncthreads();                            // (block-local tail: the inverse starts inside the wave's own blocks)
+    uint32_t ti = tid;
+    asm volatile("" : "+v"(ti));
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, ti);
+    uint64_t *o = out + ((size_t)cp * k + j) * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(ti, r)] = A.scaled(v[r]);
+}
+
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *__restrict__ A_, const uint64_t *__restrict__ B_, uint64_t *__restrict__ D,
+                                                                const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l = blockIdx.x % Lm, p = (blockIdx.x / Lm) % 3, ct = blockIdx.x / (3 * Lm), mod = base_off + l;
+    const ArCtx<AR> A(C, mod);
+    const TensorOps<AR> ops(C, mod);
+    const size_t Ln = (size_t)Lm * n;
+    const uint64_t *a0 = A_ + (size_t)ct * 2 * Ln + (size_t)l * n, *a1 = a0 + Ln;
+    const uint64_t *b0 = B_ + (size_t)ct * 2 * Ln + (size_t)l * n, *b1 = b0 + Ln;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        if (p == 0) {
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a0 + pos), y = *reinterpret_cast<const ulonglong2 *>(b0 + pos);
+            v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
+        } else if (p == 2) {
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a1 + pos), y = *reinterpret_cast<const ulonglong2 *>(b1 + pos);
+            v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
+        } else {
+            const ulonglong2 x0 = *reinterpret_cast<const ulonglong2 *>(a0 + pos), y1 = *reinterpret_cast<const ulonglong2 *>(b1 + pos);
+            const ulonglong2 x1 = *reinterpret_cast<const ulonglong2 *>(a1 + pos), y0 = *reinterpret_cast<const ulonglong2 *>(b0 + pos);
+            v[r] = ops.add(ops.mul(A.load(x0.x), A.load(y1.x), A), ops.mul(A.load(x1.x), A.load(y0.x), A));
+            v[r + 1] = ops.add(ops.mul(A.load(x0.y), A.load(y1.y), A), ops.mul(A.load(x1.y), A.load(y0.y), A));
+        }
+    }
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    uint64_t *o = D + ((size_t)ct * 3 + p) * Ln + (size_t)l * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(tid, r)] = A.scaled(v[r]);
+}
+
+// BEHZ steps 2-4 of a SQUARING in one kernel (FP64 policies): block = (ciphertext, limb) of the q or the Bsk base.  The operand polys
+// a0, a1 arrive in COEFFICIENT form (k_behz_extend's output) and the tensor (a0^2, 2 a0 a1, a1^2) leaves in coefficient form:
+//     step 0:  A0 = NTT(a0) -> parked in d1's place;               d0 = INTT(A0^2)
+//     step 1:  A1 = NTT(a1) -> parked in d2's place;  A0 back;     d1 = INTT(2 A0 A1)   (overwrites the parked A0)
+//     step 2:  A1 back;                                            d2 = INTT(A1^2)      (overwrites the parked A1)
+// Two forward and three inverse transforms like the separate launches, but every step needs only the 16 coefficients of ONE polynomial
+// per thread (126 VGPRs, two resident workgroups per CU) - keeping A0 and A1 in registers for the cross term would cost 64 more VGPRs
+// and a workgroup per CU.  The parked values are the thread's own doubles at its own 16 B/lane positions (stored and re-read by the
+// same thread: program order), 64 KiB per polynomial that is overwritten by the result a few microseconds later.  Measured HBM traffic
+// (profiles/r01_pmc_square_fused.txt): the parked limbs ARE written back before they are overwritten (5 limbs written per block, not 3)
+// and part of their re-reads comes from HBM (3.2-4.4 limbs read) - against 2R + 2W (forward transforms in place) + 4R + 3W (tensor +
+// inverse transforms) of the separate launches.
+// The inverse transform's workgroup barrier orders "everybody has re-read its parked words" before any result word is stored over them.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64_t *__restrict__ A_, size_t a_stride, const uint64_t *const *__restrict__ a_tab,
+                                                                    uint64_t *__restrict__ D, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm) {
+    // 4 waves per SIMD: two 512-thread workgroups per CU.  a_stride: words between the operands of consecutive ciphertexts (the q side
+    // reads the input ciphertexts in place, the Bsk side k_behz_extend's array); a_tab: one operand address per ciphertext instead
+    // (deferred per-ciphertext calls: every input ciphertext is its own array)
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value, "FP64 policies only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l = blockIdx.x % Lm, ct = blockIdx.x / Lm, mod = base_off + l;
+    const ArCtx<AR> A(C, mod);
+    const size_t Ln = (size_t)Lm * n;
+    const uint64_t *a0 = (a_tab ? a_tab[ct] : A_ + (size_t)ct * a_stride) + (size_t)l * n, *a1 = a0 + Ln;
+    uint64_t *d0 = D + (size_t)ct * 3 * Ln + (size_t)l * n, *d1 = d0 + Ln, *d2 = d1 + Ln;
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));                             // one transform's address math / twiddles live at a time
+        T v[16];
+        if (step < 2) {
+            const uint64_t *x = step ? a1 : a0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tl, r)]);
+            ntt_forward_regs<AR, L, true>(v, s, A.fw, A.m, tl);  // PRE: the image of the previous inverse transform is free
+            AR::renorm(v, A.m);                                  // lazy transform output (up to 28 q) -> |x| <= q/2
+            uint64_t *park = step ? d2 : d1;                     // bit patterns of the doubles: every access to D stays a u64 access
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                ulonglong2 w; w.x = (uint64_t)__double_as_longlong(v[r]); w.y = (uint64_t)__double_as_longlong(v[r + 1]);
+                *reinterpret_cast<ulonglong2 *>(park + tail_index<L>(tl, r)) = w;
+            }
+            if (step == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = AR::mulmod(v[r], v[r], A.m);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(d1 + tail_index<L>(tl, r));
+                    const T wa = __longlong_as_double((long long)w.x), wb = __longlong_as_double((long long)w.y);
+                    v[r] = AR::mulmod(__dadd_rn(wa, wa), v[r], A.m); v[r + 1] = AR::mulmod(__dadd_rn(wb, wb), v[r + 1], A.m);
+                }
+            }
+            if (!ntt_tail_local<L>()) __syncthreads();           // (block-local tail: the inverse starts inside the wave's own blocks)
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(d2 + tail_index<L>(tl, r));
+                const T wa = __longlong_as_double((long long)w.x), wb = __longlong_as_double((long long)w.y);
+                v[r] = AR::mulmod(wa, wa, A.m); v[r + 1] = AR::mulmod(wb, wb, A.m);
+            }
+            __syncthreads();                                     // no forward transform in this step: the previous inverse's image is free
+        }
+        uint32_t ti = tid;
+        asm volatile("" : "+v"(ti));                             // the inverse transform's address math starts here, not before the forward one
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, ti);
+        uint64_t *o = step == 0 ? d0 : (step == 1 ? d1 : d2);
+        uint32_t to = tid;
+        asm volatile("" : "+v"(to));
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(to, r)] = A.scaled(v[r]);
+    }
+}
+// encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t *__restrict__ u, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pt,
+                                                                 uint32_t pt_stride_words, uint64_t *__restrict__ out, const DevConsts *__restrict__ C,
+                                                                 uint64_t seed, uint64_t item0, uint64_t salt) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, p = (blockIdx.x / k) & 1, ct = blockIdx.x / (2 * k);
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t *uu = u + ((size_t)ct * k + j) * n, *pp = pk + ((size_t)p * k + j) * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t pos = tail_index<L>(tid, r);
+        const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(uu + pos), y = *reinterpret_cast<const ulonglong2 *>(pp + pos);
+        v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
+    }
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    uint64_t *o = out + (((size_t)ct * 2 + p) * k + j) * n;
+    const uint64_t q = C->q[j].q;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(tid, r);
+        uint64_t val = A.scaled(v[r]);
+        const int32_t ns = sample_noise(seed, 1 + p, item0 + ct, e, salt);
+        val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
+        if (p == 0 && pt) val = addmod(val, scale_plain(C, pt[(size_t)ct * pt_stride_words + e], j), q);
+        o[e] = val;
+    }
+}

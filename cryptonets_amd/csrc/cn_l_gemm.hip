@@ -1,0 +1,40 @@
+// Launchers of the scalar GEMM kernels (HOT LOOP A).  One translation unit per kernel family: hipcc compiles them in parallel.
+#include "cn_runtime.h"
+#include "cn_k_gemm.hip.h"
+
+template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &g) {
+    const uint32_t mtiles = (g.M + MT - 1) / MT;
+    const size_t blocks = (size_t)c->chunks * 2 * c->hc.k * mtiles * g.G;
+    hipLaunchKernelGGL((k_scalar_gemm<MT, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const uint64_t *)g.W, g.oidx, g.bias, g.bidx, g.out, c->dc,
+                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase);
+}
+template <int MT, bool ABS> static void launch_f64(cn_ctx *c, const GemmLaunch &g) {
+    const uint32_t mtiles = (g.M + MT - 1) / MT;
+    const size_t blocks = (size_t)c->chunks * 2 * c->hc.k * mtiles * g.G;
+    if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase);
+    else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
+                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase);
+}
+template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
+    if (g.small) {
+        switch (g.MT) {
+            case 20: launch_f64<20, ABS>(c, g); break;
+            case 10: launch_f64<10, ABS>(c, g); break;
+            case 5: launch_f64<5, ABS>(c, g); break;
+            case 1: launch_f64<1, ABS>(c, g); break;
+            default: return cn_fail(CN_ERR_ARG, "internal: scalar GEMM tile %u", g.MT);
+        }
+    } else {
+        switch (g.MT) {
+            case 10: launch_int<10, ABS>(c, g); break;
+            case 5: launch_int<5, ABS>(c, g); break;
+            case 1: launch_int<1, ABS>(c, g); break;
+            default: return cn_fail(CN_ERR_ARG, "internal: scalar GEMM tile %u", g.MT);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    cn_launch_count(c);
+    return 0;
+}
+int cn_l_gemm(cn_ctx *c, const GemmLaunch &g) { return g.abs ? launch<true>(c, g) : launch<false>(c, g); }

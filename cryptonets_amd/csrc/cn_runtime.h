@@ -1,0 +1,141 @@
+// Host-side structures of libcnhip.so shared by the runtime (cn_api.hip) and the kernel-launch translation units
+// (cn_l_*.hip).  The library is built from several translation units so that hipcc compiles the kernel families in parallel: the
+// register-radix kernels alone are ~180 instantiations (5 transform sizes x 3 arithmetic policies x 12 kernels).
+#pragma once
+#include "../../include/cnhip.h"
+#include "cn_internal.h"
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+int cn_fail(int code, const char *fmt, ...);       // sets the thread-local message of cn_last_error(), returns `code`
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cn_fail(CN_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+#define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct GemmPlan;
+// A captured operation sequence (cn_graph_begin / cn_graph_end): the instantiated HIP graph, the host blocks its upload nodes read at
+// every launch, and the device arrays that were handed out while it was recorded and are not owned by a live handle - they stay
+// reserved for the graph (its kernels carry their addresses), out of the pool, until the graph is freed.
+struct CapturedGraph {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    std::vector<std::unique_ptr<char[]>> staged;
+    std::vector<std::pair<uint64_t *, size_t>> reserved;
+};
+struct Buffer {
+    int kind;                 // 0 = ciphertext array, 1 = dense plaintext array, 2 = scalar GEMM plan, 3 = captured graph
+    std::shared_ptr<GemmPlan> plan;
+    std::shared_ptr<CapturedGraph> cg;
+    uint32_t count, size;     // size = polys per ciphertext
+    uint64_t *d;
+    size_t item_words;
+    std::vector<uint8_t> pt_zero;   // per plaintext: all coefficients zero?
+};
+struct KsKey { uint64_t *d; bool owned; bool f64; };   // f64: words converted to doubles for the FP64 key-switch kernel
+
+// The contexts are called from Defaults.ThreadCount threads at once (HE Wrapper/Utils.cs:46-88) and the critical sections are a few
+// hundred nanoseconds of bookkeeping (handle table, deferred-operation queue): a futex mutex hands every contended acquisition through
+// the kernel, so waiters spin briefly before they yield.
+class CnMutex {
+    std::atomic<int> s{0};
+public:
+    void lock();              // cn_host.cpp: spin briefly, then yield
+    void unlock();
+};
+
+struct DeferQueue;            // cn_api.hip, second half
+struct cn_ctx {
+    int device;
+    hipStream_t stream;
+    DevConsts hc;             // host copy
+    DevConsts *dc;            // device copy
+    uint64_t *tw;
+    CnMutex mu;
+    std::unordered_map<cn_handle, Buffer> bufs;
+    cn_handle next_handle = 1;
+    KsKey rlk{nullptr, false, false};
+    double *twd = nullptr, *twdh = nullptr;
+    bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
+    std::map<uint64_t, KsKey> gk;
+    uint64_t *sk = nullptr, *pk = nullptr;   // client-side keys (NTT form) when the data owner's GPU runs keygen/encrypt/decrypt
+    uint64_t rng_item = 0;                    // running polynomial counter of the Philox streams
+    uint64_t rng_salt = 0;                    // second 64 bits of sampler key material (cn_set_rng_salt), whitening the Philox counter
+    char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
+    std::vector<std::unique_ptr<char[]>> staged;   // host blocks of in-flight upload_tmp copies
+    cn_stats st{};
+    hipEvent_t ev0, ev1;
+    uint32_t bs, chunks;      // element-wise geometry
+    std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
+    size_t ctw2;              // words of a size-2 ciphertext
+    bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
+    // freed ciphertext / plaintext arrays are kept per size and handed out again: every op of a context is ordered on its
+    // stream, so reuse needs no synchronisation, while hipFree / hipMalloc cost ~60 / ~25 us and a device-wide sync each
+    // (a LoLa inference allocates and frees ~300 temporaries per plaintext prime)
+    std::unordered_map<size_t, std::vector<uint64_t *>> pool;
+    size_t pool_bytes = 0, pool_max;
+    void *slabs = nullptr;                // std::vector<Slab>*: small arrays are carved out of slabs (one hipMalloc per <= 64 arrays), cn_api.hip
+    bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
+    int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
+    void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
+    bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
+    bool capturing = false;   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
+    std::vector<std::unique_ptr<char[]>> cap_staged;                 // host blocks of the upload nodes recorded so far
+    std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
+    int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
+    bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
+    bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
+    // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
+    bool defer = false;
+    DeferQueue *dq = nullptr;
+};
+
+// ---------------------------------------------------------------- kernel launchers (cn_l_*.hip)
+enum { POL_U64 = 0, POL_F64 = 1, POL_F64L = 2 };       // ArU64 (Shoup, any modulus), ArF64 (< 2^49.4), ArF64L (<= 44 bits: no forward recentring)
+
+// One key switch of `cnt` ciphertexts: out[ct] = (add0[ct], add1[ct]) + KeySwitch(target[ct]) (+ extra[ct] - the fused accumulator of
+// the cn_*_add entry points).  target / add0 / add1 / extra are strided per ciphertext (in words); out is dense size-2, or - out_tab -
+// one address per ciphertext (deferred per-ciphertext calls whose results live in separate arrays).
+struct KsArgs {
+    const uint64_t *target; size_t tstride;
+    const uint64_t *add0, *add1; size_t astride;
+    const uint64_t *key; uint64_t *out; uint32_t cnt; int galois;
+    const uint64_t *extra; size_t xstride;
+    uint32_t accmax;          // FP64 accumulators: terms between recentrings
+    int mode;                 // 0 fused, 1 two launches / workgroup per digit, 2 two launches / workgroup per source limb
+    uint64_t *const *out_tab;
+};
+struct RrOps {                // register-radix kernels of one arithmetic policy; every launcher returns false when the size has no kernel
+    int (*set_attrs)(uint32_t logn, size_t lds);
+    bool (*ntt)(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse);
+    bool (*intt_tensor)(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm);
+    bool (*square_fused)(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm);   // FP64 policies
+    bool (*mul_plain_fused)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride, uint32_t pstride,
+                            uint64_t *out, uint32_t count, uint32_t polys);
+    bool (*enc_tail)(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0);   // U64, F64
+};
+struct KsOps {
+    int (*set_attrs)(uint32_t logn, size_t lds);
+    bool (*launch)(cn_ctx *c, const KsArgs &a);                        // fused / two-phase by a.mode
+    bool (*split14)(cn_ctx *c, const KsArgs &a);                       // N = 16384 as two 8192-point halves (FP64 policies)
+};
+extern const RrOps cn_rr_u64, cn_rr_f64, cn_rr_f64l;
+extern const KsOps cn_ks_u64, cn_ks_f64, cn_ks_f64l;
+
+// BEHZ element-wise steps (cn_l_behz.hip); src_tab: one source address per ciphertext instead of src + ct*stride*2kN
+int cn_l_behz_extend(cn_ctx *c, const uint64_t *src, uint32_t stride, const uint64_t *const *src_tab, uint64_t *aq, uint64_t *ab, uint32_t cnt);
+int cn_l_behz_floor(cn_ctx *c, const uint64_t *dq, const uint64_t *db, uint64_t *out, uint32_t cnt);
+
+// scalar GEMM (cn_l_gemm.hip).  Relative addressing: input / output ciphertext = base + index * ctw; absolute (ABS): the tables hold
+// device addresses (deferred per-ciphertext calls: every ciphertext is its own array), 0 = padded tap / no output.
+struct GemmLaunch {
+    bool small, two, abs; uint32_t MT;
+    const uint64_t *in; const void *idx; const void *W; const void *oidx; const uint64_t *bias; const void *bidx; uint64_t *out;
+    uint32_t G, M, K, lazy, Kp, obase;
+};
+int cn_l_gemm(cn_ctx *c, const GemmLaunch &g);
+
+inline void cn_launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }

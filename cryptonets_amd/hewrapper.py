@@ -1379,12 +1379,25 @@ class CapturedEvaluation:
         ctxs = [e.ctx for e in env.Environments]
         import gc
         gc.collect()                                  # temporaries of the rehearsal that only the collector frees go back to the pools first
-        for c in ctxs:
-            c.graph_begin()
+        self.graphs, begun, failure = [], [], None
         try:
+            for c in ctxs:
+                c.graph_begin()
+                begun.append(c)
             self.result = fn(*self.inputs)
-        finally:
-            self.graphs = [c.graph_end() for c in ctxs]
+        except BaseException as ex:                   # noqa: BLE001 - re-raised below, after every context has left capture mode
+            failure = ex
+        for c in begun:                               # every context that entered capture mode leaves it, whatever happened
+            try:
+                self.graphs.append((c, c.graph_end()))
+            except Exception as ex:                   # noqa: BLE001
+                failure = failure or ex
+        if failure is not None:                       # a failed recording keeps nothing: its graphs would pin the scratch arenas
+            for c, g in self.graphs:
+                c.free(g)
+            self.graphs = []
+            raise failure
+        self.graphs = [g for _, g in self.graphs]
 
     @staticmethod
     def _views(m):
@@ -1416,7 +1429,9 @@ class EncryptedSealBfvFactory:
     DefaultGaloisDecompositionBitCount = 20
 
     def __init__(self, primes=None, n=4096, DecompositionBitCount=10, GaloisDecompositionBitCount=20, SmallModulusCount=-1,
-                 client_factory=None, context_factory=None, device=0, galois=True):
+                 client_factory=None, context_factory=None, device=0, galois=True, client_seed=None):
+        """client_seed: None (default) = keys and encryption randomness from the OS entropy source; an integer makes the default
+        DeviceClient reproducible (tests only - whoever knows it can regenerate the secret key)."""
         if primes is None:
             primes = [40961, 65537, 114689, 147457, 188417]
             n = 4096
@@ -1436,8 +1451,8 @@ class EncryptedSealBfvFactory:
             if client_factory is not None:
                 client = client_factory(t, n, q, DecompositionBitCount, GaloisDecompositionBitCount)
             else:
-                from .client import DeviceClient                   # keygen / encrypt / decrypt on the device
-                client = DeviceClient(ctx, seed=0x5EA1 ^ t)
+                from .client import DeviceClient                   # keygen / encrypt / decrypt on the device, seeded from os.urandom
+                client = DeviceClient(ctx, seed=None if client_seed is None else client_seed ^ t)
             e = AtomicSealBfvEncryptedEnvironment(ctx, client)
             if client is not None:
                 e.GenerateEncryptionKeys(with_galois=galois)

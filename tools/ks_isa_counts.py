@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""FP64 instruction counts of the fused key-switch kernel, read from the BUILT code object (not from constants in a script).
+
+`llvm-objdump --offloading` extracts the gfx950 code object from the key-switch translation unit's object file, `llvm-objdump -d`
+disassembles it; the kernel's loops are recovered from its backward branches (limb loop > digit loop; the loop over the two inverse
+transforms) and every `v_*_f64` instruction is weighted with the trip counts of the loops that contain it.  `fp64_per_thread(k, digits
+per limb)` is what bench.py prices against the FP64 issue rate (one wave-instruction per ~4.4 cycles per SIMD,
+profiles/r01_ubench_mulmod.txt) to get the key switch's arithmetic floor.
+
+    python tools/ks_isa_counts.py            # prints the structure found in k_keyswitch_rr<13, ArF64T<0>, 1, true>
+"""
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+KERNEL = "_Z14k_keyswitch_rrILi13E6ArF64TILi0EELi1ELb1EE"          # k_keyswitch_rr<13, ArF64T<0>, 1, true>
+
+
+def disassemble(obj, kernel=KERNEL):
+    """[(address, mnemonic, operands)] of `kernel` in the device code object bundled in `obj`"""
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, os.path.basename(obj))
+        os.symlink(obj, tmp)
+        subprocess.check_call([OBJDUMP, "--offloading", tmp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in glob.glob(tmp + ".*") if "amdgcn" in f]
+        if not co:
+            raise RuntimeError("no gfx950 code object in %s" % obj)
+        txt = subprocess.check_output([OBJDUMP, "-d", co[0]], text=True)
+    ins, on = [], False
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            on = m.group(1).startswith(kernel)
+            continue
+        if not on:
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+        if m:
+            ins.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    if not ins:
+        raise RuntimeError("kernel %s not found" % kernel)
+    return ins
+
+
+def loops(ins):
+    """{header address: [addresses of its back edges]}: backward branches, minus the compiler's out-of-line trampolines (an s_branch that
+    directly follows another s_branch is the landing pad of a forward conditional branch jumping back into the body, not a loop)"""
+    out = {}
+    for k, (addr, op, args) in enumerate(ins):
+        if op.startswith("s_cbranch") or op == "s_branch":
+            m = re.search(r"(-?\d+)", args)
+            if not m or (op == "s_branch" and k and ins[k - 1][1] == "s_branch"):
+                continue
+            nxt = ins[k + 1][0] if k + 1 < len(ins) else addr + 4
+            off = int(m.group(1))
+            off = off - 65536 if off >= 32768 else off         # simm16, in dwords from the next instruction
+            tgt = nxt + 4 * off
+            if tgt <= addr:
+                out.setdefault(tgt, []).append(addr)
+    return out
+
+
+def structure(obj=None):
+    obj = obj or os.path.join(ROOT, "cryptonets_amd", "lib", "obj", "cn_l_ks_f64l.o")
+    ins = disassemble(obj)
+    f64 = [a for a, op, _ in ins if op.startswith("v_") and "_f64" in op]
+    within = lambda lo, hi: sum(lo <= a <= hi for a in f64)
+    # the kernel has two loop nests with FP64 work: (limb loop > digit loop), which the compiler rotates onto ONE header with two back
+    # edges (digit: the nearer one, limb: the farther one), and behind it the loop over the two inverse transforms
+    big = sorted((h, sorted(e)) for h, e in loops(ins).items() if within(h, max(e)) > 100)
+    if len(big) != 2 or len(big[0][1]) != 2:
+        raise RuntimeError("unrecognised loop structure in the key-switch kernel: %s" % [(hex(h), [hex(x) for x in e]) for h, e in big])
+    (h1, (digit_end, limb_end)), (h2, e2) = big
+    tail_end = max(e2)
+    return dict(kernel="k_keyswitch_rr<13, ArF64T<0>, 1, true>", instructions=len(ins), fp64_total=len(f64),
+                fp64_digit_loop=within(h1, digit_end), fp64_limb_loop_only=within(digit_end + 1, limb_end),
+                fp64_tail_loop=within(h2, tail_end), fp64_once=len(f64) - within(h1, limb_end) - within(h2, tail_end))
+
+
+def fp64_per_thread(k, digits_per_limb, obj=None):
+    """FP64 instructions one thread executes for one (ciphertext, output limb): k source limbs x their digits, 2 inverse transforms"""
+    s = structure(obj)
+    return sum(d * s["fp64_digit_loop"] + s["fp64_limb_loop_only"] for d in digits_per_limb) + 2 * s["fp64_tail_loop"] + s["fp64_once"], s
+
+
+if __name__ == "__main__":
+    s = structure(sys.argv[1] if len(sys.argv) > 1 else None)
+    print(json.dumps(s, indent=1))

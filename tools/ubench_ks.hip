@@ -111,6 +111,106 @@ __global__ void __launch_bounds__(512, 1) k_ks(const uint64_t *__restrict__ targ
         __syncthreads();
     }
 }
+
+// Software-pipelined digit loop with two LDS images: the first pass (the only exchange that crosses waves) of digit g+1 is computed and
+// written into image (g+1)&1 at the END of iteration g, the one workgroup barrier of an iteration sits at its START - a whole iteration
+// of wave-local work (passes B, C, last pass, multiply-accumulate) after the writes it publishes, and every read of the image that is
+// overwritten next lies a full iteration back.  One barrier per digit instead of two, and it no longer sits between a wave's own
+// store and load of the same exchange.  Twiddles from L2 (two images + the table exceed the 160 KiB of LDS).
+template <int F>
+__global__ void __launch_bounds__(512, 1) k_ks_pipe(const uint64_t *__restrict__ target, const double *__restrict__ key, uint64_t *out, const double *tw_, double q, double qinv) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *s = reinterpret_cast<double *>(smem);
+    const uint32_t k = 5, tid = threadIdx.x, ct = blockIdx.x / k, j = blockIdx.x % k;
+    const AR::Mod m = {q, qinv};
+    const size_t kn = (size_t)k * N;
+    typedef ArPassA<AR> FW;
+    typename FW::Tw fwt;
+    const NTT_GLOBAL double *gtw = (const NTT_GLOBAL double *)tw_ + (size_t)j * 2 * N;
+    fwt.w = gtw;
+    ntt_load_pass_a<SA>(fwt, gtw);
+    const AR::Tw ivt = {gtw + N};
+    double acc0[16], acc1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+    uint64_t raw[16];
+    auto load_raw = [&](uint32_t l) {
+        const uint64_t *src = target + (size_t)ct * 3 * kn + 2 * kn + (size_t)l * N;
+        uint32_t t0 = tid;
+        asm volatile("" : "+v"(t0));
+#pragma unroll
+        for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
+    };
+    auto first_pass = [&](uint32_t g) {                  // digit g -> pass A -> image g & 1
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        double v[16];
+        const int sh = 10 * (int)(g % 5);
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = AR::from_u64((raw[r] >> sh) & 1023);
+        fwd_stages<FW, L, SA, 0>(v, fwt, m, tl);
+        lds_put<double, L, SA, 0>(v, s + (g & 1) * ntt_lds_words(N), tl);
+    };
+    load_raw(0);
+    first_pass(0);
+    const double *kp = key;
+    for (uint32_t g = 0; g < 25; g++, kp += 2 * kn) {
+        __syncthreads();
+        {
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));
+            double *im = s + (g & 1) * ntt_lds_words(N);
+            double v[16];
+            lds_get<double, L, 4, SA>(v, im, tl);
+            fwd_stages<FW, L, 4, SA>(v, fwt, m, tl);
+            lds_put<double, L, 4, SA>(v, im, tl); ntt_wave_sync(); lds_get<double, L, 4, SA + 4>(v, im, tl);
+            fwd_stages<FW, L, 4, SA + 4>(v, fwt, m, tl);
+            lds_put<double, L, 4, SA + 4>(v, im, tl); ntt_wave_sync(); lds_get_tail<double, L>(v, im, tl);
+            fwd_tail<FW, L>(v, fwt, m, tl);
+            const double *k0 = kp + (size_t)j * N, *k1 = kp + kn + (size_t)j * N;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t pos = tail_index<L>(tl, r);
+                struct alignas(16) P2 { double a, b; };
+                const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+                acc0[r] = __dadd_rn(acc0[r], AR::mulmod(v[r], a.a, m)); acc0[r + 1] = __dadd_rn(acc0[r + 1], AR::mulmod(v[r + 1], a.b, m));
+                acc1[r] = __dadd_rn(acc1[r], AR::mulmod(v[r], b.a, m)); acc1[r + 1] = __dadd_rn(acc1[r + 1], AR::mulmod(v[r + 1], b.b, m));
+            }
+        }
+        if (g + 1 < 25) {
+            if ((g + 1) % 5 == 0) load_raw((g + 1) / 5);
+            first_pass(g + 1);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        double v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        ntt_inverse_regs<AR, L>(v, s, ivt, m, tl);
+        uint64_t *o = out + ((size_t)ct * 2 + p) * kn + (size_t)j * N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(tl, r)] = AR::to_u64(v[r], m);
+        __syncthreads();
+    }
+}
+template <int F> void run_pipe(const char *what, const uint64_t *tgt, const double *key, uint64_t *out, const double *tw, int cts) {
+    const size_t lds = (size_t)ntt_lds_words(N) * 2 * 8;
+    hipFuncSetAttribute((const void *)k_ks_pipe<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const double q = 8796092792833.0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_ks_pipe<F>, dim3(cts * 5), dim3(512), lds, 0, tgt, key, out, tw, q, 1.0 / q);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 4; r++) {
+        hipEventRecord(e0); hipLaunchKernelGGL(k_ks_pipe<F>, dim3(cts * 5), dim3(512), lds, 0, tgt, key, out, tw, q, 1.0 / q); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    printf("%-64s : %7.3f ms\n", what, best);
+}
 template <int F> void run(const char *what, const uint64_t *tgt, const double *key, uint64_t *out, const double *tw, int cts) {
     const size_t lds = ((size_t)ntt_lds_words(N) * ((F & F_DB) ? 2 : 1) + ((F & (F_TWL | F_KLDS)) ? N : 0)) * 8;
     hipFuncSetAttribute((const void *)k_ks<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -140,6 +240,7 @@ int main() {
     hipMemcpy(key, kk.data(), kk.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(tw, kk.data(), 5 * 2 * N * 8, hipMemcpyHostToDevice);
     run<127>("full (keys, LDS, math, MAC, barriers, LDS twiddles, source loads)", tgt, key, out, tw, cts);
+    run_pipe<0>("software-pipelined: first pass of digit g+1 before the barrier, 2 images", tgt, key, out, tw, cts);
     run<127 + F_PRIO>("full, waves 0-3 at priority 3, waves 4-7 at priority 0", tgt, key, out, tw, cts);
     run<127 - F_TWL>("full, twiddles from L2 instead of LDS", tgt, key, out, tw, cts);
     run<127 - F_TWL + F_DB>("two LDS images (one barrier per digit), twiddles from L2", tgt, key, out, tw, cts);
