@@ -95,6 +95,7 @@ SIGNATURES = {
     "cn_key_words": (C.c_size_t, [_CTX, C.c_int]),
     "cn_set_relin_key": (C.c_int, [_CTX, C.c_void_p, C.c_size_t, C.c_int]),
     "cn_set_galois_key": (C.c_int, [_CTX, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
+    "cn_ctx_broadcast_keys": (C.c_int, [C.POINTER(_CTX), C.c_int]),
     "cn_has_galois_key": (C.c_int, [_CTX, C.c_uint64]),
     "cn_galois_elt_from_step": (C.c_uint64, [_CTX, C.c_int]),
     "cn_ct_alloc": (C.c_int, [_CTX, _u32, _u32, C.POINTER(_H)]),
@@ -175,6 +176,14 @@ def _p64(a):
     if a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
         raise ValueError("expected contiguous uint64 array")
     return a.ctypes.data_as(U64P)
+
+
+def broadcast_keys(contexts):
+    """evaluation keys of contexts[0] into the others (cn_ctx_broadcast_keys: RCCL across GPUs, device copies on one GPU)"""
+    arr = (_CTX * len(contexts))(*[c._h for c in contexts])
+    rc = lib().cn_ctx_broadcast_keys(arr, len(contexts))
+    if rc:
+        raise CnError(rc, lib().cn_last_error().decode())
 
 
 def default_coeff_modulus(n):

@@ -1624,6 +1624,113 @@ static int defer_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astri
     return 0;
 }
 
+// ---------------------------------------------------------------- multi-GPU: evaluation keys of ctxs[0] to every other context
+// The path shards by independent batches / plaintext primes: the only exchange is this one-time key broadcast.  A host that
+// runs one process per GPU (bench.py) broadcasts with torch.distributed and adopts the buffers (cn_set_relin_key, is_device_ptr = 1); a
+// single-process multi-threaded host (the C# one) calls this: contexts on OTHER devices receive the keys with ONE RCCL broadcast per key
+// over xGMI (librccl is loaded on demand; without it: peer copies), contexts on the root's device with device-to-device copies.
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Broadcast = (decltype(Broadcast))dlsym(lib, "ncclBroadcast"); GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast) { dlclose(lib); lib = nullptr; return false; }
+        return true;
+    }
+};
+const int kNcclUint64 = 5;          // ncclDataType_t
+}
+#define NCCLCHK(x) do { int r_ = (x); if (r_) { rc = fail(CN_ERR_HIP, "%s failed: %s", #x, R.GetErrorString ? R.GetErrorString(r_) : "rccl error"); goto done; } } while (0)
+extern "C" int cn_ctx_broadcast_keys(cn_ctx **ctxs, int n) {
+    if (!ctxs || n < 1 || !ctxs[0]) return fail(CN_ERR_ARG, "null argument");
+    cn_ctx *root = ctxs[0];
+    for (int i = 1; i < n; i++) {
+        cn_ctx *c = ctxs[i];
+        if (!c || c == root) return fail(CN_ERR_ARG, "context %d is null or the root itself", i);
+        bool same = c->hc.n == root->hc.n && c->hc.k == root->hc.k && c->hc.t.q == root->hc.t.q && c->hc.dbc == root->hc.dbc && c->hc.gdbc == root->hc.gdbc;
+        for (uint32_t j = 0; same && j < root->hc.k; j++) same = c->hc.q[j].q == root->hc.q[j].q;
+        if (!same) return fail(CN_ERR_ARG, "context %d has other encryption parameters than the root", i);
+    }
+    // everything in flight on the contexts is finished first (no context lock is held across the others: callers broadcast at start-up)
+    for (int i = 0; i < n; i++) CHECK(cn_sync(ctxs[i]));
+    struct Item { uint64_t elt; bool galois; const KsKey *src; size_t words; };
+    std::vector<Item> items;
+    if (root->rlk.d) items.push_back({0, false, &root->rlk, cn_key_words(root, 0)});
+    for (auto &kv : root->gk) if (kv.second.d) items.push_back({kv.first, true, &kv.second, cn_key_words(root, 1)});
+    if (items.empty()) return fail(CN_ERR_NOKEY, "the root context has no evaluation keys");
+    // destination buffers
+    std::vector<std::vector<uint64_t *>> dst(n, std::vector<uint64_t *>(items.size(), nullptr));
+    int rc = 0;
+    Rccl R;
+    std::vector<int> devs;                   // distinct devices, the root's first; leader[d] = first context on devs[d]
+    std::vector<int> leader;
+    std::vector<void *> comms;
+    auto dev_index = [&](int device) { for (size_t d = 0; d < devs.size(); d++) if (devs[d] == device) return (int)d; return -1; };
+    for (int i = 0; i < n; i++) if (dev_index(ctxs[i]->device) < 0) { devs.push_back(ctxs[i]->device); leader.push_back(i); }
+    for (int i = 1; i < n && !rc; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = fail(CN_ERR_HIP, "hipSetDevice failed"); break; }
+        for (size_t x = 0; x < items.size(); x++)
+            if (hipMalloc((void **)&dst[i][x], items[x].words * 8) != hipSuccess) { rc = fail(CN_ERR_HIP, "out of device memory for the broadcast keys"); break; }
+    }
+    const bool force = getenv("CN_BCAST_FORCE_RCCL") && atoi(getenv("CN_BCAST_FORCE_RCCL"));
+    const bool use_rccl = !rc && (devs.size() > 1 || force) && R.load();
+    if (!rc && use_rccl) {
+        comms.assign(devs.size(), nullptr);
+        NCCLCHK(R.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        for (size_t x = 0; x < items.size(); x++) {
+            NCCLCHK(R.GroupStart());
+            for (size_t d = 0; d < devs.size(); d++) {
+                cn_ctx *c = ctxs[leader[d]];
+                void *buf = d == 0 ? (void *)items[x].src->d : (void *)dst[leader[d]][x];
+                if (hipSetDevice(c->device) != hipSuccess) { rc = fail(CN_ERR_HIP, "hipSetDevice failed"); goto done; }
+                NCCLCHK(R.Broadcast(buf, buf, items[x].words, kNcclUint64, 0, comms[d], c->stream));
+            }
+            NCCLCHK(R.GroupEnd());
+        }
+    }
+    for (int i = 1; i < n && !rc; i++) {     // contexts that did not receive through RCCL: copies from their device's leader (or from the root)
+        const int d = dev_index(ctxs[i]->device);
+        const bool got = use_rccl && leader[d] == i;
+        if (got) continue;
+        const int from = (use_rccl || d == 0) ? leader[d] : 0;
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = fail(CN_ERR_HIP, "hipSetDevice failed"); break; }
+        if (from != 0 && hipStreamSynchronize(ctxs[from]->stream) != hipSuccess) { rc = fail(CN_ERR_HIP, "synchronisation failed"); break; }
+        for (size_t x = 0; x < items.size() && !rc; x++) {
+            const void *src = from == 0 ? (const void *)items[x].src->d : (const void *)dst[from][x];
+            hipError_t e = ctxs[from]->device == ctxs[i]->device ? hipMemcpyAsync(dst[i][x], src, items[x].words * 8, hipMemcpyDeviceToDevice, ctxs[i]->stream)
+                                                                 : hipMemcpyPeerAsync(dst[i][x], ctxs[i]->device, src, ctxs[from]->device, items[x].words * 8, ctxs[i]->stream);
+            if (e != hipSuccess) rc = fail(CN_ERR_HIP, "key copy failed: %s", hipGetErrorString(e));
+        }
+    }
+done:
+    for (int i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
+    for (void *cm : comms) if (cm) (void)R.CommDestroy(cm);
+    for (int i = 1; i < n; i++) {
+        std::lock_guard<CnMutex> lk(ctxs[i]->mu);
+        for (size_t x = 0; x < items.size(); x++) {
+            if (!dst[i][x]) continue;
+            if (rc) { (void)hipSetDevice(ctxs[i]->device); (void)hipFree(dst[i][x]); continue; }
+            KsKey &slot = items[x].galois ? ctxs[i]->gk[items[x].elt] : ctxs[i]->rlk;
+            if (slot.owned && slot.d) { (void)hipSetDevice(ctxs[i]->device); (void)hipFree(slot.d); }
+            slot = KsKey{dst[i][x], true, items[x].src->f64};          // the words arrive in the form the root keeps them (FP64 image or u64)
+        }
+    }
+    (void)hipSetDevice(root->device);
+    return rc;
+}
+
 // ---------------------------------------------------------------- raw transforms / timing / stats
 static int raw_ntt(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse) {
     if (base != 0 && base != 1) return fail(CN_ERR_ARG, "base must be 0 (q) or 1 (Bsk)");

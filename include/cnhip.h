@@ -76,6 +76,12 @@ size_t cn_key_words(cn_ctx *ctx, int which);
 int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_device_ptr);
 int cn_set_galois_key(cn_ctx *ctx, uint64_t galois_elt, const uint64_t *words, size_t count, int is_device_ptr);
 int cn_has_galois_key(cn_ctx *ctx, uint64_t galois_elt);
+/* Multi-GPU, single process (the path shards by independent batches / plaintext primes, the only exchange is the one-time
+ * key broadcast): copies the relinearisation key and every Galois key of ctxs[0] into ctxs[1..n-1] (same encryption parameters, any
+ * devices) - ONE RCCL broadcast per key over xGMI to the contexts on other GPUs (librccl is loaded on demand; peer copies without it),
+ * device-to-device copies on the root's GPU.  Synchronises all contexts.  (One process per GPU: broadcast with the host framework and
+ * adopt the buffers through cn_set_relin_key / cn_set_galois_key with is_device_ptr = 1 instead - bench.py does.) */
+int cn_ctx_broadcast_keys(cn_ctx **ctxs, int n);
 /* Evaluator/util galois_elt_from_step: steps>0 left, <0 right, 0 = column swap (2N-1) */
 uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps);
 

@@ -1,0 +1,1064 @@
+// GPU twin of `HE Wrapper/AtomicSealBfvVector.cs` (microsoft/CryptoNets): the SAME classes - AtomicSealBfvEncryptedEnvironment,
+// AtomicSealBfvEncryptedVector, OperationsCount - with the SAME members, so that EncryptedSealBfvVector.cs, EncryptedSealBfvMatrix.cs,
+// IFactory.cs, CryptoTracker.cs, Utils.cs and everything in NeuralNetworks/ compile against it UNCHANGED.  Build `HE Wrapper` with the
+// symbol CNHIP defined, this file + CnHip.cs + GpuSealBfvFactory.cs added and AtomicSealBfvVector.cs wrapped in `#if !CNHIP`
+// (INTEGRATION.md has the .csproj lines).  Every `epenv.evaluator.*` call of the reference (SURVEY.md section 2a lists them with
+// their lines) becomes a libcnhip call on device-resident ciphertexts; what SEAL does on the CLIENT side stays SEAL: KeyGenerator,
+// Encryptor, Decryptor, BatchEncoder (AtomicSealBfvVector.cs:62-74, 1042, 1130, 1211) - the evaluation device never sees a secret key.
+//
+// Not compiled in this repository (no .NET toolchain in the build image); tests/test_integration_cs.py checks that every P/Invoke it
+// uses exists in include/cnhip.h with the generated signature and that every member the unchanged reference files use is defined here.
+//
+// Storage: a vector's blocks live in ONE device array (`enc`: handle + count); plaintext vectors keep their SEAL Plaintexts on the host
+// (they are created by SEAL's BatchEncoder) and a lazily uploaded device copy for AddPlain / MultiplyPlain.  Calls arrive from
+// Defaults.ThreadCount threads (Utils.ParallelProcessInEnv): libcnhip serialises per context and - with deferred submission, on by
+// default here - merges the per-ciphertext calls of a layer into a few batched launches (include/cnhip.h, cn_set_option "defer").
+#if CNHIP
+using System;
+using System.Collections.Concurrent;
+using System.Collections.Generic;
+using System.Diagnostics;
+using System.IO;
+using System.Linq;
+using System.Numerics;
+using System.Reflection;
+using System.Threading;
+using System.Threading.Tasks;
+using MathNet.Numerics.LinearAlgebra;
+using Microsoft.Research.SEAL;
+
+namespace HEWrapper
+{
+    /// <summary>One libcnhip context (= one plaintext modulus on one GPU), shared by every environment copy like the reference shares
+    /// its Evaluator and keys (AtomicSealBfvVector.cs:45-60).  Destroyed by the finalizer of the last reference.</summary>
+    public sealed class CnDevice
+    {
+        public IntPtr Ctx { get; private set; }
+        public readonly uint N, K;
+        public readonly int DeviceIndex;
+        public CnDevice(EncryptionParameters parms, int dbc, int gdbc, int deviceIndex, bool deferred)
+        {
+            var q = parms.CoeffModulus.Select(m => m.Value).ToArray();
+            N = (uint)parms.PolyModulusDegree; K = (uint)q.Length; DeviceIndex = deviceIndex;
+            CnHip.Check(CnHip.cn_ctx_create(N, q, K, parms.PlainModulus.Value, dbc, gdbc, deviceIndex, out IntPtr c));
+            Ctx = c;
+            CnHip.Check(CnHip.cn_set_option(Ctx, "defer", deferred ? 1 : 0));
+        }
+        ~CnDevice() { if (Ctx != IntPtr.Zero) { CnHip.cn_ctx_destroy(Ctx); Ctx = IntPtr.Zero; } }
+        public int CtWords(int size = 2) { return (int)(size * K * N); }
+    }
+
+    /// <summary>A device array of ciphertexts (libcnhip handle).  Released by Dispose or by the finalizer (AtomicSealBfvVector.cs:379-404).</summary>
+    public sealed class CnBuffer : IDisposable
+    {
+        public readonly CnDevice Dev; public ulong Handle; public readonly uint Count;
+        public CnBuffer(CnDevice dev, uint count, bool plain = false)
+        {
+            Dev = dev; Count = count;
+            if (plain) CnHip.Check(CnHip.cn_pt_alloc(dev.Ctx, count, out Handle)); else CnHip.Check(CnHip.cn_ct_alloc(dev.Ctx, count, 2, out Handle));
+        }
+        ~CnBuffer() { Free(); }
+        void Free() { if (Handle != 0 && Dev.Ctx != IntPtr.Zero) { CnHip.cn_free(Dev.Ctx, Handle); Handle = 0; } }
+        public void Dispose() { Free(); GC.SuppressFinalize(this); }
+    }
+
+    /// <summary>SEAL 3.2 objects <-> u64 words.  A SEAL Ciphertext is [poly][limb][N] u64 words (the layout of include/cnhip.h); its
+    /// Save() stream is  parms_id (4 x u64) | is_ntt_form (u8) | size, poly_modulus_degree, coeff_mod_count (u64 each) | scale (f64) |
+    /// word count (u64) | words  - 73 header bytes (SEAL 3.2 ciphertext.cpp).  Reading goes through Save() when that layout checks out and
+    /// through the public indexer otherwise; writing composes the same stream for Load().</summary>
+    public static class SealInterop
+    {
+        const int CtHeader = 73;
+        public static ulong[] Words(Ciphertext c)
+        {
+            ulong count = c.UInt64Count;
+            var w = new ulong[count];
+            using (var mem = new MemoryStream())
+            {
+                c.Save(mem);
+                if ((ulong)mem.Length == CtHeader + 8 * count)
+                {
+                    Buffer.BlockCopy(mem.GetBuffer(), CtHeader, w, 0, (int)(8 * count));
+                    return w;
+                }
+            }
+            for (ulong i = 0; i < count; i++) w[i] = c[i];          // layout differs from the documented one: the (slow) public indexer
+            return w;
+        }
+        public static Ciphertext ToCiphertext(ulong[] words, AtomicSealBfvEncryptedEnvironment env, bool nttForm = false)
+        {
+            ulong n = env.parameters.PolyModulusDegree, k = (ulong)env.parameters.CoeffModulus.Count();
+            ulong size = (ulong)words.Length / (n * k);
+            using (var mem = new MemoryStream())
+            using (var bw = new BinaryWriter(mem))
+            {
+                foreach (var b in env.context.FirstParmsId.Block) bw.Write(b);
+                bw.Write((byte)(nttForm ? 1 : 0));
+                bw.Write(size); bw.Write(n); bw.Write(k); bw.Write(1.0); bw.Write((ulong)words.Length);
+                var bytes = new byte[8 * words.Length];
+                Buffer.BlockCopy(words, 0, bytes, 0, bytes.Length);
+                bw.Write(bytes);
+                bw.Flush();
+                mem.Position = 0;
+                var c = new Ciphertext(env.context, env.memoryPool);
+                c.Load(env.context, mem);
+                return c;
+            }
+        }
+        /// <summary>N coefficients of a BatchEncoded plaintext (shorter plaintexts are zero padded)</summary>
+        public static ulong[] Coeffs(Plaintext p, uint n)
+        {
+            var w = new ulong[n];
+            ulong cnt = Math.Min(p.CoeffCount, (ulong)n);
+            for (ulong i = 0; i < cnt; i++) w[i] = p[i];
+            return w;
+        }
+        /// <summary>the constant of a sparse-format plaintext `Plaintext(hex)` (AtomicSealBfvVector.cs:1136)</summary>
+        public static ulong Constant(Plaintext p) { return p.CoeffCount == 0 ? 0UL : p[0]; }
+        /// <summary>Key-switch key for libcnhip: SEAL 3.2 keeps one Ciphertext (size 2, NTT form, [2][k][N] words) per (source limb l, digit d),
+        /// in the order relinearize_one_step / apply_galois walk them - l outer, d inner, digits low to high (SEAL 3.2 evaluator.cpp).  That
+        /// is the [(l,d)][2][k][N] layout of cn_set_relin_key / cn_set_galois_key: the words are concatenated as they are.</summary>
+        public static ulong[] KeySwitchKey(IEnumerable<Ciphertext> digits)
+        {
+            var parts = digits.Select(Words).ToList();
+            var all = new ulong[parts.Sum(p => p.Length)];
+            int pos = 0;
+            foreach (var p in parts) { Array.Copy(p, 0, all, pos, p.Length); pos += p.Length; }
+            return all;
+        }
+    }
+
+    public class AtomicSealBfvEncryptedEnvironment : IComputationEnvironment
+    {
+        // --- client side: SEAL, exactly as in the reference (AtomicSealBfvVector.cs:22-37)
+        public Evaluator evaluator;               // kept for source compatibility; the hot path never touches it
+        public Encryptor encryptor;
+        public Decryptor decryptor;
+        public EncryptionParameters parameters = null;
+        public SEALContext context = null;
+        public readonly MemoryPoolHandle memoryPool = MemoryPoolHandle.New();
+        public SecretKey secretKey;
+        public PublicKey publicKey;
+        public RelinKeys relinKeys;
+        public BatchEncoder builder;
+        public GaloisKeys galoisKeys;
+        public Plaintext PlainZero;
+        public ulong plainmodulusValue = 0;
+        public int PlaintextCapacity { get { return (int)parameters.PolyModulusDegree; } }
+        public ulong CiphertextCapacity { get { return 3; } }
+        public IFactory ParentFactory { get; set; }
+        // --- evaluation side: the device context (shared by all copies of this environment)
+        public CnDevice device;
+        /// <summary>GPU the NEXT environment is created on / whether its calls are queued and batched (GpuSealBfvFactory sets both)</summary>
+        public static int DefaultDeviceIndex = 0;
+        public static bool DeferredSubmission = true;
+        int decompositionBitCount, galoisDecompositionBitCount;
+
+        public AtomicSealBfvEncryptedEnvironment() { }
+        public AtomicSealBfvEncryptedEnvironment(AtomicSealBfvEncryptedEnvironment p)
+        {
+            parameters = p.parameters; context = p.context; builder = p.builder; relinKeys = p.relinKeys; secretKey = p.secretKey;
+            publicKey = p.publicKey; evaluator = p.evaluator; encryptor = p.encryptor; decryptor = p.decryptor; galoisKeys = p.galoisKeys;
+            PlainZero = p.PlainZero; ParentFactory = p.ParentFactory; plainmodulusValue = p.plainmodulusValue;
+            device = p.device;
+        }
+
+        /// <summary>uploads the PUBLIC evaluation keys into HBM (cn_set_relin_key / cn_set_galois_key); the secret key stays on the host</summary>
+        void CreateDevice(int dbc, int gdbc)
+        {
+            decompositionBitCount = dbc; galoisDecompositionBitCount = gdbc;
+            device = new CnDevice(parameters, dbc, gdbc, DefaultDeviceIndex, DeferredSubmission);
+            // RelinKeys.Data[0]: the key that takes a size-3 ciphertext to size 2 (relinearize_one_step)
+            var rk = SealInterop.KeySwitchKey(relinKeys.Data.First());
+            CnHip.Check(CnHip.cn_set_relin_key(device.Ctx, rk, (UIntPtr)rk.Length, 0));
+            // GaloisKeys.Data[(elt - 1) / 2]: the key of Galois element elt (empty when the key was not generated)
+            ulong index = 0;
+            foreach (var key in galoisKeys.Data)
+            {
+                var digits = key.ToList();
+                if (digits.Count > 0)
+                {
+                    var gk = SealInterop.KeySwitchKey(digits);
+                    CnHip.Check(CnHip.cn_set_galois_key(device.Ctx, 2 * index + 1, gk, (UIntPtr)gk.Length, 0));
+                }
+                index++;
+            }
+        }
+
+        public void SetKeys(KeyGenerator keys, int DecompositionBitCount, int GaloisDecompositionBitCount)
+        {
+            evaluator = new Evaluator(context);
+            encryptor = new Encryptor(context, keys.PublicKey);
+            decryptor = new Decryptor(context, keys.SecretKey);
+            builder = new BatchEncoder(context);
+            relinKeys = keys.RelinKeys(DecompositionBitCount);
+            galoisKeys = keys.GaloisKeys(GaloisDecompositionBitCount);
+            secretKey = new SecretKey(keys.SecretKey);
+            publicKey = new PublicKey(keys.PublicKey);
+            PlainZero = new Plaintext("0", memoryPool);
+            plainmodulusValue = parameters.PlainModulus.Value;
+            CreateDevice(DecompositionBitCount, GaloisDecompositionBitCount);
+        }
+
+        public AtomicSealBfvEncryptedEnvironment GetPublicKeys()
+        {
+            return new AtomicSealBfvEncryptedEnvironment(this) { secretKey = null, decryptor = null };
+        }
+
+        public void SaveToFile(string fileName)
+        {
+            Console.WriteLine("Opening file {0} for writing", fileName);
+            using (var file = File.Create(fileName)) SaveToStream(file);
+        }
+
+        public void SaveToStream(Stream stream, bool withPrivateKeys = true)
+        {
+            EncryptionParameters.Save(parameters, stream);
+            publicKey.Save(stream);
+            relinKeys.Save(stream);
+            galoisKeys.Save(stream);
+            if (withPrivateKeys) secretKey.Save(stream); else new SecretKey().Save(stream);
+        }
+
+        public void LoadFromStream(Stream stream)
+        {
+            parameters = EncryptionParameters.Load(stream);
+            context = SEALContext.Create(parameters);
+            publicKey = new PublicKey(); publicKey.Load(context, stream);
+            relinKeys = new RelinKeys(); relinKeys.Load(context, stream);
+            galoisKeys = new GaloisKeys(); galoisKeys.Load(context, stream);
+            secretKey = new SecretKey(); secretKey.Load(context, stream);
+            plainmodulusValue = parameters.PlainModulus.Value;
+            evaluator = new Evaluator(context);
+            encryptor = new Encryptor(context, publicKey);
+            try { decryptor = new Decryptor(context, secretKey); }
+            catch (Exception)
+            {
+                decryptor = null;
+                Console.WriteLine("WARNING: no Secret Key in file. Will not be able to decrypt messages.");
+            }
+            builder = new BatchEncoder(context);
+            PlainZero = new Plaintext("0", memoryPool);
+            CreateDevice(relinKeys.DecompositionBitCount, galoisKeys.DecompositionBitCount);
+        }
+
+        public void LoadFromFile(String fileName) { using (var file = File.OpenRead(fileName)) LoadFromStream(file); }
+
+        public static EncryptionParameters Parms(ulong t, ulong n, int SmallModulusCount)
+        {
+            var parms = new EncryptionParameters(SchemeType.BFV)
+            {
+                PlainModulus = new SmallModulus(t), PolyModulusDegree = n, CoeffModulus = DefaultParams.CoeffModulus128(n)
+            };
+            if (SmallModulusCount > 0) parms.CoeffModulus = parms.CoeffModulus.Take(SmallModulusCount).ToList();
+            return parms;
+        }
+        public static EncryptionParameters Parms(ulong t, ulong n, List<SmallModulus> coefModulus = null)
+        {
+            return new EncryptionParameters(SchemeType.BFV) { PlainModulus = new SmallModulus(t), PolyModulusDegree = n, CoeffModulus = coefModulus };
+        }
+
+        public void GenerateEncryptionKeys(ulong prime, ulong n, int DecompositionBitCount, int GaloisDecompositionBitCount, int SmallModulusCount)
+        {
+            GenerateEncryptionKeys(Parms(prime, n, SmallModulusCount), DecompositionBitCount, GaloisDecompositionBitCount);
+        }
+        public void GenerateEncryptionKeys(EncryptionParameters parms, int DecompositionBitCount, int GaloisDecompositionBitCount)
+        {
+            this.parameters = parms;
+            context = SEALContext.Create(parameters);
+            SetKeys(new KeyGenerator(context), DecompositionBitCount, GaloisDecompositionBitCount);
+        }
+        public void GenerateEncryptionKeys(string hexPrime, ulong n, int DecompositionBitCount, int GaloisDecompositionBitCount, int SmallModulusCount = -1)
+        {
+            GenerateEncryptionKeys(Convert.ToUInt64(hexPrime, 16), n, DecompositionBitCount, GaloisDecompositionBitCount, SmallModulusCount);
+        }
+
+        ConcurrentQueue<AtomicSealBfvEncryptedEnvironment> environmentQueue = new ConcurrentQueue<AtomicSealBfvEncryptedEnvironment>();
+        public IComputationEnvironment AllocateComputationEnv()
+        {
+            environmentQueue.TryDequeue(out AtomicSealBfvEncryptedEnvironment env);
+            return env ?? new AtomicSealBfvEncryptedEnvironment(this);
+        }
+        public void FreeComputationEnv(IComputationEnvironment env) { environmentQueue.Enqueue(env as AtomicSealBfvEncryptedEnvironment); }
+        public void Save(string FileName, bool withPrivateKeys) { throw new NotImplementedException(); }
+        public Stream Save(Stream stream, bool withPrivateKeys) { throw new NotImplementedException(); }
+        public ulong[] Primes { get { return new ulong[] { plainmodulusValue }; } }
+    }
+
+    /// <summary>Operation counters (AtomicSealBfvVector.cs:211-294): the managed counters the layers print in DEBUG builds; the device
+    /// keeps the same counters per context (cn_stats_get), CnHip.cn_stats_get(dev.Ctx, out stats, reset) reads them.</summary>
+    public static class OperationsCount
+    {
+        public static int Destructor, Encryption, Plain, Decryption, Multiplication, PlainMultiplication, Addition, Dispose;
+        public static int PlainAddition, Subtraction, PlainSubtraction, Rotation, AddMany, AddManyItemCount, Relinarization;
+        static Dictionary<string, int> Totals = null;
+        static OperationsCount() { AppDomain.CurrentDomain.ProcessExit += (s, e) => PrintTotals(); }
+        static IEnumerable<FieldInfo> Counters() { return typeof(OperationsCount).GetFields().Where(f => f.FieldType == typeof(int)); }
+        [Conditional("DEBUG")] public static void Add(ref int counter, int value) { Interlocked.Add(ref counter, value); }
+        [Conditional("DEBUG")]
+        public static void Print()
+        {
+            if (Totals == null) return;
+            Console.WriteLine("Operations:");
+            foreach (var f in Counters()) Console.WriteLine("\t{0}\t{1}", f.Name, (int)f.GetValue(null));
+        }
+        [Conditional("DEBUG")]
+        public static void Reset()
+        {
+            if (Totals == null) Totals = new Dictionary<string, int>();
+            foreach (var f in Counters())
+            {
+                int v = (int)f.GetValue(null);
+                Totals[f.Name] = Totals.ContainsKey(f.Name) ? Totals[f.Name] + v : v;
+                f.SetValue(null, 0);
+            }
+        }
+        [Conditional("DEBUG")]
+        public static void PrintTotals()
+        {
+            if (Totals == null) return;
+            Console.WriteLine("Operations (total):");
+            foreach (var f in Counters()) Console.WriteLine("\t{0}\t{1}", f.Name, (int)f.GetValue(null) + Totals[f.Name]);
+        }
+    }
+
+    /// <summary>A vector under ONE plaintext modulus (AtomicSealBfvVector.cs:303-1475) with its ciphertexts in HBM.</summary>
+    public class AtomicSealBfvEncryptedVector : IVector
+    {
+        CnBuffer enc = null;              // encrypted: one device array with every block (the reference's Ciphertext[] encData)
+        Plaintext[] plainData = null;     // plain: SEAL plaintexts (BatchEncoded blocks, or hex constants in sparse format)
+        CnBuffer plainDev = null;         // lazily uploaded polynomial form of plainData (AddPlain / MultiplyPlain operands)
+
+        public bool IsSigned { get; set; } = false;
+        public EVectorFormat Format { get; set; } = EVectorFormat.dense;
+        /// <summary>CryptoTracker.TestVectorBudget (CryptoTracker.cs:78-84) reads `Data as Ciphertext[]`: materialised from the device on demand</summary>
+        public object Data { get { return (enc == null) ? (object)plainData : Download(); } }
+        internal void RegisterDim(ulong dim) { this.Dim = dim; }
+        public ulong Dim { get; private set; } = 0;
+        public ulong BlockSize { get { return (enc != null) ? enc.Dev.N : plainData[0].CoeffCount; } }
+        public double Scale { get; private set; }
+        public bool IsEncrypted { get { return (plainData == null & enc != null); } }
+        AtomicSealBfvEncryptedEnvironment owner;      // for Data / Write: the SEAL context the words belong to
+
+        public AtomicSealBfvEncryptedVector(Vector<double> v, IComputationEnvironment env, double Scale = 1.0, bool SignedNumbers = true, bool EncryptData = true, EVectorFormat Format = EVectorFormat.dense)
+        {
+            this.Scale = Scale; this.IsSigned = SignedNumbers;
+            if (EncryptData) Encrypt(v, Format, env); else Plain(v, Format, env);
+        }
+        public AtomicSealBfvEncryptedVector(UInt64[] v, IComputationEnvironment env, double Scale = 1.0, bool SignedNumbers = true, bool EncryptData = true, EVectorFormat Format = EVectorFormat.dense)
+        {
+            this.Scale = Scale; this.IsSigned = SignedNumbers;
+            if (EncryptData) Encrypt(v, Format, env); else Plain(v, Format, env);
+        }
+        /// <summary>copy constructor (deep copy, :365-374): cn_copy on the device</summary>
+        public AtomicSealBfvEncryptedVector(IVector v, AtomicSealBfvEncryptedEnvironment env)
+        {
+            var ev = v as AtomicSealBfvEncryptedVector;
+            Scale = ev.Scale; Dim = ev.Dim; IsSigned = ev.IsSigned; Format = ev.Format; owner = env;
+            if (ev.enc != null)
+            {
+                enc = new CnBuffer(env.device, ev.enc.Count);
+                CnHip.Check(CnHip.cn_copy(env.device.Ctx, ev.enc.Handle, 0, enc.Handle, 0, enc.Count));
+            }
+            plainData = ev.plainData?.Select(x => { var p = new Plaintext(env.memoryPool); p.Set(x); return p; }).ToArray();
+        }
+        private AtomicSealBfvEncryptedVector() { }
+        static AtomicSealBfvEncryptedVector Result(AtomicSealBfvEncryptedEnvironment env, uint blocks)
+        {
+            return new AtomicSealBfvEncryptedVector() { owner = env, enc = new CnBuffer(env.device, blocks), plainData = null };
+        }
+
+        ~AtomicSealBfvEncryptedVector() { OperationsCount.Add(ref OperationsCount.Destructor, 1); FreeResources(); }
+        void FreeResources()
+        {
+            enc?.Dispose(); plainDev?.Dispose();
+            if (plainData != null) foreach (var p in plainData) p.Dispose();
+            enc = null; plainDev = null; plainData = null;
+        }
+        public void Dispose() { FreeResources(); GC.SuppressFinalize(this); OperationsCount.Add(ref OperationsCount.Dispose, 1); }
+
+        // ---------------------------------------------------------------------------------------------------- host <-> device
+        Ciphertext[] Download()
+        {
+            var dev = enc.Dev;
+            var words = new ulong[enc.Count * dev.CtWords()];
+            CnHip.Check(CnHip.cn_ct_download(dev.Ctx, enc.Handle, 0, enc.Count, words));       // drains the deferred queue, synchronises
+            var res = new Ciphertext[enc.Count];
+            for (int i = 0; i < res.Length; i++)
+                res[i] = SealInterop.ToCiphertext(words.Skip(i * dev.CtWords()).Take(dev.CtWords()).ToArray(), owner);
+            return res;
+        }
+        /// <summary>dense plaintext blocks as device polynomials (N coefficients each); sparse constants as constant polynomials</summary>
+        CnBuffer PlainOnDevice(AtomicSealBfvEncryptedEnvironment env)
+        {
+            if (plainDev != null) return plainDev;
+            var dev = env.device;
+            var buf = new CnBuffer(dev, (uint)plainData.Length, plain: true);
+            var w = new ulong[plainData.Length * dev.N];
+            for (int i = 0; i < plainData.Length; i++) Array.Copy(SealInterop.Coeffs(plainData[i], dev.N), 0, w, i * dev.N, dev.N);
+            CnHip.Check(CnHip.cn_pt_upload(dev.Ctx, buf.Handle, 0, buf.Count, w));
+            plainDev = buf;
+            return buf;
+        }
+
+        // ---------------------------------------------------------------------------------------------------- HOT LOOP A
+        static internal Task<AtomicSealBfvEncryptedVector> DenseMatrixBySparseVectorMultiplyTask(AtomicSealBfvEncryptedVector[] denses, AtomicSealBfvEncryptedVector sparse, AtomicSealBfvEncryptedEnvironment env)
+        {
+            return Task<AtomicSealBfvEncryptedVector>.Factory.StartNew(() => DenseMatrixBySparseVectorMultiply(denses, sparse, env));
+        }
+        /// <summary>out_block[i] = sum_k denses[k].block[i] * sparse[k]  (:434-521).  Encrypted columns x plain constants = ONE cn_scalar_dot per
+        /// block (instead of K MultiplyPlain + K Add + AddMany): this is the call PoolLayer.ConvolveOnce issues per (map, corner)
+        /// (PoolLayer.cs:113-121); with deferred submission the calls of a whole layer become one GEMM launch.</summary>
+        static internal AtomicSealBfvEncryptedVector DenseMatrixBySparseVectorMultiply(AtomicSealBfvEncryptedVector[] denses, AtomicSealBfvEncryptedVector sparse, AtomicSealBfvEncryptedEnvironment env)
+        {
+            if ((ulong)denses.Length != sparse.Dim) throw new Exception("dimensions do not match");
+            if (sparse.Format != EVectorFormat.sparse) throw new Exception("expecting a sparse vector");
+            if (!denses[0].IsEncrypted && !sparse.IsEncrypted) throw new Exception("at least one parameter has to be encrypted");
+            if (denses[0].IsSigned != sparse.IsSigned) throw new Exception("can't mix signed and unsigned messages");
+            var ctx = env.device.Ctx;
+            int l = (denses[0].enc != null) ? (int)denses[0].enc.Count : denses[0].plainData.Length;
+            int K = denses.Length;
+            var res = Result(env, (uint)l);
+            res.Format = EVectorFormat.dense; res.Scale = denses[0].Scale * sparse.Scale; res.IsSigned = sparse.IsSigned; res.Dim = denses[0].Dim;
+            if (denses[0].IsEncrypted && sparse.IsEncrypted)
+            {   // Multiply + Relinearize per term (:459-465), then AddMany (:502)
+                using (var terms = new CnBuffer(env.device, (uint)(K * l)))
+                {
+                    for (int k = 0; k < K; k++)
+                        CnHip.Check(CnHip.cn_mul_relin(ctx, denses[k].enc.Handle, 0, 1, sparse.enc.Handle, (uint)k, 0, terms.Handle, (uint)(k * l), (uint)l));
+                    for (int i = 0; i < l; i++)
+                        CnHip.Check(CnHip.cn_add_many(ctx, terms.Handle, Enumerable.Range(0, K).Select(k => (uint)(k * l + i)).ToArray(), (uint)K, res.enc.Handle, (uint)i));
+                }
+                OperationsCount.Add(ref OperationsCount.Multiplication, K * l); OperationsCount.Add(ref OperationsCount.Relinarization, K * l);
+            }
+            else if (denses[0].IsEncrypted)
+            {   // encrypted columns x plain constants (:466-474)
+                var handles = denses.Select(d => d.enc.Handle).ToArray();
+                var w = sparse.plainData.Select(SealInterop.Constant).ToArray();
+                var index = new uint[K];
+                for (int i = 0; i < l; i++)
+                {
+                    for (int k = 0; k < K; k++) index[k] = (uint)i;
+                    CnHip.Check(CnHip.cn_scalar_dot(ctx, handles, index, w, (uint)K, res.enc.Handle, (uint)i));
+                }
+                OperationsCount.Add(ref OperationsCount.PlainMultiplication, w.Count(x => x != 0) * l);
+            }
+            else
+            {   // plain dense columns x encrypted sparse entries (:476-485)
+                using (var terms = new CnBuffer(env.device, (uint)K))
+                    for (int i = 0; i < l; i++)
+                    {
+                        var used = new List<uint>();
+                        for (int k = 0; k < K; k++)
+                        {
+                            if (denses[k].plainData[i].IsZero) continue;
+                            CnHip.Check(CnHip.cn_mul_plain(ctx, sparse.enc.Handle, (uint)k, denses[k].PlainOnDevice(env).Handle, (uint)i, 1, terms.Handle, (uint)k, 1));
+                            used.Add((uint)k);
+                        }
+                        CnHip.Check(CnHip.cn_add_many(ctx, terms.Handle, used.ToArray(), (uint)used.Count, res.enc.Handle, (uint)i));
+                    }
+            }
+            OperationsCount.Add(ref OperationsCount.AddMany, l);
+            return res;
+        }
+
+        internal Task<IVector> SparseMultiplyTask(IVector v, ulong colIndex, IComputationEnvironment env)
+        {
+            return Task<IVector>.Factory.StartNew(() => SparseMultiply(v, colIndex, env));
+        }
+        /// <summary>every block of this dense vector times ELEMENT colIndex of the sparse vector v (:529-598)</summary>
+        internal IVector SparseMultiply(IVector v, ulong colIndex, IComputationEnvironment env)
+        {
+            if (colIndex >= v.Dim) throw new Exception("index exceeds dimension");
+            var ev = v as AtomicSealBfvEncryptedVector;
+            if (ev.Format != EVectorFormat.sparse) throw new Exception("expecting sparse format");
+            if (ev.enc == null && this.enc == null) throw new Exception("at least one argument is expected to be encrypted");
+            if (IsSigned != ev.IsSigned) throw new Exception("can't mix signed and unsigned numbers.");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            var ctx = eenv.device.Ctx;
+            uint n = (this.enc != null) ? this.enc.Count : (uint)this.plainData.Length;
+            var t = Result(eenv, n);
+            t.Scale = Scale * ev.Scale; t.Dim = Dim; t.IsSigned = IsSigned; t.Format = EVectorFormat.dense;
+            if (this.enc != null && ev.enc != null)
+            {
+                CnHip.Check(CnHip.cn_mul_relin(ctx, ev.enc.Handle, (uint)colIndex, 0, this.enc.Handle, 0, 1, t.enc.Handle, 0, n));
+                OperationsCount.Add(ref OperationsCount.Multiplication, (int)n); OperationsCount.Add(ref OperationsCount.Relinarization, (int)n);
+                return t;
+            }
+            if (this.enc == null)
+            {   // plain dense blocks x one encrypted element; a zero block becomes a fresh encryption of zero (:566)
+                for (uint i = 0; i < n; i++)
+                    if (plainData[i].IsZero) t.EncryptZeroInto(eenv, i);
+                    else CnHip.Check(CnHip.cn_mul_plain(ctx, ev.enc.Handle, (uint)colIndex, PlainOnDevice(eenv).Handle, i, 1, t.enc.Handle, i, 1));
+            }
+            else
+            {   // encrypted blocks x one plain constant (:580-596)
+                if (ev.plainData[colIndex].IsZero) for (uint i = 0; i < n; i++) t.EncryptZeroInto(eenv, i);
+                else CnHip.Check(CnHip.cn_mul_scalar(ctx, this.enc.Handle, 0, new ulong[] { SealInterop.Constant(ev.plainData[colIndex]) }, 0, t.enc.Handle, 0, n));
+            }
+            OperationsCount.Add(ref OperationsCount.PlainMultiplication, (int)n);
+            return t;
+        }
+        void EncryptZeroInto(AtomicSealBfvEncryptedEnvironment eenv, uint index)
+        {
+            using (var c = new Ciphertext(eenv.context, eenv.memoryPool))
+            {
+                eenv.encryptor.Encrypt(eenv.PlainZero, c, eenv.memoryPool);
+                CnHip.Check(CnHip.cn_ct_upload(eenv.device.Ctx, enc.Handle, index, 1, SealInterop.Words(c)));
+            }
+            OperationsCount.Add(ref OperationsCount.Encryption, 1);
+        }
+
+        // ---------------------------------------------------------------------------------------------------- packing (:600-761)
+        /// <summary>Interleave / Stack: rotations, the row-boundary mask split and the AddMany of the lower / upper parts, as :600-722</summary>
+        static CnBuffer Inteleave(AtomicSealBfvEncryptedVector[] vecs, int shift, int outputBlockCount, AtomicSealBfvEncryptedEnvironment env)
+        {
+            int blockSize = (int)env.builder.SlotCount;
+            int absShift = (shift < 0) ? -shift : shift;
+            if (shift < 0 && outputBlockCount > 1) throw new Exception("Negative shifts with multiple output blocks are not implemented yet");
+            if ((absShift > blockSize / 2) && outputBlockCount > 1) throw new Exception("Shifts of more than half block size with multiple output blocks are not implemented yet");
+            if (absShift * vecs.Length > blockSize * outputBlockCount) throw new Exception("not enough room for interleaving");
+            var ctx = env.device.Ctx;
+            int half = blockSize / 2;
+            var lower = Enumerable.Range(0, outputBlockCount).Select(x => new List<uint>()).ToArray();
+            var upper = Enumerable.Range(0, outputBlockCount).Select(x => new List<uint>()).ToArray();
+            using (var work = new CnBuffer(env.device, (uint)(2 * vecs.Length)))          // slot 2k: v, slot 2k+1: v2 (the split-off part)
+            using (var tmp = new CnBuffer(env.device, 1))
+            {
+                for (int k = 0; k < vecs.Length; k++)
+                {
+                    var thisShift = shift * k;
+                    if (thisShift < 0) thisShift = half + thisShift;
+                    var inBlockShift = thisShift % blockSize;
+                    var startBlock = thisShift / blockSize;
+                    var endBlock = (thisShift + absShift) / blockSize;
+                    uint v = (uint)(2 * k), v2 = v + 1;
+                    CnHip.Check(CnHip.cn_copy(ctx, vecs[k].enc.Handle, 0, work.Handle, v, 1));
+                    if (inBlockShift == 0) lower[startBlock].Add(v);
+                    else if (inBlockShift + absShift < half)
+                    {
+                        CnHip.Check(CnHip.cn_rotate_rows(ctx, work.Handle, v, -thisShift, work.Handle, v, 1));
+                        lower[startBlock].Add(v);
+                    }
+                    else if (inBlockShift >= half)
+                    {
+                        CnHip.Check(CnHip.cn_rotate_rows(ctx, work.Handle, v, -(inBlockShift - half), work.Handle, v, 1));
+                        if (startBlock == endBlock) upper[startBlock].Add(v);
+                        else
+                        {
+                            SplitByMask(env, work, v, v2, inBlockShift + absShift - blockSize);
+                            upper[startBlock].Add(v2); lower[endBlock].Add(v);
+                        }
+                    }
+                    else
+                    {
+                        CnHip.Check(CnHip.cn_rotate_rows(ctx, work.Handle, v, -inBlockShift, work.Handle, v, 1));
+                        int upperPartSize = inBlockShift + absShift - half;
+                        if (upperPartSize > 0)
+                        {
+                            SplitByMask(env, work, v, v2, upperPartSize);
+                            upper[startBlock].Add(v); lower[startBlock].Add(v2);
+                        }
+                        else lower[startBlock].Add(v);
+                    }
+                    OperationsCount.Add(ref OperationsCount.Rotation, 1);
+                }
+                var res = new CnBuffer(env.device, (uint)outputBlockCount);
+                for (int i = 0; i < outputBlockCount; i++)
+                {
+                    CnHip.Check(CnHip.cn_add_many(ctx, work.Handle, lower[i].ToArray(), (uint)lower[i].Count, res.Handle, (uint)i));
+                    OperationsCount.Add(ref OperationsCount.AddMany, 1); OperationsCount.Add(ref OperationsCount.AddManyItemCount, lower[i].Count);
+                    if (upper[i].Any())
+                    {
+                        CnHip.Check(CnHip.cn_add_many(ctx, work.Handle, upper[i].ToArray(), (uint)upper[i].Count, tmp.Handle, 0));
+                        CnHip.Check(CnHip.cn_rotate_columns_add(ctx, tmp.Handle, 0, res.Handle, (uint)i, res.Handle, (uint)i, 1));      // RotateColumnsInplace + AddInplace
+                        OperationsCount.Add(ref OperationsCount.AddMany, 1); OperationsCount.Add(ref OperationsCount.AddManyItemCount, upper[i].Count);
+                        OperationsCount.Add(ref OperationsCount.Rotation, 1);
+                    }
+                }
+                return res;
+            }
+        }
+        /// <summary>v2 = v - v*ones(upperPartSize), v = v*ones(upperPartSize): the mask split of :664-676</summary>
+        static void SplitByMask(AtomicSealBfvEncryptedEnvironment env, CnBuffer work, uint v, uint v2, int upperPartSize)
+        {
+            var ctx = env.device.Ctx;
+            CnHip.Check(CnHip.cn_copy(ctx, work.Handle, v, work.Handle, v2, 1));
+            using (var mask = new CnBuffer(env.device, 1, plain: true))
+            {
+                CnHip.Check(CnHip.cn_encode(ctx, Enumerable.Repeat(1UL, upperPartSize).ToArray(), (uint)upperPartSize, mask.Handle, 0));      // BatchEncoder.Encode(ones)
+                CnHip.Check(CnHip.cn_mul_plain(ctx, work.Handle, v, mask.Handle, 0, 0, work.Handle, v, 1));
+            }
+            CnHip.Check(CnHip.cn_sub(ctx, work.Handle, v2, work.Handle, v, work.Handle, v2, 1));
+            OperationsCount.Add(ref OperationsCount.PlainMultiplication, 1); OperationsCount.Add(ref OperationsCount.Subtraction, 1);
+        }
+        public static Task<AtomicSealBfvEncryptedVector> InterleaveTask(AtomicSealBfvEncryptedVector[] vecs, int shift, AtomicSealBfvEncryptedEnvironment env)
+        {
+            return Task<AtomicSealBfvEncryptedVector>.Factory.StartNew(() => Interleave(vecs, shift, env));
+        }
+        static public AtomicSealBfvEncryptedVector Interleave(AtomicSealBfvEncryptedVector[] vecs, int shift, AtomicSealBfvEncryptedEnvironment env)
+        {
+            if (vecs[0].Format != EVectorFormat.dense) throw new Exception("Expecting dense vector");
+            var blockSize = env.builder.SlotCount;
+            int outputBlocks = 1;
+            if (shift > 0) outputBlocks = (int)Math.Ceiling(vecs[0].Dim * (ulong)vecs.Length / (double)blockSize);
+            return new AtomicSealBfvEncryptedVector()
+            {
+                owner = env, enc = Inteleave(vecs, shift, outputBlocks, env), plainData = null, Dim = vecs[0].Dim, Scale = vecs[0].Scale,
+                IsSigned = vecs[0].IsSigned, Format = EVectorFormat.dense
+            };
+        }
+        static public Task<AtomicSealBfvEncryptedVector> StackTask(AtomicSealBfvEncryptedVector[] vecs, AtomicSealBfvEncryptedEnvironment env)
+        {
+            return Task<AtomicSealBfvEncryptedVector>.Factory.StartNew(() => Stack(vecs, env));
+        }
+        static public AtomicSealBfvEncryptedVector Stack(AtomicSealBfvEncryptedVector[] vecs, AtomicSealBfvEncryptedEnvironment env)
+        {
+            var res = Interleave(vecs, (int)vecs[0].Dim, env);
+            res.Dim = vecs[0].Dim * (ulong)vecs.Length;
+            return res;
+        }
+
+        // ---------------------------------------------------------------------------------------------------- HOT LOOP B (:774-860)
+        public Task<IVector> PointwiseMultiplyTask(IVector v, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => PointwiseMultiply(v, env)); }
+        /// <summary>one of the vectors is sparse of dimension 1: multiply every block of the other by that constant (:774-810)</summary>
+        IVector PointwiseMultiplySparseDimOne(AtomicSealBfvEncryptedVector ev, AtomicSealBfvEncryptedEnvironment eenv)
+        {
+            var ctx = eenv.device.Ctx;
+            uint n = (enc != null) ? enc.Count : (uint)plainData.Length;
+            var t = Result(eenv, n);
+            t.Scale = Scale * ev.Scale; t.Dim = Dim; t.Format = Format; t.IsSigned = IsSigned;
+            if (this.enc != null && ev.enc != null)
+            {
+                CnHip.Check(CnHip.cn_mul_relin(ctx, ev.enc.Handle, 0, 0, enc.Handle, 0, 1, t.enc.Handle, 0, n));
+                OperationsCount.Add(ref OperationsCount.Multiplication, (int)n); OperationsCount.Add(ref OperationsCount.Relinarization, (int)n);
+                return t;
+            }
+            if (this.enc != null) CnHip.Check(CnHip.cn_mul_scalar(ctx, enc.Handle, 0, new ulong[] { SealInterop.Constant(ev.plainData[0]) }, 0, t.enc.Handle, 0, n));
+            else for (uint i = 0; i < n; i++) CnHip.Check(CnHip.cn_mul_plain(ctx, ev.enc.Handle, 0, PlainOnDevice(eenv).Handle, i, 1, t.enc.Handle, i, 1));
+            OperationsCount.Add(ref OperationsCount.PlainMultiplication, (int)n);
+            return t;
+        }
+        /// <summary>per block Multiply + Relinearize (:839-840) = cn_mul_relin over all blocks; ct x pt = MultiplyPlain (:855).  SquareActivation
+        /// calls this once per column (EncryptedSealBfvMatrix.cs:140-154): deferred submission merges the columns of a layer into one batch.</summary>
+        public IVector PointwiseMultiply(IVector v, IComputationEnvironment env)
+        {
+            var ev = v as AtomicSealBfvEncryptedVector;
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            if (IsSigned != ev.IsSigned) throw new Exception("Can't mix signed and unsigned numbers.");
+            if (this.plainData != null && ev.plainData != null) throw new Exception("multiplying two plaintexts is not implemented");
+            if (Dim == 1 && Format == EVectorFormat.sparse) return ev.PointwiseMultiplySparseDimOne(this, eenv);
+            if (ev.Dim == 1 && ev.Format == EVectorFormat.sparse) return PointwiseMultiplySparseDimOne(ev, eenv);
+            if (Dim != v.Dim) throw new Exception("Dimensions do not match");
+            if (Format != ev.Format) throw new Exception("Format mismatch");
+            var ctx = eenv.device.Ctx;
+            if (this.enc != null && ev.enc != null)
+            {
+                var t = Result(eenv, ev.enc.Count);
+                t.Scale = Scale * ev.Scale; t.Dim = Dim; t.Format = Format; t.IsSigned = IsSigned;
+                CnHip.Check(CnHip.cn_mul_relin(ctx, ev.enc.Handle, 0, 1, enc.Handle, 0, 1, t.enc.Handle, 0, t.enc.Count));
+                OperationsCount.Add(ref OperationsCount.Multiplication, (int)t.enc.Count); OperationsCount.Add(ref OperationsCount.Relinarization, (int)t.enc.Count);
+                return t;
+            }
+            var e = enc ?? ev.enc;
+            var pl = (enc == null) ? this : ev;
+            var r = Result(eenv, e.Count);
+            r.Scale = Scale * ev.Scale; r.Dim = Dim; r.Format = Format; r.IsSigned = IsSigned;
+            if (Format == EVectorFormat.dense) CnHip.Check(CnHip.cn_mul_plain(ctx, e.Handle, 0, pl.PlainOnDevice(eenv).Handle, 0, 1, r.enc.Handle, 0, e.Count));
+            else CnHip.Check(CnHip.cn_mul_scalar(ctx, e.Handle, 0, pl.plainData.Select(SealInterop.Constant).ToArray(), 1, r.enc.Handle, 0, e.Count));
+            OperationsCount.Add(ref OperationsCount.PlainMultiplication, (int)e.Count);
+            return r;
+        }
+
+        // ---------------------------------------------------------------------------------------------------- HOT LOOP C (:862-977)
+        public Task<IVector> SumAllSlotsTask(IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => SumAllSlots(Int32.MaxValue, env)); }
+        public IVector SumAllSlots(IComputationEnvironment env) => SumAllSlots(env, null);
+        public IVector SumAllSlots(IComputationEnvironment env, int? ForceOutputInColumn = null) { return SumAllSlots(Int32.MaxValue, env, ForceOutputInColumn); }
+        public Task<IVector> SumAllSlotsTask(ulong length, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => SumAllSlots(length, env)); }
+        public IVector SumAllSlots(ulong length, IComputationEnvironment env) => SumAllSlots(length, env, null);
+        /// <summary>AddMany of the blocks, column swap + add when length >= N/2, log2 rotate-and-add steps (cn_sum_slots), optional one-hot mask</summary>
+        public IVector SumAllSlots(ulong length, IComputationEnvironment env, int? ForceOutputInColumn = null)
+        {
+            if (Format != EVectorFormat.dense) throw new Exception("Expecting dense vector format");
+            if (length != Int32.MaxValue && ForceOutputInColumn != null) throw new Exception("forcing output in a column works only when doing complete sum");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            if (plainData != null) throw new Exception("SumAllSlots can be applied to encrypted data only");
+            if (length <= 0) throw new Exception("Can't sum over less then one element");
+            if (length == 1) return this;
+            var ctx = eenv.device.Ctx;
+            ulong slots = eenv.builder.SlotCount;
+            var sum = new CnBuffer(eenv.device, 1);
+            if (enc.Count > 1)
+            {
+                CnHip.Check(CnHip.cn_add_many(ctx, enc.Handle, Enumerable.Range(0, (int)enc.Count).Select(i => (uint)i).ToArray(), enc.Count, sum.Handle, 0));
+                OperationsCount.Add(ref OperationsCount.AddMany, 1); OperationsCount.Add(ref OperationsCount.AddManyItemCount, (int)enc.Count);
+            }
+            else CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, sum.Handle, 0, 1));
+            CnHip.Check(CnHip.cn_sum_slots(ctx, sum.Handle, 0, 1, length >= slots ? 0 : (uint)length));      // RotateColumns + Add, then RotateRows(-2^s) + AddInplace (:914-930)
+            if (length >= slots / 2) length = slots / 2;
+            if (ForceOutputInColumn != null)
+            {
+                int col = ForceOutputInColumn.Value;
+                using (var mask = new CnBuffer(eenv.device, 1, plain: true))
+                {
+                    var onehot = new ulong[col + 1]; onehot[col] = 1;
+                    CnHip.Check(CnHip.cn_encode(ctx, onehot, (uint)onehot.Length, mask.Handle, 0));
+                    CnHip.Check(CnHip.cn_mul_plain(ctx, sum.Handle, 0, mask.Handle, 0, 0, sum.Handle, 0, 1));
+                }
+                length = 1;
+            }
+            return new AtomicSealBfvEncryptedVector()
+            {
+                owner = eenv, IsSigned = IsSigned, Scale = Scale, Dim = (length >= slots / 2) ? 1 : this.Dim, enc = sum, plainData = null,
+                Format = (length >= slots) ? EVectorFormat.sparse : EVectorFormat.dense
+            };
+        }
+        public Task<IVector> DotProductTask(IVector v, IComputationEnvironment env, int? ForceOutputInColumn = null) { return Task<IVector>.Factory.StartNew(() => DotProduct(v, env, ForceOutputInColumn)); }
+        public IVector DotProduct(IVector v, IComputationEnvironment env) => DotProduct(v, env, null);
+        public IVector DotProduct(IVector v, IComputationEnvironment env, int? ForceOutputInColumn = null)
+        {
+            using (var mul = (AtomicSealBfvEncryptedVector)PointwiseMultiply(v, env)) return mul.SumAllSlots(env, ForceOutputInColumn);
+        }
+        public Task<IVector> DotProductTask(IVector v, ulong length, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => DotProduct(v, length, env)); }
+        public IVector DotProduct(IVector v, ulong length, IComputationEnvironment env)
+        {
+            using (var mul = (AtomicSealBfvEncryptedVector)PointwiseMultiply(v, env)) return mul.SumAllSlots(length, env);
+        }
+
+        // ---------------------------------------------------------------------------------------------------- linear (:983-1024, 1238-1271)
+        public Task<IVector> AddTask(IVector v, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => Add(v, env)); }
+        public IVector Add(IVector v, IComputationEnvironment env)
+        {
+            if (Scale == 0) return v;
+            if (v.Scale == 0) return this;
+            if (Scale != v.Scale) throw new Exception("Scales do not match.");
+            if (Dim != v.Dim) throw new Exception("Dimensions do not match");
+            var ev = v as AtomicSealBfvEncryptedVector;
+            if (Format != ev.Format) throw new Exception("Format mismatch");
+            if (IsSigned != ev.IsSigned) throw new Exception("can't mix signed and unsigned numbers.");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            if (this.plainData != null && ev.plainData != null) throw new Exception("adding two plaintexts is not supported");
+            var ctx = eenv.device.Ctx;
+            if (this.enc != null && ev.enc != null)
+            {
+                var t = Result(eenv, ev.enc.Count);
+                t.Scale = Scale; t.Dim = Dim; t.Format = Format; t.IsSigned = IsSigned;
+                CnHip.Check(CnHip.cn_add(ctx, ev.enc.Handle, 0, enc.Handle, 0, t.enc.Handle, 0, t.enc.Count));
+                OperationsCount.Add(ref OperationsCount.Addition, (int)t.enc.Count);
+                return t;
+            }
+            var e = enc ?? ev.enc;
+            var pl = (enc == null) ? this : ev;
+            var r = Result(eenv, e.Count);
+            r.Scale = Scale; r.Dim = Dim; r.Format = Format; r.IsSigned = IsSigned;
+            CnHip.Check(CnHip.cn_add_plain(ctx, e.Handle, 0, pl.PlainOnDevice(eenv).Handle, 0, 0, r.enc.Handle, 0, (uint)pl.plainData.Length));      // Evaluator.AddPlain (:1019)
+            OperationsCount.Add(ref OperationsCount.PlainAddition, pl.plainData.Length);
+            return r;
+        }
+        public Task<IVector> SubtractTask(IVector v, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => Subtract(v, env)); }
+        public IVector Subtract(IVector v, IComputationEnvironment env)
+        {
+            if (v.Scale == 0) return this;
+            if (Scale != v.Scale) throw new Exception("Scales do not match.");
+            if (Dim != v.Dim) throw new Exception("Dimensions do not match");
+            var ev = v as AtomicSealBfvEncryptedVector;
+            if (Format != ev.Format) throw new Exception("Format mismatch");
+            if (IsSigned != ev.IsSigned) throw new Exception("Can't mix signed and unsigned numbers.");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            if (this.plainData != null) throw new Exception("the first argument for subtraction must be encrypted");
+            var ctx = eenv.device.Ctx;
+            var t = Result(eenv, enc.Count);
+            t.Scale = Scale; t.Dim = Dim; t.Format = Format; t.IsSigned = IsSigned;
+            if (ev.enc != null)
+            {
+                CnHip.Check(CnHip.cn_sub(ctx, enc.Handle, 0, ev.enc.Handle, 0, t.enc.Handle, 0, enc.Count));
+                OperationsCount.Add(ref OperationsCount.Subtraction, (int)enc.Count);
+                return t;
+            }
+            CnHip.Check(CnHip.cn_add_plain(ctx, enc.Handle, 0, ev.PlainOnDevice(eenv).Handle, 0, 1, t.enc.Handle, 0, enc.Count));              // Evaluator.SubPlain (:1267)
+            OperationsCount.Add(ref OperationsCount.PlainSubtraction, (int)enc.Count);
+            return t;
+        }
+
+        // ---------------------------------------------------------------------------------------------------- decryption: client side, SEAL (:1030-1110)
+        public Task<Vector<double>> DecryptTask(IComputationEnvironment env) { return Task<Vector<double>>.Factory.StartNew(() => Decrypt(env)); }
+        IEnumerable<ulong> DecryptResidues(AtomicSealBfvEncryptedEnvironment eenv)
+        {
+            var res = new List<ulong>();
+            Ciphertext[] cts = (enc != null) ? Download() : null;
+            int length = (enc == null) ? plainData.Length : cts.Length;
+            var plain = new Plaintext(eenv.memoryPool);
+            for (int i = 0; i < length; i++)
+            {
+                if (cts != null)
+                {
+                    CryptoTracker.TestBudget(cts[i], eenv.decryptor);
+                    eenv.decryptor.Decrypt(cts[i], plain);
+                    OperationsCount.Add(ref OperationsCount.Decryption, 1);
+                    cts[i].Dispose();
+                }
+                else plain = plainData[i];
+                if (Format == EVectorFormat.dense)
+                {
+                    List<ulong> local = new List<ulong>();
+                    eenv.builder.Decode(plain, local);
+                    int left = (int)Dim - res.Count;
+                    res.AddRange(local.Take((left > local.Count) ? local.Count : left));
+                }
+                else res.Add(SealInterop.Constant(plain));
+            }
+            return res;
+        }
+        public Vector<double> Decrypt(IComputationEnvironment env)
+        {
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            var mod = (double)eenv.parameters.PlainModulus.Value;
+            return Vector<double>.Build.DenseOfEnumerable(DecryptResidues(eenv)
+                .Select(v => ((IsSigned && v * 2 > eenv.parameters.PlainModulus.Value) ? v - mod : v) / Scale));
+        }
+        public Task<IEnumerable<BigInteger>> DecryptFullPrecisionTask(IComputationEnvironment env) { return Task<IEnumerable<BigInteger>>.Factory.StartNew(() => DecryptFullPrecision(env)); }
+        public IEnumerable<BigInteger> DecryptFullPrecision(IComputationEnvironment env)
+        {
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            var mod = new BigInteger(eenv.parameters.PlainModulus.Value);
+            return DecryptResidues(eenv).Select(v => (IsSigned && v * 2 > eenv.parameters.PlainModulus.Value) ? new BigInteger(v) - mod : new BigInteger(v)).ToList();
+        }
+
+        // ---------------------------------------------------------------------------------------------------- encoding / encryption: client side, SEAL (:1114-1232)
+        Plaintext[] VectorToPlaintext(Vector<double> v, AtomicSealBfvEncryptedEnvironment eenv)
+        {
+            if (Scale == 0) Scale = 1;
+            var values = v.Multiply(Scale).PointwiseRound().Select(x => (ulong)((!IsSigned || x >= 0) ? x : eenv.parameters.PlainModulus.Value + x)).ToArray();
+            return VectorToPlaintext(values, eenv);
+        }
+        Plaintext[] VectorToPlaintext(UInt64[] v, AtomicSealBfvEncryptedEnvironment eenv)
+        {
+            var lst = new List<Plaintext>();
+            int slots = (int)eenv.builder.SlotCount;
+            for (int start = 0; start < v.Length;)
+            {
+                if (Format == EVectorFormat.dense)
+                {
+                    int size = (start + slots <= v.Length) ? slots : v.Length - start;
+                    var p = new Plaintext(eenv.memoryPool);
+                    eenv.builder.Encode(v.Skip(start).Take(size).ToList(), p);
+                    lst.Add(p);
+                    start += size;
+                }
+                else
+                {
+                    lst.Add(new Plaintext(v[start].ToString("X"), eenv.memoryPool));
+                    start++;
+                }
+            }
+            return lst.ToArray();
+        }
+        Plaintext DoubleToPlaintext(double v, AtomicSealBfvEncryptedEnvironment eenv)
+        {
+            if (Scale == 0) Scale = 1;
+            var value = Math.Round(v * Scale);
+            var unsigned = (ulong)((!IsSigned || value >= 0) ? value : eenv.parameters.PlainModulus.Value + value);
+            return new Plaintext(unsigned.ToString("X"), eenv.memoryPool);
+        }
+        void Plain(Vector<double> v, EVectorFormat Format, IComputationEnvironment env)
+        {
+            OperationsCount.Add(ref OperationsCount.Plain, 1);
+            owner = env as AtomicSealBfvEncryptedEnvironment; this.Format = Format;
+            plainData = VectorToPlaintext(v, owner); enc = null; Dim = (ulong)v.Count;
+        }
+        void Plain(UInt64[] v, EVectorFormat Format, IComputationEnvironment env)
+        {
+            OperationsCount.Add(ref OperationsCount.Plain, 1);
+            owner = env as AtomicSealBfvEncryptedEnvironment; this.Format = Format;
+            plainData = VectorToPlaintext(v, owner); enc = null; Dim = (ulong)v.Length;
+        }
+        /// <summary>Encryptor.Encrypt per plaintext on the client (:1211), ONE upload of all blocks to the device</summary>
+        void EncryptPlaintexts(Plaintext[] plain, AtomicSealBfvEncryptedEnvironment eenv)
+        {
+            owner = eenv;
+            enc = new CnBuffer(eenv.device, (uint)plain.Length);
+            int ctw = eenv.device.CtWords();
+            var words = new ulong[plain.Length * ctw];
+            using (var c = new Ciphertext(eenv.context, eenv.memoryPool))
+                for (int i = 0; i < plain.Length; i++)
+                {
+                    eenv.encryptor.Encrypt(plain[i], c, eenv.memoryPool);
+                    Array.Copy(SealInterop.Words(c), 0, words, i * ctw, ctw);
+                    plain[i].Dispose();
+                }
+            CnHip.Check(CnHip.cn_ct_upload(eenv.device.Ctx, enc.Handle, 0, enc.Count, words));
+            plainData = null;
+            OperationsCount.Add(ref OperationsCount.Encryption, plain.Length);
+        }
+        void Encrypt(Vector<double> v, EVectorFormat format, IComputationEnvironment env)
+        {
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            this.Format = format;
+            EncryptPlaintexts(VectorToPlaintext(v, eenv), eenv);
+            Dim = (ulong)v.Count;
+        }
+        void Encrypt(UInt64[] v, EVectorFormat format, IComputationEnvironment env)
+        {
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            this.Format = format;
+            EncryptPlaintexts(VectorToPlaintext(v, eenv), eenv);
+            Dim = (ulong)v.Length;
+        }
+
+        // ---------------------------------------------------------------------------------------------------- persistence (:1273-1345): SEAL object streams
+        public void Write(StreamWriter str)
+        {
+            str.WriteLine("<Start EncryptedVector>");
+            str.WriteLine(Scale); str.WriteLine(IsSigned); str.WriteLine(Enum.GetName(Format.GetType(), Format)); str.WriteLine(Dim);
+            using (MemoryStream mem = new MemoryStream())
+            {
+                if (plainData == null)
+                {
+                    var cts = Download();
+                    str.WriteLine("Encrypted"); str.WriteLine(cts.Length);
+                    foreach (var c in cts) { c.Save(mem); c.Dispose(); }
+                }
+                else
+                {
+                    str.WriteLine("Plain"); str.WriteLine(plainData.Length);
+                    for (int i = 0; i < plainData.Length; i++) plainData[i].Save(mem);
+                }
+                mem.Flush(); mem.Position = 0;
+                str.WriteLine(Convert.ToBase64String(mem.ToArray(), Base64FormattingOptions.None));
+                str.WriteLine("<End EncryptedVector>");
+                str.Flush();
+            }
+        }
+        public static AtomicSealBfvEncryptedVector Read(StreamReader str, AtomicSealBfvEncryptedEnvironment env)
+        {
+            var vct = new AtomicSealBfvEncryptedVector() { owner = env };
+            if (str.ReadLine() != "<Start EncryptedVector>") throw new Exception("Bad stream format.");
+            vct.Scale = Double.Parse(str.ReadLine());
+            vct.IsSigned = Boolean.Parse(str.ReadLine());
+            vct.Format = (EVectorFormat)Enum.Parse(vct.Format.GetType(), str.ReadLine());
+            vct.Dim = ulong.Parse(str.ReadLine());
+            var mode = str.ReadLine();
+            var length = int.Parse(str.ReadLine());
+            using (var mem = new MemoryStream(Convert.FromBase64String(str.ReadLine())))
+            {
+                switch (mode)
+                {
+                    case "Encrypted":
+                        vct.enc = new CnBuffer(env.device, (uint)length);
+                        using (var c = new Ciphertext(env.context, env.memoryPool))
+                            for (int i = 0; i < length; i++)
+                            {
+                                c.Load(env.context, mem);
+                                CnHip.Check(CnHip.cn_ct_upload(env.device.Ctx, vct.enc.Handle, (uint)i, 1, SealInterop.Words(c)));
+                            }
+                        break;
+                    case "Plain":
+                        vct.plainData = new Plaintext[length];
+                        for (int i = 0; i < length; i++) { vct.plainData[i] = new Plaintext(env.memoryPool); vct.plainData[i].Load(env.context, mem); }
+                        break;
+                    default: throw new Exception("unknown format");
+                }
+            }
+            if (str.ReadLine() != "<End EncryptedVector>") throw new Exception("Bad stream format.");
+            return vct;
+        }
+
+        // ---------------------------------------------------------------------------------------------------- misc (:1347-1475)
+        public static AtomicSealBfvEncryptedVector GenerateSparseOfArray(AtomicSealBfvEncryptedVector[] encryptedVector, IComputationEnvironment env)
+        {
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            var res = Result(eenv, (uint)encryptedVector.Length);
+            res.Scale = encryptedVector[0].Scale; res.Dim = (ulong)encryptedVector.Length; res.Format = EVectorFormat.sparse; res.IsSigned = encryptedVector[0].IsSigned;
+            for (int i = 0; i < encryptedVector.Length; i++)
+                CnHip.Check(CnHip.cn_copy(eenv.device.Ctx, encryptedVector[i].enc.Handle, 0, res.enc.Handle, (uint)i, 1));
+            return res;
+        }
+        public void RegisterScale(double scale) { Scale = scale; }
+
+        public Task<IVector> DuplicateTask(ulong count, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => Duplicate(count, env)); }
+        public IVector Duplicate(ulong count, IComputationEnvironment env)
+        {
+            ulong shift = 1;
+            while (shift < Dim) shift *= 2;
+            if (enc == null) throw new Exception("Duplicate operates only on encrypted data");
+            if (Format == EVectorFormat.sparse) throw new Exception("Duplicate operates only on dense vectors");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            int slots = (int)eenv.builder.SlotCount;
+            if (shift * count > (ulong)slots) throw new Exception("Packed vector must fit in a single ciphertext");
+            var ctx = eenv.device.Ctx;
+            var res = new CnBuffer(eenv.device, 1);
+            CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, res.Handle, 0, 1));
+            bool columnRotated = false;
+            using (var rotator = new CnBuffer(eenv.device, 1))
+            {
+                CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, rotator.Handle, 0, 1));
+                for (ulong i = 1; i < count; i++)
+                {
+                    int targetShiftSize = (int)(i * shift);
+                    if (targetShiftSize * 2 >= slots)
+                    {
+                        if (!columnRotated)
+                        {
+                            columnRotated = true;
+                            CnHip.Check(CnHip.cn_rotate_columns(ctx, enc.Handle, 0, rotator.Handle, 0, 1));
+                            OperationsCount.Add(ref OperationsCount.Rotation, 1);
+                        }
+                        targetShiftSize -= slots / 2;
+                    }
+                    CnHip.Check(CnHip.cn_rotate_rows_add(ctx, rotator.Handle, 0, -targetShiftSize, res.Handle, 0, res.Handle, 0, 1));      // RotateRowsAndAdd (:862-868)
+                    OperationsCount.Add(ref OperationsCount.Rotation, 1); OperationsCount.Add(ref OperationsCount.Addition, 1);
+                }
+            }
+            return new AtomicSealBfvEncryptedVector() { owner = eenv, IsSigned = IsSigned, Scale = Scale, Dim = count * shift, enc = res, plainData = null, Format = EVectorFormat.dense };
+        }
+        public Task<IVector> RotateTask(int amount, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => Rotate(amount, env)); }
+        public IVector Rotate(int amount, IComputationEnvironment env)
+        {
+            if (enc == null) throw new Exception("Rotate operates only on encrypted data");
+            if (Format == EVectorFormat.sparse) throw new Exception("Rotate operates only on dense vectors");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            var res = new CnBuffer(eenv.device, 1);
+            CnHip.Check(CnHip.cn_rotate_rows(eenv.device.Ctx, enc.Handle, 0, amount, res.Handle, 0, 1));
+            return new AtomicSealBfvEncryptedVector() { owner = eenv, IsSigned = IsSigned, Scale = Scale, Dim = Dim, enc = res, plainData = null, Format = EVectorFormat.dense };
+        }
+        internal Task<IVector> PermuteTask(IVector[] selections, int[] shifts, ulong outputDim, IComputationEnvironment env)
+        {
+            return Task<IVector>.Factory.StartNew(() => Permute(selections, shifts, outputDim, env));
+        }
+        /// <summary>sum_i RotateRows(x * selection_i, shifts[i]) (:1436-1475); the additions ride on the rotations (cn_rotate_rows_add)</summary>
+        public IVector Permute(IVector[] selections, int[] shifts, ulong outputDim, IComputationEnvironment env)
+        {
+            if (Format != EVectorFormat.dense) throw new Exception("Permute works only on dense vectors");
+            if (selections.Length != shifts.Length) throw new Exception("number of selection vectors and number of shifts does not match");
+            if (plainData != null) throw new Exception("can permute only encrypted vectors");
+            if (enc.Count > 1) throw new Exception("can permute only a single block");
+            var eenv = env as AtomicSealBfvEncryptedEnvironment;
+            var ctx = eenv.device.Ctx;
+            CnBuffer res = null;
+            int first = -1;
+            using (var t = new CnBuffer(eenv.device, 1))
+                for (int i = 0; i < selections.Length; i++)
+                {
+                    if (selections[i] == null) continue;
+                    if (first < 0) first = i;
+                    if (selections[i].Dim != Dim) throw new Exception("dimension of selection vector does not match dimension of data vector");
+                    if (selections[i].Scale != selections[first].Scale) throw new Exception("scales of all selection vectors should be the same");
+                    var s = selections[i] as AtomicSealBfvEncryptedVector;
+                    if (s.plainData != null) CnHip.Check(CnHip.cn_mul_plain(ctx, enc.Handle, 0, s.PlainOnDevice(eenv).Handle, 0, 1, t.Handle, 0, 1));
+                    else CnHip.Check(CnHip.cn_mul_relin(ctx, enc.Handle, 0, 1, s.enc.Handle, 0, 1, t.Handle, 0, 1));      // (the reference multiplies without relinearising, :1457, and then cannot rotate)
+                    if (res == null)
+                    {
+                        res = new CnBuffer(eenv.device, 1);
+                        CnHip.Check(CnHip.cn_rotate_rows(ctx, t.Handle, 0, shifts[i], res.Handle, 0, 1));
+                    }
+                    else CnHip.Check(CnHip.cn_rotate_rows_add(ctx, t.Handle, 0, shifts[i], res.Handle, 0, res.Handle, 0, 1));
+                }
+            if (first < 0) throw new Exception("permuting with no selected values is illigal");
+            return new AtomicSealBfvEncryptedVector()
+            {
+                owner = eenv, IsSigned = IsSigned, Scale = Scale * selections[first].Scale, Dim = outputDim, enc = res, plainData = null, Format = EVectorFormat.dense
+            };
+        }
+    }
+}
+#endif

@@ -1,0 +1,105 @@
+"""The C# side of the boundary (integration/*.cs) cannot be compiled in this image (no .NET toolchain).  What CAN be checked is checked:
+the P/Invoke file is regenerated from include/cnhip.h and must equal the committed one; every libcnhip call the twin makes exists in
+the header with that many arguments; every member the UNCHANGED reference files use on the atomic classes is defined by the twin."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+INTEG = os.path.join(ROOT, "integration")
+TWIN = os.path.join(INTEG, "GpuAtomicSealBfvEncryptedVector.cs")
+FACTORY = os.path.join(INTEG, "GpuSealBfvFactory.cs")
+
+# members of AtomicSealBfvEncryptedEnvironment / AtomicSealBfvEncryptedVector / OperationsCount that EncryptedSealBfvVector.cs,
+# EncryptedSealBfvMatrix.cs, IFactory.cs, CryptoTracker.cs, BaseLayer.cs and CryptoNets.cs use (collected from /root/reference)
+USED_MEMBERS = ["Dim", "plainmodulusValue", "Write", "Scale", "GenerateEncryptionKeys", "BlockSize", "decryptor", "SumAllSlotsTask", "SumAllSlots",
+                "SubtractTask", "StackTask", "SaveToStream", "RotateTask", "Read", "PointwiseMultiplyTask", "PermuteTask", "ParentFactory",
+                "LoadFromStream", "IsEncrypted", "InterleaveTask", "GenerateSparseOfArray", "Format", "DuplicateTask", "DotProductTask",
+                "DenseMatrixBySparseVectorMultiplyTask", "Decrypt", "AddTask", "DecryptFullPrecisionTask", "DecryptTask", "SparseMultiplyTask",
+                "RegisterDim", "RegisterScale", "Data", "IsSigned", "Dispose", "parameters", "Primes", "AllocateComputationEnv", "FreeComputationEnv",
+                "Reset", "Print", "PrintTotals"]
+# every method of the IVector interface (HE Wrapper/IVector.cs:14-40)
+IVECTOR = ["Decrypt", "DecryptFullPrecision", "Write", "Data", "Subtract", "Add", "DotProduct", "PointwiseMultiply", "SumAllSlots", "Duplicate", "Rotate",
+           "Permute", "Dim", "Scale", "RegisterScale", "IsEncrypted", "IsSigned", "BlockSize", "Format"]
+
+
+def _calls(src):
+    """[(name, number of arguments)] of every CnHip.cn_*( ... ) call in a C# source"""
+    out = []
+    for m in re.finditer(r"CnHip\.(cn_[a-z0-9_]+)\(", src):
+        i, depth, args, cur = m.end(), 1, 0, ""
+        while depth:
+            ch = src[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            elif ch == "," and depth == 1:
+                args += 1
+                cur = ""
+                i += 1
+                continue
+            cur += ch
+            i += 1
+        out.append((m.group(1), args + (1 if cur.strip() or args else 0)))
+    return out
+
+
+def test_pinvoke_file_is_generated_from_the_header():
+    import gen_cs_pinvoke
+    assert open(gen_cs_pinvoke.TARGET).read() == gen_cs_pinvoke.generate(), "run python tools/gen_cs_pinvoke.py"
+    names = [n for _, n, _ in gen_cs_pinvoke.prototypes()]
+    from cryptonets_amd import _native
+    assert sorted(names) == sorted(_native.SIGNATURES)
+
+
+@pytest.mark.parametrize("path", [TWIN, FACTORY])
+def test_twin_calls_match_the_c_abi(path):
+    import gen_cs_pinvoke
+    protos = {n: len(p) for _, n, p in gen_cs_pinvoke.prototypes()}
+    src = open(path).read()
+    calls = _calls(src)
+    assert calls, "no libcnhip calls found"
+    for name, nargs in calls:
+        assert name in protos, "%s is not declared in include/cnhip.h" % name
+        assert nargs == protos[name], "%s called with %d arguments, the C ABI takes %d" % (name, nargs, protos[name])
+
+
+def test_twin_covers_the_hot_path_entry_points():
+    """the evaluator calls of SURVEY 2a / 8a must each be reachable from the twin"""
+    used = {n for n, _ in _calls(open(TWIN).read())}
+    for need in ("cn_scalar_dot", "cn_mul_relin", "cn_add", "cn_sub", "cn_add_plain", "cn_mul_plain", "cn_mul_scalar", "cn_add_many", "cn_rotate_rows",
+                 "cn_rotate_rows_add", "cn_rotate_columns", "cn_rotate_columns_add", "cn_sum_slots", "cn_copy", "cn_ct_upload", "cn_ct_download",
+                 "cn_pt_upload", "cn_encode", "cn_set_relin_key", "cn_set_galois_key", "cn_ctx_create", "cn_ctx_destroy", "cn_free", "cn_ct_alloc", "cn_pt_alloc"):
+        assert need in used, need
+    assert "cn_ctx_broadcast_keys" in {n for n, _ in _calls(open(FACTORY).read())}
+
+
+def test_twin_defines_every_member_the_unchanged_files_use():
+    src = open(TWIN).read()
+    for name in USED_MEMBERS + IVECTOR:
+        assert re.search(r"\b%s\b\s*(\(|\{|=|;|,)" % re.escape(name), src), "member %s is missing from the twin" % name
+    for cls in ("class AtomicSealBfvEncryptedEnvironment : IComputationEnvironment", "class AtomicSealBfvEncryptedVector : IVector", "static class OperationsCount"):
+        assert cls in src
+    assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
+    f = open(FACTORY).read()
+    assert "class GpuSealBfvFactory : EncryptedSealBfvFactory" in f and f.count("{") == f.count("}")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/HE Wrapper"), reason="the reference checkout is only present in the build container")
+def test_member_list_is_current_with_the_reference():
+    """every `x.Member` the unchanged wrapper files apply to the atomic classes is in USED_MEMBERS"""
+    base = "/root/reference/HE Wrapper"
+    found = set()
+    for f in ("EncryptedSealBfvVector.cs", "EncryptedSealBfvMatrix.cs", "IFactory.cs", "CryptoTracker.cs"):
+        txt = open(os.path.join(base, f), encoding="utf-8-sig").read()
+        found |= set(re.findall(r"eVectors\[[a-z0-9]*\]\.([A-Za-z]+)", txt))
+        found |= set(re.findall(r"AtomicSealBfvEncryptedVector\.([A-Za-z]+)", txt))
+        found |= set(re.findall(r"Environments\[[a-z0-9]*\]\.([A-Za-z]+)", txt))
+        found |= set(re.findall(r"envs\[i\]\.([A-Za-z]+)", txt))
+    assert found <= set(USED_MEMBERS), found - set(USED_MEMBERS)
