@@ -91,6 +91,7 @@ SIGNATURES = {
     "cn_ctx_destroy": (C.c_int, [_CTX]),
     "cn_sync": (C.c_int, [_CTX]),
     "cn_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_int]),
+    "cn_get_option": (C.c_int, [_CTX, C.c_char_p, C.POINTER(C.c_int)]),
     "cn_default_coeff_modulus": (C.c_int, [_u32, U64P]),
     "cn_key_words": (C.c_size_t, [_CTX, C.c_int]),
     "cn_set_relin_key": (C.c_int, [_CTX, C.c_void_p, C.c_size_t, C.c_int]),
@@ -216,6 +217,11 @@ class Context:
 
     def set_option(self, name, value):
         self._chk(self.L.cn_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._chk(self.L.cn_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def close(self):
         if self._h is not None:

@@ -30,7 +30,32 @@ struct DeferQueue {
     std::vector<DOp> ops;
     std::vector<uint64_t> addr, wt;
     struct Haz { int32_t w = -1, r = -1, wop = -1; uint32_t readers = 0; };   // level of the last writer / deepest reader since / index of the writing op / readers since
-    std::unordered_map<const uint64_t *, Haz> haz;
+    // address -> hazard record: open addressing, cleared by bumping the epoch (a dense-layer call touches 845 records)
+    struct HazMap {
+        struct E { const uint64_t *key = nullptr; uint32_t epoch = 0; Haz v; };
+        std::vector<E> tab = std::vector<E>(1 << 12);
+        uint32_t epoch = 1; size_t used = 0;
+        static size_t hash(const uint64_t *p) { uint64_t x = (uint64_t)p >> 8; x *= 0x9E3779B97F4A7C15ull; return (size_t)(x >> 20); }
+        Haz *find(const uint64_t *p) {
+            for (size_t i = hash(p) & (tab.size() - 1);; i = (i + 1) & (tab.size() - 1)) {
+                if (tab[i].epoch != epoch) return nullptr;
+                if (tab[i].key == p) return &tab[i].v;
+            }
+        }
+        Haz &operator[](const uint64_t *p) {
+            if (2 * (used + 1) > tab.size()) grow();
+            for (size_t i = hash(p) & (tab.size() - 1);; i = (i + 1) & (tab.size() - 1)) {
+                if (tab[i].epoch != epoch) { tab[i].key = p; tab[i].epoch = epoch; tab[i].v = Haz(); used++; return tab[i].v; }
+                if (tab[i].key == p) return tab[i].v;
+            }
+        }
+        void grow() {
+            std::vector<E> old; old.swap(tab);
+            tab.assign(old.size() * 2, E()); used = 0;
+            for (const E &e : old) if (e.epoch == epoch) (*this)[e.key] = e.v;
+        }
+        void clear() { used = 0; if (++epoch == 0) { for (E &e : tab) e.epoch = 0; epoch = 1; } }
+    } haz;
     int32_t maxlevel = -1;
     std::vector<std::pair<uint64_t *, size_t>> frees;      // arrays released by the caller while calls were pending: back to the pool after the flush
 };
@@ -91,9 +116,8 @@ template <class T> static int upload_tmp(cn_ctx *c, const T *host, size_t count,
     return 0;
 }
 static Buffer *getbuf(cn_ctx *c, cn_handle h, int kind) {
-    auto it = c->bufs.find(h);
-    if (it == c->bufs.end() || it->second.kind != kind) return nullptr;
-    return &it->second;
+    Buffer *b = c->bufs.find(h);
+    return (b && b->kind == kind) ? b : nullptr;
 }
 static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t stride = 1) {
     if (!count) return 1;
@@ -104,7 +128,7 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
     if ((sz) && var->size != (uint32_t)(sz)) return fail(CN_ERR_ARG, "ciphertext size mismatch for " #h)
 #define GETPT(var, h) Buffer *var = getbuf(ctx, h, 1); if (!var) return fail(CN_ERR_ARG, "invalid plaintext handle " #h)
 // every entry point takes the context lock; all but the deferrable ones (cn_defer.hip) first drain the queue of deferred calls
-#define LOCK_ONLY std::lock_guard<CnMutex> lk_(ctx->mu); CHECK(use(ctx))
+#define LOCK_ONLY CnGuard lk_(ctx->mu); CHECK(use(ctx))
 #define LOCK LOCK_ONLY; CHECK(cn_defer_flush(ctx))
 
 #define launch_count cn_launch_count
@@ -190,6 +214,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
+    if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
@@ -206,11 +231,11 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->bufs) {
-        if (kv.second.kind == 2) (void)free_gemm_plan(ctx, kv.second);
-        else if (kv.second.kind == 3) { (void)free_graph(ctx, kv.second); }
-        else if (!in_slab(ctx, kv.second.d)) (void)hipFree(kv.second.d);
-    }
+    ctx->bufs.for_each([&](Buffer &b) {
+        if (b.kind == 2) (void)free_gemm_plan(ctx, b);
+        else if (b.kind == 3) (void)free_graph(ctx, b);
+        else if (!in_slab(ctx, b.d)) (void)hipFree(b.d);
+    });
     pool_flush(ctx);
     for (const Slab &sl : slabs_of(ctx)) (void)hipFree(sl.base);
     delete &slabs_of(ctx);
@@ -231,11 +256,28 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
+    if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     return fail(CN_ERR_ARG, "unknown option %s", name);
+}
+// read-back of the switches and of choices the library made (tests, diagnostics)
+extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) {
+    LOCK_ONLY;
+    if (!name || !value) return fail(CN_ERR_ARG, "null argument");
+    if (!strcmp(name, "f64")) *value = ctx->use_f64;
+    else if (!strcmp(name, "defer")) *value = ctx->defer;
+    else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
+    else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
+    else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
+    else if (!strcmp(name, "behz_small_base")) *value = ctx->hc.bsk[ctx->hc.kb - 1].q < (1ull << 49);     // auxiliary primes below 2^49 (FP64 kernels) instead of SEAL's 61-bit ones
+    else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
+    else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
+    else if (!strcmp(name, "pending_calls")) *value = (int)ctx->dq->ops.size();
+    else return fail(CN_ERR_ARG, "unknown option %s", name);
+    return 0;
 }
 #define NOT_CAPTURING(what) do { if (ctx->capturing) return fail(CN_ERR_ARG, what " is not possible while a graph is recorded (cn_graph_begin .. cn_graph_end)"); } while (0)
 extern "C" int cn_sync(cn_ctx *ctx) { LOCK; NOT_CAPTURING("cn_sync"); HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; }
@@ -270,7 +312,7 @@ extern "C" int cn_set_galois_key(cn_ctx *ctx, uint64_t elt, const uint64_t *word
     if (!(elt & 1) || elt >= 2ull * ctx->hc.n) return fail(CN_ERR_ARG, "invalid Galois element");
     return set_key(ctx, ctx->gk[elt], words, count, cn_key_words(ctx, 1), is_dev);
 }
-extern "C" int cn_has_galois_key(cn_ctx *ctx, uint64_t elt) { std::lock_guard<CnMutex> lk(ctx->mu); auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
+extern "C" int cn_has_galois_key(cn_ctx *ctx, uint64_t elt) { CnGuard lk(ctx->mu); auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
 extern "C" uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps) {
     uint64_t n = ctx->hc.n, m = 2 * n;
     if (steps == 0) return m - 1;
@@ -337,9 +379,7 @@ static int alloc_buf(cn_ctx *ctx, int kind, uint32_t count, uint32_t size, cn_ha
     b.item_words = kind == 0 ? (size_t)size * ctx->hc.k * ctx->hc.n : ctx->hc.n;
     CHECK(dev_alloc(ctx, b.item_words * 8 * count, &b.d));
     if (kind == 1) b.pt_zero.assign(count, 1);
-    cn_handle h = ctx->next_handle++;
-    ctx->bufs[h] = std::move(b);
-    *out = h;
+    *out = ctx->bufs.insert(std::move(b));
     return 0;
 }
 extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) {
@@ -348,13 +388,13 @@ extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle
 extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { LOCK_ONLY; return alloc_buf(ctx, 1, count, 1, out); }
 extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
     LOCK_ONLY;
-    auto it = ctx->bufs.find(h);
-    if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    if (it->second.kind == 2) { NOT_CAPTURING("releasing a GEMM plan"); CHECK(cn_defer_flush(ctx)); CHECK(free_gemm_plan(ctx, it->second)); }
-    else if (it->second.kind == 3) { NOT_CAPTURING("releasing a graph"); CHECK(cn_defer_flush(ctx)); CHECK(free_graph(ctx, it->second)); }
-    else if (cn_defer_pending(ctx)) ctx->dq->frees.emplace_back(it->second.d, it->second.item_words * 8 * it->second.count);   // queued calls may still read it
-    else CHECK(dev_release(ctx, it->second.d, it->second.item_words * 8 * it->second.count));
-    ctx->bufs.erase(it);
+    Buffer *it = ctx->bufs.find(h);
+    if (!it) return fail(CN_ERR_ARG, "invalid handle");
+    if (it->kind == 2) { NOT_CAPTURING("releasing a GEMM plan"); CHECK(cn_defer_flush(ctx)); CHECK(free_gemm_plan(ctx, *it)); }
+    else if (it->kind == 3) { NOT_CAPTURING("releasing a graph"); CHECK(cn_defer_flush(ctx)); CHECK(free_graph(ctx, *it)); }
+    else if (cn_defer_pending(ctx)) ctx->dq->frees.emplace_back(it->d, it->item_words * 8 * it->count);   // queued calls may still read it
+    else CHECK(dev_release(ctx, it->d, it->item_words * 8 * it->count));
+    ctx->bufs.erase(h);
     return 0;
 }
 // ---- captured sequences: the launch-bound chains of small kernels of a single-image inference (LoLa: ~235 launches per plaintext
@@ -405,10 +445,8 @@ extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) {
     }
     ctx->cap_allocs.clear();
     Buffer b; b.kind = 3; b.count = 0; b.size = 0; b.d = nullptr; b.item_words = 0; b.cg = g;
-    cn_handle h = ctx->next_handle++;
-    ctx->bufs[h] = std::move(b);
     ctx->graphs_alive++;
-    *graph = h;
+    *graph = ctx->bufs.insert(std::move(b));
     return 0;
 }
 extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) {
@@ -419,7 +457,7 @@ extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) {
     ctx->st.kernel_launches += 1;
     return 0;
 }
-extern "C" int cn_live_handles(cn_ctx *ctx) { std::lock_guard<CnMutex> lk(ctx->mu); return (int)ctx->bufs.size(); }
+extern "C" int cn_live_handles(cn_ctx *ctx) { CnGuard lk(ctx->mu); return (int)ctx->bufs.size(); }
 extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
     LOCK; NOT_CAPTURING("cn_ct_upload"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -492,9 +530,8 @@ extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *value
 }
 extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) {
     LOCK;
-    auto is = ctx->bufs.find(src), id = ctx->bufs.find(dst);
-    if (is == ctx->bufs.end() || id == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    Buffer *s = &is->second, *d = &id->second;
+    Buffer *s = ctx->bufs.find(src), *d = ctx->bufs.find(dst);
+    if (!s || !d) return fail(CN_ERR_ARG, "invalid handle");
     if (s->kind != d->kind || s->item_words != d->item_words) return fail(CN_ERR_ARG, "copy between different buffer shapes");
     if (!range_ok(s, sfirst, count) || !range_ok(d, dfirst, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(d->d + dfirst * d->item_words, s->d + sfirst * s->item_words, count * s->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -502,11 +539,11 @@ extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle ds
     return 0;
 }
 extern "C" int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes) {
-    std::lock_guard<CnMutex> lk(ctx->mu);
-    auto it = ctx->bufs.find(h);
-    if (it == ctx->bufs.end()) return fail(CN_ERR_ARG, "invalid handle");
-    if (ptr) *ptr = it->second.d;
-    if (bytes) *bytes = it->second.item_words * 8 * it->second.count;
+    CnGuard lk(ctx->mu);
+    Buffer *it = ctx->bufs.find(h);
+    if (!it) return fail(CN_ERR_ARG, "invalid handle");
+    if (ptr) *ptr = it->d;
+    if (bytes) *bytes = it->item_words * 8 * it->count;
     return 0;
 }
 
@@ -812,9 +849,7 @@ extern "C" int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64
     HIPCHK(hipMemcpy(P->dev, P->host.data(), P->host.size(), hipMemcpyHostToDevice));
     P->host.clear(); P->host.shrink_to_fit();
     Buffer b; b.kind = 2; b.count = O; b.size = 0; b.d = nullptr; b.item_words = 0; b.plan = P;
-    cn_handle h = ctx->next_handle++;
-    ctx->bufs[h] = std::move(b);
-    *plan = h;
+    *plan = ctx->bufs.insert(std::move(b));
     return 0;
 }
 extern "C" int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi) {
@@ -1350,11 +1385,11 @@ static int32_t defer_level(DeferQueue *q, const uint64_t *const *ins, uint32_t n
     int32_t lv = 0;
     for (uint32_t i = 0; i < nin; i++) {
         if (!ins[i]) continue;
-        auto it = q->haz.find(ins[i]);
-        if (it != q->haz.end()) lv = std::max(lv, it->second.w + 1);
+        const DeferQueue::Haz *h = q->haz.find(ins[i]);
+        if (h) lv = std::max(lv, h->w + 1);
     }
-    auto it = q->haz.find(out);
-    if (it != q->haz.end()) lv = std::max(lv, std::max(it->second.w, it->second.r) + 1);
+    const DeferQueue::Haz *ho = q->haz.find(out);
+    if (ho) lv = std::max(lv, std::max(ho->w, ho->r) + 1);
     return lv;
 }
 // queue one operation; ins: the ciphertexts it reads
@@ -1511,16 +1546,16 @@ static int cn_defer_flush(cn_ctx *ctx) {
             for (size_t x = 0; x < ops.size(); x++) {
                 DOp &X = ops[x];
                 if (X.type != DOP_ADDPLAIN || X.a == X.out) continue;
-                auto hi = q->haz.find(X.a);
-                if (hi == q->haz.end() || hi->second.wop < 0 || hi->second.readers != 1 || !freed.count(X.a)) continue;
-                DOp &Gm = ops[hi->second.wop];
-                if (Gm.type != DOP_GEMM1 || Gm.bias || Gm.out != X.a || dead[hi->second.wop]) continue;
+                const DeferQueue::Haz *hi = q->haz.find(X.a);
+                if (!hi || hi->wop < 0 || hi->readers != 1 || !freed.count(X.a)) continue;
+                DOp &Gm = ops[hi->wop];
+                if (Gm.type != DOP_GEMM1 || Gm.bias || Gm.out != X.a || dead[hi->wop]) continue;
                 bool ok = true;
                 for (uint32_t kk = 0; kk < Gm.K && ok; kk++) {
                     const uint64_t *in = (const uint64_t *)q->addr[Gm.terms + kk];
                     if (!in) continue;
-                    auto h2 = q->haz.find(in);
-                    if (h2 != q->haz.end() && h2->second.wop > hi->second.wop) ok = false;
+                    const DeferQueue::Haz *h2 = q->haz.find(in);
+                    if (h2 && h2->wop > hi->wop) ok = false;
                 }
                 if (!ok) continue;
                 Gm.out = X.out; Gm.bias = X.b; Gm.level = X.level;
@@ -1718,7 +1753,7 @@ done:
     for (int i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
     for (void *cm : comms) if (cm) (void)R.CommDestroy(cm);
     for (int i = 1; i < n; i++) {
-        std::lock_guard<CnMutex> lk(ctxs[i]->mu);
+        CnGuard lk(ctxs[i]->mu);
         for (size_t x = 0; x < items.size(); x++) {
             if (!dst[i][x]) continue;
             if (rc) { (void)hipSetDevice(ctxs[i]->device); (void)hipFree(dst[i][x]); continue; }
@@ -1762,7 +1797,7 @@ extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) {
     return 0;
 }
 extern "C" int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset) {
-    std::lock_guard<CnMutex> lk(ctx->mu);
+    CnGuard lk(ctx->mu);
     if (out) *out = ctx->st;
     if (reset) ctx->st = cn_stats{};
     return 0;

@@ -154,8 +154,11 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_intt_tensor(const uint64_t *
 // and part of their re-reads comes from HBM (3.2-4.4 limbs read) - against 2R + 2W (forward transforms in place) + 4R + 3W (tensor +
 // inverse transforms) of the separate launches.
 // The inverse transform's workgroup barrier orders "everybody has re-read its parked words" before any result word is stored over them.
-template <int L, class AR>
-__global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64_t *__restrict__ A_, size_t a_stride, const uint64_t *const *__restrict__ a_tab,
+// PLDS (N <= 8192): the NTT-form operand is parked in LDS behind the exchange image instead (the thread's own 16 B slots, no barrier):
+// nothing but the algorithmic 2 reads + 3 writes per block reaches memory, at the price of ONE workgroup per CU (image + 8 N bytes =
+// 132 KiB of the 160 KiB) instead of two.
+template <int L, class AR, bool PLDS = false>
+__global__ void __launch_bounds__(NttPlan<L>::NT, PLDS ? 2 : 4) k_square_fused(const uint64_t *__restrict__ A_, size_t a_stride, const uint64_t *const *__restrict__ a_tab,
                                                                     uint64_t *__restrict__ D, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm) {
     // 4 waves per SIMD: two 512-thread workgroups per CU.  a_stride: words between the operands of consecutive ciphertexts (the q side
     // reads the input ciphertexts in place, the Bsk side k_behz_extend's array); a_tab: one operand address per ciphertext instead
@@ -172,6 +175,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64
     const size_t Ln = (size_t)Lm * n;
     const uint64_t *a0 = (a_tab ? a_tab[ct] : A_ + (size_t)ct * a_stride) + (size_t)l * n, *a1 = a0 + Ln;
     uint64_t *d0 = D + (size_t)ct * 3 * Ln + (size_t)l * n, *d1 = d0 + Ln, *d2 = d1 + Ln;
+    struct alignas(16) P2 { T a, b; };
+    P2 *pk = reinterpret_cast<P2 *>(s + ntt_lds_words(n)) + tid;                  // PLDS: slot (r >> 1) of this thread at pk[(r >> 1) * NT]
 #pragma unroll 1
     for (int step = 0; step < 3; step++) {
         uint32_t tl = tid;
@@ -183,6 +188,21 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64
             for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tl, r)]);
             ntt_forward_regs<AR, L, true>(v, s, A.fw, A.m, tl);  // PRE: the image of the previous inverse transform is free
             AR::renorm(v, A.m);                                  // lazy transform output (up to 28 q) -> |x| <= q/2
+            if constexpr (PLDS) {
+                if (step == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) pk[(r >> 1) * NttPlan<L>::NT] = P2{v[r], v[r + 1]};
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = AR::mulmod(v[r], v[r], A.m);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const P2 w = pk[(r >> 1) * NttPlan<L>::NT];                 // A0 out, A1 in: the same thread's slot
+                        pk[(r >> 1) * NttPlan<L>::NT] = P2{v[r], v[r + 1]};
+                        v[r] = AR::mulmod(__dadd_rn(w.a, w.a), v[r], A.m); v[r + 1] = AR::mulmod(__dadd_rn(w.b, w.b), v[r + 1], A.m);
+                    }
+                }
+            } else {
             uint64_t *park = step ? d2 : d1;                     // bit patterns of the doubles: every access to D stays a u64 access
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -200,12 +220,17 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_square_fused(const uint64
                     v[r] = AR::mulmod(__dadd_rn(wa, wa), v[r], A.m); v[r + 1] = AR::mulmod(__dadd_rn(wb, wb), v[r + 1], A.m);
                 }
             }
+            }
             if (!ntt_tail_local<L>()) __syncthreads();           // (block-local tail: the inverse starts inside the wave's own blocks)
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(d2 + tail_index<L>(tl, r));
-                const T wa = __longlong_as_double((long long)w.x), wb = __longlong_as_double((long long)w.y);
+                T wa, wb;
+                if constexpr (PLDS) { const P2 w = pk[(r >> 1) * NttPlan<L>::NT]; wa = w.a; wb = w.b; }
+                else {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(d2 + tail_index<L>(tl, r));
+                    wa = __longlong_as_double((long long)w.x); wb = __longlong_as_double((long long)w.y);
+                }
                 v[r] = AR::mulmod(wa, wa, A.m); v[r + 1] = AR::mulmod(wb, wb, A.m);
             }
             __syncthreads();                                     // no forward transform in this step: the previous inverse's image is free

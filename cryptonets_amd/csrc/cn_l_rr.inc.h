@@ -12,7 +12,7 @@ template <class K> static int big_lds(K kern, size_t bytes) {
 }
 template <int L> static int set_attrs_l(size_t bytes) {
     CHECK(big_lds(k_ntt_rr<L, AR, false>, bytes)); CHECK(big_lds(k_ntt_rr<L, AR, true>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes));
-    if constexpr (kF64) CHECK(big_lds(k_square_fused<L, AR>, bytes));
+    if constexpr (kF64) { CHECK(big_lds(k_square_fused<L, AR>, bytes)); if constexpr (L <= 13) CHECK(big_lds(k_square_fused<L, AR, true>, bytes + ((size_t)8 << L))); }
     CHECK(big_lds(k_lift_ntt<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_fused<L, AR>, bytes));
 #ifdef RR_ENC_TAIL
     CHECK(big_lds(k_encrypt_tail<L, AR>, bytes));
@@ -20,6 +20,7 @@ template <int L> static int set_attrs_l(size_t bytes) {
     return 0;
 }
 static int set_attrs(uint32_t logn, size_t bytes) {      // transforms whose padded LDS image exceeds the default dynamic-LDS limit (N >= 8192)
+    if constexpr (kF64) { if (logn == 12) CHECK(big_lds(k_square_fused<12, AR, true>, bytes + ((size_t)8 << 12))); }   // image + parked operand = 66.5 KiB
     if (logn == 13) return set_attrs_l<13>(bytes);
     if (logn == 14) return set_attrs_l<14>(bytes);
     return 0;
@@ -43,8 +44,16 @@ static bool intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_
 
 // squaring: forward transforms, tensor and inverse transforms of one (ciphertext, limb) in ONE kernel (FP64 policies)
 template <int L> static void l_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
-    if constexpr (kF64)
-        hipLaunchKernelGGL((k_square_fused<L, AR>), dim3(cnt * Lm), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, A, astride, atab, D, c->dc, base_off, Lm);
+    if constexpr (kF64) {
+        const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
+        if constexpr (L <= 13) {
+            if (c->sq_lds) {             // NTT-form operand parked in LDS (one workgroup per CU) instead of in the outputs' place (two)
+                hipLaunchKernelGGL((k_square_fused<L, AR, true>), dim3(cnt * Lm), dim3(NttPlan<L>::NT), lds + ((size_t)8 << L), c->stream, A, astride, atab, D, c->dc, base_off, Lm);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_square_fused<L, AR>), dim3(cnt * Lm), dim3(NttPlan<L>::NT), lds, c->stream, A, astride, atab, D, c->dc, base_off, Lm);
+    }
 }
 static bool square_fused(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm) {
     if (!kF64) return false;

@@ -35,16 +35,54 @@ struct Buffer {
     size_t item_words;
     std::vector<uint8_t> pt_zero;   // per plaintext: all coefficients zero?
 };
+// Handle table: a handle is (generation << 32) | (slot + 1) - looked up by indexing, not hashing (a dense-layer call of the unchanged
+// caller names 845 input handles), stale handles are recognised by their generation.
+class HandleTable {
+    struct Slot { Buffer b; uint32_t gen = 0; bool live = false; };
+    std::vector<Slot> slots;
+    std::vector<uint32_t> free_;
+    size_t live_ = 0;
+public:
+    Buffer *find(cn_handle h) {
+        const uint32_t s = (uint32_t)h - 1u;
+        if ((uint32_t)h == 0 || s >= slots.size() || !slots[s].live || slots[s].gen != (uint32_t)(h >> 32)) return nullptr;
+        return &slots[s].b;
+    }
+    cn_handle insert(Buffer &&b) {
+        uint32_t s;
+        if (!free_.empty()) { s = free_.back(); free_.pop_back(); } else { s = (uint32_t)slots.size(); slots.emplace_back(); }
+        slots[s].b = std::move(b); slots[s].live = true; slots[s].gen = (slots[s].gen + 1) & 0x7fffffffu;
+        live_++;
+        return ((cn_handle)slots[s].gen << 32) | (cn_handle)(s + 1);
+    }
+    void erase(cn_handle h) {
+        const uint32_t s = (uint32_t)h - 1u;
+        slots[s].live = false; slots[s].b = Buffer(); free_.push_back(s); live_--;
+    }
+    size_t size() const { return live_; }
+    template <class F> void for_each(F f) { for (Slot &s : slots) if (s.live) f(s.b); }
+};
 struct KsKey { uint64_t *d; bool owned; bool f64; };   // f64: words converted to doubles for the FP64 key-switch kernel
 
 // The contexts are called from Defaults.ThreadCount threads at once (HE Wrapper/Utils.cs:46-88) and the critical sections are a few
 // hundred nanoseconds of bookkeeping (handle table, deferred-operation queue): a futex mutex hands every contended acquisition through
-// the kernel, so waiters spin briefly before they yield.
+// the kernel, so waiters spin (and yield when the wait gets long).
+// Queue (MCS) lock: every waiter spins on a flag in ITS OWN node (on the holder's stack, cn_host.cpp), the holder hands the lock to its
+// successor with one store - a hand-over costs one cache-line transfer however many threads wait, and waiters are served in order.
 class CnMutex {
-    std::atomic<int> s{0};
 public:
-    void lock();              // cn_host.cpp: spin briefly, then yield
-    void unlock();
+    struct Node { std::atomic<Node *> next{nullptr}; std::atomic<int> locked{0}; };
+    void lock(Node &n);
+    void unlock(Node &n);
+private:
+    std::atomic<Node *> tail{nullptr};
+};
+struct CnGuard {
+    CnMutex &m; CnMutex::Node n;
+    explicit CnGuard(CnMutex &m_) : m(m_) { m.lock(n); }
+    ~CnGuard() { m.unlock(n); }
+    CnGuard(const CnGuard &) = delete;
+    CnGuard &operator=(const CnGuard &) = delete;
 };
 
 struct DeferQueue;            // cn_api.hip, second half
@@ -55,8 +93,7 @@ struct cn_ctx {
     DevConsts *dc;            // device copy
     uint64_t *tw;
     CnMutex mu;
-    std::unordered_map<cn_handle, Buffer> bufs;
-    cn_handle next_handle = 1;
+    HandleTable bufs;
     KsKey rlk{nullptr, false, false};
     double *twd = nullptr, *twdh = nullptr;
     bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
@@ -87,6 +124,7 @@ struct cn_ctx {
     std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
+    bool sq_lds = false;      // fused squaring with the NTT-form operand parked in LDS (N <= 8192; cn_set_option("sq_lds", 1)) instead of in the outputs' place
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
     // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
     bool defer = false;

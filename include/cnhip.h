@@ -67,6 +67,10 @@ int cn_sync(cn_ctx *ctx);
  * argument errors are reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle
  * with pending readers is safe (the array returns to the pool after the flush). */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
+/* reads a switch back, or a choice the library made: "behz_small_base" (1: k+1 auxiliary primes below 2^49 - the FP64 kernels; 0: SEAL's
+ * 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not hold for the small primes or a data prime has 49 bits
+ * or more), "behz_f64", "aux_primes", "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "sq_fused", "mp_fused" */
+int cn_get_option(cn_ctx *ctx, const char *name, int *value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
 /* number of u64 words of one key-switch key for this context (relin: which=0, galois: which=1) */

@@ -205,8 +205,9 @@ def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
     out3, out2 = g.ct_alloc(cnt, 3), g.ct_alloc(cnt)
     exp3 = [o.multiply(c, c) for c in cts]
     got = {}
-    for fused in (1, 0):
-        g.set_option("sq_fused", fused)
+    for fused in (1, 2, 0):                                      # 2: fused with the NTT-form operand parked in LDS (cn_set_option("sq_lds", 1))
+        g.set_option("sq_fused", int(fused > 0))
+        g.set_option("sq_lds", int(fused == 2))
         g.multiply(h, 1, h, 1, out3, 1, cnt - 1)                 # squares of ciphertexts 1.. (offset into the array)
         got[fused] = g.ct_download(out3, 1, cnt - 1, size=3)
         for i in range(cnt - 1):
@@ -214,7 +215,8 @@ def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
         g.mul_relin(h, 0, h, 0, out2, 0, cnt)
         assert np.array_equal(g.ct_download(out2, 0, cnt), o.mul_relin_batch(cts, cts)), (name, fused)
     g.set_option("sq_fused", 1)
-    assert np.array_equal(got[0], got[1])
+    g.set_option("sq_lds", 0)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
     assert np.array_equal(g.ct_download(h, 0, cnt), cts)         # operands intact (the q side is read in place)
     for x in (h, out3, out2):
         g.free(x)
@@ -473,7 +475,66 @@ def test_key_switch_variants_agree(name, f64, rng):
         g.free(x)
 
 
-@pytest.mark.parametrize("name", ["tiny", "c3"])
+def _extreme_ciphertexts(o):
+    """ciphertext WORDS (not valid encryptions: the multiplication is a function of words) at the corners of the BEHZ argument: every
+    coefficient 0, q-1 (= -1), floor(q/2) and ceil(q/2) (the largest centred magnitudes: the tensor product then reaches N (q/2)^2, the
+    bound the Shenoy-Kumaresan step must survive), alternating +-floor(q/2), and one limb at q_j - 1 with the others 0"""
+    Q = 1
+    for qj in o.q:
+        Q *= qj
+    n = o.n
+    pats = [[0] * n, [Q - 1] * n, [Q // 2] * n, [Q // 2 + 1] * n, [(Q // 2) if i % 2 else (Q - Q // 2) for i in range(n)]]
+    cts = []
+    for pa in pats:
+        for pb in (pats[2], pa):
+            cts.append(np.concatenate([np.array([x % qj for x in poly], dtype=np.uint64) for poly in (pa, pb) for qj in o.q]))
+    lone = np.zeros((2, o.k, n), dtype=np.uint64)
+    lone[:, 0, :] = o.q[0] - 1
+    cts.append(lone.reshape(-1))
+    return np.stack(cts)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c2", "c4", "n16k7"])
+def test_behz_auxiliary_base_on_extreme_operands(name, monkeypatch):
+    """the small (k+1 primes below 2^49) and SEAL's (61-bit) auxiliary base against the oracle on operands at the corners of the
+    base-independence argument: zero, -1, +-q/2 everywhere - products at the Shenoy-Kumaresan bound"""
+    from cryptonets_amd._native import Context
+    o = get_oracle(name, galois=False)
+    p = PARAMS[name]
+    cts = _extreme_ciphertexts(o)
+    m = len(cts)
+    exp3 = np.stack([o.multiply(cts[i], cts[(i + 3) % m]) for i in range(m)])
+    exp2 = o.mul_relin_batch(cts, cts)
+    for seal_aux in ("1", "0"):
+        monkeypatch.setenv("CN_SEAL_AUX", seal_aux)
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        assert g.get_option("behz_small_base") == (0 if seal_aux == "1" else 1)
+        g.set_relin_key(o.relin_key())
+        h, out3, out2 = up(g, cts), g.ct_alloc(m, 3), g.ct_alloc(m)
+        for i in range(m):
+            g.multiply(h, i, h, (i + 3) % m, out3, i, 1)
+        assert np.array_equal(g.ct_download(out3, 0, m, size=3), exp3), seal_aux
+        g.mul_relin(h, 0, h, 0, out2, 0, m)                          # squarings: the fused kernel on the FP64 path
+        assert np.array_equal(g.ct_download(out2, 0, m), exp2), seal_aux
+        g.close()
+
+
+def test_behz_base_falls_back_when_the_bound_does_not_hold(monkeypatch):
+    """k+1 primes below 2^49 are only used when log2 t + log2 N + log2 q + 2 < log2(B m_sk) (cn_build_consts): N = 16384 with the eight
+    CIFAR primes is 5 bits short and keeps SEAL's 61-bit base; so does any set with a modulus of 49 bits or more"""
+    from cryptonets_amd._native import Context
+    monkeypatch.delenv("CN_SEAL_AUX", raising=False)
+    for name, small in (("c3", 1), ("n16k7", 1), ("c5", 0)):
+        p = PARAMS[name]
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        assert g.get_option("behz_small_base") == small, name
+        g.close()
+    g = Context(1024, 12289, q=[0xffffee001, 0x3ffffffffc001], dbc=10, gdbc=20, device=0)      # a 50-bit data prime: integer transforms, SEAL's base
+    assert g.get_option("behz_small_base") == 0
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c2", "c3", "c4", "n16k7"])
 def test_behz_auxiliary_base_does_not_change_the_words(name, rng, monkeypatch):
     """libcnhip extends to k+1 auxiliary primes just below 2^49 (exact-FP64 transforms) where SEAL - and the oracle - use k+1 primes
     of 61 bits: the product ciphertext is the same integer polynomial floor(t d / q) - beta reduced mod q_j for ANY sufficiently
