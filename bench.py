@@ -79,6 +79,122 @@ def cpu_baseline(cores, layers):
                       "845/100/10/945 x 2 primes (%.1f s per batch); single_thread: the same on one thread from 8/2/2/4 items" % (4 * ns, ns, ns, 2 * ns, total)}
 
 
+def single_image_workload(args, rank, world, local, dist, torch, result_fd):
+    """--workload lola | cifar: the single-image networks of BASELINE configs 4 / 5 (LoLa-MNIST, LoLa-CIFAR shapes) on N GPUs.
+    --shard images (default): every rank evaluates its own images with its own replica of all plaintext-prime channels - round-robin over
+    ranks, no data-path collective (throughput; weak scaling).  --shard primes: the plaintext primes of ONE inference are dealt to the ranks
+    (`distributed.shard_primes`), every rank evaluates the whole network for its primes and the only exchange is the client-side CRT join
+    of the decrypted residues (latency of one image; strong scaling, at most #primes ranks do work).  Each prime channel has its own keys,
+    generated where the channel lives: no key broadcast is needed for either split in this benchmark (a server that replicates a
+    client's channel on several GPUs receives that client's evaluation keys once - cn_ctx_broadcast_keys / the C3 path above)."""
+    from cryptonets_amd import cryptonets_mnist as cm, networks
+    from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
+    from cryptonets_amd.distributed import crt_join_over_ranks, max_over_ranks, shard_primes
+    dev = torch.device("cuda", local)
+    cifar = args.workload == "cifar"
+    name = "LoLaCifar" if cifar else "LoLa"
+    parms = dict(networks.FACTORY_PARAMETERS[name], device=local)
+    all_primes = list(parms["primes"])
+    if args.shard == "primes":
+        parms["primes"] = shard_primes(all_primes, rank, world)
+    active = len(parms["primes"]) > 0
+    rng = np.random.default_rng(5)
+    if cifar:
+        qz = lambda a, sc: np.rint(a * sc) / sc
+        W = [qz(rng.normal(0, 0.05, 83 * 192), 256), qz(rng.normal(0, 0.02, 112 * 8300), 512), qz(rng.normal(0, 0.05, 10 * 5488), 512)]
+        B = [qz(rng.normal(0, 0.05, 83), 256), qz(rng.normal(0, 0.05, 112), 512), qz(rng.normal(0, 0.05, 10), 512)]
+        images = rng.integers(0, 256, size=(args.warmup + args.steps, 3 * 32 * 32)).astype(float)
+    else:
+        w = dict(zip(("Weights_0", "Weights_1", "Biases_2", "Weights_3", "Biases_3"), cm.reference_weights()))
+        images = cm.synthetic_images(args.warmup + args.steps, seed=1000 + (rank if args.shard == "images" else 0))
+    results, dt, verified = [], 0.0, None
+    if active:
+        Factory = EncryptedSealBfvFactory(**parms)
+        env = Factory.AllocateComputationEnv()
+        if cifar:
+            reader = networks.cifar_reader(Factory=Factory)
+            net = networks.LoLaCifar(Factory, reader, W, B, timing=False)
+        else:
+            tsv = "/tmp/bench_lola_rank%d.tsv" % rank
+            with open(tsv, "w") as f:
+                for img in images:
+                    f.write("7\t784\t" + "\t".join("%d:%d" % (i, int(img[i])) for i in np.nonzero(img)[0]) + "\n")
+            reader = networks.lola_reader(name, tsv, Factory=Factory)
+            net = networks.LOLA_NETWORKS[name](Factory, reader, w)
+        net.PrepareNetwork()
+        layers = list(networks._chain(net))[::-1]            # reader, encrypt, evaluated layers ...
+
+        def sync():
+            for e in env.Environments:
+                e.ctx.sync()
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+        if not active:
+            continue
+        if cifar:
+            reader.Features = images[it] / 256.0
+            m = layers[1].GetNext()
+        else:
+            m = layers[1].Apply(layers[0].GetNext())
+        for L in layers[2:]:
+            m2 = L.Apply(m)
+            if m2 is not m:
+                m.Dispose()
+            m = m2
+        sync()
+        if it >= args.warmup:
+            results.append(m)
+        else:
+            m.Dispose()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
+    # ---- outside the timed window: decrypt, CRT-join (over ranks when the primes are split), compare with the exact integer model
+    if not cifar:
+        M = 1
+        for p_ in all_primes:
+            M *= p_
+        verified = True
+        for i, m in enumerate(results if active else [None] * args.steps):
+            res = {}
+            if active:
+                col = m.GetColumn(0)
+                res = {p_: np.asarray(a._decrypt_ints(e), dtype=object)[:10] for p_, a, e in zip(parms["primes"], col.eVectors, env.Environments)}
+            if args.shard == "primes":
+                joined = crt_join_over_ranks(res, all_primes, dist)
+                want = cm.centred(cm.int_logits(w, cm.synthetic_images(args.warmup + args.steps, seed=1000)[args.warmup + i]), M)
+            else:
+                joined = crt_join_over_ranks(res, all_primes, None)
+                want = cm.centred(cm.int_logits(w, images[args.warmup + i]), M)
+            verified = verified and [int(x) for x in joined] == [int(x) for x in want]
+        if dist is not None:
+            flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
+    for m in results:
+        m.Dispose()
+    if rank == 0:
+        images_done = args.steps * (world if args.shard == "images" else 1)
+        out = {"metric": "encrypted images/sec (%s single-image inference, N=%d)" % ("LoLa-CIFAR shapes" if cifar else "LoLa-MNIST", parms["n"]),
+               "value": round(images_done / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak" if args.shard == "images" else "strong",
+               "vs_baseline": None, "dtype": "u64", "data": "synthetic images" + (", synthetic weights of the reference's shapes" if cifar else ", the reference's trained weights"),
+               "verified_against_integer_model": verified,
+               "config": {"workload": "%s (BASELINE config %d), one image per step and %s" % (name, 5 if cifar else 4, "rank" if args.shard == "images" else "job"),
+                          "plaintext_primes": all_primes, "sharding": args.shard,
+                          "parallelism": ("images round-robin over %d ranks, full replica per rank" % world) if args.shard == "images"
+                                         else ("plaintext primes dealt to %d ranks, CRT join of decrypted residues on the client" % world)}}
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def _conv_tile():
     """BENCH_CONV_TILE=2 or 1x2: outputs of neighbouring positions share a gather list (same outputs; developer A/B switch)."""
     v = os.environ.get("BENCH_CONV_TILE", "1")
@@ -96,6 +212,9 @@ def main():
     ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
     ap.add_argument("--caller-threads", type=int, default=8)
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
+    ap.add_argument("--workload", choices=("cryptonets", "lola", "cifar"), default="cryptonets",
+                    help="cryptonets: BASELINE config 3, the headline metric (default); lola / cifar: the single-image networks of configs 4 / 5")
+    ap.add_argument("--shard", choices=("images", "primes"), default="images", help="lola / cifar on N GPUs: independent images per rank, or the plaintext primes of one image")
     args = ap.parse_args()
 
     # the contract is ONE JSON line on stdout: RCCL / HIP runtime banners are C stdio writes to fd 1 (flushed at exit), so fd 1 is
@@ -117,6 +236,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    if args.workload != "cryptonets":
+        return single_image_workload(args, rank, world, local, dist, torch, result_fd)
 
     from cryptonets_amd._native import Context
     from cryptonets_amd import cryptonets_mnist as cm

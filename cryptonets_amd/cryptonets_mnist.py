@@ -145,12 +145,18 @@ class CryptoNetsChannel:
         self.h5 = ctx.ct_alloc(10)
 
     def forward(self):
+        from . import tracing                      # roctx ranges per layer (no-ops unless CN_ROCTX=1)
         g, L = self.g, self.layers
-        g.gemm_apply(L[0]["plan"], self.h_in, self.h1, 0)
-        g.mul_relin(self.h1, 0, self.h1, 0, self.h2, 0, 845)
-        g.gemm_apply(L[1]["plan"], self.h2, self.h3, 0)
-        g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
-        g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
+        with tracing.range("PoolLayer conv 5x5 s2 x5 (784 -> 845)"):
+            g.gemm_apply(L[0]["plan"], self.h_in, self.h1, 0)
+        with tracing.range("SquareActivation 845"):
+            g.mul_relin(self.h1, 0, self.h1, 0, self.h2, 0, 845)
+        with tracing.range("PoolLayer dense 845 -> 100"):
+            g.gemm_apply(L[1]["plan"], self.h2, self.h3, 0)
+        with tracing.range("SquareActivation 100"):
+            g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
+        with tracing.range("PoolLayer dense 100 -> 10"):
+            g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
 
 
 def constant_plaintext(n):

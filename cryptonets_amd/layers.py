@@ -11,6 +11,7 @@ from .convolution import ConvolutionEngine
 from .hewrapper import EMatrixFormat, EVectorFormat
 from .raw import Defaults, RawMatrix
 from .cryptotracker import CryptoTracker, OperationsCount
+from . import tracing
 
 
 class RawData(RawMatrix):
@@ -73,7 +74,8 @@ class BaseLayer:
         if m is None:                                            # a single-record reader at end of file
             return None
         if not self.Verbose:
-            res = self.Apply(m)
+            with tracing.range(type(self).__name__):             # roctx range per layer (no-op unless CN_ROCTX=1)
+                res = self.Apply(m)
         else:                                                    # BaseLayer.cs:30-43: per-layer wall time and width
             import time
             OperationsCount.Reset(self.Factory)
