@@ -127,6 +127,17 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
         def sync():
             for e in env.Environments:
                 e.ctx.sync()
+    # EncryptLayer runs outside the timed window, like the reference's "Prediction-Time" / "Inference-Time" brackets (LoLaCryptonets.cs:64-115,
+    # LolaCifarCryptoNet.cs:57,128): every image of the run is encrypted first
+    encrypted = []
+    for it in range(args.warmup + args.steps if active else 0):
+        if cifar:
+            reader.Features = images[it] / 256.0
+            encrypted.append(layers[1].GetNext())
+        else:
+            encrypted.append(layers[1].Apply(layers[0].GetNext()))
+    if active:
+        sync()
     for it in range(args.warmup + args.steps):
         if it == args.warmup:
             torch.cuda.synchronize()
@@ -135,11 +146,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
             t0 = time.perf_counter()
         if not active:
             continue
-        if cifar:
-            reader.Features = images[it] / 256.0
-            m = layers[1].GetNext()
-        else:
-            m = layers[1].Apply(layers[0].GetNext())
+        m = encrypted[it]
         for L in layers[2:]:
             m2 = L.Apply(m)
             if m2 is not m:

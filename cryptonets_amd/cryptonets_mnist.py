@@ -147,15 +147,15 @@ class CryptoNetsChannel:
     def forward(self):
         from . import tracing                      # roctx ranges per layer (no-ops unless CN_ROCTX=1)
         g, L = self.g, self.layers
-        with tracing.range("PoolLayer conv 5x5 s2 x5 (784 -> 845)"):
+        with tracing.range("PoolLayer conv 5x5 s2 x5 (784 -> 845)", sync=g.sync):
             g.gemm_apply(L[0]["plan"], self.h_in, self.h1, 0)
-        with tracing.range("SquareActivation 845"):
+        with tracing.range("SquareActivation 845", sync=g.sync):
             g.mul_relin(self.h1, 0, self.h1, 0, self.h2, 0, 845)
-        with tracing.range("PoolLayer dense 845 -> 100"):
+        with tracing.range("PoolLayer dense 845 -> 100", sync=g.sync):
             g.gemm_apply(L[1]["plan"], self.h2, self.h3, 0)
-        with tracing.range("SquareActivation 100"):
+        with tracing.range("SquareActivation 100", sync=g.sync):
             g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
-        with tracing.range("PoolLayer dense 100 -> 10"):
+        with tracing.range("PoolLayer dense 100 -> 10", sync=g.sync):
             g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
 
 

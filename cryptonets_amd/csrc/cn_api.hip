@@ -215,6 +215,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
+    if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
@@ -257,6 +258,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
+    if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
@@ -272,6 +274,8 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) {
     else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
+    else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
+    else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "behz_small_base")) *value = ctx->hc.bsk[ctx->hc.kb - 1].q < (1ull << 49);     // auxiliary primes below 2^49 (FP64 kernels) instead of SEAL's 61-bit ones
     else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
@@ -726,11 +730,12 @@ static bool gemm_weights_small(cn_ctx *ctx, const uint64_t *W, size_t count) {
     }
     return true;
 }
-struct GemmArith { bool small, two; uint32_t lazy; };
+struct GemmArith { bool small, two; uint32_t lazy; int bits; };
 static GemmArith gemm_arith(cn_ctx *ctx, bool weights_small) {
     uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
     GemmArith g;
+    g.bits = bits;
     g.small = weights_small && ctx->use_f64 && bits <= 49;       // the kernel folds its limb sums with exact-FP64 modular arithmetic (q < 2^49.4)
     g.two = bits <= 44;                                          // 2 limbs of 22 bits, else 3 limbs of 17 bits
     if (g.small) g.lazy = g.two ? 1024u : 32768u;                // terms whose limb products (< 2^42 / 2^37) still sum exactly below 2^52
@@ -738,12 +743,44 @@ static GemmArith gemm_arith(cn_ctx *ctx, bool weights_small) {
     return g;
 }
 
+// ---- the matrix-core form of a scalar GEMM (k_scalar_gemm_mfma): eligibility, weight digit planes, A fragments
+// 6 signed base-256 digits cover residues below 2^46 (x + 0x80..80 must stay below 2^48); i32 accumulators hold K * P * 2^14 < 2^31
+static bool gemm_mfma_ok(cn_ctx *ctx, const GemmArith &ar, uint32_t M, uint32_t K) {
+    return ctx->gemm_mfma && ar.small && ar.bits <= 46 && M >= 16 && (uint64_t)K * 3 < (1u << 17) && !(ctx->hc.n & 31);
+}
+static uint32_t gemm_weight_planes(cn_ctx *ctx, const uint64_t *W, size_t count) {
+    uint64_t amax = 0;
+    for (size_t x = 0; x < count; x++) { const uint64_t w = W[x]; amax = std::max(amax, w >= ctx->hc.t_half ? ctx->hc.t.q - w : w); }
+    return amax <= 127 ? 1u : (amax <= 32639 ? 2u : 3u);          // signed digits -128..127: |w| <= 127 / 32639 / 8355711
+}
+// fragments [g][p][mtile][kstep][lane][16]: lane l, byte t = digit p of the weight of output row 32 mtile + (l & 31) for term
+// 32 kstep + 16 (l >> 5) + t; zero for padded rows / terms / taps.  row(g, m): residues mod t of member m, or null; tap_ok(g, kk).
+template <class ROW, class TAP> static void pack_gemm_mfma(cn_ctx *ctx, uint32_t G, uint32_t M, uint32_t K, uint32_t P, ROW row, TAP tap_ok, std::vector<char> &wbytes) {
+    const uint32_t mtiles = (M + 31) / 32, ksteps = (K + 31) / 32;
+    const uint64_t t = ctx->hc.t.q;
+    wbytes.assign((size_t)G * P * mtiles * ksteps * 1024, 0);
+    for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+        const uint64_t *wr = row(g, m);
+        if (!wr) continue;
+        const uint32_t mt = m / 32, r = m % 32;
+        for (uint32_t kk = 0; kk < K; kk++) {
+            const uint64_t w = wr[kk];
+            if (!w || !tap_ok(g, kk)) continue;
+            const int64_t sw = w >= ctx->hc.t_half ? -(int64_t)(t - w) : (int64_t)w;
+            const uint32_t rec = ((uint32_t)(sw + 0x808080) ^ 0x808080u);          // byte p = signed digit p
+            const uint32_t ks = kk / 32, half = (kk % 32) / 16, tt = kk % 16;
+            for (uint32_t p = 0; p < P; p++)
+                wbytes[((((size_t)g * P + p) * mtiles + mt) * ksteps + ks) * 1024 + (size_t)(half * 32 + r) * 16 + tt] = (char)(uint8_t)(rec >> (8 * p));
+        }
+    }
+}
 // A scalar GEMM is planned once per (gather table, weight matrix): validation, grouping of the outputs that share a gather list,
 // weight tiles in the kernel's layout.  A plan can live in HBM (cn_gemm_plan_create: the weights of a layer are uploaded once, every
 // inference only launches) or in the per-call scratch (cn_scalar_gemm).
 struct GemmPlan {
     uint32_t O = 0, K = 0, Kp = 0, G = 0, M = 0, MT = 0, lazy = 0, max_in = 0;
-    bool small = false, two = false, has_bias = false;
+    bool small = false, two = false, has_bias = false, mfma = false;
+    uint32_t P = 0, mtiles = 0, ksteps = 0;  // matrix-core form: weight digit planes, 32-row output tiles, 32-term steps
     cn_handle bias_pt = 0; uint32_t bias_count = 0;
     uint64_t nnz = 0;                        // non-zero, non-padded terms (statistics)
     std::vector<char> host;                  // [idx | out_idx | bias_idx | weights], each 256 B aligned
@@ -782,7 +819,10 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
     const uint32_t NONE = 0xffffffffu;
     uint32_t G = (uint32_t)groups.size(), M = 0;
     for (auto &g : groups) M = std::max<uint32_t>(M, (uint32_t)g.second.size());
-    const uint32_t Kp = ((K + 7) & ~7u) + 8;                     // gather rows padded with -1 to 16 B multiples (+ 8 spare): the kernels read 4 at a time
+    const GemmArith ar = gemm_arith(ctx, gemm_weights_small(ctx, W, (size_t)O * K));
+    const bool small = ar.small, mfma = gemm_mfma_ok(ctx, ar, M, K);
+    // gather rows padded with -1 to 16 B multiples (+ 8 spare): the kernels read 4 at a time; matrix-core form: 32 entries per K step
+    const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 7) & ~7u) + 8;
     std::vector<int32_t> hidx((size_t)G * Kp, -1), hoidx((size_t)G * M, -1), hbidx((size_t)G * M, 0);
     std::vector<uint32_t> member((size_t)G * M, NONE);           // output index of (group, m)
     {
@@ -794,13 +834,14 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
         }
     }
     for (size_t x = 0; x < member.size(); x++) if (member[x] != NONE) { hoidx[x] = (int32_t)member[x]; if (BP) hbidx[x] = bias_idx[member[x]]; }   // relative to the output base
-    const GemmArith ar = gemm_arith(ctx, gemm_weights_small(ctx, W, (size_t)O * K));
-    const bool small = ar.small;
     P.O = O; P.K = K; P.Kp = Kp; P.G = G; P.M = M; P.small = small; P.has_bias = BP != nullptr; P.bias_pt = bias_pt; P.bias_count = BP ? BP->count : 0;
-    P.two = ar.two; P.lazy = ar.lazy;
+    P.two = ar.two; P.lazy = ar.lazy; P.mfma = mfma;
     std::vector<char> wbytes;
-    pack_gemm_weights(ctx, G, M, K, small, [&](uint32_t g, uint32_t m) -> const uint64_t * {
-        return member[(size_t)g * M + m] == NONE ? nullptr : W + (size_t)member[(size_t)g * M + m] * K; }, P.MT, wbytes);
+    auto row = [&](uint32_t g, uint32_t m) -> const uint64_t * { return member[(size_t)g * M + m] == NONE ? nullptr : W + (size_t)member[(size_t)g * M + m] * K; };
+    if (mfma) {
+        P.P = gemm_weight_planes(ctx, W, (size_t)O * K); P.mtiles = (M + 31) / 32; P.ksteps = (K + 31) / 32;
+        pack_gemm_mfma(ctx, G, M, K, P.P, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] >= 0; }, wbytes);
+    } else pack_gemm_weights(ctx, G, M, K, small, row, P.MT, wbytes);
     P.off_oidx = al(hidx.size() * 4); P.off_bidx = P.off_oidx + al(hoidx.size() * 4); P.off_w = P.off_bidx + al(hbidx.size() * 4);
     P.host.assign(P.off_w + al(wbytes.size()), 0);
     memcpy(P.host.data(), hidx.data(), hidx.size() * 4);
@@ -821,8 +862,8 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
         bias = BP->d;
     }
     GemmLaunch gl{P.small, P.two, false, P.MT, I->d, tables, tables + P.off_w, tables + P.off_oidx, bias, tables + P.off_bidx, OB->d,
-                  P.G, P.M, P.K, P.lazy, P.Kp, oi};
-    CHECK(cn_l_gemm(ctx, gl));
+                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps};
+    CHECK(P.mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl));
     ctx->st.PlainMultiplication += P.nnz; ctx->st.Addition += P.nnz - P.O;
     if (P.has_bias) ctx->st.PlainAddition += P.O;
     return 0;
@@ -1453,7 +1494,11 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
     const uint32_t G = (uint32_t)groups.size();
     uint32_t M = 0;
     for (auto &g : groups) M = std::max<uint32_t>(M, (uint32_t)g.second.size());
-    const uint32_t Kp = ((K + 7) & ~7u) + 8;
+    bool wsmall = true;
+    for (const DOp *op : ops) wsmall = wsmall && gemm_weights_small(ctx, &q->wt[op->terms], K);
+    const GemmArith ar = gemm_arith(ctx, wsmall);
+    const bool mfma = gemm_mfma_ok(ctx, ar, M, K);
+    const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 7) & ~7u) + 8;
     std::vector<uint64_t> hidx((size_t)G * Kp, 0), hoidx((size_t)G * M, 0), hbidx((size_t)G * M, 0);
     std::vector<const DOp *> member((size_t)G * M, nullptr);
     bool any_bias = false;
@@ -1471,13 +1516,13 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
             g++;
         }
     }
-    bool wsmall = true;
-    for (const DOp *op : ops) wsmall = wsmall && gemm_weights_small(ctx, &q->wt[op->terms], K);
-    const GemmArith ar = gemm_arith(ctx, wsmall);
-    const bool small = ar.small, two = ar.two; const uint32_t lazy = ar.lazy; uint32_t MT = 1;
+    const bool small = ar.small, two = ar.two; const uint32_t lazy = ar.lazy; uint32_t MT = 1, WP = 0;
     std::vector<char> wbytes;
-    pack_gemm_weights(ctx, G, M, K, small, [&](uint32_t g, uint32_t m) -> const uint64_t * { const DOp *op = member[(size_t)g * M + m]; return op ? &q->wt[op->terms] : nullptr; },
-                      MT, wbytes);
+    auto row = [&](uint32_t g, uint32_t m) -> const uint64_t * { const DOp *op = member[(size_t)g * M + m]; return op ? &q->wt[op->terms] : nullptr; };
+    if (mfma) {
+        for (const DOp *op : ops) WP = std::max(WP, gemm_weight_planes(ctx, &q->wt[op->terms], K));
+        pack_gemm_mfma(ctx, G, M, K, WP, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; }, wbytes);
+    } else pack_gemm_weights(ctx, G, M, K, small, row, MT, wbytes);
     const size_t off_oidx = al(hidx.size() * 8), off_bidx = off_oidx + al(hoidx.size() * 8), off_w = off_bidx + al(hbidx.size() * 8);
     std::vector<char> host(off_w + al(wbytes.size()), 0);
     memcpy(host.data(), hidx.data(), hidx.size() * 8);
@@ -1487,8 +1532,8 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
     CHECK(ensure_scratch(ctx, al(host.size())));
     char *tables; CHECK(upload_tmp(ctx, host.data(), host.size(), &tables));
     GemmLaunch gl{small, two, true, MT, fallback, tables, tables + off_w, tables + off_oidx, nullptr, any_bias ? tables + off_bidx : nullptr, nullptr,
-                  G, M, K, lazy, Kp, 0};
-    return cn_l_gemm(ctx, gl);
+                  G, M, K, lazy, Kp, 0, WP, (M + 31) / 32, (K + 31) / 32};
+    return mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl);
 }
 static int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, int type) {
     std::vector<Tab3> tab(ops.size());

@@ -241,3 +241,128 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         }
     }
 }
+
+// ------------------------------------------------------------------ scalar GEMM on the int8 matrix cores (exact)
+// out[o][e] = sum_k W[o][k] * x[k][e] mod q_j is an integer contraction over K input ciphertexts: M = outputs, N = coefficients, K = inputs.
+// With SMALL signed weights it maps onto v_mfma_i32_32x32x32_i8 EXACTLY: the residue x < 2^48 is recoded into 6 signed base-256 digits
+// (x + 0x80..80 has bytes b_i; b_i - 128 = b_i ^ 0x80 as int8), the weight into P <= 3 signed digits the same way; digit x digit products
+// (< 2^14) accumulate in i32 over K <= 2^15 terms without overflow, products of equal weight 256^(i+p) share one accumulator ("diagonal"),
+// and the 6 + P - 1 diagonals are folded mod q_j in exact FP64 at the end.  One wave owns a 32 (outputs) x 32 (coefficients) tile; the
+// up to four waves of a workgroup take the m-tiles of the same coefficient columns.  Every lane loads the 16 input words of its K slots
+// itself (32 lanes x 8 B = 256 B contiguous per input ciphertext) and transposes their bytes into the six B fragments with v_perm_b32;
+// the A fragments (weight digits) are laid out in HBM in fragment order by the plan, one 16 B load per lane and weight digit plane.
+// K-slot convention: lane l, byte t of an operand <-> k = 32 ks + 16 (l >> 5) + t for BOTH operands (the instruction pairs equal slots,
+// so any convention shared by A and B is correct).  C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }   // byte n of the result = byte sel[n] of {hi: 4..7, lo: 0..3}
+template <int P, bool ABS>
+__global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const int8_t *__restrict__ Wf,
+                                                             const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
+                                                             uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t G, uint32_t M, uint32_t mtiles,
+                                                             uint32_t ksteps, uint32_t obase) {
+    typedef typename GemmTab<ABS>::T TT;
+    const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
+    constexpr int ND = 6, D = ND + P - 1;
+    const uint32_t n = C->n, k = C->k, limbs = 2 * k, ctiles = n >> 5;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    uint32_t b = blockIdx.x;
+    const uint32_t ctile = b % ctiles; b /= ctiles;
+    const uint32_t limb = b % limbs; b /= limbs;
+    const uint32_t mgroups = (mtiles + 3) >> 2, mg = b % mgroups, g = b / mgroups;
+    const uint32_t mt = mg * 4 + wave;
+    if (mt >= mtiles) return;                                  // (no workgroup barrier in this kernel)
+    const uint32_t j = limb % k;
+    const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + (size_t)ctile * 32 + col;
+    const uint32_t Kp = ksteps * 32;
+    const TT *gi = idx + (size_t)g * Kp;
+    const int8_t *wf = Wf + ((((size_t)g * P) * mtiles + mt) * ksteps) * 1024 + (size_t)lane * 16;       // + (p * mtiles * ksteps + ks) * 1024
+    v16i_t acc[D];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[d][r] = 0;
+    const uint64_t BIAS = 0x0000808080808080ull;
+    for (uint32_t ks = 0; ks < ksteps; ks++) {
+        // ---- the 16 input words of this lane's K slots, recoded: byte i of y = signed digit i
+        uint32_t lo[16], hi[16];
+#pragma unroll
+        for (int t4 = 0; t4 < 16; t4 += 4) {
+            uint64_t x[4];
+            if constexpr (ABS) {
+                const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + t4, 16));
+                const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + t4 + 2, 16));
+                const ulonglong2 c01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 16 + t4, 16));
+                const ulonglong2 c23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 16 + t4 + 2, 16));
+                const uint64_t a0[4] = {a01.x, a01.y, a23.x, a23.y}, a1[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint64_t ad = half ? a1[u] : a0[u];
+                    x[u] = (ad ? reinterpret_cast<const uint64_t *>(ad) : in)[e];          // padded tap: any readable word (its weight digits are 0)
+                }
+            } else {
+                const int4 i0 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32 + t4, 16));
+                const int4 i1 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32 + 16 + t4, 16));
+                const int32_t a0[4] = {i0.x, i0.y, i0.z, i0.w}, a1[4] = {i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int32_t id = half ? a1[u] : a0[u];
+                    x[u] = in[(size_t)max(id, 0) * ctw + e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t y = (x[u] + BIAS) ^ BIAS;
+                lo[t4 + u] = (uint32_t)y; hi[t4 + u] = (uint32_t)(y >> 32);
+            }
+        }
+        // ---- byte transpose: B fragment of digit plane i, dword q = byte i of slots 4q .. 4q+3
+        v4i_t bf[ND];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a = lo[4 * q], bb = lo[4 * q + 1], c = lo[4 * q + 2], d = lo[4 * q + 3];
+            const uint32_t ab02 = byte_perm(bb, a, 0x06020400u), cd02 = byte_perm(d, c, 0x06020400u);     // (a0 b0 a2 b2), (c0 d0 c2 d2)
+            const uint32_t ab13 = byte_perm(bb, a, 0x07030501u), cd13 = byte_perm(d, c, 0x07030501u);     // (a1 b1 a3 b3), (c1 d1 c3 d3)
+            bf[0][q] = (int)byte_perm(cd02, ab02, 0x05040100u);                                           // a0 b0 c0 d0
+            bf[2][q] = (int)byte_perm(cd02, ab02, 0x07060302u);                                           // a2 b2 c2 d2
+            bf[1][q] = (int)byte_perm(cd13, ab13, 0x05040100u);
+            bf[3][q] = (int)byte_perm(cd13, ab13, 0x07060302u);
+            const uint32_t ha = hi[4 * q], hb = hi[4 * q + 1], hc = hi[4 * q + 2], hd = hi[4 * q + 3];
+            const uint32_t hab = byte_perm(hb, ha, 0x05010400u), hcd = byte_perm(hd, hc, 0x05010400u);    // (a4 b4 a5 b5), (c4 d4 c5 d5)
+            bf[4][q] = (int)byte_perm(hcd, hab, 0x05040100u);
+            bf[5][q] = (int)byte_perm(hcd, hab, 0x07060302u);
+        }
+        // ---- P x 6 matrix instructions; equal digit weights share an accumulator
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const v4i_t af = *reinterpret_cast<const v4i_t *>(wf + ((size_t)p * mtiles * ksteps + ks) * 1024);
+#pragma unroll
+            for (int i = 0; i < ND; i++) acc[i + p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[i], acc[i + p], 0, 0, 0);
+        }
+    }
+    // ---- fold the diagonals: value = sum_d acc_d 256^d mod q_j (exact FP64), bias, store
+    const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
+    const DMod qm = C->q[j];
+    double cpow[D];
+    cpow[0] = 1.0;
+#pragma unroll
+    for (int d = 1; d < D; d++) cpow[d] = BzF::center(__dmul_rn(cpow[d - 1], 256.0), mq);          // 256^d mod q_j, centred (exact: |x| <= q/2 times 256 < 2^53)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t row = (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * half, o = g * M + mt * 32 + row;
+        if (mt * 32 + row >= M) continue;
+        double v = (double)acc[0][r];
+#pragma unroll
+        for (int d = 1; d < D; d++) v = __dadd_rn(v, BzF::mulmod((double)acc[d][r], cpow[d], mq));
+        uint64_t res = BzF::to_u64(v, mq);
+        if constexpr (ABS) {
+            if (!out_idx[o]) continue;
+            if (bias_idx && bias_idx[o] && limb < k) res = addmod(res, scale_plain(C, reinterpret_cast<const uint64_t *>(bias_idx[o])[(size_t)ctile * 32 + col], j), qm.q);
+            reinterpret_cast<uint64_t *>(out_idx[o])[e] = res;
+        } else {
+            if (out_idx[o] < 0) continue;
+            if (bias && limb < k) res = addmod(res, scale_plain(C, bias[(size_t)bias_idx[o] * n + (size_t)ctile * 32 + col], j), qm.q);
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = res;
+        }
+    }
+}

@@ -1,5 +1,6 @@
 // Launchers of the scalar GEMM kernels (HOT LOOP A).  One translation unit per kernel family: hipcc compiles them in parallel.
 #include "cn_runtime.h"
+#include <algorithm>
 #include "cn_k_gemm.hip.h"
 
 template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &g) {
@@ -38,3 +39,22 @@ template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
     return 0;
 }
 int cn_l_gemm(cn_ctx *c, const GemmLaunch &g) { return g.abs ? launch<true>(c, g) : launch<false>(c, g); }
+
+template <int P, bool ABS> static void launch_mfma(cn_ctx *c, const GemmLaunch &g) {
+    const uint32_t mgroups = (g.mtiles + 3) / 4, waves = std::min<uint32_t>(g.mtiles, 4);
+    const size_t blocks = (size_t)g.G * mgroups * 2 * c->hc.k * (c->hc.n / 32);
+    hipLaunchKernelGGL((k_scalar_gemm_mfma<P, ABS>), dim3((uint32_t)blocks), dim3(64 * waves), 0, c->stream, g.in, g.idx, (const int8_t *)g.W, g.oidx, g.bias, g.bidx, g.out,
+                       c->dc, g.G, g.M, g.mtiles, g.ksteps, g.obase);
+}
+template <bool ABS> static int launch_mfma_p(cn_ctx *c, const GemmLaunch &g) {
+    switch (g.P) {
+        case 1: launch_mfma<1, ABS>(c, g); break;
+        case 2: launch_mfma<2, ABS>(c, g); break;
+        case 3: launch_mfma<3, ABS>(c, g); break;
+        default: return cn_fail(CN_ERR_ARG, "internal: %u weight digit planes", g.P);
+    }
+    HIPCHK(hipGetLastError());
+    cn_launch_count(c);
+    return 0;
+}
+int cn_l_gemm_mfma(cn_ctx *c, const GemmLaunch &g) { return g.abs ? launch_mfma_p<true>(c, g) : launch_mfma_p<false>(c, g); }

@@ -67,15 +67,14 @@ struct KsKey { uint64_t *d; bool owned; bool f64; };   // f64: words converted t
 // The contexts are called from Defaults.ThreadCount threads at once (HE Wrapper/Utils.cs:46-88) and the critical sections are a few
 // hundred nanoseconds of bookkeeping (handle table, deferred-operation queue): a futex mutex hands every contended acquisition through
 // the kernel, so waiters spin (and yield when the wait gets long).
-// Queue (MCS) lock: every waiter spins on a flag in ITS OWN node (on the holder's stack, cn_host.cpp), the holder hands the lock to its
-// successor with one store - a hand-over costs one cache-line transfer however many threads wait, and waiters are served in order.
+// Spin lock (cn_host.cpp): the critical sections are short, waiters spin briefly and then yield.
 class CnMutex {
 public:
-    struct Node { std::atomic<Node *> next{nullptr}; std::atomic<int> locked{0}; };
+    struct Node {};           // (per-acquisition state of a queue lock; the current lock needs none)
     void lock(Node &n);
     void unlock(Node &n);
 private:
-    std::atomic<Node *> tail{nullptr};
+    std::atomic<int> held{0};
 };
 struct CnGuard {
     CnMutex &m; CnMutex::Node n;
@@ -124,6 +123,7 @@ struct cn_ctx {
     std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
+    bool gemm_mfma = true;    // scalar GEMMs with >= 16 outputs per gather list on the int8 matrix cores (exact); cn_set_option("gemm_mfma", 0): FP64 kernel
     bool sq_lds = false;      // fused squaring with the NTT-form operand parked in LDS (N <= 8192; cn_set_option("sq_lds", 1)) instead of in the outputs' place
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
     // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
@@ -173,7 +173,9 @@ struct GemmLaunch {
     bool small, two, abs; uint32_t MT;
     const uint64_t *in; const void *idx; const void *W; const void *oidx; const uint64_t *bias; const void *bidx; uint64_t *out;
     uint32_t G, M, K, lazy, Kp, obase;
+    uint32_t P = 0, mtiles = 0, ksteps = 0;          // matrix-core kernel: weight digit planes, 32-row output tiles, 32-term K steps
 };
 int cn_l_gemm(cn_ctx *c, const GemmLaunch &g);
+int cn_l_gemm_mfma(cn_ctx *c, const GemmLaunch &g);   // k_scalar_gemm_mfma: W = weight digit fragments, idx rows of ksteps * 32 entries
 
 inline void cn_launch_count(cn_ctx *c, int n = 1) { c->st.kernel_launches += n; }

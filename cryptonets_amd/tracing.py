@@ -32,7 +32,9 @@ def _load():
 
 
 @contextlib.contextmanager
-def range(name):
+def range(name, sync=None):
+    """`sync`: called before the range closes WHEN TRACING IS ON (e.g. Context.sync): the range then covers the device time of the work
+    it queued, not only the time to queue it - per-layer device time straight from the marker statistics of a profiling run."""
     L = _load() if _on else False
     if L:
         L.roctxRangePushA(str(name).encode())
@@ -40,4 +42,6 @@ def range(name):
         yield
     finally:
         if L:
+            if sync is not None:
+                sync()
             L.roctxRangePop()
