@@ -244,13 +244,16 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 
 // ------------------------------------------------------------------ scalar GEMM on the int8 matrix cores (exact)
 // out[o][e] = sum_k W[o][k] * x[k][e] mod q_j is an integer contraction over K input ciphertexts: M = outputs, N = coefficients, K = inputs.
-// With SMALL signed weights it maps onto v_mfma_i32_32x32x32_i8 EXACTLY: the residue x < 2^48 is recoded into 6 signed base-256 digits
+// With SMALL signed weights it maps onto v_mfma_i32_32x32x32_i8 EXACTLY: the residue x < 2^46 is recoded into 6 signed base-256 digits
 // (x + 0x80..80 has bytes b_i; b_i - 128 = b_i ^ 0x80 as int8), the weight into P <= 3 signed digits the same way; digit x digit products
-// (< 2^14) accumulate in i32 over K <= 2^15 terms without overflow, products of equal weight 256^(i+p) share one accumulator ("diagonal"),
-// and the 6 + P - 1 diagonals are folded mod q_j in exact FP64 at the end.  One wave owns a 32 (outputs) x 32 (coefficients) tile; the
-// up to four waves of a workgroup take the m-tiles of the same coefficient columns.  Every lane loads the 16 input words of its K slots
-// itself (32 lanes x 8 B = 256 B contiguous per input ciphertext) and transposes their bytes into the six B fragments with v_perm_b32;
-// the A fragments (weight digits) are laid out in HBM in fragment order by the plan, one 16 B load per lane and weight digit plane.
+// (<= 2^14) accumulate in i32 over K P < 2^17 terms without overflow, products of equal weight 256^(i+p) share one accumulator
+// ("diagonal"), and the 6 + P - 1 diagonals are folded mod q_j in exact FP64 at the end.
+// Workgroup = 4 waves = 32 coefficient columns x up to four 32-row output tiles (wave w: m-tile 4 mg + w).  The B operand (digits of 32
+// inputs x 32 columns per K step) is the same for the four waves, so they build it TOGETHER: wave w loads the input words of K slots
+// 4w .. 4w+3 of its lanes' half (4 loads of 256 contiguous bytes per half-wave instead of 16), recodes them, transposes their bytes with
+// v_perm_b32 into one dword per digit plane, and publishes the six dwords in LDS; after one barrier every wave reads its complete
+// fragments back as 16 B per lane and plane.  Two LDS buffers and a one-step-ahead prefetch of the input words and of the A fragments
+// (weight digits, laid out in fragment order by the plan: one 16 B load per lane and plane) keep one barrier per K step.
 // K-slot convention: lane l, byte t of an operand <-> k = 32 ks + 16 (l >> 5) + t for BOTH operands (the instruction pairs equal slots,
 // so any convention shared by A and B is correct).  C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -264,6 +267,7 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     constexpr int ND = 6, D = ND + P - 1;
+    __shared__ __align__(16) uint32_t frag[2][ND][64][4];          // [buffer][digit plane][lane][slot group q]: 12 KiB
     const uint32_t n = C->n, k = C->k, limbs = 2 * k, ctiles = n >> 5;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     uint32_t b = blockIdx.x;
@@ -271,75 +275,81 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
     const uint32_t limb = b % limbs; b /= limbs;
     const uint32_t mgroups = (mtiles + 3) >> 2, mg = b % mgroups, g = b / mgroups;
     const uint32_t mt = mg * 4 + wave;
-    if (mt >= mtiles) return;                                  // (no workgroup barrier in this kernel)
+    const bool active = mt < mtiles;                           // a wave without an output tile still loads its share of the B operand
     const uint32_t j = limb % k;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + (size_t)ctile * 32 + col;
     const uint32_t Kp = ksteps * 32;
-    const TT *gi = idx + (size_t)g * Kp;
-    const int8_t *wf = Wf + ((((size_t)g * P) * mtiles + mt) * ksteps) * 1024 + (size_t)lane * 16;       // + (p * mtiles * ksteps + ks) * 1024
+    const TT *gi = idx + (size_t)g * Kp + 4 * wave;            // + 32 ks + 16 half + u
+    const int8_t *wf = Wf + ((((size_t)g * P) * mtiles + (active ? mt : 0)) * ksteps) * 1024 + (size_t)lane * 16;       // + (p * mtiles * ksteps + ks) * 1024
     v16i_t acc[D];
 #pragma unroll
     for (int d = 0; d < D; d++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[d][r] = 0;
     const uint64_t BIAS = 0x0000808080808080ull;
-    for (uint32_t ks = 0; ks < ksteps; ks++) {
-        // ---- the 16 input words of this lane's K slots, recoded: byte i of y = signed digit i
-        uint32_t lo[16], hi[16];
-#pragma unroll
-        for (int t4 = 0; t4 < 16; t4 += 4) {
-            uint64_t x[4];
-            if constexpr (ABS) {
-                const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + t4, 16));
-                const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + t4 + 2, 16));
-                const ulonglong2 c01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 16 + t4, 16));
-                const ulonglong2 c23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 16 + t4 + 2, 16));
-                const uint64_t a0[4] = {a01.x, a01.y, a23.x, a23.y}, a1[4] = {c01.x, c01.y, c23.x, c23.y};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint64_t ad = half ? a1[u] : a0[u];
-                    x[u] = (ad ? reinterpret_cast<const uint64_t *>(ad) : in)[e];          // padded tap: any readable word (its weight digits are 0)
-                }
-            } else {
-                const int4 i0 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32 + t4, 16));
-                const int4 i1 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32 + 16 + t4, 16));
-                const int32_t a0[4] = {i0.x, i0.y, i0.z, i0.w}, a1[4] = {i1.x, i1.y, i1.z, i1.w};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int32_t id = half ? a1[u] : a0[u];
-                    x[u] = in[(size_t)max(id, 0) * ctw + e];
-                }
-            }
+    auto load_x = [&](uint64_t (&x)[4], uint32_t ks) {          // the 4 input words of this lane's slots 4 wave .. 4 wave + 3
+        if constexpr (ABS) {
+            const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32, 16));
+            const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 2, 16));
+            const ulonglong2 c01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 16, 16));
+            const ulonglong2 c23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 18, 16));
+            const uint64_t a0[4] = {a01.x, a01.y, a23.x, a23.y}, a1[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint64_t y = (x[u] + BIAS) ^ BIAS;
-                lo[t4 + u] = (uint32_t)y; hi[t4 + u] = (uint32_t)(y >> 32);
+                const uint64_t ad = half ? a1[u] : a0[u];
+                x[u] = (ad ? reinterpret_cast<const uint64_t *>(ad) : in)[e];              // padded tap: any readable word (its weight digits are 0)
+            }
+        } else {
+            const int4 i0 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32, 16));
+            const int4 i1 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32 + 16, 16));
+            const int32_t a0[4] = {i0.x, i0.y, i0.z, i0.w}, a1[4] = {i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int32_t id = half ? a1[u] : a0[u];
+                x[u] = in[(size_t)max(id, 0) * ctw + e];
             }
         }
-        // ---- byte transpose: B fragment of digit plane i, dword q = byte i of slots 4q .. 4q+3
-        v4i_t bf[ND];
+    };
+    auto load_a = [&](v4i_t (&af)[P], uint32_t ks) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t a = lo[4 * q], bb = lo[4 * q + 1], c = lo[4 * q + 2], d = lo[4 * q + 3];
-            const uint32_t ab02 = byte_perm(bb, a, 0x06020400u), cd02 = byte_perm(d, c, 0x06020400u);     // (a0 b0 a2 b2), (c0 d0 c2 d2)
-            const uint32_t ab13 = byte_perm(bb, a, 0x07030501u), cd13 = byte_perm(d, c, 0x07030501u);     // (a1 b1 a3 b3), (c1 d1 c3 d3)
-            bf[0][q] = (int)byte_perm(cd02, ab02, 0x05040100u);                                           // a0 b0 c0 d0
-            bf[2][q] = (int)byte_perm(cd02, ab02, 0x07060302u);                                           // a2 b2 c2 d2
-            bf[1][q] = (int)byte_perm(cd13, ab13, 0x05040100u);
-            bf[3][q] = (int)byte_perm(cd13, ab13, 0x07060302u);
-            const uint32_t ha = hi[4 * q], hb = hi[4 * q + 1], hc = hi[4 * q + 2], hd = hi[4 * q + 3];
-            const uint32_t hab = byte_perm(hb, ha, 0x05010400u), hcd = byte_perm(hd, hc, 0x05010400u);    // (a4 b4 a5 b5), (c4 d4 c5 d5)
-            bf[4][q] = (int)byte_perm(hcd, hab, 0x05040100u);
-            bf[5][q] = (int)byte_perm(hcd, hab, 0x07060302u);
+        for (int p = 0; p < P; p++) af[p] = *reinterpret_cast<const v4i_t *>(wf + ((size_t)p * mtiles * ksteps + ks) * 1024);
+    };
+    uint64_t xa[4], xb[4];
+    v4i_t afa[P], afb[P];
+    load_x(xa, 0); load_a(afa, 0);
+    auto step = [&](uint64_t (&x)[4], v4i_t (&af)[P], uint64_t (&xn)[4], v4i_t (&afn)[P], uint32_t ks) {
+        // recode: byte i of y = signed digit i; transpose the 4 words into one dword per digit plane; publish
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint64_t y = (x[u] + BIAS) ^ BIAS; lo[u] = (uint32_t)y; hi[u] = (uint32_t)(y >> 32); }
+        const uint32_t ab02 = byte_perm(lo[1], lo[0], 0x06020400u), cd02 = byte_perm(lo[3], lo[2], 0x06020400u);     // (a0 b0 a2 b2), (c0 d0 c2 d2)
+        const uint32_t ab13 = byte_perm(lo[1], lo[0], 0x07030501u), cd13 = byte_perm(lo[3], lo[2], 0x07030501u);     // (a1 b1 a3 b3), (c1 d1 c3 d3)
+        const uint32_t hab = byte_perm(hi[1], hi[0], 0x05010400u), hcd = byte_perm(hi[3], hi[2], 0x05010400u);       // (a4 b4 a5 b5), (c4 d4 c5 d5)
+        uint32_t (*fb)[64][4] = frag[ks & 1];
+        fb[0][lane][wave] = byte_perm(cd02, ab02, 0x05040100u);          // a0 b0 c0 d0
+        fb[1][lane][wave] = byte_perm(cd13, ab13, 0x05040100u);
+        fb[2][lane][wave] = byte_perm(cd02, ab02, 0x07060302u);          // a2 b2 c2 d2
+        fb[3][lane][wave] = byte_perm(cd13, ab13, 0x07060302u);
+        fb[4][lane][wave] = byte_perm(hcd, hab, 0x05040100u);
+        fb[5][lane][wave] = byte_perm(hcd, hab, 0x07060302u);
+        if (ks + 1 < ksteps) { load_x(xn, ks + 1); load_a(afn, ks + 1); }      // in flight over the barrier and the matrix instructions
+        __syncthreads();
+        if (active) {
+            v4i_t bf[ND];
+#pragma unroll
+            for (int i = 0; i < ND; i++) bf[i] = *reinterpret_cast<const v4i_t *>(&fb[i][lane][0]);
+            // P x 6 matrix instructions; equal digit weights share an accumulator
+#pragma unroll
+            for (int p = 0; p < P; p++)
+#pragma unroll
+                for (int i = 0; i < ND; i++) acc[i + p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[p], bf[i], acc[i + p], 0, 0, 0);
         }
-        // ---- P x 6 matrix instructions; equal digit weights share an accumulator
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const v4i_t af = *reinterpret_cast<const v4i_t *>(wf + ((size_t)p * mtiles * ksteps + ks) * 1024);
-#pragma unroll
-            for (int i = 0; i < ND; i++) acc[i + p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[i], acc[i + p], 0, 0, 0);
-        }
+    };
+    for (uint32_t ks = 0; ks < ksteps; ks += 2) {
+        step(xa, afa, xb, afb, ks);
+        if (ks + 1 < ksteps) step(xb, afb, xa, afa, ks + 1);
     }
+    if (!active) return;
     // ---- fold the diagonals: value = sum_d acc_d 256^d mod q_j (exact FP64), bias, store
     const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
     const DMod qm = C->q[j];

@@ -41,9 +41,9 @@ template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
 int cn_l_gemm(cn_ctx *c, const GemmLaunch &g) { return g.abs ? launch<true>(c, g) : launch<false>(c, g); }
 
 template <int P, bool ABS> static void launch_mfma(cn_ctx *c, const GemmLaunch &g) {
-    const uint32_t mgroups = (g.mtiles + 3) / 4, waves = std::min<uint32_t>(g.mtiles, 4);
+    const uint32_t mgroups = (g.mtiles + 3) / 4;
     const size_t blocks = (size_t)g.G * mgroups * 2 * c->hc.k * (c->hc.n / 32);
-    hipLaunchKernelGGL((k_scalar_gemm_mfma<P, ABS>), dim3((uint32_t)blocks), dim3(64 * waves), 0, c->stream, g.in, g.idx, (const int8_t *)g.W, g.oidx, g.bias, g.bidx, g.out,
+    hipLaunchKernelGGL((k_scalar_gemm_mfma<P, ABS>), dim3((uint32_t)blocks), dim3(256), 0, c->stream, g.in, g.idx, (const int8_t *)g.W, g.oidx, g.bias, g.bidx, g.out,
                        c->dc, g.G, g.M, g.mtiles, g.ksteps, g.obase);
 }
 template <bool ABS> static int launch_mfma_p(cn_ctx *c, const GemmLaunch &g) {

@@ -124,7 +124,8 @@ struct cn_ctx {
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
     bool gemm_mfma = true;    // scalar GEMMs with >= 16 outputs per gather list on the int8 matrix cores (exact); cn_set_option("gemm_mfma", 0): FP64 kernel
-    bool sq_lds = false;      // fused squaring with the NTT-form operand parked in LDS (N <= 8192; cn_set_option("sq_lds", 1)) instead of in the outputs' place
+    bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per
+                              // block (profiles/r02_pmc_square_gemm.txt); cn_set_option("sq_lds", 0): parked in the outputs' place (two workgroups per CU)
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
     // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
     bool defer = false;

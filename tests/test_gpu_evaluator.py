@@ -448,6 +448,8 @@ def test_scalar_gemm_matrix_core_kernel(name, rng):
         if K > 3:
             Ws[3, :] = 0
             Ws[3, 3] = 1
+        dead = ~np.any((Ws != 0) & (idx >= 0), axis=1)               # a row without any term is an error on both sides (AddMany of nothing)
+        Ws[dead, 0] = 1
         W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
         bias_idx = (np.arange(O) % 3).astype(np.int32)
         exp = o.add_plain_batch(o.scalar_gemm(cts, W, idx), bias_plain[bias_idx])
