@@ -183,3 +183,99 @@ def test_basic_example_on_the_default_encrypted_factory():
     assert enc["norm_squared"][0] == raw["norm_squared"][0] == 14.0
     assert enc["sum"][0] == raw["sum"][0] == 6.0
     assert enc["elementwise"][:3] == raw["elementwise"] == [-1.0, 10.0, -12.0]
+
+
+@pytest.mark.gpu
+def test_default_client_draws_its_randomness_from_the_os():
+    """The default DeviceClient seeds key generation and EVERY encryption from os.urandom (plus a per-context salt): two factories never
+    share keys, two encryptions of one plaintext never share (u, e1, e2); an explicit seed (tests) reproduces keys and ciphertexts."""
+    from cryptonets_amd._native import Context
+    from cryptonets_amd.client import DeviceClient
+    n, t = 4096, 40961
+    keys, cts = [], []
+    for _ in range(2):
+        g = Context(n, t)
+        c = DeviceClient(g)
+        c.generate_keys(with_galois=False)
+        keys.append(g.get_key(3))
+        p = np.zeros(n, dtype=np.uint64)
+        p[0] = 7
+        cts.append([c.encrypt(p), c.encrypt(p)])
+        assert np.array_equal(c.decrypt(cts[-1][0]), p) and np.array_equal(c.decrypt(cts[-1][1]), p)
+        g.close()
+    assert not np.array_equal(keys[0], keys[1])
+    assert not np.array_equal(cts[0][0], cts[0][1]) and not np.array_equal(cts[0][0], cts[1][0])
+    fixed = []
+    for _ in range(2):
+        g = Context(n, t)
+        c = DeviceClient(g, seed=1234)
+        c.generate_keys(with_galois=False)
+        fixed.append((g.get_key(3), c.encrypt(np.arange(n, dtype=np.uint64) % t)))
+        g.close()
+    assert np.array_equal(fixed[0][0], fixed[1][0]) and np.array_equal(fixed[0][1], fixed[1][1])
+
+
+@pytest.mark.gpu
+def test_rng_salt_changes_every_stream():
+    from cryptonets_amd._native import Context
+    outs = []
+    for salt in (0, 0, 0x1234567890ABCDEF):
+        g = Context(1024, 12289, q=[0xffffee001, 0xffffc4001, 0x1ffffe0001])
+        g.set_rng_salt(salt)
+        g.keygen(99, galois=False)
+        outs.append((g.get_key(3), g.get_key(2)))
+        g.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert not np.array_equal(outs[0][0], outs[2][0]) and not np.array_equal(outs[0][1], outs[2][1])
+
+
+@pytest.mark.gpu
+def test_recording_rejects_encryption_and_key_changes():
+    """a replayed graph would reuse the randomness of a recorded cn_encrypt; key changes synchronise and reallocate: both are refused
+    while a graph is recorded, and the recording can still be closed afterwards"""
+    from cryptonets_amd._native import Context, CnError
+    g = Context(1024, 12289, q=[0xffffee001, 0xffffc4001, 0x1ffffe0001])
+    g.keygen(5, galois=False)
+    rk = g.get_key(0)
+    pt, ct = g.pt_alloc(1), g.ct_alloc(1)
+    g.pt_upload(pt, 0, np.ones((1, 1024), dtype=np.uint64))
+    g.encrypt(pt, 0, ct, 0, 1, seed=3)
+    g.graph_begin()
+    with pytest.raises(CnError):
+        g.encrypt(pt, 0, ct, 0, 1, seed=3)
+    with pytest.raises(CnError):
+        g.set_relin_key(rk)
+    g.add(ct, 0, ct, 0, ct, 0)
+    graph = g.graph_end()
+    g.graph_launch(graph)
+    g.sync()
+    g.free(graph)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_multiply_plain_rejects_partially_overlapping_ranges():
+    from cryptonets_amd._native import Context, CnError
+    g = Context(1024, 12289, q=[0xffffee001, 0xffffc4001, 0x1ffffe0001])
+    g.keygen(5, galois=False)
+    pt, ct = g.pt_alloc(1), g.ct_alloc(4)
+    g.pt_upload(pt, 0, np.ones((1, 1024), dtype=np.uint64))
+    g.encrypt(pt, 0, ct, 0, 4, seed=3, pt_stride=0)
+    g.mul_plain(ct, 0, pt, 0, ct, 0, 2, pt_stride=0)               # exactly in place: fine
+    g.mul_plain(ct, 0, pt, 0, ct, 2, 2, pt_stride=0)               # disjoint: fine
+    with pytest.raises(CnError):
+        g.mul_plain(ct, 0, pt, 0, ct, 1, 2, pt_stride=0)           # [0,2) -> [1,3): a block would read what another has overwritten
+    g.close()
+
+
+@pytest.mark.gpu
+def test_ct_upload_checks_the_row_width():
+    from cryptonets_amd._native import Context
+    g = Context(1024, 12289, q=[0xffffee001, 0xffffc4001, 0x1ffffe0001])
+    h3 = g.ct_alloc(2, 3)
+    with pytest.raises(ValueError):
+        g.ct_upload(h3, 0, np.zeros((2, 2 * 3 * 1024), dtype=np.uint64))      # size-2 rows into a size-3 handle
+    with pytest.raises(ValueError):
+        g.ct_upload(h3, 1, np.zeros((2, 3 * 3 * 1024), dtype=np.uint64))      # past the end
+    g.ct_upload(h3, 0, np.zeros((2, 3 * 3 * 1024), dtype=np.uint64))
+    g.close()

@@ -218,3 +218,27 @@ def test_small_lola_single_image(backend):
     M = env.bigFactor
     exp = [((v % M) - M) if (v % M) * 2 > M else (v % M) for v in exp]
     assert got == exp
+
+
+@pytest.mark.gpu
+def test_failed_recording_leaves_the_contexts_usable():
+    """an evaluation that raises while it is recorded must not leave a context in capture mode or pin the scratch arenas with a
+    half-made graph (hewrapper.CapturedEvaluation ends the capture on every context and frees what was instantiated)"""
+    from cryptonets_amd.hewrapper import CapturedEvaluation, EMatrixFormat, EncryptedSealBfvFactory
+    F = EncryptedSealBfvFactory([40961, 65537], 4096, galois=False, client_seed=5)
+    env = F.AllocateComputationEnv()
+    m = F.GetEncryptedMatrix(np.arange(8, dtype=float).reshape(4, 2), EMatrixFormat.ColumnMajor, 1)
+    m.ElementWiseMultiply(m, env).Dispose()                       # rehearsal: temporaries are in the pools
+
+    def bad(x):
+        x.ElementWiseMultiply(x, env)
+        raise RuntimeError("boom")
+    with pytest.raises(RuntimeError, match="boom"):
+        CapturedEvaluation(env, bad, [m])
+    for e in env.Environments:
+        e.ctx.sync()                                              # raises while a graph is being recorded
+    big = F.GetEncryptedMatrix(np.ones((4, 40)), EMatrixFormat.ColumnMajor, 1)
+    sq = big.ElementWiseMultiply(big, env)                        # needs a larger scratch arena: refused while a graph exists
+    assert np.array_equal(sq.Decrypt(env), np.ones((4, 40)))
+    sq2 = m.ElementWiseMultiply(m, env)
+    assert np.array_equal(sq2.Decrypt(env), np.arange(8, dtype=float).reshape(4, 2) ** 2)

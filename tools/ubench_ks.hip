@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(512, 1) k_ks_pipe(const uint64_t *__restrict__
     extern __shared__ __align__(16) unsigned char smem[];
     double *s = reinterpret_cast<double *>(smem);
     const uint32_t k = 5, tid = threadIdx.x, ct = blockIdx.x / k, j = blockIdx.x % k;
+    if constexpr ((F & F_PRIO) != 0) { if (tid < 256) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
     const AR::Mod m = {q, qinv};
     const size_t kn = (size_t)k * N;
     typedef ArPassA<AR> FW;
@@ -241,6 +242,7 @@ int main() {
     hipMemcpy(tw, kk.data(), 5 * 2 * N * 8, hipMemcpyHostToDevice);
     run<127>("full (keys, LDS, math, MAC, barriers, LDS twiddles, source loads)", tgt, key, out, tw, cts);
     run_pipe<0>("software-pipelined: first pass of digit g+1 before the barrier, 2 images", tgt, key, out, tw, cts);
+    run_pipe<F_PRIO>("software-pipelined + waves 0-3 at priority 3", tgt, key, out, tw, cts);
     run<127 + F_PRIO>("full, waves 0-3 at priority 3, waves 4-7 at priority 0", tgt, key, out, tw, cts);
     run<127 - F_TWL>("full, twiddles from L2 instead of LDS", tgt, key, out, tw, cts);
     run<127 - F_TWL + F_DB>("two LDS images (one barrier per digit), twiddles from L2", tgt, key, out, tw, cts);
