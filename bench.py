@@ -405,7 +405,12 @@ def main():
                           "arithmetic": "exact modular integers over 43-49-bit RNS primes (results are u64 words, bit-identical to the integer "
                                         "oracle); products evaluated with error-free FP64 instruction sequences where the modulus is below 2^49, "
                                         "64-bit integer instructions otherwise"},
-               "roofline": roofline, "key_switch": key_switch, "unchanged_caller": unchanged}
+               "roofline": roofline, "key_switch": key_switch, "unchanged_caller": unchanged,
+               # the WHOLE batch against HBM (inputs read once + outputs written once per layer, 640 KiB per ciphertext, per prime:
+               # conv (784+845), square 845 x 2, dense (845+100), square 100 x 2, dense (100+10)): the path is FP64-issue bound, not HBM bound
+               "batch_hbm": (lambda nbytes: {"algorithmic_bytes_per_step": nbytes, "achieved": round(nbytes / (dt / args.steps) / 1e9, 1), "peak": 8000.0,
+                                             "unit": "GB/s", "frac": round(nbytes / (dt / args.steps) / 8e12, 4)})(
+                   2 * (784 + 845 + 2 * 845 + 845 + 100 + 2 * 100 + 100 + 10) * 2 * g.k * g.n * 8)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1, layers)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -205,6 +205,7 @@ class Context:
         self.n, self.t, self.q, self.k = int(n), int(t), [int(x) for x in q], len(q)
         self.dbc, self.gdbc, self.device = dbc, gdbc, device
         self.ctw = 2 * self.k * self.n
+        self._ct_size = {}
         qa = (C.c_uint64 * self.k)(*self.q)
         h = _CTX()
         self._h = None
@@ -262,6 +263,7 @@ class Context:
     def ct_alloc(self, count, size=2):
         h = _H()
         self._chk(self.L.cn_ct_alloc(self._h, count, size, C.byref(h)))
+        self._ct_size[h.value] = size
         return h.value
 
     def pt_alloc(self, count):
@@ -271,14 +273,16 @@ class Context:
 
     def free(self, h):
         self._chk(self.L.cn_free(self._h, h))
+        self._ct_size.pop(h, None)
 
     def ct_upload(self, h, first, data):
         d = np.ascontiguousarray(data, dtype=np.uint64)
         count = d.shape[0] if d.ndim > 1 else 1
         _, nbytes = self.device_ptr(h)                     # the library reads count * item words from the host pointer: check the row width here
         row = d.size // count if count else 0
+        size = self._ct_size.get(h)                        # polynomials per ciphertext of this handle, when it was allocated through this object
         if count == 0 or d.size != count * row or row % (self.k * self.n) or row // (self.k * self.n) not in (2, 3) \
-                or nbytes % (row * 8) or first + count > nbytes // (row * 8):
+                or (size is not None and row != size * self.k * self.n) or nbytes % (row * 8) or first + count > nbytes // (row * 8):
             raise ValueError("ct_upload: data of shape %s does not fit the ciphertexts of this handle" % (d.shape,))
         self._chk(self.L.cn_ct_upload(self._h, h, first, count, _p64(d)))
 
