@@ -357,6 +357,8 @@ def main():
         for _ in range(5):
             g.relinearize(t3, 0, t2, 0, cts)
         ks_ms = g.time_end() / 5
+        fp64_ns = g.fp64_issue_ns(iters=4096, launches=6)                 # ~3 ms of pure FP64 chains right behind the key switches: the issue rate NOW
+        valu_ns = g.valu32_issue_ns(iters=16384, launches=6)              # and of full-rate 32-bit VALU instructions
         g.free(t3); g.free(t2)
         per_limb = [-(-int(q).bit_length() // 10) for q in g.q]           # base-2^10 digits of every source limb
         digits = sum(per_limb)
@@ -369,8 +371,18 @@ def main():
             import ks_isa_counts
             fp64_per_thread, isa = ks_isa_counts.fp64_per_thread(g.k, per_limb)
             floor_ms = cts * g.k * 8 * fp64_per_thread / 1024 * 2.15e-6   # 8 waves per workgroup, 4 SIMDs x 256 CUs
+            floor_now = cts * g.k * 8 * fp64_per_thread / 1024 * fp64_ns * 1e-6
             key_switch.update({"fp64_per_thread": fp64_per_thread, "fp64_digit_loop": isa["fp64_digit_loop"], "fp64_tail_loop": isa["fp64_tail_loop"],
-                               "fp64_issue_floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ks_ms, 3)})
+                               "fp64_issue_floor_ms": round(floor_ms, 3), "frac": round(floor_ms / ks_ms, 3),
+                               "fp64_ns_per_instr_in_situ": round(fp64_ns, 3), "fp64_issue_floor_in_situ_ms": round(floor_now, 3),
+                               "frac_in_situ": round(floor_now / ks_ms, 3)})
+            # the SIMD's VALU port issues the FP64 AND the other vector instructions of the kernel (253 per digit: digit extraction,
+            # selects, addressing), one at a time: the issue floor of the whole VALU stream, every non-FP64 instruction priced as a
+            # full-rate one (a lower bound: 64-bit shifts and 32-bit multiplies take longer)
+            valu_per_thread = ks_isa_counts.valu_per_thread(per_limb, isa)
+            floor_valu = cts * g.k * 8 * (fp64_per_thread * fp64_ns + valu_per_thread * valu_ns) / 1024 * 1e-6
+            key_switch.update({"valu_other_per_thread": valu_per_thread, "valu32_ns_per_instr_in_situ": round(valu_ns, 3),
+                               "valu_issue_floor_in_situ_ms": round(floor_valu, 3), "frac_valu_in_situ": round(floor_valu / ks_ms, 3)})
         except Exception as ex:                                            # no disassembler / unrecognised code shape: no floor rather than a stale one
             key_switch.update({"fp64_issue_floor_ms": None, "frac": None, "isa_error": str(ex)[:200]})
 

@@ -147,6 +147,7 @@ SIGNATURES = {
     "cn_ntt_inverse": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int]),
     "cn_ct_ntt": (C.c_int, [_CTX, _H, _u32, _u32, C.c_int]),
     "cn_ntt_time": (C.c_int, [_CTX, C.c_void_p, _u32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "cn_valu_issue_time": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "cn_stream": (C.c_void_p, [_CTX]),
     "cn_event_time_begin": (C.c_int, [_CTX]),
     "cn_event_time_end": (C.c_int, [_CTX, C.POINTER(C.c_float)]),
@@ -497,6 +498,18 @@ class Context:
         ms = C.c_float()
         self._chk(self.L.cn_ntt_time(self._h, dev_ptr, limbs, base, int(inverse), iters, C.byref(ms)))
         return ms.value
+
+    def fp64_issue_ns(self, iters=2048, launches=4):
+        """ns per FP64 wave-instruction per SIMD right now (cn_valu_issue_time, kind 0)"""
+        ns = C.c_float()
+        self._chk(self.L.cn_valu_issue_time(self._h, 0, iters, launches, C.byref(ns)))
+        return ns.value
+
+    def valu32_issue_ns(self, iters=8192, launches=4):
+        """ns per full-rate 32-bit VALU wave-instruction per SIMD right now (cn_valu_issue_time, kind 1)"""
+        ns = C.c_float()
+        self._chk(self.L.cn_valu_issue_time(self._h, 1, iters, launches, C.byref(ns)))
+        return ns.value
 
     def stream(self):
         return self.L.cn_stream(self._h)

@@ -175,7 +175,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (device < 0 || device >= ndev) return fail(CN_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
     if (n > 16384) return fail(CN_ERR_ARG, "poly modulus degree %u too large for the LDS-resident NTT (max 16384)", n);
     if (k == 0 || k > CN_MAXK) return fail(CN_ERR_ARG, "coeff modulus count out of range");
-    std::vector<uint64_t> tw((size_t)(2 * k + 2) * 4 * n);
+    std::vector<uint64_t> tw((size_t)(2 * k + 3) * 4 * n);             // k data + up to k + 2 auxiliary moduli + t
     cn_ctx *c = new cn_ctx();
     char err[256];
     c->index_map.assign(n, 0);
@@ -188,7 +188,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     HIPCHK(hipMemcpy(c->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
     c->hc.tw = c->tw;
     {
-        std::vector<double> twd((size_t)(2 * k + 2) * 2 * n, 0.0);
+        std::vector<double> twd((size_t)(2 * k + 3) * 2 * n, 0.0);
         cn_build_f64_tables(&c->hc, tw.data(), twd.data());
         HIPCHK(hipMalloc((void **)&c->twd, twd.size() * 8));
         HIPCHK(hipMemcpy(c->twd, twd.data(), twd.size() * 8, hipMemcpyHostToDevice));
@@ -1832,6 +1832,34 @@ extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int i
     HIPCHK(hipEventSynchronize(ctx->ev1));
     float t = 0; HIPCHK(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
     *ms = t / iters;
+    return 0;
+}
+// ns per wave-instruction per SIMD RIGHT NOW (same occupancy as the fused key switch: 512-thread workgroups, one per CU, two waves per
+// SIMD), over `launches` launches.  kind 0: FP64 (8 independent chains of the 6-instruction modular multiply per thread, `iters` x 48
+// instructions); kind 1: full-rate 32-bit VALU (4 chains x 6 instructions, `iters` x 24)
+extern "C" int cn_valu_issue_time(cn_ctx *ctx, int kind, int iters, int launches, float *ns_per_instr) {
+    LOCK; NOT_CAPTURING("cn_valu_issue_time");
+    if (iters < 1 || launches < 1 || !ns_per_instr || kind < 0 || kind > 1) return fail(CN_ERR_ARG, "bad arguments");
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const size_t lds = 96 * 1024;                                   // > half of the 160 KiB: one workgroup per CU
+    HIPCHK(hipFuncSetAttribute((const void *)k_fp64_probe<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_valu_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(ensure_scratch(ctx, al((size_t)cus * 512 * 8)));
+    double *out = salloc<double>(ctx, (size_t)cus * 512);
+    const double q = 8796092792833.0, w = 1234567891011.0;
+    auto launch = [&]() {
+        if (kind == 0) hipLaunchKernelGGL(k_fp64_probe<8>, dim3(cus), dim3(512), lds, ctx->stream, out, w, q, 1.0 / q, iters);
+        else hipLaunchKernelGGL(k_valu_probe, dim3(cus), dim3(512), lds, ctx->stream, out, 0x9e3779b9u, 0x7f4a7c15u, iters);
+    };
+    launch();
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < launches; i++) launch();
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipGetLastError());
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ns_per_instr = ms * 1e6f / ((float)launches * 2.0f * (float)iters * (kind == 0 ? 48.0f : 24.0f));       // 2 waves per SIMD
     return 0;
 }
 extern "C" int cn_event_time_begin(cn_ctx *ctx) { LOCK; HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return 0; }

@@ -302,3 +302,44 @@ __global__ void __launch_bounds__(256) k_decrypt_scale(const uint64_t *__restric
     const uint64_t r = vg > (gm.q >> 1) ? addmod(vt, (gm.q - vg) % tm.q, tm.q) : submod(vt, vg % tm.q, tm.q);
     plain[(size_t)ct * n + i] = r ? mulmod(r, C->inv_g_t, tm) : 0;
 }
+
+// FP64 issue-rate probe (cn_fp64_issue_time): ILP independent chains of the 6-instruction exact modular multiply per thread, nothing else -
+// the rate at which the FP64 pipe issues under the power state of the moment (the key switch's floor in bench.py is priced with it).
+template <int ILP>
+__global__ void __launch_bounds__(512) k_fp64_probe(double *out, double w, double q, double qinv, int iters) {
+    extern __shared__ double probe_lds[];               // (dynamic LDS only pins the occupancy: one workgroup per CU, two waves per SIMD)
+    double a[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; i++) a[i] = (double)(threadIdx.x * 131 + i * 7 + 1);
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            const double p = __dmul_rn(a[i], w);
+            const double e = __fma_rn(a[i], w, -p);
+            const double h = __builtin_rint(__dmul_rn(p, qinv));
+            a[i] = __dadd_rn(__fma_rn(-h, q, p), e);
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; i++) s += a[i];
+    if (s == 1.2345e-300) probe_lds[threadIdx.x] = s;   // never true: keeps the LDS allocation and the chains alive
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// the same for full-rate 32-bit VALU instructions (add / xor / shift-add / and-or: what the key switch runs besides FP64 - digit extraction,
+// addressing, selects): 4 interleaved chains x 6 instructions per iteration, written out so that the count is exact
+__global__ void __launch_bounds__(512) k_valu_probe(double *out, uint32_t c1, uint32_t c2, int iters) {
+    extern __shared__ double probe_lds[];
+    uint32_t a0 = threadIdx.x, a1 = threadIdx.x * 3 + 1, a2 = threadIdx.x * 5 + 2, a3 = threadIdx.x * 7 + 3;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n"
+                     "v_xor_b32 %0, %0, %5\n v_xor_b32 %1, %1, %5\n v_xor_b32 %2, %2, %5\n v_xor_b32 %3, %3, %5\n"
+                     "v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %4\n v_lshl_add_u32 %2, %2, 1, %4\n v_lshl_add_u32 %3, %3, 1, %4\n"
+                     "v_and_or_b32 %0, %0, %5, %4\n v_and_or_b32 %1, %1, %5, %4\n v_and_or_b32 %2, %2, %5, %4\n v_and_or_b32 %3, %3, %5, %4\n"
+                     "v_sub_u32 %0, %0, %5\n v_sub_u32 %1, %1, %5\n v_sub_u32 %2, %2, %5\n v_sub_u32 %3, %3, %5\n"
+                     "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c1), "v"(c2));
+    const double s = (double)(a0 ^ a1 ^ a2 ^ a3);
+    if (s == 1.2345e-300) probe_lds[threadIdx.x] = s;
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}

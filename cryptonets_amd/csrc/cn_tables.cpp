@@ -128,27 +128,38 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
     // is exact whenever |floor(t d / q)| < B m_sk / 2.  SEAL's k+1 primes of 61 bits need integer (Shoup) transforms; k+1 primes just
     // below 2^49 run on the exact-FP64 transform kernels like the data primes do.  Used when every q_j < 2^49 and the base is large
     // enough with 2 bits to spare:  log2(t) + log2(N) + log2(q) + 2 < log2(B m_sk)   (|d| <= N q^2 / 2 (1 + eps)).
-    // CN_SEAL_AUX=1 keeps SEAL's base (A/B runs and the parity test that both bases give the oracle's words).
+    // Nothing in that argument needs B to have exactly k primes either: where k + 1 primes below 2^49 fall a few bits short (the data
+    // primes of N = 16384 are 48-49 bits themselves and t, N take 30+ bits more), k + 2 of them are used (kb = k + 2; k >= 6 only - the
+    // kernels are instantiated for those shapes).  CN_SEAL_AUX=1 keeps SEAL's base (A/B runs and the parity test that both bases give
+    // the oracle's words); CN_AUX_EXTRA=0 forbids the extra prime.
     {
         bool small = !(getenv("CN_SEAL_AUX") && atoi(getenv("CN_SEAL_AUX")));
+        const bool extra = !(getenv("CN_AUX_EXTRA") && !atoi(getenv("CN_AUX_EXTRA")));
         long double need = log2l((long double)t) + (long double)c->logn + 2.0L;
         for (uint32_t j = 0; j < k; j++) { if (q[j] >> 49) small = false; need += log2l((long double)q[j]); }
         if (small) {
             std::vector<uint64_t> sm;
-            for (uint64_t x = (1ull << 49) - 2ull * n + 1; sm.size() < (size_t)k + 1 && x > (1ull << 48); x -= 2ull * n) {
+            for (uint64_t x = (1ull << 49) - 2ull * n + 1; sm.size() < (size_t)k + 2 && x > (1ull << 48); x -= 2ull * n) {
                 bool used = false;
                 for (uint32_t j = 0; j < k; j++) if (q[j] == x) used = true;
                 if (!used && is_prime_u64(x)) sm.push_back(x);
             }
-            long double have = 0;
-            for (uint64_t x : sm) have += log2l((long double)x);
-            if (sm.size() == (size_t)k + 1 && need < have) {
-                for (uint32_t i = 0; i < k; i++) bsk[i] = sm[i + 1];
-                bsk[k] = sm[0];
+            for (uint32_t kb = k + 1; kb <= k + 2 && kb <= sm.size(); kb++) {
+                if (kb == k + 2 && !(extra && k >= 6 && k <= 9)) break;
+                long double have = 0;
+                for (uint32_t i = 0; i < kb; i++) have += log2l((long double)sm[i]);
+                if (need < have) {
+                    bsk.assign(kb, 0);
+                    for (uint32_t i = 0; i + 1 < kb; i++) bsk[i] = sm[i + 1];
+                    bsk[kb - 1] = sm[0];
+                    c->kb = kb;
+                    break;
+                }
             }
         }
     }
-    for (uint32_t i = 0; i <= k; i++) set_mod(c->bsk[i], bsk[i]);
+    const uint32_t nb = c->kb - 1;                            // primes of B; bsk[nb] is m_sk
+    for (uint32_t i = 0; i <= nb; i++) set_mod(c->bsk[i], bsk[i]);
     // twiddles
     for (uint32_t m = 0; m < k + c->kb; m++) {
         uint64_t mod = m < k ? q[m] : bsk[m - k];
@@ -197,20 +208,22 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         uint64_t pm = 1;
         for (uint32_t j = 0; j < k; j++) if (j != i) pm = (pm * q[j]) & (MT - 1);
         c->qhat_mt[i] = pm;
-        for (uint32_t b = 0; b <= k; b++) c->qhat_bsk[b][i] = prod_except(q, k, (int)i, bsk[b]);
-        c->inv_bhat_b[i] = invm_prime(prod_except(bsk.data(), k, (int)i, bsk[i]), bsk[i]);
-        for (uint32_t j = 0; j < k; j++) c->bhat_q[j][i] = prod_except(bsk.data(), k, (int)i, q[j]);
-        c->bhat_msk[i] = prod_except(bsk.data(), k, (int)i, bsk[k]);
-        c->B_q[i] = prod_except(bsk.data(), k, -1, q[i]);
+        for (uint32_t b = 0; b <= nb; b++) c->qhat_bsk[b][i] = prod_except(q, k, (int)i, bsk[b]);
+        c->B_q[i] = prod_except(bsk.data(), nb, -1, q[i]);
         c->t_q[i] = t % q[i];
     }
-    for (uint32_t b = 0; b <= k; b++) {
+    for (uint32_t i = 0; i < nb; i++) {
+        c->inv_bhat_b[i] = invm_prime(prod_except(bsk.data(), nb, (int)i, bsk[i]), bsk[i]);
+        for (uint32_t j = 0; j < k; j++) c->bhat_q[j][i] = prod_except(bsk.data(), nb, (int)i, q[j]);
+        c->bhat_msk[i] = prod_except(bsk.data(), nb, (int)i, bsk[nb]);
+    }
+    for (uint32_t b = 0; b <= nb; b++) {
         c->q_bsk[b] = prod_except(q, k, -1, bsk[b]);
         c->inv_q_bsk[b] = invm_prime(c->q_bsk[b], bsk[b]);
         c->inv_mt_bsk[b] = invm_prime(MT % bsk[b], bsk[b]);
         c->t_bsk[b] = t % bsk[b];
     }
-    c->inv_B_msk = invm_prime(prod_except(bsk.data(), k, -1, bsk[k]), bsk[k]);
+    c->inv_B_msk = invm_prime(prod_except(bsk.data(), nb, -1, bsk[nb]), bsk[nb]);
     {   // decryption constants; gamma = second largest 61-bit prime == 1 mod 2^18 (aux[1])
         const uint64_t g = aux[1];
         set_mod(c->gamma, g);
@@ -225,11 +238,9 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         c->neg_inv_q_t = iqt ? t - iqt : 0; c->neg_inv_q_g = g - iqg;
         c->inv_g_t = is_prime_u64(t) ? invm_prime(g % t, t) : 0;
     }
-    for (uint32_t i = 0; i < k; i++) {
-        c->fl_c1_q[i] = mulm(c->t_q[i], c->inv_qhat_q[i], q[i]);
-        c->fl_A_msk[i] = mulm(c->bhat_msk[i], c->inv_B_msk, bsk[k]);
-    }
-    for (uint32_t b = 0; b <= k; b++) {
+    for (uint32_t i = 0; i < k; i++) c->fl_c1_q[i] = mulm(c->t_q[i], c->inv_qhat_q[i], q[i]);
+    for (uint32_t i = 0; i < nb; i++) c->fl_A_msk[i] = mulm(c->bhat_msk[i], c->inv_B_msk, bsk[nb]);
+    for (uint32_t b = 0; b <= nb; b++) {
         c->ex_R_bsk[b] = mulm(c->q_bsk[b], c->inv_mt_bsk[b], bsk[b]);
         c->fl_T_bsk[b] = mulm(c->t_bsk[b], c->inv_q_bsk[b], bsk[b]);
         for (uint32_t i = 0; i < k; i++) {
@@ -264,13 +275,13 @@ void cn_build_f64_tables(DevConsts *c, const uint64_t *tw_host, double *twd_host
     c->behz_f64 = 1;
     for (uint32_t m = 0; m < c->k + c->kb; m++) if (!c->f64ok[m]) c->behz_f64 = 0;
     if (c->behz_f64) {
-        const uint32_t k = c->k;
+        const uint32_t k = c->k, nb = c->kb - 1;
         for (uint32_t i = 0; i < k; i++) {
-            c->bd.mt_inv_qhat_q[i] = (double)c->mt_inv_qhat_q[i]; c->bd.fl_c1_q[i] = (double)c->fl_c1_q[i];
-            c->bd.inv_bhat_b[i] = (double)c->inv_bhat_b[i]; c->bd.fl_A_msk[i] = (double)c->fl_A_msk[i]; c->bd.B_q[i] = (double)c->B_q[i];
-            for (uint32_t j = 0; j < k; j++) c->bd.bhat_q[i][j] = (double)c->bhat_q[i][j];
+            c->bd.mt_inv_qhat_q[i] = (double)c->mt_inv_qhat_q[i]; c->bd.fl_c1_q[i] = (double)c->fl_c1_q[i]; c->bd.B_q[i] = (double)c->B_q[i];
+            for (uint32_t j = 0; j < nb; j++) c->bd.bhat_q[i][j] = (double)c->bhat_q[i][j];
         }
-        for (uint32_t b = 0; b <= k; b++) {
+        for (uint32_t i = 0; i < nb; i++) { c->bd.inv_bhat_b[i] = (double)c->inv_bhat_b[i]; c->bd.fl_A_msk[i] = (double)c->fl_A_msk[i]; }
+        for (uint32_t b = 0; b <= nb; b++) {
             c->bd.ex_R_bsk[b] = (double)c->ex_R_bsk[b]; c->bd.fl_T_bsk[b] = (double)c->fl_T_bsk[b];
             for (uint32_t i = 0; i < k; i++) { c->bd.ex_Q_bsk[b][i] = (double)c->ex_Q_bsk[b][i]; c->bd.fl_N_bsk[b][i] = (double)c->fl_N_bsk[b][i]; }
         }

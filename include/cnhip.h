@@ -214,6 +214,11 @@ int cn_ct_ntt(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, int inve
 /* times `iters` back-to-back launches of the forward NTT kernel with HIP events on the ctx
  * stream; returns average milliseconds per launch in *ms. */
 int cn_ntt_time(cn_ctx *ctx, void *dev_ptr, uint32_t limbs, int base, int inverse, int iters, float *ms);
+/* VALU issue rate of the device at this moment: ns per wave-instruction per SIMD, measured with `launches` launches of a kernel that only
+ * runs arithmetic chains (512-thread workgroups, one per CU, two waves per SIMD - the fused key switch's occupancy).  kind 0: FP64, chains
+ * of the exact modular multiply (`iters` x 48 instructions per thread); kind 1: full-rate 32-bit integer VALU (`iters` x 24).  bench.py
+ * prices the key switch's instruction counts with them. */
+int cn_valu_issue_time(cn_ctx *ctx, int kind, int iters, int launches, float *ns_per_instr);
 void *cn_stream(cn_ctx *ctx);                       /* hipStream_t of the context */
 int cn_event_time_begin(cn_ctx *ctx);               /* HIP-event stopwatch on the ctx stream */
 int cn_event_time_end(cn_ctx *ctx, float *ms);

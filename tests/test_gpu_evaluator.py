@@ -542,10 +542,10 @@ def _extreme_ciphertexts(o):
     return np.stack(cts)
 
 
-@pytest.mark.parametrize("name", ["tiny", "c2", "c4", "n16k7"])
+@pytest.mark.parametrize("name", ["tiny", "c2", "c4", "n16k7", "c5"])
 def test_behz_auxiliary_base_on_extreme_operands(name, monkeypatch):
-    """the small (k+1 primes below 2^49) and SEAL's (61-bit) auxiliary base against the oracle on operands at the corners of the
-    base-independence argument: zero, -1, +-q/2 everywhere - products at the Shenoy-Kumaresan bound"""
+    """the small (k+1 - at N = 16384, k+2 - primes below 2^49) and SEAL's (61-bit) auxiliary base against the oracle on operands at the
+    corners of the base-independence argument: zero, -1, +-q/2 everywhere - products at the Shenoy-Kumaresan bound"""
     from cryptonets_amd._native import Context
     o = get_oracle(name, galois=False)
     p = PARAMS[name]
@@ -556,10 +556,8 @@ def test_behz_auxiliary_base_on_extreme_operands(name, monkeypatch):
     for seal_aux in ("1", "0"):
         monkeypatch.setenv("CN_SEAL_AUX", seal_aux)
         g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
-        if seal_aux == "1":
-            assert g.get_option("behz_small_base") == 0
-        elif name != "n16k7":                                      # (n16k7: the small primes are 4 bits short, SEAL's base either way)
-            assert g.get_option("behz_small_base") == 1
+        assert g.get_option("behz_small_base") == (seal_aux == "0")
+        assert g.get_option("aux_primes") == o.k + (2 if seal_aux == "0" and o.n == 16384 else 1)      # N = 16384: one more small prime
         g.set_relin_key(o.relin_key())
         h, out3, out2 = up(g, cts), g.ct_alloc(m, 3), g.ct_alloc(m)
         for i in range(m):
@@ -572,20 +570,29 @@ def test_behz_auxiliary_base_on_extreme_operands(name, monkeypatch):
 
 def test_behz_base_falls_back_when_the_bound_does_not_hold(monkeypatch):
     """k+1 primes below 2^49 are only used when log2 t + log2 N + log2 q + 2 < log2(B m_sk) (cn_build_consts): N = 16384 with seven or
-    eight of the CIFAR primes (48-49 bits each) is a few bits short and keeps SEAL's 61-bit base; so does any set with a modulus of 49 bits or more"""
+    eight of the CIFAR primes (48-49 bits each) is a few bits short and takes k+2 of them - or, when that is forbidden (CN_AUX_EXTRA=0),
+    keeps SEAL's 61-bit base; so does any set with a modulus of 49 bits or more"""
     from cryptonets_amd._native import Context
     monkeypatch.delenv("CN_SEAL_AUX", raising=False)
-    for name, small in (("c3", 1), ("c4", 1), ("n16k7", 0), ("c5", 0)):
-        p = PARAMS[name]
-        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
-        assert g.get_option("behz_small_base") == small, name
-        g.close()
+    for extra in ("1", "0"):
+        monkeypatch.setenv("CN_AUX_EXTRA", extra)
+        for name, small, more in (("c3", 1, 0), ("c4", 1, 0), ("n16k7", 1, 1), ("c5", 1, 1)):
+            p = PARAMS[name]
+            g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+            k = g.k
+            # the inequality itself, from the primes the context chose
+            if more and extra == "0":
+                assert g.get_option("behz_small_base") == 0 and g.get_option("aux_primes") == k + 1, name
+            else:
+                assert g.get_option("behz_small_base") == small and g.get_option("aux_primes") == k + 1 + more, name
+            g.close()
+    monkeypatch.delenv("CN_AUX_EXTRA")
     g = Context(1024, 12289, q=[0xffffee001, 0x3ffffffffc001], dbc=10, gdbc=20, device=0)      # a 50-bit data prime: integer transforms, SEAL's base
     assert g.get_option("behz_small_base") == 0
     g.close()
 
 
-@pytest.mark.parametrize("name", ["tiny", "c2", "c3", "c4", "n16k7"])
+@pytest.mark.parametrize("name", ["tiny", "c2", "c3", "c4", "n16k7", "c5"])
 def test_behz_auxiliary_base_does_not_change_the_words(name, rng, monkeypatch):
     """libcnhip extends to k+1 auxiliary primes just below 2^49 (exact-FP64 transforms) where SEAL - and the oracle - use k+1 primes
     of 61 bits: the product ciphertext is the same integer polynomial floor(t d / q) - beta reduced mod q_j for ANY sufficiently

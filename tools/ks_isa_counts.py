@@ -70,7 +70,9 @@ def structure(obj=None):
     obj = obj or os.path.join(ROOT, "cryptonets_amd", "lib", "obj", "cn_l_ks_f64l.o")
     ins = disassemble(obj)
     f64 = [a for a, op, _ in ins if op.startswith("v_") and "_f64" in op]
+    other = [a for a, op, _ in ins if op.startswith("v_") and "_f64" not in op and not op.startswith("v_readfirstlane")]   # the rest of the VALU stream
     within = lambda lo, hi: sum(lo <= a <= hi for a in f64)
+    owithin = lambda lo, hi: sum(lo <= a <= hi for a in other)
     # the kernel has two loop nests with FP64 work: (limb loop > digit loop), which the compiler rotates onto ONE header with two back
     # edges (digit: the nearer one, limb: the farther one), and behind it the loop over the two inverse transforms
     big = sorted((h, sorted(e)) for h, e in loops(ins).items() if within(h, max(e)) > 100)
@@ -80,13 +82,20 @@ def structure(obj=None):
     tail_end = max(e2)
     return dict(kernel="k_keyswitch_rr<13, ArF64T<0>, 1, true>", instructions=len(ins), fp64_total=len(f64),
                 fp64_digit_loop=within(h1, digit_end), fp64_limb_loop_only=within(digit_end + 1, limb_end),
-                fp64_tail_loop=within(h2, tail_end), fp64_once=len(f64) - within(h1, limb_end) - within(h2, tail_end))
+                fp64_tail_loop=within(h2, tail_end), fp64_once=len(f64) - within(h1, limb_end) - within(h2, tail_end),
+                valu_digit_loop=owithin(h1, digit_end), valu_limb_loop_only=owithin(digit_end + 1, limb_end),
+                valu_tail_loop=owithin(h2, tail_end), valu_once=len(other) - owithin(h1, limb_end) - owithin(h2, tail_end))
 
 
 def fp64_per_thread(k, digits_per_limb, obj=None):
     """FP64 instructions one thread executes for one (ciphertext, output limb): k source limbs x their digits, 2 inverse transforms"""
     s = structure(obj)
     return sum(d * s["fp64_digit_loop"] + s["fp64_limb_loop_only"] for d in digits_per_limb) + 2 * s["fp64_tail_loop"] + s["fp64_once"], s
+
+
+def valu_per_thread(digits_per_limb, s):
+    """non-FP64 VALU instructions of the same thread (digit extraction, selects, addressing; every one at least a full-rate issue slot)"""
+    return sum(d * s["valu_digit_loop"] + s["valu_limb_loop_only"] for d in digits_per_limb) + 2 * s["valu_tail_loop"] + s["valu_once"]
 
 
 if __name__ == "__main__":
