@@ -215,6 +215,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
+    HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;

@@ -48,6 +48,8 @@ template <class FW0> struct KsPassA<FW0, true> { typedef ArPassA<FW0> P; };
 #ifndef KS_MAC_FENCE
 #define KS_MAC_FENCE 0      // FP64 path: letting the scheduler interleave key loads with the MACs measured 11-14 % faster (same VGPRs)
 #endif
+// (Measured, not kept - round 2: the first key component of a digit requested BEFORE the digit's transform into registers nobody else
+// uses, read back behind it.  Bit-exact; 3.37 vs 3.33 ms: the key stream costs bandwidth on the vector memory path, not exposed latency.)
 template <int L, class AR, int MINW = 1, bool TWL = false>
 __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                                  const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,

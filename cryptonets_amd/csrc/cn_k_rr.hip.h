@@ -34,6 +34,10 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ntt_rr(uint64_t *data, const
         for (int r = 0; r < 16; r++) x[pass_index<L, SA, 0>(tid, r)] = A.scaled(v[r]);
     }
 }
+// (Measured, not kept - round 2: the same transform on a RESIDENT grid, one 512-thread workgroup per CU walking limbs b, b + G, ... of one
+// modulus with the twiddle table in LDS, the first-pass roots in SGPRs and the next limb's words prefetched a whole transform ahead.
+// 311 us against 301 us for the 8450-limb batch: the time of a limb is not its HBM latency.  tools/ubench_stream.hip: the same access
+// pattern with MORE FP64 work but no LDS exchanges runs at 212 us (5.2 TB/s), without arithmetic at 185 us (6.0 TB/s).)
 // BEHZ step 2 fused into the inverse transform: block = (ciphertext, output poly p of the tensor product, limb).  The NTT-form
 // operands are read at the positions the inverse transform starts from (16 B/lane), d_p = a0*b0 | a0*b1 + a1*b0 | a1*b1 is formed
 // in registers and transformed back at once - the 3-poly NTT-form tensor never exists in HBM (saves one write + one read of

@@ -124,6 +124,7 @@ struct cn_ctx {
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
     bool gemm_mfma = true;    // scalar GEMMs with >= 16 outputs per gather list on the int8 matrix cores (exact); cn_set_option("gemm_mfma", 0): FP64 kernel
+    int cus = 0;              // compute units of the device
     bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per
                               // block (profiles/r02_pmc_square_gemm.txt); cn_set_option("sq_lds", 0): parked in the outputs' place (two workgroups per CU)
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches

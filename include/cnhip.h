@@ -58,7 +58,9 @@ int cn_sync(cn_ctx *ctx);
  * halves per limb (no register spills), 0 = the fused 1024-thread kernel; "sq_fused" = 1 (default) runs the transforms and the tensor
  * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
  * MultiplyPlain as two launches (lift + transform of the plaintexts; transform, product, inverse transform of the ciphertext limbs),
- * 0 = six.  All variants produce identical words. */
+ * 0 = six; "sq_lds" = 1 (default) parks the NTT-form operand of a fused squaring in LDS (N <= 8192), 0 = in the outputs' place;
+ * "gemm_mfma" = 1 (default) runs wide scalar GEMMs (cn_scalar_gemm / cn_scalar_dot batches with >= 16 outputs) on the int8 matrix
+ * cores.  All variants produce identical words. */
 /* "defer" = 1: DEFERRED SUBMISSION for callers that issue one evaluator call per ciphertext from many threads - the unchanged
  * NeuralNetworks layers of the reference (PoolLayer.cs:113-121,182,214; EncryptedSealBfvMatrix.cs:140-154; Utils.cs:46-88).  cn_scalar_dot,
  * cn_add, cn_sub, cn_add_plain and cn_mul_relin are then queued with their operand addresses, ordered by data dependence, and
@@ -67,9 +69,9 @@ int cn_sync(cn_ctx *ctx);
  * argument errors are reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle
  * with pending readers is safe (the array returns to the pool after the flush). */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
-/* reads a switch back, or a choice the library made: "behz_small_base" (1: k+1 auxiliary primes below 2^49 - the FP64 kernels; 0: SEAL's
- * 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not hold for the small primes or a data prime has 49 bits
- * or more), "behz_f64", "aux_primes", "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "sq_fused", "mp_fused" */
+/* reads a switch back, or a choice the library made: "behz_small_base" (1: auxiliary primes below 2^49 - the FP64 kernels - k+1 of them,
+ * or k+2 where k+1 are too few (N = 16384); 0: SEAL's 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not
+ * hold for the small primes or a data prime has 49 bits or more), "behz_f64", "aux_primes" (primes of B plus m_sk), "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "sq_fused", "mp_fused" */
 int cn_get_option(cn_ctx *ctx, const char *name, int *value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
