@@ -26,7 +26,7 @@ PARAMS = {
     # small ring for exhaustive/edge cases
     "tiny": dict(n=1024, t=12289, q=[0xffffee001, 0xffffc4001, 0x1ffffe0001], dbc=10, gdbc=20),
     # LoLa-Dense shapes: N=16384 with 7 of the CIFAR primes (LoLaCryptonets.cs:118-199 takes SmallModulusCount 7): k+1 primes below 2^49
-    # are a valid BEHZ auxiliary base here, so the N=16384 multiplications run on the FP64 kernels (the k=8 set keeps SEAL's 61-bit base)
+    # are 4 bits short of a valid BEHZ auxiliary base here, k+2 are one: the N=16384 multiplications run on the FP64 kernels (k=7 and k=8)
     "n16k7": dict(n=16384, t=957181001729, q=[0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001,
                                                0x1ffffffee8001, 0x1ffffffea0001], dbc=60, gdbc=60),
     # BASELINE config 5 shapes: LoLa-CIFAR N=16384, k=8, dbc 60/60 (LolaCifarCryptoNet.cs:35)
