@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--weights", choices=("trained", "synthetic"), default="trained",
                     help="trained: the reference's CryptoNets/Weights.cs (shipped as package data); synthetic: random-init weights of the same shapes")
     ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
-    ap.add_argument("--caller-threads", type=int, default=8)
+    ap.add_argument("--caller-threads", type=int, default=4)
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
     ap.add_argument("--workload", choices=("cryptonets", "lola", "cifar"), default="cryptonets",
                     help="cryptonets: BASELINE config 3, the headline metric (default); lola / cifar: the single-image networks of configs 4 / 5")

@@ -57,15 +57,17 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         const uint32_t o = g * M + mt * MT + m;
+        // bias: a PoolLayer bias is the constant polynomial (BatchEncoder of a constant vector) - every coefficient but one is zero and
+        // scales to zero: the 128-bit multiply + Barrett of scale_plain is skipped there (wave-uniformly almost everywhere)
         if constexpr (ABS) {
             if ((uint32_t)m < mcnt && out_idx[o]) {
                 uint64_t r = bred128(acc[m], qm);
-                if (bias_idx && bias_idx[o] && limb < k) r = addmod(r, scale_plain(C, reinterpret_cast<const uint64_t *>(bias_idx[o])[i], j), qm.q);
+                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = reinterpret_cast<const uint64_t *>(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
                 reinterpret_cast<uint64_t *>(out_idx[o])[e] = r;
             }
         } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {                     // -1: padding member of a smaller group
             uint64_t r = bred128(acc[m], qm);
-            if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
+            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
             out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
         }
     }
@@ -231,12 +233,12 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         if constexpr (ABS) {
             if ((uint32_t)m < mcnt && out_idx[o]) {
                 uint64_t r = BzF::to_u64(res[m], mq);
-                if (bias_idx && bias_idx[o] && limb < k) r = addmod(r, scale_plain(C, reinterpret_cast<const uint64_t *>(bias_idx[o])[i], j), qm.q);
+                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = reinterpret_cast<const uint64_t *>(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
                 reinterpret_cast<uint64_t *>(out_idx[o])[e] = r;
             }
         } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {
             uint64_t r = BzF::to_u64(res[m], mq);
-            if (bias && limb < k) r = addmod(r, scale_plain(C, bias[(size_t)bias_idx[o] * n + i], j), qm.q);
+            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
             out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
         }
     }
@@ -367,11 +369,11 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
         uint64_t res = BzF::to_u64(v, mq);
         if constexpr (ABS) {
             if (!out_idx[o]) continue;
-            if (bias_idx && bias_idx[o] && limb < k) res = addmod(res, scale_plain(C, reinterpret_cast<const uint64_t *>(bias_idx[o])[(size_t)ctile * 32 + col], j), qm.q);
+            if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = reinterpret_cast<const uint64_t *>(bias_idx[o])[(size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }
             reinterpret_cast<uint64_t *>(out_idx[o])[e] = res;
         } else {
             if (out_idx[o] < 0) continue;
-            if (bias && limb < k) res = addmod(res, scale_plain(C, bias[(size_t)bias_idx[o] * n + (size_t)ctile * 32 + col], j), qm.q);
+            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + (size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }
             out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = res;
         }
     }

@@ -20,7 +20,7 @@ namespace HEWrapper
     public class GpuSealBfvFactory : EncryptedSealBfvFactory
     {
         /// <summary>threads that issue evaluator calls; the reference's default (ProcessorCount) is capped here</summary>
-        public const int DefaultCallerThreads = 8;
+        public const int DefaultCallerThreads = 4;
 
         public static int DeviceCount { get { return CnHip.cn_device_count(); } }
 
