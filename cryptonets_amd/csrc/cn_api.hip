@@ -1465,7 +1465,7 @@ static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t 
 }
 
 // element-wise kernels over address tables: entry c = {a, b, out} (b: second ciphertext or plaintext polynomial)
-struct Tab3 { const uint64_t *a, *b; uint64_t *out; };
+struct Tab3 { const NTT_GLOBAL uint64_t *a, *b; NTT_GLOBAL uint64_t *out; };          // global addresses (global_load / global_store, not flat)
 __global__ void k_addsub_tab(const Tab3 *__restrict__ tab, const DevConsts *__restrict__ C, uint32_t chunks, int op) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t per = 2 * C->k, ct = limb / per, l = limb % per;
@@ -1538,7 +1538,7 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
 }
 static int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, int type) {
     std::vector<Tab3> tab(ops.size());
-    for (size_t i = 0; i < ops.size(); i++) tab[i] = {ops[i]->a, ops[i]->b, ops[i]->out};
+    for (size_t i = 0; i < ops.size(); i++) tab[i] = {(const NTT_GLOBAL uint64_t *)ops[i]->a, (const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)ops[i]->out};
     CHECK(ensure_scratch(ctx, al(tab.size() * sizeof(Tab3))));
     Tab3 *dt; CHECK(upload_tmp(ctx, tab.data(), tab.size(), &dt));
     const uint32_t limbs = (uint32_t)ops.size() * 2 * ctx->hc.k;

@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(256) k_behz_extend(const uint64_t *__restrict_
     const uint32_t n = C->n;
     const uint32_t cp = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;   // cp = ct*2 + poly
     const uint32_t ct = cp >> 1, p = cp & 1;
-    const uint64_t *x = (src_tab ? src_tab[ct] : src + (size_t)ct * stride * 2 * K * n) + (size_t)p * K * n + i;   // src_tab: one address per ciphertext
+    const NTT_GLOBAL uint64_t *x = (const NTT_GLOBAL uint64_t *)(src_tab ? src_tab[ct] : src + (size_t)ct * stride * 2 * K * n) + (size_t)p * K * n + i;   // src_tab: one address per ciphertext
     uint64_t *oq = aq + (size_t)cp * K * n + i, *ob = ab + (size_t)cp * (NB + 1) * n + i;
     uint64_t y[K], mt = 0;
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_behz_extend_f64(const uint64_t *__restr
     const uint32_t n = C->n;
     const uint32_t cp = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;   // cp = ct*2 + poly
     const uint32_t ct = cp >> 1, p = cp & 1;
-    const uint64_t *x = (src_tab ? src_tab[ct] : src + (size_t)ct * stride * 2 * K * n) + (size_t)p * K * n + i;   // src_tab: one address per ciphertext
+    const NTT_GLOBAL uint64_t *x = (const NTT_GLOBAL uint64_t *)(src_tab ? src_tab[ct] : src + (size_t)ct * stride * 2 * K * n) + (size_t)p * K * n + i;   // src_tab: one address per ciphertext
     uint64_t *oq = aq + (size_t)cp * K * n + i, *ob = ab + (size_t)cp * (NB + 1) * n + i;
     double y[K];
     uint32_t mt = 0;

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(1024) k_keyswitch(const uint64_t *__restrict__
         __syncthreads();
         ntt_inv_lds(s, tw + 2 * (size_t)n, tw + 3 * (size_t)n, q, n);
         const uint64_t *ad = p ? add1 : add0;
-        uint64_t *o = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
+        NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             uint64_t v = shoup_lazy(s[tid + e * nt], ni, nis, q);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict
         const uint64_t *x2 = extra + (size_t)ct * ex_stride + ((size_t)p * k + j) * n;
         lo = addmod(lo, x2[i], qm.q); hi = addmod(hi, x2[i + n2], qm.q);
     }
-    uint64_t *o = out_tab ? out_tab[ct] + ((size_t)p * k + j) * n : out + (size_t)limb * n;
+    NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] + ((size_t)p * k + j) * n : out + (size_t)limb * n);
     o[i] = lo; o[i + n2] = hi;
 }
 // in-place conversion of key words to the FP64 form used by k_keyswitch_rr<L, ArF64> (exact: residues < 2^49)

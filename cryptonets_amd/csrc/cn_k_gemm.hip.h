@@ -19,6 +19,11 @@ DEV void gemm_block_coords(uint32_t b, uint32_t chunks, uint32_t limbs, uint32_t
 // Products accumulate lazily in 128 bits; one Barrett reduction per `lazy` terms.
 // ABS: the gather / output / bias tables hold DEVICE ADDRESSES (u64, 0 = padded tap / no output / no bias) instead of indices relative
 // to `in` / `out` / `bias` - the form the deferred per-ciphertext calls arrive in, where every ciphertext is its own array.
+// A device address read from a table is a GLOBAL address: said so, the access is global_load / global_store.  As a generic pointer it is
+// flat_load - counted on lgkmcnt as well, so every wait for a scalar weight load also drained the input loads in flight (the address-table
+// kernels of the deferred calls ran 30-60 % behind their index-table twins).
+DEV const NTT_GLOBAL uint64_t *gmem(uint64_t a) { return (const NTT_GLOBAL uint64_t *)a; }
+DEV NTT_GLOBAL uint64_t *gmem_w(uint64_t a) { return (NTT_GLOBAL uint64_t *)a; }
 template <bool ABS> struct GemmTab { typedef int32_t T; };
 template <> struct GemmTab<true> { typedef uint64_t T; };
 template <int MT, bool ABS = false>
@@ -44,7 +49,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
         const uint32_t k1 = min(K, k0 + lazy);
         for (uint32_t kk = k0; kk < k1; kk++) {
             uint64_t x;
-            if constexpr (ABS) { const uint64_t a = gi[kk]; if (!a) continue; x = reinterpret_cast<const uint64_t *>(a)[e]; }
+            if constexpr (ABS) { const uint64_t a = gi[kk]; if (!a) continue; x = gmem(a)[e]; }
             else { const int32_t id = gi[kk]; if (id < 0) continue; x = in[(size_t)id * ctw + e]; }
 #pragma unroll
             for (int m = 0; m < MT; m++) acc[m] += (u128)x * gw[(size_t)kk * MT + m];       // zero-padded beyond mcnt
@@ -62,8 +67,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
         if constexpr (ABS) {
             if ((uint32_t)m < mcnt && out_idx[o]) {
                 uint64_t r = bred128(acc[m], qm);
-                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = reinterpret_cast<const uint64_t *>(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
-                reinterpret_cast<uint64_t *>(out_idx[o])[e] = r;
+                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = gmem(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
+                gmem_w(out_idx[o])[e] = r;
             }
         } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {                     // -1: padding member of a smaller group
             uint64_t r = bred128(acc[m], qm);
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 #pragma unroll
             for (int p = 0; p < PF; p++) {
                 const bool ok = kk + p < k1 && ad[p] != 0;
-                const uint64_t v = (ad[p] ? reinterpret_cast<const uint64_t *>(ad[p]) : in)[e];
+                const uint64_t v = gmem(ad[p] ? ad[p] : (uint64_t)in)[e];
                 x[p] = ok ? v : 0;
             }
         } else {
@@ -233,8 +238,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         if constexpr (ABS) {
             if ((uint32_t)m < mcnt && out_idx[o]) {
                 uint64_t r = BzF::to_u64(res[m], mq);
-                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = reinterpret_cast<const uint64_t *>(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
-                reinterpret_cast<uint64_t *>(out_idx[o])[e] = r;
+                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = gmem(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
+                gmem_w(out_idx[o])[e] = r;
             }
         } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {
             uint64_t r = BzF::to_u64(res[m], mq);
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint64_t ad = half ? a1[u] : a0[u];
-                x[u] = (ad ? reinterpret_cast<const uint64_t *>(ad) : in)[e];              // padded tap: any readable word (its weight digits are 0)
+                x[u] = gmem(ad ? ad : (uint64_t)in)[e];              // padded tap: any readable word (its weight digits are 0)
             }
         } else {
             const int4 i0 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32, 16));
@@ -369,8 +374,8 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
         uint64_t res = BzF::to_u64(v, mq);
         if constexpr (ABS) {
             if (!out_idx[o]) continue;
-            if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = reinterpret_cast<const uint64_t *>(bias_idx[o])[(size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }
-            reinterpret_cast<uint64_t *>(out_idx[o])[e] = res;
+            if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = gmem(bias_idx[o])[(size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }
+            gmem_w(out_idx[o])[e] = res;
         } else {
             if (out_idx[o] < 0) continue;
             if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + (size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
         asm volatile("" : "+v"(tl));               // see above: no hoisting / sharing of address math across the two transforms
         ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
         const uint64_t *ad = p ? add1 : add0;
-        uint64_t *o = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
+        NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t e = pass_index<L, SA, 0>(tl, r);
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__re
     }
     ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
     const uint64_t *ad = p ? add1 : add0;
-    uint64_t *o = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
+    NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const uint32_t e = pass_index<L, SA, 0>(tid, r);

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, PLDS ? 2 : 4) k_square_fused(c
     const uint32_t l = blockIdx.x % Lm, ct = blockIdx.x / Lm, mod = base_off + l;
     const ArCtx<AR> A(C, mod);
     const size_t Ln = (size_t)Lm * n;
-    const uint64_t *a0 = (a_tab ? a_tab[ct] : A_ + (size_t)ct * a_stride) + (size_t)l * n, *a1 = a0 + Ln;
+    const NTT_GLOBAL uint64_t *a0 = (const NTT_GLOBAL uint64_t *)(a_tab ? a_tab[ct] : A_ + (size_t)ct * a_stride) + (size_t)l * n, *a1 = a0 + Ln;   // (global, not flat, loads)
     uint64_t *d0 = D + (size_t)ct * 3 * Ln + (size_t)l * n, *d1 = d0 + Ln, *d2 = d1 + Ln;
     struct alignas(16) P2 { T a, b; };
     P2 *pk = reinterpret_cast<P2 *>(s + ntt_lds_words(n)) + tid;                  // PLDS: slot (r >> 1) of this thread at pk[(r >> 1) * NT]
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, PLDS ? 2 : 4) k_square_fused(c
         asm volatile("" : "+v"(tl));                             // one transform's address math / twiddles live at a time
         T v[16];
         if (step < 2) {
-            const uint64_t *x = step ? a1 : a0;
+            const NTT_GLOBAL uint64_t *x = step ? a1 : a0;
 #pragma unroll
             for (int r = 0; r < 16; r++) v[r] = A.load(x[pass_index<L, SA, 0>(tl, r)]);
             ntt_forward_regs<AR, L, true>(v, s, A.fw, A.m, tl);  // PRE: the image of the previous inverse transform is free

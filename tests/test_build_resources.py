@@ -46,3 +46,15 @@ def test_hot_kernel_stays_inside_its_register_budget(built, obj, kernel, budget,
     r = res[kernel]
     assert r["vgpr_spill"] == 0 and r["scratch"] == 0, "%s spills (%s): %s" % (kernel, why, r)
     assert r["vgpr"] + r["agpr"] <= budget, "%s: %d registers, budget %d (%s)" % (kernel, r["vgpr"] + r["agpr"], budget, why)
+
+
+@pytest.mark.parametrize("obj", ["cn_l_gemm.o", "cn_l_behz.o", "cn_l_rr_u64.o", "cn_l_rr_f64.o", "cn_l_rr_f64l.o", "cn_l_ks_f64.o", "cn_l_ks_f64l.o"])
+def test_hot_kernels_use_global_not_flat_memory_instructions(obj):
+    """addresses that come out of tables (deferred per-ciphertext calls) are cast to the global address space in the kernels: a generic
+    pointer compiles to flat_load / flat_store, which count on lgkmcnt too and made the address-table GEMMs 30-60 % slower than their
+    index-table twins"""
+    from cryptonets_amd import _native
+    _native.build()
+    import kernel_resources
+    flat = kernel_resources.flat_instructions(os.path.join(OBJ, obj))
+    assert not flat, flat

@@ -34,6 +34,27 @@ def resources(obj):
     return {d.split("(")[0]: out[n] for d, n in zip(dem, names)}
 
 
+
+def flat_instructions(obj):
+    """{mangled kernel name: count} of flat_load / flat_store / flat_atomic instructions in the gfx950 code of `obj`.  A flat access is what a
+    pointer of unknown address space compiles to (an address read from a table, a select between a table entry and a kernel argument); it
+    is counted on lgkmcnt as well as vmcnt, so waits for scalar loads and LDS traffic drain it too."""
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, os.path.basename(obj))
+        os.symlink(os.path.abspath(obj), tmp)
+        subprocess.check_call([LLVM + "/llvm-objdump", "--offloading", tmp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in glob.glob(tmp + ".*") if "amdgcn" in f]
+        txt = subprocess.check_output([LLVM + "/llvm-objdump", "-d", co[0]], text=True)
+    out, name = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            name = m.group(1)
+        elif name and re.match(r"^\s+flat_(load|store|atomic)", line):
+            out[name] = out.get(name, 0) + 1
+    return out
+
+
 if __name__ == "__main__":
     res = resources(sys.argv[1])
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
