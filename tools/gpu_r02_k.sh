@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 closing visit: full GPU suite, smoke, the default bench line, the LoLa / CIFAR bench lines, a serialised kernel trace of the bench
-OUT=gpurun_out/r02k
+# Round-2 closing visit (run as r02k, again as r02p after the last kernel changes): full GPU suite, smoke, the default bench line, the LoLa / CIFAR bench lines, a serialised kernel trace of the bench
+OUT=gpurun_out/r02p
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.txt 2>&1
 tail -3 $OUT/pytest.txt
