@@ -66,9 +66,9 @@ def loops(ins):
     return out
 
 
-def structure(obj=None):
+def structure(obj=None, kernel=KERNEL):
     obj = obj or os.path.join(ROOT, "cryptonets_amd", "lib", "obj", "cn_l_ks_f64l.o")
-    ins = disassemble(obj)
+    ins = disassemble(obj, kernel)
     f64 = [a for a, op, _ in ins if op.startswith("v_") and "_f64" in op]
     other = [a for a, op, _ in ins if op.startswith("v_") and "_f64" not in op and not op.startswith("v_readfirstlane")]   # the rest of the VALU stream
     within = lambda lo, hi: sum(lo <= a <= hi for a in f64)
@@ -87,9 +87,9 @@ def structure(obj=None):
                 valu_tail_loop=owithin(h2, tail_end), valu_once=len(other) - owithin(h1, limb_end) - owithin(h2, tail_end))
 
 
-def fp64_per_thread(k, digits_per_limb, obj=None):
+def fp64_per_thread(k, digits_per_limb, obj=None, kernel=KERNEL):
     """FP64 instructions one thread executes for one (ciphertext, output limb): k source limbs x their digits, 2 inverse transforms"""
-    s = structure(obj)
+    s = structure(obj, kernel)
     return sum(d * s["fp64_digit_loop"] + s["fp64_limb_loop_only"] for d in digits_per_limb) + 2 * s["fp64_tail_loop"] + s["fp64_once"], s
 
 
