@@ -208,9 +208,73 @@ def _conv_tile():
     return tuple(int(x) for x in v.split("x")) if "x" in v else int(v)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves - the same
+    command line the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`), one process per GPU, LOCAL_RANK -> device.  Rank 0 prints the ONE JSON line on the inherited stdout;
+    the exit status is torchrun's."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_workload(args, rank, world, result_fd):
+    """--stub: the launcher / rendezvous / barrier / max-over-ranks / one-line plumbing of the N-rank run with NO device work (gloo on
+    CPU; tests/test_bench_launch.py runs `bench.py --gpus 2 --stub` here, where there is no GPU).  The line is marked `"stub": true` and
+    carries no throughput claim: `value` counts the stub's sleep steps."""
+    import torch
+    import torch.distributed as dist
+    from cryptonets_amd.distributed import broadcast_words, max_over_ranks, shard_batches
+    d = None
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    words = np.arange(1024, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) if rank == 0 else None
+    got = broadcast_words(words, 1024, 0, "cpu", d).numpy().view(np.uint64)          # the key broadcast of the real run, on gloo
+    ok = bool(np.array_equal(got, np.arange(1024, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)))
+    mine = shard_batches(args.steps * world, rank, world)                               # every rank its own batches
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    if d is not None:
+        d.barrier()
+    t0 = time.perf_counter()
+    for _ in mine:
+        time.sleep(0.01 * (1 + rank))                                                  # rank r is slower: the line must carry the MAX
+    if d is not None:
+        d.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, "cpu", d)
+    if d is not None:
+        flag = torch.tensor([1 if ok and len(mine) == args.steps else 0], dtype=torch.int32)
+        d.all_reduce(flag, op=d.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        out = {"metric": "encrypted images/sec (CryptoNets-MNIST, N=8192)", "stub": True, "value": round(8192 * args.steps * world / dt, 1), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (launcher stub)", "plumbing_ok": ok,
+               "config": {"workload": "STUB: no device work - launcher, gloo rendezvous, key broadcast, barrier and MAX-over-ranks timing only"}}
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if d is not None:
+        d.barrier()
+        d.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--stub", action="store_true", help="launcher plumbing only (gloo, no device work): what the CPU test of `--gpus N` runs")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -224,16 +288,24 @@ def main():
     ap.add_argument("--shard", choices=("images", "primes"), default="images", help="lola / cifar on N GPUs: independent images per rank, or the plaintext primes of one image")
     args = ap.parse_args()
 
+    # N > 1 without a launcher around us: start the ranks ourselves (the driver's own torchrun line sets WORLD_SIZE and is honoured as is)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %s ranks: the launcher wins" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+
     # the contract is ONE JSON line on stdout: RCCL / HIP runtime banners are C stdio writes to fd 1 (flushed at exit), so fd 1 is
     # pointed at stderr for the whole run and the result line goes to the saved descriptor
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stub:
+        return stub_workload(args, rank, world, result_fd)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libcnhip has no CPU path")
     torch.cuda.set_device(local)
@@ -308,16 +380,20 @@ def main():
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, torch.device("cuda", local), dist)
 
-    # ---- the measured run is checked: decrypt the logits on the device and compare 256 slots x 10 outputs per prime with the
-    # exact integer model of the network (same weights, same inputs)
+    # ---- the measured run is checked: decrypt the logits on the device and compare ALL 8192 slots x 10 outputs per prime with the
+    # exact integer model of the network (same weights, same inputs); the digest of the final ciphertext words identifies the run
+    # (fixed key / encryption seeds: a run with the relinearisation key adopted from a broadcast buffer must give the same digest)
+    import hashlib
     verified = True
+    digest = hashlib.sha256()
     for ch in chans:
         gg = ch.g
         dh = gg.pt_alloc(10)
         gg.decrypt(ch.h5, 0, 10, dh, 0)
-        got = np.stack([gg.decode(dh, c) for c in range(10)], axis=1)[:256]
+        got = np.stack([gg.decode(dh, c) for c in range(10)], axis=1)
         gg.free(dh)
-        verified = verified and bool(np.array_equal(got, cm.model_mod_p(x_int[:256], layers, gg.t)))
+        verified = verified and bool(np.array_equal(got, cm.model_mod_p_dense(x_int, layers, gg.t)))
+        digest.update(gg.ct_download(ch.h5, 0, 10).tobytes())
 
     if dist is not None:                                  # every rank checked its own batch: report the conjunction
         flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
@@ -332,15 +408,20 @@ def main():
     ms = g.ntt_time(ptr, limbs, 0, False, 20)
     alg_bytes = limbs * g.n * 8 * 2                      # each limb read once + written once (128 KiB per N=8192 limb)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    traffic = None                                        # HBM bytes per launch from the committed PMC passes (same launch geometry)
+    # HBM bytes per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the command), so the figure is the one
+    # of the latest COMMITTED counter passes of this launch geometry (tools/visit_*.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs) and
+    # is labelled with the file it comes from; null when no such file travels with the tree
+    traffic, traffic_source = None, None
     try:
         import glob
-        prof = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ntt_hbm_traffic.json")))[-1]))    # the latest round's PMC passes
+        src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ntt_hbm_traffic.json")))[-1]
+        prof = json.load(open(src))
         traffic = [v["hbm_traffic_corrected_bytes"] for kname, v in prof.items() if "k_ntt" in kname and "forward" in kname][0]
+        traffic_source = os.path.relpath(src, ROOT) + " (committed rocprofv3 --pmc passes of the same launch; not measured by this run)"
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "k_ntt_rr (forward, %d limbs of N=%d u64)" % (limbs, g.n), "achieved": round(achieved, 1),
-                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "ms_per_launch": round(ms, 4), "bytes_per_launch": alg_bytes}
 
     # ---- the kernel that takes the largest share of the batch (a third): the fused key switch of the first squaring layer, timed the same
@@ -409,7 +490,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                "data": "synthetic images" + (", the reference's trained weights (CryptoNets/Weights.cs)" if args.weights == "trained" else ", synthetic weights"),
-               "verified_against_integer_model": verified,
+               "verified_against_integer_model": verified, "verified_slots": 8192 * 10 * len(chans), "logit_words_sha256": digest.hexdigest(),
                "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
                                       "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; weights: " + args.weights,

@@ -200,6 +200,34 @@ def model_mod_p(x_int, layers, p):
     return act
 
 
+def model_mod_p_dense(x_int, layers, p):
+    """model_mod_p for MANY samples (bench.py checks all 8192 slots of the measured batch): the same exact network over Z_p, every layer
+    as one dense integer matrix product evaluated exactly in float64 BLAS - the activations (< p < 2^40) are split into 14-bit limbs,
+    limb (< 2^14) x weight (|w| < 2^28) x K (<= 2^11 terms) stays below 2^53, so every partial sum is an exact integer; the limbs are
+    recombined mod p in integer arithmetic.  tests/test_cryptonets_mnist.py holds it equal to model_mod_p."""
+    P = int(p)
+    pu = np.uint64(P)
+    act = np.mod(np.asarray(x_int, dtype=np.int64), P).astype(np.uint64)
+    for li, L in enumerate(layers):
+        idx = np.asarray(L["idx"])
+        O, K = idx.shape
+        Wi = np.array(L["W"], dtype=np.int64)
+        if np.abs(Wi).max() >= 1 << 28 or K > 2048:
+            raise ValueError("weights / term count beyond the exact-float64 range of this model")
+        dense = np.zeros((O, act.shape[1]), dtype=np.float64)
+        rows, cols = np.nonzero(idx >= 0)
+        np.add.at(dense, (rows, idx[rows, cols]), Wi[rows, cols].astype(np.float64))
+        out = np.zeros((act.shape[0], O), dtype=np.uint64)
+        for limb in range(3):
+            part = ((act >> np.uint64(14 * limb)) & np.uint64(0x3FFF)).astype(np.float64) @ dense.T          # exact integers, |.| < 2^53
+            part = np.mod(part.astype(np.int64), P).astype(np.uint64)
+            out = (out + mulmod_u64(part, np.uint64((1 << (14 * limb)) % P), pu)) % pu
+        bias = np.array([b % P for b in L["bias"]], dtype=np.uint64)
+        out = (out + bias[None, :]) % pu
+        act = mulmod_u64(out, out, pu) if li < 2 else out
+    return act
+
+
 def synthetic_images(count, seed=1):
     """MNIST-like sparsity: a pixel is 0 with probability 0.81, else uniform in 1..255"""
     r = np.random.default_rng(seed)

@@ -161,3 +161,18 @@ def test_cryptonets_mnist_end_to_end_gpu():
     ints = np.array(full, dtype=object).T
     assert all(int(np.argmax(dec[s])) == int(np.argmax([int(v) for v in ints[s]])) for s in range(0, cm.N, 97))
     out.Dispose()
+
+
+def test_dense_exact_model_equals_the_term_by_term_model():
+    """bench.py verifies all 8192 slots of the measured batch with cm.model_mod_p_dense (float64 BLAS on 14-bit limbs, exact);
+    it must be the same function as the term-by-term integer model and as the unbounded Python-integer model reduced mod p"""
+    layers = cm.layer_tables(*weights())
+    imgs = synthetic_images(48, seed=77)
+    imgs[0, :] = 255.0                                                  # the largest activations the network can see
+    x = np.rint(imgs * cm.NORMALIZATION * cm.INPUT_SCALE).astype(np.int64)
+    w = dict(zip(("Weights_0", "Weights_1", "Biases_2", "Weights_3", "Biases_3"), weights()))
+    for p in cm.PLAIN_PRIMES:
+        fast = cm.model_mod_p_dense(x, layers, p)
+        assert np.array_equal(fast, cm.model_mod_p(x, layers, p))
+        for s in (0, 1, 47):
+            assert [int(v) for v in fast[s]] == [v % p for v in cm.int_logits(w, imgs[s])]
