@@ -289,7 +289,8 @@ def main():
     args = ap.parse_args()
 
     # N > 1 without a launcher around us: start the ranks ourselves (the driver's own torchrun line sets WORLD_SIZE and is honoured as is)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or os.environ.get("BENCH_SELF_LAUNCH")) and "WORLD_SIZE" not in os.environ:      # BENCH_SELF_LAUNCH=1: also at N = 1 (GPU test of the launcher)
+        os.environ["BENCH_LAUNCHER"] = "self (torch.distributed.run)"
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         print("bench.py: --gpus %d but the launcher started %s ranks: the launcher wins" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
@@ -310,7 +311,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libcnhip has no CPU path")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # BENCH_FORCE_DIST=1: exercise the RCCL plumbing with a single rank
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") or os.environ.get("BENCH_LAUNCHER"):      # BENCH_FORCE_DIST=1: exercise the RCCL plumbing with a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -351,8 +352,7 @@ def main():
         # EncryptLayer on the device: 784 pixel columns -> BatchEncoder.Encode -> Encryptor.Encrypt (outside the timed window,
         # like the reference's TimingLayer placement)
         ph = g.pt_alloc(784)
-        for c in range(784):
-            g.encode(np.mod(x_int[:, c], p).astype(np.uint64), ph, c)
+        g.encode_batch(np.ascontiguousarray(np.mod(x_int, p).astype(np.uint64).T), ph, 0)
         g.encrypt(ph, 0, ch.h_in, 0, 784, seed=0xFEED ^ rank)
         g.free(ph)
         chans.append(ch)
@@ -390,7 +390,7 @@ def main():
         gg = ch.g
         dh = gg.pt_alloc(10)
         gg.decrypt(ch.h5, 0, 10, dh, 0)
-        got = np.stack([gg.decode(dh, c) for c in range(10)], axis=1)
+        got = np.ascontiguousarray(gg.decode_batch(dh, 0, 10).T)
         gg.free(dh)
         verified = verified and bool(np.array_equal(got, cm.model_mod_p_dense(x_int, layers, gg.t)))
         digest.update(gg.ct_download(ch.h5, 0, 10).tobytes())
@@ -491,6 +491,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                "data": "synthetic images" + (", the reference's trained weights (CryptoNets/Weights.cs)" if args.weights == "trained" else ", synthetic weights"),
                "verified_against_integer_model": verified, "verified_slots": 8192 * 10 * len(chans), "logit_words_sha256": digest.hexdigest(),
+               "launcher": os.environ.get("BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"), "process_group": "nccl" if dist is not None else None,
                "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
                                       "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; weights: " + args.weights,

@@ -108,6 +108,8 @@ SIGNATURES = {
     "cn_pt_download": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_encode": (C.c_int, [_CTX, U64P, _u32, _H, _u32]),
     "cn_decode": (C.c_int, [_CTX, _H, _u32, U64P]),
+    "cn_encode_batch": (C.c_int, [_CTX, U64P, _u32, _u32, _H, _u32]),
+    "cn_decode_batch": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_copy": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
     "cn_device_ptr": (C.c_int, [_CTX, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cn_live_handles": (C.c_int, [_CTX]),
@@ -308,6 +310,19 @@ class Context:
     def decode(self, pt, pi):
         out = np.empty(self.n, dtype=np.uint64)
         self._chk(self.L.cn_decode(self._h, pt, pi, _p64(out)))
+        return out
+
+    def encode_batch(self, values, pt, pi):
+        """BatchEncoder.Encode of values[count, nvalues] into pt[pi .. pi + count) with one library call"""
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        if v.ndim != 2:
+            raise ValueError("encode_batch expects a [count, nvalues] array")
+        self._chk(self.L.cn_encode_batch(self._h, _p64(v), v.shape[1], v.shape[0], pt, pi))
+
+    def decode_batch(self, pt, pi, count):
+        """slot values [count, N] of pt[pi .. pi + count)"""
+        out = np.empty((count, self.n), dtype=np.uint64)
+        self._chk(self.L.cn_decode_batch(self._h, pt, pi, count, _p64(out)))
         return out
 
     def copy(self, src, sfirst, dst, dfirst, count):

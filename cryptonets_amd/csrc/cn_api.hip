@@ -232,6 +232,12 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
 extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
+    {   // queued per-ciphertext calls are launched (their results die with the context, but the arrays parked behind them - cn_free while
+        // calls were pending - go back to the pool and are released with it)
+        CnGuard lk(ctx->mu);
+        if (ctx->capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(ctx->stream, &g); if (g) (void)hipGraphDestroy(g); ctx->capturing = false; }
+        (void)cn_defer_flush(ctx);
+    }
     (void)hipStreamSynchronize(ctx->stream);
     ctx->bufs.for_each([&](Buffer &b) {
         if (b.kind == 2) (void)free_gemm_plan(ctx, b);
@@ -243,7 +249,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     delete &slabs_of(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
-    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part);
+    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -289,6 +295,8 @@ extern "C" int cn_sync(cn_ctx *ctx) { LOCK; NOT_CAPTURING("cn_sync"); HIPCHK(hip
 extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
 extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ? ctx->hc.gk_tot : ctx->hc.rl_tot) * ctx->ctw2; }
 
+// does this context keep its key-switch keys as FP64 images (the FP64 key-switch kernels read doubles)?
+static bool keys_as_f64(const cn_ctx *ctx) { return ctx->use_f64 && ctx->hc.q_f64 && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14; }
 static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count, size_t expect, int is_dev) {
     if (!words || count != expect) return fail(CN_ERR_ARG, "key has %zu words, expected %zu", count, expect);
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -300,7 +308,7 @@ static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count
         slot.owned = true;
         HIPCHK(hipMemcpy(slot.d, words, count * 8, hipMemcpyHostToDevice));
     }
-    if (ctx->use_f64 && ctx->hc.q_f64 && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) {
+    if (keys_as_f64(ctx)) {
         // FP64 key-switch kernel reads the key as doubles: convert once, in place (an adopted device buffer is converted too)
         hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, slot.d, count);
         HIPCHK(hipGetLastError());
@@ -497,42 +505,74 @@ extern "C" int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
-// BatchEncoder.Encode: slot values -> plaintext coefficients (scatter by the index map, INTT mod t on the device)
-extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi) {
+// BatchEncoder.Encode / Decode of `count` plaintexts with ONE upload, one scatter launch and one batched (I)NTT mod t: the slot order is
+// SEAL's index map (matrix rows -> bit-reversed coefficient positions), kept on the device
+__global__ void k_encode_scatter(const uint64_t *__restrict__ values, uint32_t nvalues, const uint32_t *__restrict__ index_map, uint64_t *__restrict__ out, uint32_t n) {
+    const uint32_t pt = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(size_t)pt * n + index_map[i]] = i < nvalues ? values[(size_t)pt * nvalues + i] : 0;
+}
+__global__ void k_decode_gather(const uint64_t *__restrict__ coeffs, const uint32_t *__restrict__ index_map, uint64_t *__restrict__ values, uint32_t n) {
+    const uint32_t pt = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) values[(size_t)pt * n + i] = coeffs[(size_t)pt * n + index_map[i]];
+}
+static int ensure_index_map(cn_ctx *ctx) {
+    if (ctx->d_index_map) return 0;
+    HIPCHK(hipMalloc((void **)&ctx->d_index_map, (size_t)ctx->hc.n * 4));
+    HIPCHK(hipMemcpy(ctx->d_index_map, ctx->index_map.data(), (size_t)ctx->hc.n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+// BatchEncoder.Encode: values [count][nvalues] (slot order, each < t; slots beyond nvalues are zero) -> plaintexts pt[pi .. pi + count)
+extern "C" int cn_encode_batch(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, uint32_t count, cn_handle pt, uint32_t pi) {
     LOCK; NOT_CAPTURING("cn_encode"); GETPT(b, pt);
     if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
     const uint32_t n = ctx->hc.n;
-    if (pi >= b->count || nvalues > n || (nvalues && !values)) return fail(CN_ERR_ARG, "bad encode arguments");
-    std::vector<uint64_t> tmp(n, 0);
-    uint8_t zero = 1;
-    for (uint32_t i = 0; i < nvalues; i++) {
-        if (values[i] >= ctx->hc.t.q) return fail(CN_ERR_ARG, "value >= plain modulus");
-        if (values[i]) zero = 0;
-        tmp[ctx->index_map[i]] = values[i];
+    if (!range_ok(b, pi, count) || nvalues > n || (nvalues && !values)) return fail(CN_ERR_ARG, "bad encode arguments");
+    if (!count) return 0;
+    const uint64_t t = ctx->hc.t.q;
+    std::vector<uint8_t> zero(count, 1);
+    for (uint32_t c = 0; c < count; c++) {
+        const uint64_t *v = values + (size_t)c * nvalues;
+        uint64_t any = 0, big = 0;
+        for (uint32_t i = 0; i < nvalues; i++) { any |= v[i]; big |= (uint64_t)(v[i] >= t); }
+        if (big) return fail(CN_ERR_ARG, "value >= plain modulus");
+        zero[c] = any == 0;
     }
+    CHECK(ensure_index_map(ctx));
     uint64_t *d = b->d + (size_t)pi * n;
-    HIPCHK(hipMemcpyAsync(d, tmp.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    CHECK(cn_run_ntt(ctx, d, 1, ctx->hc.k + ctx->hc.kb, 1, 1));
-    b->pt_zero[pi] = zero;
+    if (nvalues) {
+        const size_t words = (size_t)count * nvalues;
+        CHECK(ensure_scratch(ctx, al(words * 8)));
+        uint64_t *stage = salloc<uint64_t>(ctx, words);
+        HIPCHK(hipMemcpyAsync(stage, values, words * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_encode_scatter, dim3((n + 255) / 256, count), dim3(256), 0, ctx->stream, stage, nvalues, ctx->d_index_map, d, n);
+        HIPCHK(hipGetLastError()); launch_count(ctx);
+        HIPCHK(hipStreamSynchronize(ctx->stream));              // the caller's buffer may be released when the call returns
+    } else HIPCHK(hipMemsetAsync(d, 0, (size_t)count * n * 8, ctx->stream));
+    CHECK(cn_run_ntt(ctx, d, count, ctx->hc.k + ctx->hc.kb, 1, 1));
+    for (uint32_t c = 0; c < count; c++) b->pt_zero[pi + c] = zero[c];
     return 0;
 }
-// BatchEncoder.Decode: plaintext coefficients -> N slot values
-extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values) {
+extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi) { return cn_encode_batch(ctx, values, nvalues, 1, pt, pi); }
+// BatchEncoder.Decode: plaintexts pt[pi .. pi + count) -> values [count][N] in slot order
+extern "C" int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t count, uint64_t *values) {
     LOCK; NOT_CAPTURING("cn_decode"); GETPT(b, pt);
     if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
     const uint32_t n = ctx->hc.n;
-    if (pi >= b->count || !values) return fail(CN_ERR_ARG, "bad decode arguments");
-    CHECK(ensure_scratch(ctx, al((size_t)n * 8)));
-    uint64_t *tmp = salloc<uint64_t>(ctx, n);
-    HIPCHK(hipMemcpyAsync(tmp, b->d + (size_t)pi * n, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    CHECK(cn_run_ntt(ctx, tmp, 1, ctx->hc.k + ctx->hc.kb, 1, 0));
-    std::vector<uint64_t> host(n);
-    HIPCHK(hipMemcpyAsync(host.data(), tmp, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!range_ok(b, pi, count) || !values) return fail(CN_ERR_ARG, "bad decode arguments");
+    if (!count) return 0;
+    CHECK(ensure_index_map(ctx));
+    const size_t words = (size_t)count * n;
+    CHECK(ensure_scratch(ctx, 2 * al(words * 8)));
+    uint64_t *tmp = salloc<uint64_t>(ctx, words), *slots = salloc<uint64_t>(ctx, words);
+    HIPCHK(hipMemcpyAsync(tmp, b->d + (size_t)pi * n, words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CHECK(cn_run_ntt(ctx, tmp, count, ctx->hc.k + ctx->hc.kb, 1, 0));
+    hipLaunchKernelGGL(k_decode_gather, dim3((n + 255) / 256, count), dim3(256), 0, ctx->stream, tmp, ctx->d_index_map, slots, n);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    HIPCHK(hipMemcpyAsync(values, slots, words * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (uint32_t i = 0; i < n; i++) values[i] = host[ctx->index_map[i]];
     return 0;
 }
+extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values) { return cn_decode_batch(ctx, pt, pi, 1, values); }
 extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) {
     LOCK;
     Buffer *s = ctx->bufs.find(src), *d = ctx->bufs.find(dst);
@@ -1274,7 +1314,7 @@ static int adopt_ksk(cn_ctx *ctx, KsKey &slot, uint64_t *dev, size_t words) {   
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (slot.owned && slot.d) HIPCHK(hipFree(slot.d));
     slot = {dev, true, false};
-    if (ctx->use_f64 && ctx->hc.q_f64 && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) {
+    if (keys_as_f64(ctx)) {
         hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, dev, words);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1593,7 +1633,10 @@ static int cn_defer_flush(cn_ctx *ctx) {
                 DOp &X = ops[x];
                 if (X.type != DOP_ADDPLAIN || X.a == X.out) continue;
                 const DeferQueue::Haz *hi = q->haz.find(X.a);
-                if (!hi || hi->wop < 0 || hi->readers != 1 || !freed.count(X.a)) continue;
+                // the recorded writer must be the op that PRODUCED X's operand: a handle reused as the output of a later call has its last
+                // writer BEHIND X (GEMM1 -> tmp, AddPlain(tmp) -> r1, GEMM2 -> tmp ...: folding GEMM2 into the first AddPlain would be wrong)
+                if (!hi || hi->wop < 0 || hi->wop >= (int32_t)x || hi->readers != 1 || !freed.count(X.a)) continue;
+                if (ops[hi->wop].level >= X.level) continue;
                 DOp &Gm = ops[hi->wop];
                 if (Gm.type != DOP_GEMM1 || Gm.bias || Gm.out != X.a || dead[hi->wop]) continue;
                 bool ok = true;
@@ -1744,12 +1787,15 @@ extern "C" int cn_ctx_broadcast_keys(cn_ctx **ctxs, int n) {
         for (uint32_t j = 0; same && j < root->hc.k; j++) same = c->hc.q[j].q == root->hc.q[j].q;
         if (!same) return fail(CN_ERR_ARG, "context %d has other encryption parameters than the root", i);
     }
-    // everything in flight on the contexts is finished first (no context lock is held across the others: callers broadcast at start-up)
+    // everything in flight on the contexts is finished first; then the ROOT's lock is held for the whole broadcast (its key table is
+    // read and its key buffers are the sources: a concurrent cn_set_galois_key on the root must not free or re-map them meanwhile).
+    // Callers broadcast at start-up, from one thread, with one root.
     for (int i = 0; i < n; i++) CHECK(cn_sync(ctxs[i]));
-    struct Item { uint64_t elt; bool galois; const KsKey *src; size_t words; };
+    CnGuard root_lock(root->mu);
+    struct Item { uint64_t elt; bool galois; KsKey src; size_t words; };
     std::vector<Item> items;
-    if (root->rlk.d) items.push_back({0, false, &root->rlk, cn_key_words(root, 0)});
-    for (auto &kv : root->gk) if (kv.second.d) items.push_back({kv.first, true, &kv.second, cn_key_words(root, 1)});
+    if (root->rlk.d) items.push_back({0, false, root->rlk, cn_key_words(root, 0)});
+    for (auto &kv : root->gk) if (kv.second.d) items.push_back({kv.first, true, kv.second, cn_key_words(root, 1)});
     if (items.empty()) return fail(CN_ERR_NOKEY, "the root context has no evaluation keys");
     // destination buffers
     std::vector<std::vector<uint64_t *>> dst(n, std::vector<uint64_t *>(items.size(), nullptr));
@@ -1774,7 +1820,7 @@ extern "C" int cn_ctx_broadcast_keys(cn_ctx **ctxs, int n) {
             NCCLCHK(R.GroupStart());
             for (size_t d = 0; d < devs.size(); d++) {
                 cn_ctx *c = ctxs[leader[d]];
-                void *buf = d == 0 ? (void *)items[x].src->d : (void *)dst[leader[d]][x];
+                void *buf = d == 0 ? (void *)items[x].src.d : (void *)dst[leader[d]][x];
                 if (hipSetDevice(c->device) != hipSuccess) { rc = fail(CN_ERR_HIP, "hipSetDevice failed"); goto done; }
                 NCCLCHK(R.Broadcast(buf, buf, items[x].words, kNcclUint64, 0, comms[d], c->stream));
             }
@@ -1789,7 +1835,7 @@ extern "C" int cn_ctx_broadcast_keys(cn_ctx **ctxs, int n) {
         if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = fail(CN_ERR_HIP, "hipSetDevice failed"); break; }
         if (from != 0 && hipStreamSynchronize(ctxs[from]->stream) != hipSuccess) { rc = fail(CN_ERR_HIP, "synchronisation failed"); break; }
         for (size_t x = 0; x < items.size() && !rc; x++) {
-            const void *src = from == 0 ? (const void *)items[x].src->d : (const void *)dst[from][x];
+            const void *src = from == 0 ? (const void *)items[x].src.d : (const void *)dst[from][x];
             hipError_t e = ctxs[from]->device == ctxs[i]->device ? hipMemcpyAsync(dst[i][x], src, items[x].words * 8, hipMemcpyDeviceToDevice, ctxs[i]->stream)
                                                                  : hipMemcpyPeerAsync(dst[i][x], ctxs[i]->device, src, ctxs[from]->device, items[x].words * 8, ctxs[i]->stream);
             if (e != hipSuccess) rc = fail(CN_ERR_HIP, "key copy failed: %s", hipGetErrorString(e));
@@ -1805,7 +1851,16 @@ done:
             if (rc) { (void)hipSetDevice(ctxs[i]->device); (void)hipFree(dst[i][x]); continue; }
             KsKey &slot = items[x].galois ? ctxs[i]->gk[items[x].elt] : ctxs[i]->rlk;
             if (slot.owned && slot.d) { (void)hipSetDevice(ctxs[i]->device); (void)hipFree(slot.d); }
-            slot = KsKey{dst[i][x], true, items[x].src->f64};          // the words arrive in the form the root keeps them (FP64 image or u64)
+            slot = KsKey{dst[i][x], true, items[x].src.f64};           // the words arrive in the form the root keeps them (FP64 image or u64) ...
+            const bool want = keys_as_f64(ctxs[i]);                    // ... and are converted when this context keeps the other form (f64 = 0, legacy_ntt)
+            if (want != slot.f64) {
+                (void)hipSetDevice(ctxs[i]->device);
+                const size_t words = items[x].words;
+                if (want) hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctxs[i]->stream, slot.d, words);
+                else hipLaunchKernelGGL(k_f64_to_u64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctxs[i]->stream, slot.d, words);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) rc = fail(CN_ERR_HIP, "key conversion failed on context %d", i);
+                slot.f64 = want;
+            }
         }
     }
     (void)hipSetDevice(root->device);
@@ -1871,7 +1926,7 @@ extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) {
     return 0;
 }
 extern "C" int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset) {
-    CnGuard lk(ctx->mu);
+    LOCK;                                        // queued calls are launched first: Multiplication is counted by the batched multiply at flush time
     if (out) *out = ctx->st;
     if (reset) ctx->st = cn_stats{};
     return 0;

@@ -246,6 +246,11 @@ __global__ void k_u64_to_f64(uint64_t *p, size_t words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < words) { double d = (double)(long long)p[i]; reinterpret_cast<double *>(p)[i] = d; }
 }
+// the way back (a key that arrived as an FP64 image in a context that runs the integer kernels: cn_ctx_broadcast_keys)
+__global__ void k_f64_to_u64(uint64_t *p, size_t words) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) { double d = reinterpret_cast<double *>(p)[i]; p[i] = (uint64_t)(long long)d; }
+}
 // out[item][j][i]: kind 0 ternary residues, kind 1 noise residues, kind 2 uniform residues mod q_j (item = blockIdx / (k*chunks))
 __global__ void k_sample(uint64_t *out, const DevConsts *__restrict__ C, uint32_t chunks, int kind, uint64_t seed, uint64_t stream, uint64_t item0, uint64_t salt) {
     uint32_t limb, i; decode(chunks, limb, i);

@@ -106,6 +106,7 @@ struct cn_ctx {
     hipEvent_t ev0, ev1;
     uint32_t bs, chunks;      // element-wise geometry
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
+    uint32_t *d_index_map = nullptr;   // the same table in HBM (cn_encode_batch / cn_decode_batch)
     size_t ctw2;              // words of a size-2 ciphertext
     bool legacy_ntt = false;  // CN_LEGACY_NTT=1: radix-2 LDS kernels (A/B reference)
     // freed ciphertext / plaintext arrays are kept per size and handed out again: every op of a context is ordered on its

@@ -255,11 +255,11 @@ class AtomicSealBfvEncryptedVector:
             if blocks == 0:
                 raise Exception("empty vector")
             pv = _Buf(env.ctx, "pt", blocks).view()
-            zero = []
-            for b in range(blocks):
-                chunk = values[b * slots:(b + 1) * slots]
-                env.ctx.encode(chunk, pv.h, b)
-                zero.append(not chunk.any())
+            padded = np.zeros(blocks * slots, dtype=np.uint64)          # all blocks in ONE BatchEncoder call (cn_encode_batch)
+            padded[:len(values)] = values
+            padded = padded.reshape(blocks, slots)
+            env.ctx.encode_batch(padded, pv.h, 0)
+            zero = [not bool(padded[b].any()) for b in range(blocks)]
             return pv, zero, None
         return None, None, [int(x) for x in values]
 
@@ -721,12 +721,12 @@ class AtomicSealBfvEncryptedVector:
         else:
             plains = None
         if self.Format == EVectorFormat.dense:
-            tmp = _Buf(ctx, "pt", 1).view()
+            tmp = _Buf(ctx, "pt", n_items).view()
+            ctx.pt_upload(tmp.h, 0, np.asarray(plains)[:n_items])
+            slots = ctx.decode_batch(tmp.h, 0, n_items)                               # every block in one BatchEncoder.Decode call
             for i in range(n_items):
-                ctx.pt_upload(tmp.h, 0, plains[i])
-                local = ctx.decode(tmp.h, 0)
                 left = int(self.Dim) - len(res)
-                res.extend(int(x) for x in local[:min(left, len(local))])
+                res.extend(int(x) for x in slots[i][:min(left, slots.shape[1])])
             tmp.release()
         else:
             for i in range(n_items):
@@ -1258,10 +1258,7 @@ class EncryptedSealBfvMatrix:
                 mcache = self.__dict__.setdefault("_rowmask", {})
                 if i not in mcache:                                  # one-hot masks e_r (SumAllSlots ForceOutputInColumn, :936-945)
                     masks = _Buf(ctx, "pt", R).view()
-                    for r in range(R):
-                        mk = np.zeros(r + 1, dtype=np.uint64)
-                        mk[r] = 1
-                        ctx.encode(mk, masks.h, r)
+                    ctx.encode_batch(np.eye(R, dtype=np.uint64), masks.h, 0)          # e_0 .. e_{R-1} in one call
                     mcache[i] = masks
                 masks = mcache[i]
                 ctx.mul_plain(work.h, 0, masks.h, 0, work.h, 0, R)

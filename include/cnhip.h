@@ -104,6 +104,11 @@ int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uin
  * coefficients; the (I)NTT mod t runs on the device.  Requires t prime, t == 1 mod 2N. */
 int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi);
 int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values /* N */);
+/* the same for `count` plaintexts in one call (one upload, one scatter launch, one batched transform mod t): values is
+ * [count][nvalues] for encode (slots beyond nvalues are zero), [count][N] for decode.  A layer's weight rows / masks / bias vectors
+ * (LLDenseLayer.Prepare: thousands of Plaintexts, EncryptedSealBfvMatrix.cs:79-120) are encoded with ONE call. */
+int cn_encode_batch(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, uint32_t count, cn_handle pt, uint32_t pi);
+int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t count, uint64_t *values /* [count][N] */);
 int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count);
 int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes);
 int cn_live_handles(cn_ctx *ctx);                                              /* leak counter */

@@ -105,7 +105,7 @@ class OracleBackend:
     # Uploads / downloads / synchronisation are refused while recording, like the library does.
     _REPLAYED = ("copy", "add", "sub", "add_many", "add_plain", "mul_plain", "mul_scalar", "scalar_gemm", "gemm_apply", "mul_relin", "multiply",
                  "relinearize", "rotate_rows", "rotate_rows_add", "rotate_columns", "rotate_columns_add", "sum_slots", "rowdot_batch")
-    _REFUSED = ("sync", "ct_upload", "ct_download", "pt_upload", "pt_download", "encode", "decode", "set_relin_key", "set_galois_key")
+    _REFUSED = ("sync", "ct_upload", "ct_download", "pt_upload", "pt_download", "encode", "decode", "encode_batch", "decode_batch", "set_relin_key", "set_galois_key")
 
     def graph_begin(self):
         if self._recording is not None:
@@ -146,6 +146,13 @@ class OracleBackend:
 
     def decode(self, pt, pi):
         return self.o.decode(self.bufs[pt][pi])
+
+    def encode_batch(self, values, pt, pi):
+        for c, row in enumerate(np.asarray(values, dtype=np.uint64)):
+            self.encode(row, pt, pi + c)
+
+    def decode_batch(self, pt, pi, count):
+        return np.stack([self.decode(pt, pi + c) for c in range(count)])
 
     def copy(self, src, sfirst, dst, dfirst, count):
         self.bufs[dst][dfirst:dfirst + count] = self.bufs[src][sfirst:sfirst + count].copy()

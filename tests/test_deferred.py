@@ -256,3 +256,69 @@ def test_unchanged_caller_replay_cryptonets_batch():
         gg.free(dh)
         assert np.array_equal(got, cm.model_mod_p(x_int[:64], layers, gg.t))
         gg.close()
+
+
+@pytest.mark.gpu
+def test_bias_fold_with_a_reused_output_handle(rng):
+    """GEMM1 -> tmp, AddPlain(tmp) -> r1, GEMM2 -> tmp (the SAME handle again), AddPlain(tmp) -> r2, free(tmp).  The bias fold
+    pairs an AddPlain with the last writer of its operand: that writer must be the op BEFORE it, or r1 would receive GEMM2 + bias1."""
+    o, g = get_oracle("tiny", galois=False), get_gpu("tiny", galois=False)
+    cts = _fresh(o, rng, 5)
+    bias = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in (3, 11)])
+    W = rng.integers(1, 30, size=(2, 5), dtype=np.uint64)
+    W[1, 3] = o.t - 2
+    g.set_option("defer", 1)
+    try:
+        hs = []
+        for c in cts:
+            h = g.ct_alloc(1)
+            g.ct_upload(h, 0, c[None, :])
+            hs.append(h)
+        ph = g.pt_alloc(2)
+        g.pt_upload(ph, 0, bias)
+        tmp, r1, r2 = g.ct_alloc(1), g.ct_alloc(1), g.ct_alloc(1)
+        z = np.zeros(5, dtype=np.uint32)
+        g.scalar_dot(hs, z, W[0], tmp, 0)
+        g.add_plain(tmp, 0, ph, 0, r1, 0)
+        g.scalar_dot(hs, z, W[1], tmp, 0)
+        g.add_plain(tmp, 0, ph, 1, r2, 0)
+        g.free(tmp)
+        assert g.get_option("pending_calls") == 4
+        got = [g.ct_download(r, 0, 1)[0] for r in (r1, r2)]
+        lin = o.scalar_gemm(cts, W)
+        want = o.add_plain_batch(lin, bias)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        for h in hs + [r1, r2, ph]:
+            g.free(h)
+    finally:
+        g.set_option("defer", 0)
+
+
+@pytest.mark.gpu
+def test_stats_and_destroy_drain_the_queue(rng):
+    """OperationsCount read without a sync counts the queued multiplications (cn_stats_get flushes); a context destroyed with calls and
+    released arrays still pending launches / releases them instead of leaking (cn_ctx_destroy drains under the lock)"""
+    from cryptonets_amd._native import Context
+    p = PARAMS["tiny"]
+    o = get_oracle("tiny", galois=False)
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    g.set_relin_key(o.relin_key())
+    g.set_option("defer", 1)
+    cts = _fresh(o, rng, 3)
+    hs = []
+    for c in cts:
+        h = g.ct_alloc(1)
+        g.ct_upload(h, 0, c[None, :])
+        hs.append(h)
+    g.stats(reset=True)
+    outs = [g.ct_alloc(1) for _ in hs]
+    for h, out in zip(hs, outs):
+        g.mul_relin(h, 0, h, 0, out, 0)
+    assert g.get_option("pending_calls") == 3
+    st = g.stats()
+    assert st["Multiplication"] == 3 and st["Relinarization"] == 3 and g.get_option("pending_calls") == 0
+    for h, out in zip(hs, outs):
+        g.mul_relin(h, 0, h, 0, out, 0)
+        g.free(h)                                  # parked behind the queued squarings
+    assert g.get_option("pending_calls") == 3
+    g.close()                                      # must not crash or leave the parked arrays behind

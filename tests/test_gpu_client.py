@@ -10,7 +10,7 @@ Fresh encryption is randomised (and SEAL's RNG is not reproducible), so the chec
 import numpy as np
 import pytest
 
-from conftest import PARAMS
+from conftest import PARAMS, get_gpu, get_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -279,3 +279,36 @@ def test_ct_upload_checks_the_row_width():
         g.ct_upload(h3, 1, np.zeros((2, 3 * 3 * 1024), dtype=np.uint64))      # past the end
     g.ct_upload(h3, 0, np.zeros((2, 3 * 3 * 1024), dtype=np.uint64))
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_encode_decode_batch_equal_the_oracle(name, rng):
+    """cn_encode_batch / cn_decode_batch (one upload, one scatter, one batched transform mod t) against BatchEncoder of the oracle, with
+    ragged rows (fewer values than slots), an all-zero row (IsZero bookkeeping: MultiplyPlain must refuse it) and the single-plaintext calls"""
+    from cryptonets_amd._native import CnError
+    o, g = get_oracle(name), get_gpu(name)
+    vals = rng.integers(0, o.t, size=(7, o.n), dtype=np.uint64)
+    vals[3] = 0
+    ph = g.pt_alloc(9)
+    g.encode_batch(vals, ph, 1)
+    got = g.pt_download(ph, 1, 7)
+    for r in range(7):
+        assert np.array_equal(got[r], o.encode(vals[r]))
+    assert np.array_equal(g.decode_batch(ph, 1, 7), vals)
+    short = rng.integers(0, o.t, size=(2, 5), dtype=np.uint64)
+    g.encode_batch(short, ph, 0)
+    assert np.array_equal(g.pt_download(ph, 0, 1)[0], o.encode(short[0]))
+    assert np.array_equal(g.pt_download(ph, 1, 1)[0], o.encode(short[1]))
+    assert np.array_equal(g.decode(ph, 1)[:5], short[1]) and not g.decode(ph, 1)[5:].any()
+    g.encode(vals[6], ph, 8)
+    assert np.array_equal(g.pt_download(ph, 8, 1)[0], o.encode(vals[6]))
+    ct = g.ct_alloc(1)
+    g.ct_upload(ct, 0, o.encrypt(o.encode(vals[0]))[None, :])
+    with pytest.raises(CnError):
+        g.mul_plain(ct, 0, ph, 4, ct, 0)                  # row 3 of the batch: the zero plaintext
+    with pytest.raises(CnError):
+        g.encode_batch(np.full((1, 4), o.t, dtype=np.uint64), ph, 0)
+    with pytest.raises(CnError):
+        g.encode_batch(vals, ph, 3)                       # 7 plaintexts do not fit behind index 3
+    g.free(ph), g.free(ct)

@@ -1,0 +1,118 @@
+"""SURVEY 8(e) pieces that one GPU can execute: `cn_ctx_broadcast_keys` - the single-process key replication of a
+multi-threaded host (the C# twin's `GpuSealBfvFactory.ReplicateTo`) - through its device-copy path AND, with CN_BCAST_FORCE_RCCL=1, through
+librccl (ncclCommInitAll + grouped ncclBroadcast on a one-device communicator); and the one-process-per-GPU path of bench.py with the process
+group forced at world 1 (BENCH_FORCE_DIST=1: RCCL broadcast of the relinearisation key, the key ADOPTED from the broadcast buffer).  Every
+replica must evaluate to the oracle's words."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PARAMS, get_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ctx(name, **opts):
+    from cryptonets_amd._native import Context
+    p = PARAMS[name]
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    return g
+
+
+def _check_replica(g, o, rng):
+    """mul_relin + rotate_rows + rotate_columns on the replica against the oracle, word for word"""
+    cts = np.stack([o.encrypt(o.encode(rng.integers(0, 40, size=o.n, dtype=np.uint64))) for _ in range(3)])
+    h, out = g.ct_alloc(3), g.ct_alloc(3)
+    g.ct_upload(h, 0, cts)
+    g.mul_relin(h, 0, h, 0, out, 0, 3)
+    assert np.array_equal(g.ct_download(out, 0, 3), o.mul_relin_batch(cts, cts))
+    g.rotate_rows(h, 0, 5, out, 0, 3)                    # NAF: 4 + 1, two Galois keys
+    got = g.ct_download(out, 0, 3)
+    for c in range(3):
+        assert np.array_equal(got[c], o.rotate_rows(cts[c], 5))
+    g.rotate_columns(h, 0, out, 0, 1)
+    assert np.array_equal(g.ct_download(out, 0, 1)[0], o.rotate_columns(cts[0]))
+    g.free(h), g.free(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_rccl", [0, 1])
+@pytest.mark.parametrize("name", ["tiny", "c2"])
+def test_broadcast_keys_to_contexts_on_one_device(name, force_rccl, rng):
+    from cryptonets_amd import _native
+    o = get_oracle(name, galois=True)
+    root = _ctx(name)
+    root.set_relin_key(o.relin_key())
+    for i, e in enumerate(o.galois_elts()):
+        root.set_galois_key(e, o.galois_key(i))
+    same = _ctx(name)                                    # keeps its keys as the root does (FP64 images)
+    other = _ctx(name, f64=0)                            # integer key-switch kernels: the FP64 image must be converted on arrival
+    old = os.environ.get("CN_BCAST_FORCE_RCCL")
+    os.environ["CN_BCAST_FORCE_RCCL"] = str(force_rccl)
+    try:
+        _native.broadcast_keys([root, same, other])
+    finally:
+        if old is None:
+            os.environ.pop("CN_BCAST_FORCE_RCCL")
+        else:
+            os.environ["CN_BCAST_FORCE_RCCL"] = old
+    for g in (same, other):
+        assert g.has_galois_key(o.galois_elts()[0])
+        assert np.array_equal(g.get_key(0), o.relin_key())            # exported as u64 residues whatever the resident form
+        _check_replica(g, o, rng)
+    _check_replica(root, o, rng)                          # the root's own keys are untouched
+    for g in (root, same, other):
+        g.close()
+
+
+@pytest.mark.gpu
+def test_broadcast_keys_argument_errors():
+    from cryptonets_amd import _native
+    a, b = _ctx("tiny"), _ctx("default4096")
+    with pytest.raises(_native.CnError):
+        _native.broadcast_keys([a, b])                    # other encryption parameters
+    c = _ctx("tiny")
+    with pytest.raises(_native.CnError):
+        _native.broadcast_keys([a, c])                    # the root has no evaluation keys
+    for g in (a, b, c):
+        g.close()
+
+
+def _bench(extra_env, *args):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-unchanged-caller", *args],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_with_the_process_group_forced_equals_the_plain_run():
+    """bench.py at world 1 with the RCCL process group created anyway: the relinearisation key travels through dist.broadcast and is adopted
+    from the broadcast buffer (cn_set_relin_key(..., is_device_ptr=1)).  Same seeds -> the final ciphertext words must be the plain run's."""
+    plain = _bench({})
+    forced = _bench({"BENCH_FORCE_DIST": "1", "MASTER_PORT": "29547"})
+    for line in (plain, forced):
+        assert line["n_gpus"] == 1 and line["verified_against_integer_model"] is True and line["verified_slots"] == 2 * 8192 * 10
+        assert line["roofline"]["frac"] > 0.2 and line["metric"].startswith("encrypted images/sec")
+    assert plain["logit_words_sha256"] == forced["logit_words_sha256"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_launches_ranks_on_the_gpu_box():
+    """`bench.py --gpus 1` under its own torchrun launcher (BENCH_SELF_LAUNCH=1 forces the re-exec at N = 1): the N > 1 command line, rendezvous
+    and RCCL initialisation executed for real on the device that is here"""
+    line = _bench({"BENCH_SELF_LAUNCH": "1"}, "--gpus", "1")
+    assert line["n_gpus"] == 1 and line["verified_against_integer_model"] is True
+    assert line["launcher"] == "self (torch.distributed.run)" and line["process_group"] == "nccl"

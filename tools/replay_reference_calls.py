@@ -175,7 +175,7 @@ def main():
         ch = cm.CryptoNetsChannel(g, layers, cm.constant_plaintext(cm.N))
         ph = g.pt_alloc(784)
         for c in range(784):
-            g.encode(np.mod(x_int[:, c], p).astype(np.uint64), ph, c)
+            g.encode(np.mod(x_int[:, c], p).astype(np.uint64), ph, c)          # (one call per column: as the reference's EncryptLayer does)
         g.encrypt(ph, 0, ch.h_in, 0, 784, seed=0xFEED)
         g.free(ph)
         chans.append(ch)
