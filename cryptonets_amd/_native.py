@@ -54,8 +54,13 @@ def build(force=False, verbose=False, defines=(), out=None):
     parallel into lib/obj/ (only those whose sources changed), then linked.  `defines` / `out`: A/B builds of tools/ (-D switches,
     another library name - their objects go to a directory of their own)."""
     from concurrent.futures import ThreadPoolExecutor
+    if defines and out is None:
+        raise ValueError("build(defines=...) needs `out`: an A/B build must not share objects or the library name with the default build")
     lib_path = out or LIB_PATH
-    obj_dir = OBJ_DIR if out is None else os.path.splitext(out)[0] + "_obj"
+    obj_dir = OBJ_DIR
+    if out is not None:                  # objects of another flag set never mix: the directory name carries a digest of the -D switches
+        import hashlib
+        obj_dir = os.path.splitext(out)[0] + "_obj" + ("_" + hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:8] if defines else "")
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", *["-D" + d for d in defines]]
