@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
     ap.add_argument("--caller-threads", type=int, default=4)
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
+    ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "0")),
+                    help="1: the plaintext-prime channels run half a batch apart (key switch of one beside the HBM-bound layers of the other)")
     ap.add_argument("--workload", choices=("cryptonets", "lola", "cifar"), default="cryptonets",
                     help="cryptonets: BASELINE config 3, the headline metric (default); lola / cifar: the single-image networks of configs 4 / 5")
     ap.add_argument("--shard", choices=("images", "primes"), default="images", help="lola / cifar on N GPUs: independent images per rank, or the plaintext primes of one image")
@@ -358,6 +360,16 @@ def main():
         chans.append(ch)
 
     def step():
+        if args.stagger and not args.serialize and len(chans) > 1:
+            # The two plaintext-prime channels are independent kernel chains on two streams.  Issued one after the other they run in lock
+            # step - key switch beside key switch (both FP64-issue bound), scalar GEMM beside scalar GEMM (both HBM bound).  Staggered by
+            # half a batch (device-side ordering between the contexts, cn_ctx_wait_for; no host wait) the long FP64-bound kernel of one
+            # channel runs beside the HBM-bound layers of the other, which fit into the registers and issue slots it leaves free.
+            for i, ch in enumerate(chans):
+                ch.front()
+                chans[(i + 1) % len(chans)].g.wait_for(ch.g)          # the next channel('s next batch) starts where this one's key switch starts
+                ch.back()
+            return
         for ch in chans:
             ch.forward()
             if args.serialize:

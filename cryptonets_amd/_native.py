@@ -95,6 +95,7 @@ SIGNATURES = {
     "cn_ctx_create": (C.c_int, [_u32, U64P, _u32, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(_CTX)]),
     "cn_ctx_destroy": (C.c_int, [_CTX]),
     "cn_sync": (C.c_int, [_CTX]),
+    "cn_ctx_wait_for": (C.c_int, [_CTX, _CTX]),
     "cn_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_int]),
     "cn_get_option": (C.c_int, [_CTX, C.c_char_p, C.POINTER(C.c_int)]),
     "cn_default_coeff_modulus": (C.c_int, [_u32, U64P]),
@@ -343,6 +344,10 @@ class Context:
 
     def sync(self):
         self._chk(self.L.cn_sync(self._h))
+
+    def wait_for(self, other):
+        """work submitted to this context from now on starts after everything submitted to `other` so far (device-side ordering)"""
+        self._chk(self.L.cn_ctx_wait_for(self._h, other._h))
 
     # ---- evaluator
     def add(self, a, ai, b, bi, out, oi, count=1):

@@ -158,6 +158,22 @@ class CryptoNetsChannel:
         with tracing.range("PoolLayer dense 100 -> 10", sync=g.sync):
             g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
 
+    # The same five layers in two halves, for a host that STAGGERS the plaintext-prime channels (bench.py --stagger): front() ends where the
+    # long FP64-bound kernel of the batch - the key switch of the 845-ciphertext squaring layer - begins.  Same kernels, same words.
+    def front(self):
+        g, L = self.g, self.layers
+        if not hasattr(self, "t3"):
+            self.t3 = g.ct_alloc(845, 3)
+        g.gemm_apply(L[0]["plan"], self.h_in, self.h1, 0)
+        g.multiply(self.h1, 0, self.h1, 0, self.t3, 0, 845)          # Evaluator.Multiply of SquareActivation (AtomicSealBfvVector.cs:839)
+
+    def back(self):
+        g, L = self.g, self.layers
+        g.relinearize(self.t3, 0, self.h2, 0, 845)                   # Evaluator.Relinearize (AtomicSealBfvVector.cs:840)
+        g.gemm_apply(L[1]["plan"], self.h2, self.h3, 0)
+        g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
+        g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
+
 
 def constant_plaintext(n):
     def enc(v):

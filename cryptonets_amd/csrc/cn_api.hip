@@ -213,6 +213,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
+    if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD")) != 0;
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -251,7 +252,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
     (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
-    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     (void)hipStreamDestroy(ctx->stream);
     cn_defer_delete(ctx->dq);
     delete ctx;
@@ -263,6 +264,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
+    if (!strcmp(name, "ks_xcd")) { ctx->ks_xcd = value != 0; return 0; }
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
@@ -279,6 +281,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) {
     if (!strcmp(name, "f64")) *value = ctx->use_f64;
     else if (!strcmp(name, "defer")) *value = ctx->defer;
     else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
+    else if (!strcmp(name, "ks_xcd")) *value = ctx->ks_xcd;
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
     else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
@@ -293,6 +296,21 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) {
 #define NOT_CAPTURING(what) do { if (ctx->capturing) return fail(CN_ERR_ARG, what " is not possible while a graph is recorded (cn_graph_begin .. cn_graph_end)"); } while (0)
 extern "C" int cn_sync(cn_ctx *ctx) { LOCK; NOT_CAPTURING("cn_sync"); HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; }
 extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
+// ctx's later work waits (on the device) for other's earlier work.  The two locks are taken one after the other, never together.
+extern "C" int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other) {
+    if (!ctx || !other) return fail(CN_ERR_ARG, "null argument");
+    if (ctx == other) return 0;
+    hipEvent_t ev = nullptr;
+    {
+        cn_ctx *c0 = ctx; ctx = other;                    // (the macros name the context `ctx`)
+        { LOCK; NOT_CAPTURING("cn_ctx_wait_for"); if (!ctx->ev_order) HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+          HIPCHK(hipEventRecord(ctx->ev_order, ctx->stream)); ev = ctx->ev_order; }
+        ctx = c0;
+    }
+    LOCK; NOT_CAPTURING("cn_ctx_wait_for");
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    return 0;
+}
 extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ? ctx->hc.gk_tot : ctx->hc.rl_tot) * ctx->ctw2; }
 
 // does this context keep its key-switch keys as FP64 images (the FP64 key-switch kernels read doubles)?
@@ -1036,6 +1054,7 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     KsArgs a{target, tstride, add0, add1, astride, key.d, out, cnt, galois, extra, xstride,
              key.f64 ? (bits >= 50 ? 1u : (1u << std::min(10, 50 - bits))) : 0xffffffffu,     // lazy FP64 accumulators: |term| <= 2.1 q, sum below 2^52
              0, out_tab};
+    if (ctx->ks_xcd) a.xcd_cts = cnt & ~7u;
     const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;                // register-radix kernels available
     if (rr && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * k <= KS_WIDE_MAX_BLOCKS))) {
         // N = 16384: 1024-thread workgroups cannot hold two accumulator sets without spilling -> per-digit only

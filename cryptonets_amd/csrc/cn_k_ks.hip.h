@@ -54,7 +54,8 @@ template <int L, class AR, int MINW = 1, bool TWL = false>
 __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                                  const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
                                                                  uint64_t *out, const DevConsts *__restrict__ C, int galois, uint32_t accmax,
-                                                                 const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab) {
+                                                                 const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab,
+                                                                 uint32_t xcd_cts) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -66,7 +67,12 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
     // limb-major order that lets an XCD's workgroups share one key slice in L2 was measured: no gain at N = 8192 - the 15.6 MB of
     // keys stream from the infinity cache fast enough - and 30 % slower at N = 16384, where the source limbs then come from HBM
     // once per (limb, half) workgroup.)
-    const uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
+    // xcd_cts (a multiple of 8, 0 = off): XCD-aware placement for the first xcd_cts ciphertexts - block b runs on XCD b % 8 (observed
+    // dispatch rule; a speed assumption only), so the k workgroups of ONE ciphertext are given block ids of one residue class: they
+    // follow each other on one XCD and the k - 1 later ones find the ciphertext's source limbs in THAT XCD's L2 instead of fetching
+    // them through k different L2s.  Bijective: b -> (x = b % 8, s = b / 8) -> ct = 8 (s / k) + x, j = s % k.
+    uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
+    if (blockIdx.x < xcd_cts * k) { const uint32_t x = blockIdx.x & 7, sl = blockIdx.x >> 3; ct = 8 * (sl / k) + x; j = sl % k; }
     const DMod qm = C->q[j];
     const uint64_t q = qm.q;
     const ArCtx<AR> A(C, j);

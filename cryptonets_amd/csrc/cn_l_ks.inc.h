@@ -34,12 +34,12 @@ template <int L, int MINW = 1> static void launch_fused(cn_ctx *c, const KsArgs 
     if constexpr (KsFwd<AR, L>::lds && MINW == 1) {
         if (tot >= KS_TWL_MIN_DIGITS) {
             hipLaunchKernelGGL((k_keyswitch_rr<L, AR, 1, true>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), ks_twl_lds<L>(), c->stream, a.target, a.tstride, a.add0, a.add1,
-                               a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab);
+                               a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.xcd_cts);
             return;
         }
     }
     hipLaunchKernelGGL((k_keyswitch_rr<L, AR, MINW>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, a.target, a.tstride,
-                       a.add0, a.add1, a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab);
+                       a.add0, a.add1, a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.xcd_cts);
 }
 template <int L> static void launch_two_phase(cn_ctx *c, const KsArgs &a) {
     const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;

@@ -104,6 +104,7 @@ struct cn_ctx {
     std::vector<std::unique_ptr<char[]>> staged;   // host blocks of in-flight upload_tmp copies
     cn_stats st{};
     hipEvent_t ev0, ev1;
+    hipEvent_t ev_order = nullptr;     // cn_ctx_wait_for: marks a point of this context's stream another context waits for
     uint32_t bs, chunks;      // element-wise geometry
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position
     uint32_t *d_index_map = nullptr;   // the same table in HBM (cn_encode_batch / cn_decode_batch)
@@ -118,6 +119,7 @@ struct cn_ctx {
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
+    bool ks_xcd = false;      // cn_set_option("ks_xcd", 1) / CN_KS_XCD=1: the k workgroups of a ciphertext on one XCD (share its source limbs in that L2)
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
     bool capturing = false;   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
     std::vector<std::unique_ptr<char[]>> cap_staged;                 // host blocks of the upload nodes recorded so far
@@ -148,6 +150,7 @@ struct KsArgs {
     uint32_t accmax;          // FP64 accumulators: terms between recentrings
     int mode;                 // 0 fused, 1 two launches / workgroup per digit, 2 two launches / workgroup per source limb
     uint64_t *const *out_tab;
+    uint32_t xcd_cts = 0;     // fused kernel: ciphertexts (a multiple of 8) placed XCD-aware, see k_keyswitch_rr
 };
 struct RrOps {                // register-radix kernels of one arithmetic policy; every launcher returns false when the size has no kernel
     int (*set_attrs)(uint32_t logn, size_t lds);

@@ -50,6 +50,12 @@ int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc
                   int device, cn_ctx **out);
 int cn_ctx_destroy(cn_ctx *ctx);
 int cn_sync(cn_ctx *ctx);
+/* Ordering between contexts without a host wait: everything submitted to `ctx` AFTER this call starts only when everything submitted to
+ * `other` BEFORE it has finished (an event on other's stream that ctx's stream waits for; same or different device).  The plaintext-prime
+ * channels of one vector are independent contexts (EncryptedSealBfvVector.cs:225-236); a host that issues them from one thread uses this to
+ * stagger them - the FP64-bound key switch of one channel then runs beside the HBM-bound layers of the other instead of beside its twin
+ * (bench.py --stagger).  Neither context is synchronised with the host. */
+int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
 /* tuning switches (A/B testing): "f64" = 1 (default) runs transforms of moduli < 2^49 and key switching in exact FP64
  * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels;
  * "ks_wide" = -1 (default: automatic by batch size) / 0 fused one-launch kernel / 1 two launches with one workgroup per digit

@@ -860,3 +860,28 @@ def test_captured_sequence_replays_on_new_inputs(name, rng):
         g.graph_launch(graph)
     for x in (h, out):
         g.free(x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "c3"])
+def test_key_switch_xcd_placement_is_only_a_placement(name, rng):
+    """cn_set_option("ks_xcd", 1): the k workgroups of a ciphertext get block ids of one residue class mod 8 (one XCD).  A pure relabelling of
+    (ciphertext, limb) -> block id: 19 ciphertexts = two full groups of 8 through the remap + 3 through the plain tail, words equal to the
+    oracle's and to the unmapped launch (fused kernel forced: the automatic choice would take the two-launch variant for so few)"""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    vals, cts = enc_batch(o, rng, 19)
+    h, out = up(g, cts), g.ct_alloc(19)
+    want = o.mul_relin_batch(cts, cts)
+    rot = np.stack([o.rotate_rows(c, 1) for c in cts])
+    try:
+        g.set_option("ks_wide", 0)
+        for xcd in (1, 0):
+            g.set_option("ks_xcd", xcd)
+            g.mul_relin(h, 0, h, 0, out, 0, 19)
+            assert np.array_equal(g.ct_download(out, 0, 19), want), xcd
+            g.rotate_rows(h, 0, 1, out, 0, 19)
+            assert np.array_equal(g.ct_download(out, 0, 19), rot), xcd
+    finally:
+        g.set_option("ks_wide", -1)
+        g.set_option("ks_xcd", 0)
+    g.free(h), g.free(out)
