@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
     ap.add_argument("--caller-threads", type=int, default=4)
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
-    ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "0")),
+    ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "1")),
                     help="1: the plaintext-prime channels run half a batch apart (key switch of one beside the HBM-bound layers of the other)")
     ap.add_argument("--workload", choices=("cryptonets", "lola", "cifar"), default="cryptonets",
                     help="cryptonets: BASELINE config 3, the headline metric (default); lola / cifar: the single-image networks of configs 4 / 5")
