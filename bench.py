@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--weights", choices=("trained", "synthetic"), default="trained",
                     help="trained: the reference's CryptoNets/Weights.cs (shipped as package data); synthetic: random-init weights of the same shapes")
     ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
-    ap.add_argument("--caller-threads", type=int, default=4)
+    ap.add_argument("--caller-threads", type=int, default=0, help="threads of the unchanged-caller replay; 0 = all host cores (the reference's Defaults.ThreadCount)")
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
     ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "1")),
                     help="1: the plaintext-prime channels run half a batch apart (key switch of one beside the HBM-bound layers of the other)")
@@ -479,20 +479,31 @@ def main():
         except Exception as ex:                                            # no disassembler / unrecognised code shape: no floor rather than a stale one
             key_switch.update({"fp64_issue_floor_ms": None, "frac": None, "isa_error": str(ex)[:200]})
 
-    # ---- the reference's UNCHANGED caller: one evaluator call per ciphertext from `caller-threads` threads (tools/replay_reference_calls.cpp),
-    # merged by libcnhip's deferred submission; same inputs, its final words must equal the batched run's
+    # ---- the reference's UNCHANGED caller: one evaluator call per ciphertext from the caller's threads (tools/replay_reference_calls.cpp), merged
+    # by libcnhip's deferred submission; same inputs.  Main figure: the LITERAL pattern - a padded convolution tap is a fresh encryption of
+    # the zero vector (PoolLayer.ElementAt, PoolLayer.cs:67-80: 645 per plaintext prime and batch, made on the device and queued like the
+    # evaluator calls) - from Defaults.ThreadCount = all host cores (Defaults.cs), every decrypted slot checked against the integer model.
+    # `skipped_taps`: padded taps passed as "no ciphertext" (what the batched path does): its final WORDS must equal the batched run's.
     unchanged = None
     if rank == 0 and world == 1 and not args.no_unchanged_caller:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import replay_reference_calls as rp
             ref_words = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
-            ums, uwords = rp.measure(chans, layers, args.caller_threads, max(2, min(args.steps, 5)), warmup=1)
-            unchanged = {"value": round(8192e3 / ums, 1), "unit": "images/s", "ms_per_step": round(ums, 2), "threads": args.caller_threads,
-                         "frac_of_batched": round((1e3 * dt / args.steps) / ums, 3),
-                         "words_identical_to_batched": bool(all(np.array_equal(a, b) for a, b in zip(uwords, ref_words))),
-                         "pattern": "PoolLayer.Apply: per (map, corner) cn_scalar_dot + cn_add_plain + cn_free; SquareActivation: per column "
-                                    "cn_mul_relin(count 1); every ciphertext its own handle; 2 x 2855 calls per batch; cn_set_option(defer, 1)"}
+            batched_ms = 1e3 * dt / args.steps
+            nthreads = args.caller_threads or (os.cpu_count() or 1)
+            reps = max(2, min(args.steps, 5))
+            lms, lwords = rp.measure(chans, layers, nthreads, reps, warmup=1, literal_taps=True)
+            dec = rp.decrypt_outputs(chans, lwords)
+            lok = all(bool(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t))) for d, ch in zip(dec, chans))
+            ums, uwords = rp.measure(chans, layers, 4, reps, warmup=1)
+            unchanged = {"value": round(8192e3 / lms, 1), "unit": "images/s", "ms_per_step": round(lms, 2), "threads": nthreads,
+                         "frac_of_batched": round(batched_ms / lms, 3), "verified_against_integer_model": lok, "verified_slots": 8192 * 10 * len(chans),
+                         "pattern": "PoolLayer.Apply: per (map, corner) [cn_ct_alloc + cn_encrypt(zero) per padded tap] + cn_scalar_dot (K = 25 real handles) + "
+                                    "cn_add_plain + cn_free, ReleaseTemp: cn_free per zero encryption; SquareActivation: per column cn_mul_relin(count 1); every "
+                                    "ciphertext its own handle; 2 x (2855 + 3 x 645) calls per batch; cn_set_option(defer, 1); threads = Defaults.ThreadCount",
+                         "skipped_taps": {"value": round(8192e3 / ums, 1), "ms_per_step": round(ums, 2), "threads": 4, "frac_of_batched": round(batched_ms / ums, 3),
+                                          "words_identical_to_batched": bool(all(np.array_equal(a, b) for a, b in zip(uwords, ref_words)))}}
         except Exception as ex:
             unchanged = {"error": str(ex)[:300]}
 

@@ -144,6 +144,8 @@ SIGNATURES = {
     "cn_sum_slots": (C.c_int, [_CTX, _H, _u32, _u32, _u32]),
     "cn_rowdot_batch": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32, _u32, _H, _u32]),
     "cn_set_rng_salt": (C.c_int, [_CTX, C.c_uint64]),
+    "cn_set_rng_key": (C.c_int, [_CTX, C.c_char_p]),
+    "cn_rng_selftest": (C.c_int, [_CTX, C.c_char_p, C.c_uint64, C.c_uint64, U32P]),
     "cn_keygen": (C.c_int, [_CTX, C.c_uint64, C.c_int]),
     "cn_set_public_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
     "cn_set_secret_key": (C.c_int, [_CTX, U64P, C.c_size_t]),
@@ -459,6 +461,19 @@ class Context:
     # ---- client side on the device
     def set_rng_salt(self, salt):
         self._chk(self.L.cn_set_rng_salt(self._h, salt))
+
+    def set_rng_key(self, key32):
+        """256-bit ChaCha20 key of the context's sampler (bytes of length 32)"""
+        key32 = bytes(key32)
+        if len(key32) != 32:
+            raise ValueError("the sampler key has 32 bytes")
+        self._chk(self.L.cn_set_rng_key(self._h, key32))
+
+    def rng_block(self, key32, counter, nonce):
+        """one raw block (16 words) of the device sampler's generator (known-answer tests)"""
+        out = np.zeros(16, dtype=np.uint32)
+        self._chk(self.L.cn_rng_selftest(self._h, bytes(key32), counter, nonce, out.ctypes.data_as(U32P)))
+        return out
 
     def keygen(self, seed, galois=True):
         self._chk(self.L.cn_keygen(self._h, seed, int(galois)))

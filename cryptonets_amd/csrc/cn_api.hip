@@ -18,13 +18,14 @@ static DeferQueue *cn_defer_new();
 static void cn_defer_delete(DeferQueue *q);
 static int cn_defer_flush(cn_ctx *ctx);
 static bool cn_defer_pending(cn_ctx *ctx);
-enum { DOP_GEMM1 = 0, DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN, DOP_MULRELIN, DOP_TYPES };
+enum { DOP_GEMM1 = 0, DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN, DOP_MULRELIN, DOP_ENCRYPT, DOP_TYPES };
 struct DOp {
     int type; int32_t level;
     uint64_t *out;                 // output ciphertext (size 2)
     const uint64_t *a, *b;         // operands (ADD/SUB/MULRELIN: ciphertexts; ADDPLAIN/SUBPLAIN: b = plaintext polynomial)
     uint32_t K; size_t terms;      // GEMM1: K (address, weight) pairs from DeferQueue::addr / ::wt [terms ..)
     const uint64_t *bias;          // GEMM1: plaintext polynomial added to the result (an AddPlain folded in at flush time), or null
+    uint64_t nonce = 0, item = 0;  // ENCRYPT: the call's seed and the sampler item of this ciphertext (a = plaintext polynomial or null)
 };
 struct DeferQueue {
     std::vector<DOp> ops;
@@ -1305,8 +1306,24 @@ extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, 
     if (f64) for (size_t i = 0; i < words; i++) { double d; memcpy(&d, &host[i], 8); host[i] = (uint64_t)d; }
     return 0;
 }
+static RngKey rng_key_of(const cn_ctx *ctx) { RngKey k; memcpy(k.k, ctx->rng_key, sizeof k.k); return k; }
+// `polys` polynomials [polys][k][N] of residues: kind 0 ternary, 1 clipped normal (both drawn ONCE per coefficient into an int8 array in
+// scratch - the caller's ensure_scratch leaves room for polys * N bytes - and expanded to the k limbs), 2 uniform per limb
 static int sample_poly(cn_ctx *ctx, uint64_t *dst, uint32_t polys, int kind, uint64_t seed, uint64_t stream) {
-    hipLaunchKernelGGL(k_sample, dim3(polys * ctx->hc.k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, dst, ctx->dc, ctx->chunks, kind, seed, stream, ctx->rng_item, ctx->rng_salt);
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k;
+    if (n < 16) return fail(CN_ERR_ARG, "device sampling needs N >= 16");
+    if (kind == 2) {
+        const uint64_t threads = (uint64_t)polys * k * (n / 8);
+        hipLaunchKernelGGL(k_sample_uniform, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, dst, ctx->dc, polys, rng_key_of(ctx), seed, (uint32_t)stream, ctx->rng_item);
+    } else {
+        int8_t *small = salloc<int8_t>(ctx, (size_t)polys * n);
+        if (!small) return fail(CN_ERR_HIP, "internal: scratch exhausted in the sampler");
+        const uint64_t threads = (uint64_t)polys * (n / (kind == 0 ? 16 : 8));
+        hipLaunchKernelGGL(k_sample_small, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, small, n, kind, 1u, polys, rng_key_of(ctx), seed, (uint32_t)stream,
+                           ctx->rng_item, (const EncTab *)nullptr);
+        hipLaunchKernelGGL(k_expand_small, dim3(polys * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, small, dst, ctx->dc, ctx->chunks);
+        launch_count(ctx);
+    }
     HIPCHK(hipGetLastError()); launch_count(ctx);
     ctx->rng_item += polys;
     return 0;
@@ -1341,16 +1358,38 @@ static int adopt_ksk(cn_ctx *ctx, KsKey &slot, uint64_t *dev, size_t words) {   
     }
     return 0;
 }
-// second 64 bits of sampler key material: XOR-ed into the counter word of every Philox block keygen / encrypt draw from now on
-extern "C" int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt) { LOCK; ctx->rng_salt = salt; return 0; }
+// sampler key material: the 256-bit ChaCha20 key of every block keygen / encrypt draw from now on (cn_set_rng_salt: its first 64 bits)
+extern "C" int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt) { LOCK; ctx->rng_key[0] = (uint32_t)salt; ctx->rng_key[1] = (uint32_t)(salt >> 32); return 0; }
+// known-answer hook: the generator's block for (key, counter words 12-13, nonce words 14-15) - RFC 7539 section 2.3.2 is reproduced with
+// counter = 0x09000000'00000001, nonce = 0x00000000'4a000000 (tests/test_gpu_client.py)
+extern "C" int cn_rng_selftest(cn_ctx *ctx, const uint8_t *key32, uint64_t counter, uint64_t nonce, uint32_t *out16) {
+    LOCK; NOT_CAPTURING("cn_rng_selftest");
+    if (!key32 || !out16) return fail(CN_ERR_ARG, "null argument");
+    RngKey k; memcpy(k.k, key32, 32);
+    CHECK(ensure_scratch(ctx, 256));
+    uint32_t *d = salloc<uint32_t>(ctx, 16);
+    hipLaunchKernelGGL(k_rng_block, dim3(1), dim3(1), 0, ctx->stream, k, counter, nonce, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out16, d, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int cn_set_rng_key(cn_ctx *ctx, const uint8_t *key32) {
+    LOCK;
+    if (!key32) return fail(CN_ERR_ARG, "null argument");
+    memcpy(ctx->rng_key, key32, 32);
+    return 0;
+}
 // KeyGenerator (AtomicSealBfvVector.cs:62-74,163-173 runs it inside SEAL): secret, public, relinearisation and the default Galois
-// key set (2N-1, 3^(2^i), 3^(-2^i)) generated on the device from a Philox stream.
+// key set (2N-1, 3^(2^i), 3^(-2^i)) generated on the device from the ChaCha20 sampler.
 extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
     LOCK; NOT_CAPTURING("cn_keygen");
     const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
     if (!ctx->sk) HIPCHK(hipMalloc((void **)&ctx->sk, kn * 8));
     if (!ctx->pk) HIPCHK(hipMalloc((void **)&ctx->pk, 2 * kn * 8));
-    CHECK(ensure_scratch(ctx, al(kn * 8) * 4));
+    // the sampler carves an N-byte int8 array out of the scratch arena per call and keygen makes ~2 such calls per key digit: room for all of them
+    const size_t draws = 4 + 2 * ((size_t)ctx->hc.rl_tot + (with_galois ? (size_t)ctx->hc.gk_tot * (2 * ctx->hc.logn) : 0));
+    CHECK(ensure_scratch(ctx, al(kn * 8) * 4 + draws * al(n)));
     uint64_t *e = salloc<uint64_t>(ctx, kn), *snew = salloc<uint64_t>(ctx, kn), *tmp = salloc<uint64_t>(ctx, kn);
     ctx->rng_item = 0;
     CHECK(sample_poly(ctx, ctx->sk, 1, 0, seed, 0));
@@ -1388,26 +1427,42 @@ extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
-// Encryptor.Encrypt (AtomicSealBfvVector.cs:1211,1227): (pk0 u + e1 + Delta m [+ r_t(q)], pk1 u + e2); pt = 0 encrypts zero
+// Encryptor.Encrypt (AtomicSealBfvVector.cs:1211,1227): (pk0 u + e1 + Delta m [+ r_t(q)], pk1 u + e2); pt = 0 encrypts zero.
+// tab != null: `cnt` encryptions whose outputs / plaintexts / nonces / items come from the table (host copy `htab`), else dense out / ptd
+static int encrypt_chain(cn_ctx *ctx, uint32_t cnt, const uint64_t *ptd, uint32_t pt_stride_words, uint64_t *out, uint64_t seed, const EncTab *htab) {
+    const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
+    CHECK(ensure_scratch(ctx, al((size_t)cnt * kn * 8) + al((size_t)cnt * n) + al((size_t)cnt * 2 * n) + (htab ? al(cnt * sizeof(EncTab)) : 0) + 1024));
+    uint64_t *u = salloc<uint64_t>(ctx, (size_t)cnt * kn);
+    int8_t *us = salloc<int8_t>(ctx, (size_t)cnt * n), *es = salloc<int8_t>(ctx, (size_t)cnt * 2 * n);
+    EncTab *dtab = nullptr;
+    if (htab) CHECK(upload_tmp(ctx, htab, cnt, &dtab));
+    if (!u || !us || !es) return fail(CN_ERR_HIP, "internal: scratch exhausted in encrypt");
+    const RngKey key = rng_key_of(ctx);
+    const uint64_t item0 = ctx->rng_item;
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, seed, 0u, item0, (const EncTab *)dtab);
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, seed, 1u, item0, (const EncTab *)dtab);
+    hipLaunchKernelGGL(k_expand_small, dim3(cnt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, us, u, ctx->dc, ctx->chunks);
+    HIPCHK(hipGetLastError()); launch_count(ctx, 3);
+    if (!htab) ctx->rng_item += cnt;
+    CHECK(cn_run_ntt(ctx, u, cnt * k, 0, k, 0));
+    const bool f64 = ctx->use_f64 && ctx->hc.q_f64;
+    if (!rr_ops[f64 ? POL_F64 : POL_U64]->enc_tail(ctx, u, ptd, pt_stride_words, out, cnt, es, dtab)) return fail(CN_ERR_ARG, "unsupported size");
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    return 0;
+}
+static int defer_encrypt(cn_ctx *ctx, const uint64_t *ptd, uint32_t pt_stride_words, Buffer *O, uint32_t oi, uint32_t count, uint64_t seed);
 extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) {
-    LOCK; NOT_CAPTURING("cn_encrypt (a replayed graph would reuse its randomness)"); GETCT(O, out, 2);
+    LOCK_ONLY; NOT_CAPTURING("cn_encrypt (a replayed graph would reuse its randomness)"); GETCT(O, out, 2);
     if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
     if (!range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
     const uint64_t *ptd = nullptr;
     if (pt) { Buffer *P = getbuf(ctx, pt, 1); if (!P || !range_ok(P, pi, pt_stride ? count : 1, pt_stride ? pt_stride : 1)) return fail(CN_ERR_ARG, "invalid plaintext range"); ptd = P->d + (size_t)pi * ctx->hc.n; }
     if (!count) return 0;
-    const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
-    CHECK(ensure_scratch(ctx, al((size_t)count * kn * 8)));
-    uint64_t *u = salloc<uint64_t>(ctx, (size_t)count * kn);
-    const uint64_t item0 = ctx->rng_item;
-    CHECK(sample_poly(ctx, u, count, 0, seed, 0));
-    CHECK(cn_run_ntt(ctx, u, count * k, 0, k, 0));
-    bool f64 = ctx->use_f64 && ctx->hc.q_f64;
-    bool ok = rr_ops[f64 ? POL_F64 : POL_U64]->enc_tail(ctx, u, ptd, pt_stride ? n : 0, O->d + oi * O->item_words, count, seed, item0);
-    if (!ok) return fail(CN_ERR_ARG, "unsupported size");
-    HIPCHK(hipGetLastError()); launch_count(ctx);
-    return 0;
+    // per-ciphertext callers (PoolLayer.ElementAt encrypts a zero vector per padded tap, PoolLayer.cs:67-80): queued like the evaluator calls
+    if (deferring(ctx) && count <= 4) return defer_encrypt(ctx, ptd, pt_stride ? ctx->hc.n : 0, O, oi, count, seed);
+    CHECK(cn_defer_flush(ctx));
+    return encrypt_chain(ctx, count, ptd, pt_stride ? ctx->hc.n : 0, O->d + oi * O->item_words, seed, nullptr);
 }
 #define DISPATCH_K2(fn, ...) switch (ctx->hc.k) { \
     case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; \
@@ -1634,6 +1689,27 @@ static int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all
     return 0;
 }
 
+// all queued Encryptor.Encrypt calls of one level: one sampling / transform / tail launch chain over a table
+static int flush_encrypt_group(cn_ctx *ctx, const std::vector<const DOp *> &ops) {
+    std::vector<EncTab> tab(ops.size());
+    for (size_t i = 0; i < ops.size(); i++) tab[i] = {(NTT_GLOBAL uint64_t *)ops[i]->out, (const NTT_GLOBAL uint64_t *)ops[i]->a, ops[i]->nonce, ops[i]->item};
+    const size_t per = (size_t)ctx->hc.k * ctx->hc.n * 8 + 3 * (size_t)ctx->hc.n + sizeof(EncTab) + 64;
+    const uint32_t ch = chunk_for(ctx, per, (uint32_t)ops.size());
+    for (uint32_t s0 = 0; s0 < ops.size(); s0 += ch) {
+        const uint32_t c = std::min<uint32_t>(ch, (uint32_t)ops.size() - s0);
+        CHECK(encrypt_chain(ctx, c, nullptr, 0, nullptr, 0, tab.data() + s0));
+    }
+    return 0;
+}
+static int defer_encrypt(cn_ctx *ctx, const uint64_t *ptd, uint32_t pt_stride_words, Buffer *O, uint32_t oi, uint32_t count, uint64_t seed) {
+    for (uint32_t c = 0; c < count; c++) {
+        DOp op{DOP_ENCRYPT, 0, O->d + (size_t)(oi + c) * O->item_words, ptd ? ptd + (size_t)c * pt_stride_words : nullptr, nullptr, 0, 0, nullptr};
+        op.nonce = seed; op.item = ctx->rng_item++;
+        CHECK(defer_push(ctx, op, nullptr, 0));
+    }
+    return 0;
+}
+
 static int cn_defer_flush(cn_ctx *ctx) {
     DeferQueue *q = ctx->dq;
     if (!q) return 0;
@@ -1681,6 +1757,7 @@ static int cn_defer_flush(cn_ctx *ctx) {
                 for (auto &kv : byK) if (!rc) rc = flush_gemm_group(ctx, q, kv.second, kv.first);
             }
             for (int t : {DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN}) if (!rc && !by_type[t].empty()) rc = flush_elementwise_group(ctx, by_type[t], t);
+            if (!rc && !by_type[DOP_ENCRYPT].empty()) rc = flush_encrypt_group(ctx, by_type[DOP_ENCRYPT]);
             if (!rc && !by_type[DOP_MULRELIN].empty()) rc = flush_mulrelin_group(ctx, by_type[DOP_MULRELIN]);
         }
     }

@@ -87,46 +87,83 @@ template <int RN> struct TensorOps<ArF64T<RN>> {
     DEV double add(double a, double b) const { return __dadd_rn(a, b); }
 };
 // ------------------------------------------------------------------ client-side operations on the device
-// KeyGenerator / Encryptor / Decryptor of the data owner, for deployments where the client has a GPU too.  Randomness is a
-// counter-based Philox4x32-10 stream keyed by a caller seed: reproducible and statistically sound, NOT a certified DRBG.
-struct Philox { uint32_t c[4]; };
-DEV Philox philox(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo) {
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+// KeyGenerator / Encryptor / Decryptor of the data owner, for deployments where the client has a GPU too.  Randomness: ChaCha20 (RFC 7539
+// block function, 20 rounds) as a counter-mode DRBG - 256-bit key per context (cn_set_rng_key: the data owner draws it from the OS
+// entropy source), 64-bit nonce per call (the `seed` argument of cn_keygen / cn_encrypt), 64-bit block counter made of
+// (polynomial item, stream, redraw trial, block index inside the polynomial): every block of every polynomial of every call is distinct.
+// One block (512 bits) yields 16 ternary coefficients (32 bits each: 16 two-bit rejection trials), 8 clipped-normal coefficients (four
+// Box-Muller pairs, both branches used) or 8 uniform 64-bit words; secrets and noise are drawn ONCE per coefficient into int8 arrays
+// and expanded to the k residues afterwards.
+struct RngKey { uint32_t k[8]; };
+// EncTab: per-ciphertext parameters of an encryption whose outputs are separate arrays and whose calls carried their own nonce (deferred
+// per-ciphertext cn_encrypt calls merged into one launch chain): output address, plaintext polynomial or null, nonce, polynomial item
+struct EncTab { NTT_GLOBAL uint64_t *out; const NTT_GLOBAL uint64_t *pt; uint64_t nonce, item; };
+DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+#define CN_QR(a, b, c, d) a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+DEV void chacha20_block(const RngKey &key, uint64_t counter, uint64_t nonce, uint32_t (&out)[16]) {
+    uint32_t x[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3], key.k[4], key.k[5], key.k[6], key.k[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)nonce, (uint32_t)(nonce >> 32)};
+    uint32_t w[16];
 #pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = x[i];
+#pragma unroll 2
     for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        CN_QR(w[0], w[4], w[8], w[12]) CN_QR(w[1], w[5], w[9], w[13]) CN_QR(w[2], w[6], w[10], w[14]) CN_QR(w[3], w[7], w[11], w[15])
+        CN_QR(w[0], w[5], w[10], w[15]) CN_QR(w[1], w[6], w[11], w[12]) CN_QR(w[2], w[7], w[8], w[13]) CN_QR(w[3], w[4], w[9], w[14])
     }
-    return {{c0, c1, c2, c3}};
-}
-// streams: 0 = ternary, 1/2 = noise polys, 3 = uniform.  `salt` (cn_set_rng_salt) whitens the counter word: with the 64-bit Philox key
-// `seed` the sampler then depends on 128 secret bits (distinct (stream, trial) pairs stay distinct under the XOR)
-DEV int32_t sample_ternary(uint64_t seed, uint64_t stream, uint64_t item, uint32_t i, uint64_t salt) {
-    for (uint32_t tr = 0;; tr++) {
-        Philox p = philox(seed, ((stream << 32) | tr) ^ salt, (item << 20) | i);
 #pragma unroll
-        for (int w = 0; w < 4; w++) for (int b = 0; b < 32; b += 2) { uint32_t v = (p.c[w] >> b) & 3; if (v != 3) return (int32_t)v - 1; }
+    for (int i = 0; i < 16; i++) out[i] = w[i] + x[i];
+}
+// block counter: item (40 bits) | stream (4) | trial (4) | block index inside the polynomial (16)
+DEV uint64_t rng_counter(uint64_t item, uint32_t stream, uint32_t trial, uint32_t blk) { return (item << 24) | ((uint64_t)(stream & 15) << 20) | ((uint64_t)(trial & 15) << 16) | (blk & 0xffffu); }
+// streams: 0 = ternary (secret key, u), 1 / 2 = noise polynomials e1 / e2 (and key noise), 3 = uniform (the `a` component of keys)
+// 16 ternary coefficients {-1, 0, 1} from one block: coefficient c takes word c, two bits at a time, the first pair that is not 3
+DEV void sample_ternary16(const RngKey &key, uint64_t nonce, uint32_t stream, uint64_t item, uint32_t blk, int8_t (&out)[16]) {
+    uint32_t w[16];
+    chacha20_block(key, rng_counter(item, stream, 0, blk), nonce, w);
+    uint32_t pending = 0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        int v = 2;                                                   // 2 = every pair was 3 (probability 4^-16): redraw below
+        for (int b = 30; b >= 0; b -= 2) { const uint32_t t = (w[c] >> b) & 3; if (t != 3) v = (int)t - 1; }   // ends with the LOWEST non-3 pair
+        out[c] = (int8_t)v;
+        if (v == 2) pending |= 1u << c;
+    }
+    for (uint32_t trial = 1; pending; trial++) {                     // (practically never runs)
+        chacha20_block(key, rng_counter(item, stream, trial, blk), nonce, w);
+        for (int c = 0; c < 16; c++) if (pending & (1u << c)) {
+            for (int b = 30; b >= 0; b -= 2) { const uint32_t t = (w[c] >> b) & 3; if (t != 3) { out[c] = (int8_t)((int)t - 1); pending &= ~(1u << c); } }
+        }
     }
 }
-DEV int32_t sample_noise(uint64_t seed, uint64_t stream, uint64_t item, uint32_t i, uint64_t salt) {      // clipped normal sigma 3.2, 6 sigma, cast
-    for (uint32_t tr = 0;; tr++) {
-        Philox p = philox(seed, ((stream << 32) | tr) ^ salt, (item << 20) | i);
-        const double u1 = ((double)(((uint64_t)p.c[0] << 21) ^ (p.c[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
-        const double u2 = ((double)(((uint64_t)p.c[2] << 21) ^ (p.c[3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
-        const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2) * 3.2;
-        if (fabs(g) <= 19.2) return (int32_t)g;
+// 8 coefficients of the clipped normal (sigma 3.2, clipped at 6 sigma, rounded towards zero like SEAL's cast) from one block
+DEV void sample_noise8(const RngKey &key, uint64_t nonce, uint32_t stream, uint64_t item, uint32_t blk, int8_t (&out)[8]) {
+    uint32_t pending = 0xff;
+    for (uint32_t trial = 0; pending; trial++) {
+        uint32_t w[16];
+        chacha20_block(key, rng_counter(item, stream, trial, blk), nonce, w);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const double u1 = ((double)(((uint64_t)w[4 * p] << 21) ^ (w[4 * p + 1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+            const double u2 = ((double)(((uint64_t)w[4 * p + 2] << 21) ^ (w[4 * p + 3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+            const double r = sqrt(-2.0 * log(u1)) * 3.2;
+            const double g0 = r * cospi(2.0 * u2), g1 = r * sinpi(2.0 * u2);
+            if ((pending & (1u << (2 * p))) && fabs(g0) <= 19.2) { out[2 * p] = (int8_t)(int32_t)g0; pending &= ~(1u << (2 * p)); }
+            if ((pending & (2u << (2 * p))) && fabs(g1) <= 19.2) { out[2 * p + 1] = (int8_t)(int32_t)g1; pending &= ~(2u << (2 * p)); }
+        }
     }
 }
-DEV uint64_t sample_uniform(uint64_t seed, uint64_t stream, uint64_t item, uint32_t i, uint64_t q, uint64_t salt) {
+// 8 uniform residues mod q from one block (64-bit words, rejection of the incomplete top range)
+DEV void sample_uniform8(const RngKey &key, uint64_t nonce, uint32_t stream, uint64_t item, uint32_t blk, uint64_t q, uint64_t (&out)[8]) {
     const uint64_t lim = ~0ull - (~0ull % q) - 1;
-    for (uint32_t tr = 0;; tr++) {
-        Philox p = philox(seed, ((stream << 32) | tr) ^ salt, (item << 20) | i);
-        uint64_t v = ((uint64_t)p.c[0] << 32) | p.c[1];
-        if (v <= lim) return v % q;
-        v = ((uint64_t)p.c[2] << 32) | p.c[3];
-        if (v <= lim) return v % q;
+    uint32_t pending = 0xff;
+    for (uint32_t trial = 0; pending; trial++) {
+        uint32_t w[16];
+        chacha20_block(key, rng_counter(item, stream, trial, blk), nonce, w);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint64_t v = ((uint64_t)w[2 * c] << 32) | w[2 * c + 1];
+            if ((pending & (1u << c)) && v <= lim) { out[c] = v % q; pending &= ~(1u << c); }
+        }
     }
 }

@@ -251,16 +251,52 @@ __global__ void k_f64_to_u64(uint64_t *p, size_t words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < words) { double d = reinterpret_cast<double *>(p)[i]; p[i] = (uint64_t)(long long)d; }
 }
-// out[item][j][i]: kind 0 ternary residues, kind 1 noise residues, kind 2 uniform residues mod q_j (item = blockIdx / (k*chunks))
-__global__ void k_sample(uint64_t *out, const DevConsts *__restrict__ C, uint32_t chunks, int kind, uint64_t seed, uint64_t stream, uint64_t item0, uint64_t salt) {
-    uint32_t limb, i; decode(chunks, limb, i);
-    const uint32_t k = C->k, j = limb % k; const uint64_t item = item0 + limb / k, q = C->q[j].q;
-    uint64_t v;
-    if (kind == 2) v = sample_uniform(seed, stream, item * k + j, i, q, salt);
-    else { int32_t s = kind == 0 ? sample_ternary(seed, stream, item, i, salt) : sample_noise(seed, stream, item, i, salt); v = s >= 0 ? (uint64_t)s : q - (uint64_t)(-s); }
-    out[(size_t)limb * C->n + i] = v;
+// ---- samplers (ChaCha20 DRBG, cn_dev_common.hip.h).  Secrets and noise are drawn once per coefficient into int8 arrays.
+// small[it][p][i], it < items, p < polys: kind 0 ternary {-1, 0, 1} (stream0 + p), kind 1 clipped normal (stream0 + p)
+__global__ void k_sample_small(int8_t *__restrict__ small, uint32_t n, int kind, uint32_t polys, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream0,
+                               uint64_t item0, const EncTab *__restrict__ tab) {
+    const uint32_t per = kind == 0 ? 16u : 8u, bpp = n / per;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)items * polys * bpp) return;
+    const uint32_t blk = (uint32_t)(gid % bpp), pi = (uint32_t)(gid / bpp), it = pi / polys, p = pi % polys;
+    const uint64_t item = tab ? tab[it].item : item0 + it, nc = tab ? tab[it].nonce : nonce;
+    int8_t *o = small + (size_t)pi * n + (size_t)blk * per;
+    if (kind == 0) {
+        int8_t v[16];
+        sample_ternary16(key, nc, stream0 + p, item, blk, v);
+#pragma unroll
+        for (int c = 0; c < 16; c++) o[c] = v[c];
+    } else {
+        int8_t v[8];
+        sample_noise8(key, nc, stream0 + p, item, blk, v);
+#pragma unroll
+        for (int c = 0; c < 8; c++) o[c] = v[c];
+    }
 }
-// b = -(a*s + e) (+ f * snew on limb `hot`), all NTT form; a, e, b: [k][N]; s, snew: [k][N]; f[k] factor per limb
+// one raw generator block (known-answer self-test, cn_rng_selftest)
+__global__ void k_rng_block(RngKey key, uint64_t counter, uint64_t nonce, uint32_t *out) {
+    uint32_t w[16];
+    chacha20_block(key, counter, nonce, w);
+    for (int i = 0; i < 16; i++) out[i] = w[i];
+}
+// out[it][j][i] = small[it][i] as a residue mod q_j
+__global__ void k_expand_small(const int8_t *__restrict__ small, uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks) {
+    uint32_t limb, i; decode(chunks, limb, i);
+    const uint32_t k = C->k, j = limb % k; const uint64_t q = C->q[j].q;
+    const int32_t s = small[(size_t)(limb / k) * C->n + i];
+    out[(size_t)limb * C->n + i] = s >= 0 ? (uint64_t)s : q - (uint64_t)(-s);
+}
+// out[it][j][i]: uniform residues mod q_j (the `a` component of keys, directly in the NTT domain); thread = 8 coefficients of one limb
+__global__ void k_sample_uniform(uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream, uint64_t item0) {
+    const uint32_t n = C->n, k = C->k, bpl = n / 8;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)items * k * bpl) return;
+    const uint32_t b = (uint32_t)(gid % bpl), limb = (uint32_t)(gid / bpl), j = limb % k;
+    uint64_t v[8];
+    sample_uniform8(key, nonce, stream, item0 + limb / k, j * bpl + b, C->q[j].q, v);
+#pragma unroll
+    for (int c = 0; c < 8; c++) out[(size_t)limb * n + (size_t)b * 8 + c] = v[c];
+}
 __global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, uint64_t factor, int hot, uint64_t *b,
                         const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);

@@ -249,11 +249,13 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, PLDS ? 2 : 4) k_square_fused(c
         for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(to, r)] = A.scaled(v[r]);
     }
 }
-// encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form
+// encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form, e = the int8 noise polynomials
+// [ct][2][N] of k_sample_small.  tab: per-ciphertext output address and plaintext (deferred per-ciphertext calls), else out + ct*2kN and
+// pt + ct*pt_stride_words (pt null: encryptions of zero)
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t *__restrict__ u, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pt,
                                                                  uint32_t pt_stride_words, uint64_t *__restrict__ out, const DevConsts *__restrict__ C,
-                                                                 uint64_t seed, uint64_t item0, uint64_t salt) {
+                                                                 const int8_t *__restrict__ noise, const EncTab *__restrict__ tab) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -271,15 +273,17 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t 
         v[r] = ops.mul(A.load(x.x), A.load(y.x), A); v[r + 1] = ops.mul(A.load(x.y), A.load(y.y), A);
     }
     ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
-    uint64_t *o = out + (((size_t)ct * 2 + p) * k + j) * n;
+    NTT_GLOBAL uint64_t *o = (tab ? tab[ct].out : (NTT_GLOBAL uint64_t *)out + (size_t)ct * 2 * k * n) + ((size_t)p * k + j) * n;
+    const NTT_GLOBAL uint64_t *m = tab ? tab[ct].pt : (pt ? (const NTT_GLOBAL uint64_t *)pt + (size_t)ct * pt_stride_words : nullptr);
+    const int8_t *ee = noise + ((size_t)ct * 2 + p) * n;
     const uint64_t q = C->q[j].q;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const uint32_t e = pass_index<L, SA, 0>(tid, r);
         uint64_t val = A.scaled(v[r]);
-        const int32_t ns = sample_noise(seed, 1 + p, item0 + ct, e, salt);
+        const int32_t ns = ee[e];
         val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
-        if (p == 0 && pt) val = addmod(val, scale_plain(C, pt[(size_t)ct * pt_stride_words + e], j), q);
+        if (p == 0 && m) val = addmod(val, scale_plain(C, m[e], j), q);
         o[e] = val;
     }
 }

@@ -71,15 +71,15 @@ static bool mul_plain_fused(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint3
                             uint64_t *out, uint32_t count, uint32_t polys) { BY_SIZE(l_mul_plain_fused, c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys) }
 
 #ifdef RR_ENC_TAIL
-template <int L> static void l_enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0) {
+template <int L> static void l_enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
     hipLaunchKernelGGL((k_encrypt_tail<L, AR>), dim3(cnt * 2 * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, u, c->pk, pt, pts, out, c->dc,
-                       seed, item0, c->rng_salt);
+                       noise, (const EncTab *)tab);
 }
-static bool enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0) {
-    BY_SIZE(l_enc_tail, c, u, pt, pts, out, cnt, seed, item0)
+static bool enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
+    BY_SIZE(l_enc_tail, c, u, pt, pts, out, cnt, noise, tab)
 }
 #else
-static bool enc_tail(cn_ctx *, const uint64_t *, const uint64_t *, uint32_t, uint64_t *, uint32_t, uint64_t, uint64_t) { return false; }
+static bool enc_tail(cn_ctx *, const uint64_t *, const uint64_t *, uint32_t, uint64_t *, uint32_t, const int8_t *, const void *) { return false; }
 #endif
 
 #ifndef __HIP_DEVICE_COMPILE__      // host-side table (in the device pass a const global would be emitted as device data)

@@ -75,6 +75,7 @@ public:
     void unlock(Node &n);
 private:
     std::atomic<int> held{0};
+    std::atomic<int> spinners{0};      // waiters that spin; the others sleep (cn_host.cpp)
 };
 struct CnGuard {
     CnMutex &m; CnMutex::Node n;
@@ -98,8 +99,8 @@ struct cn_ctx {
     bool use_f64 = true;      // CN_NO_F64=1 / cn_set_option("f64",0): integer (Shoup) transforms everywhere
     std::map<uint64_t, KsKey> gk;
     uint64_t *sk = nullptr, *pk = nullptr;   // client-side keys (NTT form) when the data owner's GPU runs keygen/encrypt/decrypt
-    uint64_t rng_item = 0;                    // running polynomial counter of the Philox streams
-    uint64_t rng_salt = 0;                    // second 64 bits of sampler key material (cn_set_rng_salt), whitening the Philox counter
+    uint64_t rng_item = 0;                    // running polynomial counter of the sampler (part of the ChaCha20 block counter)
+    uint32_t rng_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 256-bit ChaCha20 key of the sampler (cn_set_rng_key; cn_set_rng_salt sets the first 64 bits)
     char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
     std::vector<std::unique_ptr<char[]>> staged;   // host blocks of in-flight upload_tmp copies
     cn_stats st{};
@@ -159,7 +160,7 @@ struct RrOps {                // register-radix kernels of one arithmetic policy
     bool (*square_fused)(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm);   // FP64 policies
     bool (*mul_plain_fused)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride, uint32_t pstride,
                             uint64_t *out, uint32_t count, uint32_t polys);
-    bool (*enc_tail)(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, uint64_t seed, uint64_t item0);   // U64, F64
+    bool (*enc_tail)(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);   // U64, F64; tab: EncTab[cnt] or null
 };
 struct KsOps {
     int (*set_attrs)(uint32_t logn, size_t lds);

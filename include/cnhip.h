@@ -201,15 +201,23 @@ int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle pt, uint32_
 
 /* ---- client side on the device (what SEAL's KeyGenerator / Encryptor / Decryptor do for
  * AtomicSealBfvEncryptedEnvironment.SetKeys / Encrypt / Decrypt, AtomicSealBfvVector.cs:62-74,1030-1110,1202-1232), for data
- * owners that have a GPU.  Randomness: counter-based Philox4x32-10 keyed by `seed` (reproducible; not a certified DRBG). ---- */
-/* Sampler key material: `seed` (per call) is the 64-bit Philox key; cn_set_rng_salt adds 64 more secret bits that whiten the counter word
- * of every block drawn afterwards (default 0).  A data owner draws both from the OS entropy source; fixed values are for tests. */
+ * owners that have a GPU.  Randomness: a ChaCha20 counter-mode generator (256-bit key per context, 64-bit nonce per call). ---- */
+/* Sampler: ChaCha20 (RFC 7539 block function) in counter mode.  cn_set_rng_key installs the 256-bit key of the context (the data owner draws
+ * it from the OS entropy source; default all zero = reproducible, for tests); the `seed` argument of cn_keygen / cn_encrypt is the 64-bit
+ * nonce of the call - distinct calls under one key need distinct nonces (a counter or fresh entropy).  cn_set_rng_salt sets only the first
+ * 64 key bits (kept for callers of the round-1 interface). */
+int cn_set_rng_key(cn_ctx *ctx, const uint8_t *key32);
 int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt);
+/* known-answer self-test of the generator: one raw block (16 words) for a key, the 64-bit block counter (state words 12-13) and the
+ * 64-bit nonce (state words 14-15); RFC 7539 section 2.3.2 is the case counter = 0x0900000000000001, nonce = 0x4a000000 */
+int cn_rng_selftest(cn_ctx *ctx, const uint8_t *key32, uint64_t counter, uint64_t nonce, uint32_t *out16);
 int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois);          /* secret, public, relin (dbc) and default Galois (gdbc) keys */
 int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count);   /* [2][k][N], NTT form */
 int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count);   /* [k][N], NTT form */
 int cn_get_key(cn_ctx *ctx, int which /*0 relin,1 galois,2 public,3 secret*/, uint64_t galois_elt, uint64_t *host, size_t count);
-/* Encryptor.Encrypt of `count` dense plaintexts (pt = 0: encryptions of zero; pt_stride 0: the same plaintext) */
+/* Encryptor.Encrypt of `count` dense plaintexts (pt = 0: encryptions of zero; pt_stride 0: the same plaintext).  With
+ * cn_set_option("defer", 1) a call for up to 4 ciphertexts is queued like the evaluator calls (the unchanged PoolLayer encrypts a zero
+ * vector per padded convolution tap, PoolLayer.cs:67-80: 645 calls per layer and plaintext prime become one launch chain). */
 int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed);
 /* Decryptor.Decrypt of size-2 or size-3 ciphertexts into dense plaintexts */
 int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi);

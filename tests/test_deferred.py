@@ -322,3 +322,85 @@ def test_stats_and_destroy_drain_the_queue(rng):
         g.free(h)                                  # parked behind the queued squarings
     assert g.get_option("pending_calls") == 3
     g.close()                                      # must not crash or leave the parked arrays behind
+
+
+@pytest.mark.gpu
+def test_deferred_encryptions_equal_immediate_ones(rng):
+    """cn_encrypt of single ciphertexts is queued under "defer" (PoolLayer.ElementAt encrypts a zero vector per padded tap, PoolLayer.cs:67-80)
+    and merged into one sampling / transform / tail launch chain per level: same key, nonce and item -> the same words as the immediate
+    calls; a queued scalar product reads queued encryptions (read-after-write through the queue); zero and non-zero plaintexts"""
+    from cryptonets_amd._native import Context
+    p = PARAMS["tiny"]
+    o = get_oracle("tiny", galois=False)
+    words = []
+    for defer in (0, 1):
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        g.keygen(42, galois=False)
+        g.set_option("defer", defer)
+        ph = g.pt_alloc(2)
+        g.encode_batch(np.array([[1, 2, 3], [4, 5, 6]], dtype=np.uint64), ph, 0)
+        hs = [g.ct_alloc(1) for _ in range(6)]
+        for i, h in enumerate(hs):
+            g.encrypt(ph if i % 3 else 0, i % 2, h, 0, 1, seed=1000 + i)           # pt handle 0: an encryption of zero
+        if defer:
+            assert g.get_option("pending_calls") == 6
+        out = g.ct_alloc(1)
+        g.scalar_dot(hs, np.zeros(6, dtype=np.uint32), np.array([3, 1, 4, 1, 5, 9], dtype=np.uint64), out, 0)
+        w = [g.ct_download(h, 0, 1)[0] for h in hs + [out]]
+        # the data owner's view: decryptions (device keys -> the oracle cannot decrypt; use the device)
+        dh = g.pt_alloc(7)
+        for i, h in enumerate(hs + [out]):
+            g.decrypt(h, 0, 1, dh, i)
+        slots = g.decode_batch(dh, 0, 7)
+        plain = [np.zeros(3, dtype=np.uint64) if i % 3 == 0 else np.array([[1, 2, 3], [4, 5, 6]], dtype=np.uint64)[i % 2] for i in range(6)]
+        for i in range(6):
+            assert np.array_equal(slots[i][:3], plain[i]) and not slots[i][3:].any()
+        assert np.array_equal(slots[6][:3], sum(int(c) * plain[i].astype(np.int64) for i, c in enumerate([3, 1, 4, 1, 5, 9])) % p["t"])
+        words.append(w)
+        g.close()
+    for a, b in zip(*words):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_literal_padded_taps_in_the_unchanged_caller(rng):
+    """The LITERAL PoolLayer.ElementAt: every padded convolution tap is a fresh encryption of zero (device, queued), K = 25 real handles per
+    output.  Convolution layer of CryptoNets alone (N = 8192, one plaintext prime): outputs without a padded tap carry the batched path's
+    WORDS, outputs with padded taps decrypt to the same slots; nothing leaks (handle count back to where it was)."""
+    import replay_reference_calls as rp
+    from cryptonets_amd import cryptonets_mnist as cm
+    from cryptonets_amd._native import Context
+    layers = cm.layer_tables(*cm.reference_weights())[:1]
+    t = cm.PLAIN_PRIMES[0]
+    g = Context(cm.N, t, dbc=10, gdbc=20, device=0)
+    g.keygen(7, galois=False)
+    ch = cm.CryptoNetsChannel(g, layers, cm.constant_plaintext(cm.N))
+    x = rng.integers(0, 16, size=(784, 64), dtype=np.uint64)
+    ph = g.pt_alloc(784)
+    g.encode_batch(x, ph, 0)
+    g.encrypt(ph, 0, ch.h_in, 0, 784, seed=3)
+    g.free(ph)
+    g.gemm_apply(ch.layers[0]["plan"], ch.h_in, ch.h1, 0)
+    ref = g.ct_download(ch.h1, 0, 845)
+    live = g.live_handles()
+    spec = rp.replay_layers([ch], layers)
+    spec[0]["square"] = False
+    r = rp.Replay([g], spec)
+    ins = rp.split_columns(g, ch.h_in, 784)[None, :]
+    g.set_option("defer", 1)
+    try:
+        out = r.run(ins, 8, literal_taps=True, nonce0=77)
+    finally:
+        g.set_option("defer", 0)
+    got = np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[0]])
+    padded = (layers[0]["idx"] < 0).any(axis=1)
+    assert padded.sum() == 125 and (layers[0]["idx"] < 0).sum() == 645
+    assert np.array_equal(got[~padded], ref[~padded])
+    assert not any(np.array_equal(got[i], ref[i]) for i in np.nonzero(padded)[0])            # fresh randomness went in
+    dec = rp.decrypt_outputs([ch], [got])[0]
+    want = rp.decrypt_outputs([ch], [ref])[0]
+    assert np.array_equal(dec, want)
+    for h in list(out[0]) + list(ins[0]):
+        g.free(int(h))
+    assert g.live_handles() == live
+    g.close()

@@ -312,3 +312,62 @@ def test_encode_decode_batch_equal_the_oracle(name, rng):
     with pytest.raises(CnError):
         g.encode_batch(vals, ph, 3)                       # 7 plaintexts do not fit behind index 3
     g.free(ph), g.free(ct)
+
+
+@pytest.mark.gpu
+def test_sampler_generator_is_chacha20_rfc7539():
+    """the device sampler's generator against the RFC 7539 section 2.3.2 block-function test vector (key 00..1f, block counter 1, nonce
+    00:00:00:09:00:00:00:4a:00:00:00:00) and against a host model of the same 20-round function on a second input"""
+    from cryptonets_amd._native import Context
+    p = PARAMS["tiny"]
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    key = bytes(range(32))
+    got = g.rng_block(key, (0x09000000 << 32) | 1, 0x4a000000)
+    want = [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+            0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert [int(x) for x in got] == want
+
+    def model(key, counter, nonce):
+        rot = lambda x, r: ((x << r) | (x >> (32 - r))) & 0xffffffff
+        st = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + [int.from_bytes(key[4 * i:4 * i + 4], "little") for i in range(8)] + \
+             [counter & 0xffffffff, counter >> 32, nonce & 0xffffffff, nonce >> 32]
+        w = list(st)
+
+        def qr(a, b, c, d):
+            w[a] = (w[a] + w[b]) & 0xffffffff; w[d] = rot(w[d] ^ w[a], 16)
+            w[c] = (w[c] + w[d]) & 0xffffffff; w[b] = rot(w[b] ^ w[c], 12)
+            w[a] = (w[a] + w[b]) & 0xffffffff; w[d] = rot(w[d] ^ w[a], 8)
+            w[c] = (w[c] + w[d]) & 0xffffffff; w[b] = rot(w[b] ^ w[c], 7)
+        for _ in range(10):
+            qr(0, 4, 8, 12), qr(1, 5, 9, 13), qr(2, 6, 10, 14), qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15), qr(1, 6, 11, 12), qr(2, 7, 8, 13), qr(3, 4, 9, 14)
+        return [(a + b) & 0xffffffff for a, b in zip(w, st)]
+    assert model(key, (0x09000000 << 32) | 1, 0x4a000000) == want
+    key2 = bytes((7 * i + 3) & 255 for i in range(32))
+    assert [int(x) for x in g.rng_block(key2, 0x0123456789abcdef, 0xfedcba9876543210)] == model(key2, 0x0123456789abcdef, 0xfedcba9876543210)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_encryptions_depend_on_key_nonce_and_item(rng):
+    """fresh encryptions of the same plaintext: equal words for equal (key, nonce, item), different words when any of the three changes; the
+    default client draws a 256-bit key from the OS"""
+    from cryptonets_amd._native import Context
+    p = PARAMS["tiny"]
+
+    def enc(key, nonce, skip):
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        g.keygen(99, galois=False)                       # (all-zero sampler key: the same keys every time)
+        if key is not None:
+            g.set_rng_key(key)
+        ph, ct = g.pt_alloc(1), g.ct_alloc(2)
+        g.encode(np.arange(8, dtype=np.uint64), ph, 0)
+        g.encrypt(ph, 0, ct, 0, 2, seed=nonce, pt_stride=0)          # two ciphertexts of one plaintext: items i, i + 1
+        w = g.ct_download(ct, skip, 1)[0]
+        g.close()
+        return w
+    base = enc(bytes(32), 5, 0)
+    assert np.array_equal(base, enc(bytes(32), 5, 0))
+    assert not np.array_equal(base, enc(bytes(32), 6, 0))
+    assert not np.array_equal(base, enc(bytes([1] + [0] * 31), 5, 0))
+    assert not np.array_equal(base, enc(bytes(32), 5, 1))

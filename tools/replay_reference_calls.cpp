@@ -10,14 +10,22 @@
 //   SquareActivation.Apply (SquareActivation.cs:10-13) -> EncryptedSealBfvMatrix.ElementWiseMultiply (EncryptedSealBfvMatrix.cs:140-154):
 //        ParallelProcessInEnv(columns, k => PointwiseMultiply -> Multiply + Relinearize (AtomicSealBfvVector.cs:839-840)  = cn_mul_relin, count 1)
 //   BaseLayer.GetNext (BaseLayer.cs:23-49) disposes a layer's input matrix once its output exists                         = cn_free per column
-//   Utils.ParallelProcessInEnv (HE Wrapper/Utils.cs:46-88): `threads` workers pulling item indices from an interlocked counter.
+//   PoolLayer.ElementAt (PoolLayer.cs:67-80), `literal_taps`: a convolution tap that falls into the padding is a FRESH encryption of the
+//        zero vector - Factory.GetEncryptedVector(zeros) per (map, corner, padded offset), kept in TempVectors and disposed by
+//        ReleaseTemp() after the layer (:83-90, :189,226)                                              = cn_ct_alloc + cn_encrypt(pt = 0) ... cn_free
+//        (645 per plaintext prime and batch for the 5x5 stride-2 convolution of CryptoNets; without `literal_taps` the tap is passed as
+//        handle 0 = skipped - the batched path's deviation, identical plaintext)
+//   Utils.ParallelProcessInEnv (HE Wrapper/Utils.cs:46-88): `threads` tasks pulling item indices from an interlocked counter; the tasks run
+//        on pooled threads (.NET thread pool) - here a pool of `threads` workers that lives as long as the library.
 //
 // Every ciphertext is its own handle (count 1), exactly like the individually allocated SEAL Ciphertext objects of the reference.
 // Used by tools/replay_reference_calls.py, bench.py (`unchanged_caller`) and tests/test_deferred.py; measurement tooling, not product.
 //   g++ -O2 -std=c++17 -shared -fPIC tools/replay_reference_calls.cpp -Iinclude -Lcryptonets_amd/lib -lcnhip -Wl,-rpath,'$ORIGIN' -pthread
 #include "../include/cnhip.h"
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -41,23 +49,52 @@ void note(Err &e, int rc) {
     int expect = 0;
     if (rc && e.rc.compare_exchange_strong(expect, rc)) snprintf(e.msg, sizeof e.msg, "%s", cn_last_error());
 }
-// Utils.ParallelProcessInEnv: up to `threads` workers, work items handed out by an interlocked counter
-void parallel_process(int count, int threads, const std::function<void(int)> &body) {
-    if (count < 2 || threads < 2) { for (int k = 0; k < count; k++) body(k); return; }
-    std::atomic<int> next{-1};
-    const int nt = threads > count ? count : threads;
-    std::vector<std::thread> pool;
-    pool.reserve(nt);
-    for (int t = 0; t < nt; t++) pool.emplace_back([&] { for (;;) { const int k = ++next; if (k >= count) break; body(k); } });
-    for (auto &t : pool) t.join();
-}
+// Utils.ParallelProcessInEnv: `threads` tasks (Task.Run on the .NET thread pool), work items handed out by an interlocked counter.  The
+// pool threads are created once and reused by every region, like the runtime's pool.
+class Pool {
+    std::mutex mu; std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void(int)> *body = nullptr;
+    std::atomic<int> next{0};
+    int count = 0, want = 0, gen = 0, running = 0; bool stop = false;
+    void work(int id) {
+        int seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop || (gen != seen && id < want); });
+                if (stop) return;
+                seen = gen;
+            }
+            for (;;) { const int k = next.fetch_add(1) + 0; if (k >= count) break; (*body)(k); }
+            std::lock_guard<std::mutex> lk(mu);
+            if (--running == 0) cv_done.notify_one();
+        }
+    }
+public:
+    ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_go.notify_all(); for (auto &t : workers) t.join(); }
+    void run(int n_items, int threads, const std::function<void(int)> &fn) {
+        if (n_items < 2 || threads < 2) { for (int k = 0; k < n_items; k++) fn(k); return; }
+        const int nt = threads > n_items ? n_items : threads;
+        while ((int)workers.size() < nt) { const int id = (int)workers.size(); workers.emplace_back([this, id] { work(id); }); }
+        std::unique_lock<std::mutex> lk(mu);
+        body = &fn; count = n_items; next = 0; want = nt; running = nt; gen++;
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return running == 0; });
+        want = 0;
+    }
+};
+Pool &pool() { static Pool p; return p; }
+void parallel_process(int count, int threads, const std::function<void(int)> &body) { pool().run(count, threads, body); }
 }  // namespace
 
 // in:  [primes][n_in] one handle per input column (count 1 each); out: [primes][O_last] receives the handles of the last layer's
 // columns (owned by the caller from then on).  The inputs are left alive (the reference's EncryptLayer output would be disposed).
-extern "C" int rp_run(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nlayers, const cn_handle *in, uint32_t n_in, cn_handle *out, int threads,
-                      char *errmsg, size_t errlen) {
+// literal_taps: padded taps are fresh encryptions of zero (needs the public key in the contexts); nonce0: first encryption nonce
+extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nlayers, const cn_handle *in, uint32_t n_in, cn_handle *out, int threads,
+                       int literal_taps, uint64_t nonce0, char *errmsg, size_t errlen) {
     Err err;
+    std::atomic<uint64_t> nonce{nonce0};
     std::vector<std::vector<cn_handle>> cur(nprimes);
     for (int p = 0; p < nprimes; p++) cur[p].assign(in + (size_t)p * n_in, in + (size_t)(p + 1) * n_in);
     bool cur_owned = false;
@@ -67,14 +104,26 @@ extern "C" int rp_run(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nla
     for (int li = 0; li < nlayers && !err.rc; li++) {
         const rp_layer &L = layers[li];
         std::vector<std::vector<cn_handle>> res(nprimes, std::vector<cn_handle>(L.O, 0));
+        std::vector<std::vector<std::pair<int, cn_handle>>> temps(L.O);              // TempVectors: the zero encryptions of item k, per prime
         // ---- PoolLayer.Apply
         parallel_process((int)L.O, threads, [&](int k) {
             if (err.rc) return;
             std::vector<cn_handle> patch(L.K);
             for (int p = 0; p < nprimes; p++) {                                      // ForEveryEncryptedVector: one task per plaintext prime
-                for (uint32_t t = 0; t < L.K; t++) { const int32_t c = L.idx[(size_t)k * L.K + t]; patch[t] = c < 0 ? 0 : cur[p][c]; }
+                int rc = 0;
+                for (uint32_t t = 0; t < L.K && !rc; t++) {
+                    const int32_t c = L.idx[(size_t)k * L.K + t];
+                    if (c >= 0) { patch[t] = cur[p][c]; continue; }
+                    patch[t] = 0;
+                    if (!literal_taps) continue;
+                    cn_handle z = 0;                                                 // ElementAt: Factory.GetEncryptedVector(zeros, dense, m.Scale)
+                    rc = cn_ct_alloc(ctx[p], 1, 2, &z);
+                    if (!rc) rc = cn_encrypt(ctx[p], 0, 0, 0, z, 0, 1, nonce.fetch_add(1));
+                    if (!rc) { patch[t] = z; temps[k].emplace_back(p, z); }
+                }
+                if (rc) { note(err, rc); return; }
                 cn_handle conv = 0, r = 0;
-                int rc = cn_ct_alloc(ctx[p], 1, 2, &conv);                         // AllocateCiphertext(env)
+                rc = cn_ct_alloc(ctx[p], 1, 2, &conv);                             // AllocateCiphertext(env)
                 if (!rc) rc = cn_scalar_dot(ctx[p], patch.data(), nullptr, L.W + ((size_t)p * L.O + k) * L.K, L.K, conv, 0);
                 if (!rc && L.bias_pt) {
                     rc = cn_ct_alloc(ctx[p], 1, 2, &r);
@@ -85,6 +134,11 @@ extern "C" int rp_run(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nla
                 if (rc) { note(err, rc); return; }
             }
         });
+        if (literal_taps) {                                                         // ReleaseTemp(): Parallel.ForEach(TempVectors, v => v.Dispose())
+            std::vector<std::pair<int, cn_handle>> all;
+            for (auto &v : temps) all.insert(all.end(), v.begin(), v.end());
+            parallel_process((int)all.size(), threads, [&](int i) { note(err, cn_free(ctx[all[i].first], all[i].second)); });
+        }
         if (cur_owned) dispose(cur);                                                // BaseLayer.GetNext: m.Dispose()
         cur.swap(res); cur_owned = true;
         if (err.rc || !L.square) continue;
@@ -111,4 +165,8 @@ extern "C" int rp_run(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nla
     const uint32_t O = layers[nlayers - 1].O;
     for (int p = 0; p < nprimes; p++) memcpy(out + (size_t)p * O, cur[p].data(), (size_t)O * sizeof(cn_handle));
     return 0;
+}
+extern "C" int rp_run(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nlayers, const cn_handle *in, uint32_t n_in, cn_handle *out, int threads,
+                      char *errmsg, size_t errlen) {
+    return rp_run2(ctx, nprimes, layers, nlayers, in, n_in, out, threads, 0, 0, errmsg, errlen);
 }

@@ -56,6 +56,9 @@ def lib():
         L.rp_run.restype = C.c_int
         L.rp_run.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RpLayer), C.c_int, C.POINTER(C.c_uint64), C.c_uint32,
                              C.POINTER(C.c_uint64), C.c_int, C.c_char_p, C.c_size_t]
+        L.rp_run2.restype = C.c_int
+        L.rp_run2.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RpLayer), C.c_int, C.POINTER(C.c_uint64), C.c_uint32,
+                              C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -87,13 +90,15 @@ class Replay:
         self.n_out = int(self.arr[len(layers) - 1].O)
         self.hctx = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
 
-    def run(self, in_handles, threads):
-        """in_handles: uint64 [primes, n_in] (one count-1 handle per input column) -> uint64 [primes, O_last] handles (caller frees)"""
+    def run(self, in_handles, threads, literal_taps=False, nonce0=1):
+        """in_handles: uint64 [primes, n_in] (one count-1 handle per input column) -> uint64 [primes, O_last] handles (caller frees).
+        literal_taps: a padded convolution tap is a fresh device encryption of zero, as PoolLayer.ElementAt makes it (the contexts need
+        their public key); nonce0: first nonce of those encryptions (consecutive values are used)"""
         ih = np.ascontiguousarray(in_handles, dtype=np.uint64)
         out = np.zeros((len(self.ctxs), self.n_out), dtype=np.uint64)
         msg = C.create_string_buffer(512)
-        rc = lib().rp_run(self.hctx, len(self.ctxs), self.arr, len(self.arr), ih.ctypes.data_as(C.POINTER(C.c_uint64)), ih.shape[1],
-                          out.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads), msg, 512)
+        rc = lib().rp_run2(self.hctx, len(self.ctxs), self.arr, len(self.arr), ih.ctypes.data_as(C.POINTER(C.c_uint64)), ih.shape[1],
+                           out.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads), int(bool(literal_taps)), int(nonce0), msg, 512)
         if rc:
             raise RuntimeError("replay failed (%d): %s" % (rc, msg.value.decode()))
         return out
@@ -118,8 +123,10 @@ def replay_layers(chans, layers):
     return out
 
 
-def measure(chans, layers, threads, steps, warmup=1, defer=True):
-    """images/s of the unchanged caller on the inputs resident in chans[p].h_in; returns (ms per batch, output words [primes][O][...])"""
+def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False):
+    """images/s of the unchanged caller on the inputs resident in chans[p].h_in; returns (ms per batch, output words [primes][O][...]).
+    literal_taps: padded taps are fresh encryptions of zero (PoolLayer.cs:67-80) - the words then differ from the batched path's (fresh
+    randomness), the DECRYPTED outputs must not (decrypt_outputs)"""
     ctxs = [ch.g for ch in chans]
     rp = Replay(ctxs, replay_layers(chans, layers))
     n_in = 784
@@ -134,7 +141,7 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True):
                 for g in ctxs:
                     g.sync()
                 t0 = time.perf_counter()
-            out = rp.run(ins, threads)
+            out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000)
             if it == warmup + steps - 1:
                 for g in ctxs:
                     g.sync()
@@ -152,12 +159,26 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True):
     return 1e3 * dt / steps, words
 
 
+def decrypt_outputs(chans, words):
+    """slot values [8192, O] per prime of output ciphertext words [primes][O][...] (device decryption: the contexts hold their secret key)"""
+    res = []
+    for ch, w in zip(chans, words):
+        g = ch.g
+        h, ph = g.ct_alloc(len(w)), g.pt_alloc(len(w))
+        g.ct_upload(h, 0, w)
+        g.decrypt(h, 0, len(w), ph, 0)
+        res.append(np.ascontiguousarray(g.decode_batch(ph, 0, len(w)).T))
+        g.free(h), g.free(ph)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", default="1,8,32")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--immediate", action="store_true", help="also time the unchanged caller with every call launched on its own")
     ap.add_argument("--trained", action="store_true", help="the reference's trained weights (tests/golden/cryptonets_weights.npz)")
+    ap.add_argument("--literal-threads", default="", help="thread counts for the LITERAL caller: padded taps as fresh encryptions of zero (PoolLayer.cs:67-80)")
     args = ap.parse_args()
     from cryptonets_amd._native import Context
     from cryptonets_amd import cryptonets_mnist as cm
@@ -197,6 +218,13 @@ def main():
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
         rows.append(dict(caller="unchanged (per-ciphertext calls), deferred submission", threads=t, ms_per_batch=round(ms, 2),
                          images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same))
+    for t in [int(x) for x in args.literal_threads.split(",") if x]:
+        ms, words = measure(chans, layers, t, args.steps, literal_taps=True)
+        dec = decrypt_outputs(chans, words)
+        same = all(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t)) for d, ch in zip(dec, chans))
+        rows.append(dict(caller="unchanged, padded taps as fresh encryptions of zero (PoolLayer.ElementAt), deferred submission", threads=t, ms_per_batch=round(ms, 2),
+                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same,
+                         note="words_identical here = every decrypted slot of every output equals the integer model (fresh randomness: words cannot match)"))
     if args.immediate:
         ms, words = measure(chans, layers, 8, 1, warmup=1, defer=False)
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
