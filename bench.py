@@ -40,29 +40,46 @@ def _omp_threads(n):
     return False
 
 
-def _cpu_sample(o, layers, p, ns):
-    """seconds per 8192-image batch and plaintext prime, extrapolated from ns-sized samples of every layer (the layers' own weight rows)"""
+def _cpu_sample(o, layers, p, ns, min_seconds=0.0):
+    """seconds per 8192-image batch and plaintext prime, extrapolated from ns-sized samples of every layer (the layers' own weight rows).
+    Each sample is repeated until it has run for `min_seconds` (all-core run: every core gets several items of every layer type and works
+    for about a second per type, so that thread start-up and the tail of the dynamic schedule do not decide the figure)."""
     from cryptonets_amd import cryptonets_mnist as cm
     rng = np.random.default_rng(7)
     cts = uniform_ct_words(rng, o.q, o.n, 64)
     W = [cm.residues(L["W"], p) for L in layers]
     rows = lambda Wl, cnt: np.ascontiguousarray(Wl[np.arange(cnt) % Wl.shape[0]])
-    t0 = time.perf_counter(); o.scalar_gemm(cts[:25], rows(W[0], 4 * ns)); t_conv = (time.perf_counter() - t0) / (4 * ns)
+
+    def timed(fn, items):
+        fn()                                              # warm: arenas, page tables, OpenMP team
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds:
+                return dt / (reps * items)
     big = np.tile(cts, (14, 1))[:845]
-    t0 = time.perf_counter(); o.scalar_gemm(big, rows(W[1], ns)); t_d3 = (time.perf_counter() - t0) / ns
-    t0 = time.perf_counter(); o.scalar_gemm(big[:100], rows(W[2], ns)); t_d5 = (time.perf_counter() - t0) / ns
+    wc, w3, w5 = rows(W[0], 4 * ns), rows(W[1], ns), rows(W[2], ns)
+    t_conv = timed(lambda: o.scalar_gemm(cts[:25], wc), 4 * ns)
+    t_d3 = timed(lambda: o.scalar_gemm(big, w3), ns)
+    t_d5 = timed(lambda: o.scalar_gemm(big[:100], w5), ns)
     sq = np.tile(cts, (max(1, (2 * ns + 63) // 64), 1))[:2 * ns]
-    t0 = time.perf_counter(); o.mul_relin_batch(sq, sq); t_sq = (time.perf_counter() - t0) / (2 * ns)
+    t_sq = timed(lambda: o.mul_relin_batch(sq, sq), 2 * ns)
     return 845 * t_conv + 945 * t_sq + 100 * t_d3 + 10 * t_d5
 
 
 def cpu_baseline(cores, layers):
     """Time the CPU oracle (port of the SEAL 3.2 path the reference runs) on a bounded sample of the same workload - the same weight
     rows the GPU run used - and extrapolate to one 8192-image batch over both plaintext primes: on all host cores (OpenMP over
-    ciphertexts, mirroring ParallelProcessInEnv) and on ONE thread (SURVEY 8d asks for both)."""
-    from oracle.cno import Oracle
+    ciphertexts, mirroring ParallelProcessInEnv; large blocks kept in the per-thread malloc arenas - cno_tune_allocator - and every
+    layer type sampled for about a second per core) and on ONE thread (SURVEY 8d asks for both).  `scaling_efficiency` = the all-core rate
+    over cores x the single-thread rate."""
+    from oracle.cno import Oracle, lib as oracle_lib
     from cryptonets_amd import cryptonets_mnist as cm
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    oracle_lib().cno_tune_allocator()
     p = cm.PLAIN_PRIMES[0]
     o = Oracle(cm.N, p, dbc=10, gdbc=20)
     o.keygen(1, galois=False)
@@ -71,12 +88,16 @@ def cpu_baseline(cores, layers):
         t1 = 2 * _cpu_sample(o, layers, p, 2)
         single = {"value": round(8192.0 / t1, 2), "unit": "images/s", "cores": 1, "seconds_per_batch": round(t1, 1)}
         _omp_threads(cores)
-    ns = max(8, cores)                                # sample sizes that keep every core busy
-    total = 2 * _cpu_sample(o, layers, p, ns)
-    return {"value": 8192.0 / total, "unit": "images/s", "cores": cores, "kind": "port", "single_thread": single,
-            "sample": "oracle (C restatement of SEAL 3.2 BFV, OpenMP) timed on %d conv outputs, %d dense-845 outputs, %d dense-100 "
-                      "outputs, %d square+relinearize ciphertexts of the N=8192 k=5 workload with the run's own weight rows, extrapolated to "
-                      "845/100/10/945 x 2 primes (%.1f s per batch); single_thread: the same on one thread from 8/2/2/4 items" % (4 * ns, ns, ns, 2 * ns, total)}
+    ns = max(8, 2 * cores)                            # several items per core and layer type
+    total = 2 * _cpu_sample(o, layers, p, ns, min_seconds=1.0)
+    out = {"value": round(8192.0 / total, 1), "unit": "images/s", "cores": cores, "kind": "port", "single_thread": single,
+           "sample": "oracle (C restatement of SEAL 3.2 BFV, OpenMP over ciphertexts, malloc arenas tuned) timed on %d conv outputs, %d dense-845 outputs, "
+                     "%d dense-100 outputs, %d square+relinearize ciphertexts of the N=8192 k=5 workload with the run's own weight rows, each sample repeated "
+                     "for >= 1 s, extrapolated to 845/100/10/945 x 2 primes (%.1f s per batch); single_thread: the same on one thread from 8/2/2/4 items"
+                     % (4 * ns, ns, ns, 2 * ns, total)}
+    if single:
+        out["scaling_efficiency"] = round(out["value"] / (cores * single["value"]), 3)
+    return out
 
 
 def single_image_workload(args, rank, world, local, dist, torch, result_fd):

@@ -75,7 +75,8 @@ public:
     void unlock(Node &n);
 private:
     std::atomic<int> held{0};
-    std::atomic<int> spinners{0};      // waiters that spin; the others sleep (cn_host.cpp)
+    std::atomic<int> spinners{0};      // waiters that spin; the others sleep on wake_seq (cn_host.cpp)
+    std::atomic<int> sleepers{0}, wake_seq{0};
 };
 struct CnGuard {
     CnMutex &m; CnMutex::Node n;

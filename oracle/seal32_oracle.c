@@ -224,6 +224,16 @@ static uint64_t prod_mod_pow2_32(const mod_t *arr, uint32_t cnt, int skip) {
 
 void cno_ctx_destroy(cno_ctx *c);
 
+/* CPU-baseline fairness: every evaluator call of this file takes its megabyte-sized temporaries from malloc.  glibc hands blocks above
+ * 128 KiB to mmap / munmap - one address-space lock for the whole process and a page fault per 4 KiB on every call, which is what the
+ * all-core timing of bench.py measured in rounds 1-2 (6 x speed-up on 256 cores).  SEAL itself draws from memory pools
+ * (MemoryPoolHandle); keeping large blocks inside the per-thread arenas is the equivalent for a malloc-based restatement. */
+#include <malloc.h>
+void cno_tune_allocator(void) {
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);          /* glibc's maximum: blocks up to 32 MiB stay in the arenas */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);           /* ... and the arenas keep what they got */
+    mallopt(M_TOP_PAD, 64 << 20);
+}
 cno_ctx *cno_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc) {
     if (k == 0 || k > MAXK || n < 2 || (n & (n - 1))) return NULL;
     cno_ctx *c = calloc(1, sizeof *c);

@@ -23,9 +23,11 @@
 //   g++ -O2 -std=c++17 -shared -fPIC tools/replay_reference_calls.cpp -Iinclude -Lcryptonets_amd/lib -lcnhip -Wl,-rpath,'$ORIGIN' -pthread
 #include "../include/cnhip.h"
 #include <atomic>
-#include <condition_variable>
+#include <climits>
 #include <cstdio>
-#include <mutex>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -52,36 +54,34 @@ void note(Err &e, int rc) {
 // Utils.ParallelProcessInEnv: `threads` tasks (Task.Run on the .NET thread pool), work items handed out by an interlocked counter.  The
 // pool threads are created once and reused by every region, like the runtime's pool.
 class Pool {
-    std::mutex mu; std::condition_variable cv_go, cv_done;
     std::vector<std::thread> workers;
     const std::function<void(int)> *body = nullptr;
-    std::atomic<int> next{0};
-    int count = 0, want = 0, gen = 0, running = 0; bool stop = false;
+    std::atomic<int> next{0}, gen{0}, running{0}, want{0}, done_flag{0};
+    int count = 0; std::atomic<bool> stop{false};
+    static long fut(std::atomic<int> *a, int op, int v) { return syscall(SYS_futex, reinterpret_cast<int *>(a), op, v, nullptr, nullptr, 0); }
     void work(int id) {
         int seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_go.wait(lk, [&] { return stop || (gen != seen && id < want); });
-                if (stop) return;
-                seen = gen;
+            for (int spins = 0;; spins++) {                                   // idle pool thread: spin briefly, then sleep on the generation word
+                const int g = gen.load(std::memory_order_acquire);
+                if (stop.load()) return;
+                if (g != seen) { seen = g; if (id < want.load(std::memory_order_acquire)) break; else continue; }
+                if (spins < 200) __builtin_ia32_pause(); else fut(&gen, FUTEX_WAIT_PRIVATE, g);
             }
-            for (;;) { const int k = next.fetch_add(1) + 0; if (k >= count) break; (*body)(k); }
-            std::lock_guard<std::mutex> lk(mu);
-            if (--running == 0) cv_done.notify_one();
+            for (;;) { const int k = next.fetch_add(1); if (k >= count) break; (*body)(k); }
+            if (running.fetch_sub(1, std::memory_order_acq_rel) == 1) { done_flag.store(1, std::memory_order_release); fut(&done_flag, FUTEX_WAKE_PRIVATE, 1); }
         }
     }
 public:
-    ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_go.notify_all(); for (auto &t : workers) t.join(); }
+    ~Pool() { stop = true; gen.fetch_add(1); fut(&gen, FUTEX_WAKE_PRIVATE, INT_MAX); for (auto &t : workers) t.join(); }
     void run(int n_items, int threads, const std::function<void(int)> &fn) {
         if (n_items < 2 || threads < 2) { for (int k = 0; k < n_items; k++) fn(k); return; }
         const int nt = threads > n_items ? n_items : threads;
         while ((int)workers.size() < nt) { const int id = (int)workers.size(); workers.emplace_back([this, id] { work(id); }); }
-        std::unique_lock<std::mutex> lk(mu);
-        body = &fn; count = n_items; next = 0; want = nt; running = nt; gen++;
-        cv_go.notify_all();
-        cv_done.wait(lk, [&] { return running == 0; });
-        want = 0;
+        body = &fn; count = n_items; next.store(0); running.store(nt); done_flag.store(0); want.store(nt, std::memory_order_release);
+        gen.fetch_add(1, std::memory_order_acq_rel);
+        fut(&gen, FUTEX_WAKE_PRIVATE, INT_MAX);
+        while (!done_flag.load(std::memory_order_acquire)) fut(&done_flag, FUTEX_WAIT_PRIVATE, 0);
     }
 };
 Pool &pool() { static Pool p; return p; }
