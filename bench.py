@@ -97,6 +97,27 @@ def cpu_baseline(cores, layers):
                      % (4 * ns, ns, ns, 2 * ns, total)}
     if single:
         out["scaling_efficiency"] = round(out["value"] / (cores * single["value"]), 3)
+    # what the host grants to pure compute: the same register-only loop on 1 thread and on all of them
+    try:
+        import ctypes
+        L = oracle_lib()
+        L.cno_compute_probe.restype = ctypes.c_uint64
+        L.cno_compute_probe.argtypes = [ctypes.c_uint64]
+        _omp_threads(1)
+        t0 = time.perf_counter(); L.cno_compute_probe(20_000_000); t_one = time.perf_counter() - t0
+        _omp_threads(cores)
+        L.cno_compute_probe(1_000_000)
+        t0 = time.perf_counter(); L.cno_compute_probe(20_000_000); t_all = time.perf_counter() - t0
+        out["host_compute_speedup"] = round(cores * t_one / t_all, 1)
+        out["host_note"] = ("a register-only loop runs %.0f x faster on %d OpenMP threads than on one: the ceiling for any all-core figure on this host"
+                            % (cores * t_one / t_all, cores))
+        try:
+            out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+        except OSError:
+            pass
+    except Exception as ex:
+        out["host_compute_speedup"] = None
+        out["host_note"] = str(ex)[:120]
     return out
 
 
@@ -128,7 +149,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
     else:
         w = dict(zip(("Weights_0", "Weights_1", "Biases_2", "Weights_3", "Biases_3"), cm.reference_weights()))
         images = cm.synthetic_images(args.warmup + args.steps, seed=1000 + (rank if args.shard == "images" else 0))
-    results, dt, verified = [], 0.0, None
+    results, dt, verified, kept = [], 0.0, None, None
     if active:
         Factory = EncryptedSealBfvFactory(**parms)
         env = Factory.AllocateComputationEnv()
@@ -168,11 +189,16 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
         if not active:
             continue
         m = encrypted[it]
-        for L in layers[2:]:
+        for li, L in enumerate(layers[2:]):
             m2 = L.Apply(m)
             if m2 is not m:
-                m.Dispose()
+                if m is kept:
+                    pass                                  # (the big dense layer's output of the last image: decrypted after the timed window)
+                else:
+                    m.Dispose()
             m = m2
+            if cifar and li == 3 and it == args.warmup + args.steps - 1:
+                kept = m                                  # layers[5] = LLDenseLayer 5488 x 16268
         sync()
         if it >= args.warmup:
             results.append(m)
@@ -204,6 +230,21 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
             flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             verified = bool(flag.item())
+    if cifar and active and kept is not None:
+        # LoLa-CIFAR with the reference's 8 limbs keeps a positive noise budget through the 5488 x 16268 dense layer but not through the
+        # whole network (DESIGN: a property of the reference's operation sequence): the measured run is verified THERE - all 5488 outputs of
+        # the last timed image, every plaintext prime, against the exact integer model
+        verified = True
+        img = images[args.warmup + args.steps - 1]
+        for p_, a, e in zip(parms["primes"], kept.GetColumn(0).eVectors, env.Environments):
+            got = [int(v) for v in a._decrypt_ints(e)]
+            want = [int(v) for v in networks.lola_cifar_dense_model(reader, layers[2], W, B, img, p_)]
+            verified = verified and got == want
+        kept.Dispose()
+        if dist is not None:
+            flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
     for m in results:
         m.Dispose()
     if rank == 0:
@@ -213,6 +254,9 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak" if args.shard == "images" else "strong",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic images" + (", synthetic weights of the reference's shapes" if cifar else ", the reference's trained weights"),
                "verified_against_integer_model": verified,
+               "verified_what": ("all 5488 outputs of the 5488 x 16268 dense layer of the last timed image, every plaintext prime (the 8-limb network has no "
+                                 "noise budget left behind its second squaring - a property of the reference's operation sequence)") if cifar
+                                else "the 10 logits of every timed image, CRT-joined over the plaintext primes",
                "config": {"workload": "%s (BASELINE config %d), one image per step and %s" % (name, 5 if cifar else 4, "rank" if args.shard == "images" else "job"),
                           "plaintext_primes": all_primes, "sharding": args.shard,
                           "parallelism": ("images round-robin over %d ranks, full replica per rank" % world) if args.shard == "images"

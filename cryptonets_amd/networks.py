@@ -129,6 +129,38 @@ def LoLaCifar(Factory, reader, Weights, Biases, timing=True):
     return TimingLayer(Source=d6, StopCounters=["Inference-Time"]) if timing else d6
 
 
+def lola_cifar_dense_model(reader, conv_layer, Weights, Biases, image, p):
+    """Exact integer model mod p of LoLa-CIFAR through its big dense layer (conv 83 x (3x8x8) -> square -> dense 5488 x 16268): the 5488 values
+    a decryption of that layer's output must show (tests/test_lola_cifar.py, bench.py --workload cifar).  `image`: 3072 pixel values 0..255."""
+    from .convolution import ConvolutionEngine
+
+    def mulmod(a, b, pp):
+        b = np.asarray(b, dtype=np.uint64)
+        hi = (a * (b >> np.uint64(20))) % pp
+        return (hi * np.uint64(1 << 20) + a * (b & np.uint64(0xFFFFF))) % pp
+    w0, w1 = Weights[0], Weights[1]
+    b0, b1 = Biases[0], Biases[1]
+    eng = ConvolutionEngine([83, 14, 14], [83, 10, 10], [83, 2, 2], Upperpadding=[0, 4, 4], Lowerpadding=[0, 4, 4], MapCount=[112, 1, 1])
+    W1 = eng.GetDenseWeights(w1).reshape(5488, 16268)
+    x = np.rint(np.asarray(image, dtype=np.float64) / 256.0 * 8.0).astype(np.int64)
+    g = reader.engine.gather_table()                                # [196, 192]
+    patches = np.where(g >= 0, x[np.maximum(g, 0)], 0)
+    W0i = np.rint(conv_layer.engine.weight_windows(w0, 192) * 256).astype(np.int64)
+    B0i = np.rint(np.asarray(b0) * 8 * 256).astype(np.int64)
+    act1 = (patches @ W0i.T + B0i).T.reshape(-1)                    # map-major stacking: 83 x 196
+    s1 = (8 * 256) ** 2
+    W1i = np.rint(W1 * 512).astype(np.int64)
+    B1i = [int(round(float(b) * s1 * 512)) for b in eng.GetDenseBias(b1)]
+    pp = np.uint64(p)
+    a1 = np.mod(act1, int(p)).astype(np.uint64)
+    a1 = mulmod(a1, a1, pp)
+    acc = np.zeros(5488, dtype=np.uint64)
+    W1p = np.mod(W1i, int(p)).astype(np.uint64)
+    for c0 in range(0, 16268, 512):
+        acc = (acc + (mulmod(W1p[:, c0:c0 + 512], a1[None, c0:c0 + 512], pp) % pp).sum(axis=1) % pp) % pp
+    return (acc + np.array([b % int(p) for b in B1i], dtype=np.uint64)) % pp
+
+
 def lola_reader(name, FileName=None, Factory=None):
     """the input layer each LoLa variant reads MNIST with (LoLaCryptonets.cs:131-137,212-223,294-305)"""
     if name == "LoLaLarge":                                      # :346-357: pixels are NOT normalised here

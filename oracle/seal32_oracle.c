@@ -234,6 +234,20 @@ void cno_tune_allocator(void) {
     mallopt(M_TRIM_THRESHOLD, 1 << 30);           /* ... and the arenas keep what they got */
     mallopt(M_TOP_PAD, 64 << 20);
 }
+/* How many cores does this process really get?  Every OpenMP thread runs the same register-only loop of modular multiplications; the caller
+ * times the call with 1 thread and with all of them: (threads x t_1) / t_all is the parallel speed-up the host grants to compute that touches
+ * no memory at all - the ceiling for the all-core CPU baseline (a container with a CPU quota below its visible core count shows it here). */
+uint64_t cno_compute_probe(uint64_t iters) {
+    uint64_t total = 0;
+    #pragma omp parallel reduction(+:total)
+    {
+        mod_t m; mod_init(&m, 0x7fffffd8001ull);
+        uint64_t x = 0x123456789abull, y = 0x3243f6a8885ull;
+        for (uint64_t i = 0; i < iters; i++) { x = mulmod(x, y, &m); y = addmod(y, x, m.q); }
+        total += x ^ y;
+    }
+    return total;
+}
 cno_ctx *cno_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc) {
     if (k == 0 || k > MAXK || n < 2 || (n & (n - 1))) return NULL;
     cno_ctx *c = calloc(1, sizeof *c);

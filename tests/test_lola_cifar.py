@@ -54,28 +54,14 @@ def test_lola_cifar_shapes_end_to_end(limbs):
         a5v = a5.Apply(out4)
         out = d6.Apply(a5v)
         a5v.Dispose()
-    # integer model modulo each plaintext prime
-    x = np.rint(img / 256.0 * 8.0).astype(np.int64)
-    g = reader.engine.gather_table()                                # [196, 192]
-    patches = np.where(g >= 0, x[np.maximum(g, 0)], 0)              # [196, 192]
-    W0i = np.rint(c1.engine.weight_windows(w0, 192) * 256).astype(np.int64)     # window order = Offsets order
-    B0i = np.rint(b0 * 8 * 256).astype(np.int64)
-    act1 = (patches @ W0i.T + B0i).T.reshape(-1)                    # map-major stacking: 83 x 196
-    s1 = (8 * 256) ** 2
-    W1i = np.rint(W1 * 512).astype(np.int64)
-    B1i = [int(round(float(b) * s1 * 512)) for b in eng.GetDenseBias(b1)]
+    # integer model modulo each plaintext prime (networks.lola_cifar_dense_model: also what bench.py --workload cifar verifies with)
     W2i = np.rint(w2.reshape(10, 5488) * 512).astype(np.int64)
+    s1 = (8 * 256) ** 2
     s2 = (s1 * 512) ** 2
     B2i = [int(round(float(b) * s2 * 512)) for b in b2]
     for i, e in enumerate(env.Environments):
         p = np.uint64(e.plainmodulusValue)
-        a1 = np.mod(act1, int(p)).astype(np.uint64)
-        a1 = mulmod(a1, a1, p)
-        acc = np.zeros(5488, dtype=np.uint64)
-        W1p = np.mod(W1i, int(p)).astype(np.uint64)
-        for c0 in range(0, 16268, 512):
-            acc = (acc + (mulmod(W1p[:, c0:c0 + 512], a1[None, c0:c0 + 512], p) % p).sum(axis=1) % p) % p
-        a2 = (acc + np.array([b % int(p) for b in B1i], dtype=np.uint64)) % p
+        a2 = networks.lola_cifar_dense_model(reader, c1, [w0, w1, w2], [b0, b1, b2], img, int(p))
         got4 = out4.GetColumn(0).eVectors[i]._decrypt_ints(e)
         assert len(got4) == 5488 and [int(v) for v in got4] == [int(v) for v in a2], "dense 5488x16268, prime %d" % int(p)
         if out is None:
