@@ -28,6 +28,22 @@ def uniform_ct_words(rng, q, n, count, polys=2):
     return out.reshape(count, -1)
 
 
+def effective_cores():
+    """(cores the process may use at once, visible logical CPUs, cgroup quota string): a container with a CPU quota (cgroup v2 cpu.max) below its
+    visible CPU count gets quota / period CPUs' worth of time - the number a runtime's processor count reports (.NET's Environment.ProcessorCount
+    honours it) and the only honest `cores` for an all-core CPU figure"""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+        q, per = quota.split()
+        if q != "max":
+            return max(1, min(visible, -(-int(q) // int(per)))), visible, quota
+    except (OSError, ValueError):
+        pass
+    return visible, visible, quota
+
+
 def _omp_threads(n):
     """OpenMP team size of the oracle library for the parallel regions that follow (omp_set_num_threads of the loaded runtime)"""
     import ctypes
@@ -95,6 +111,8 @@ def cpu_baseline(cores, layers):
                      "%d dense-100 outputs, %d square+relinearize ciphertexts of the N=8192 k=5 workload with the run's own weight rows, each sample repeated "
                      "for >= 1 s, extrapolated to 845/100/10/945 x 2 primes (%.1f s per batch); single_thread: the same on one thread from 8/2/2/4 items"
                      % (4 * ns, ns, ns, 2 * ns, total)}
+    eff, visible, quota = effective_cores()
+    out["host"] = {"visible_cpus": visible, "cgroup_cpu_max": quota, "effective_cores": eff}
     if single:
         out["scaling_efficiency"] = round(out["value"] / (cores * single["value"]), 3)
     # what the host grants to pure compute: the same register-only loop on 1 thread and on all of them
@@ -111,10 +129,6 @@ def cpu_baseline(cores, layers):
         out["host_compute_speedup"] = round(cores * t_one / t_all, 1)
         out["host_note"] = ("a register-only loop runs %.0f x faster on %d OpenMP threads than on one: the ceiling for any all-core figure on this host"
                             % (cores * t_one / t_all, cores))
-        try:
-            out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
-        except OSError:
-            pass
     except Exception as ex:
         out["host_compute_speedup"] = None
         out["host_note"] = str(ex)[:120]
@@ -261,6 +275,20 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                           "plaintext_primes": all_primes, "sharding": args.shard,
                           "parallelism": ("images round-robin over %d ranks, full replica per rank" % world) if args.shard == "images"
                                          else ("plaintext primes dealt to %d ranks, CRT join of decrypted residues on the client" % world)}}
+        if not cifar and world == 1 and not args.no_unchanged_caller:
+            # the UNCHANGED per-call sequence of the reference's LL layers (one vector method per row / column / map), recorded at the C ABI and
+            # replayed from C++ (tools/lola_unchanged_caller.py): ms per image next to the batched conveniences measured the same way
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import lola_unchanged_caller
+                rows = lola_unchanged_caller.measure(name, reps=max(5, min(20, args.steps)), device=local)
+                pick = lambda lit, host: [r for r in rows if r["pattern"].startswith("unchanged") == lit and r["host"].startswith(host)][0]
+                lit, bat = pick(True, "C++ replay, one host thread"), pick(False, "C++ replay, one host thread")
+                out["unchanged_caller"] = {"ms_per_image": lit["ms_per_image"], "logits_exact": lit["logits_exact"], "calls_per_prime": lit["calls_per_prime"],
+                                           "batched_from_the_same_host_ms": bat["ms_per_image"], "batched_calls_per_prime": bat["calls_per_prime"],
+                                           "frac_of_batched": round(bat["ms_per_image"] / lit["ms_per_image"], 3), "all_rows": rows}
+            except Exception as ex:
+                out["unchanged_caller"] = {"error": str(ex)[:300]}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
@@ -346,7 +374,8 @@ def main():
     ap.add_argument("--weights", choices=("trained", "synthetic"), default="trained",
                     help="trained: the reference's CryptoNets/Weights.cs (shipped as package data); synthetic: random-init weights of the same shapes")
     ap.add_argument("--no-unchanged-caller", action="store_true", help="skip the per-ciphertext-call replay of the reference's unchanged layers")
-    ap.add_argument("--caller-threads", type=int, default=0, help="threads of the unchanged-caller replay; 0 = all host cores (the reference's Defaults.ThreadCount)")
+    ap.add_argument("--caller-threads", type=int, default=0, help="threads of the unchanged-caller replay; 0 = the processor count a runtime reports here "
+                    "(cgroup CPU quota honoured) - the reference's Defaults.ThreadCount = Environment.ProcessorCount")
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
     ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "1")),
                     help="1: the plaintext-prime channels run half a batch apart (key switch of one beside the HBM-bound layers of the other)")
@@ -556,7 +585,7 @@ def main():
             import replay_reference_calls as rp
             ref_words = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
             batched_ms = 1e3 * dt / args.steps
-            nthreads = args.caller_threads or (os.cpu_count() or 1)
+            nthreads = args.caller_threads or effective_cores()[0]
             reps = max(2, min(args.steps, 5))
             lms, lwords = rp.measure(chans, layers, nthreads, reps, warmup=1, literal_taps=True)
             dec = rp.decrypt_outputs(chans, lwords)
@@ -566,7 +595,8 @@ def main():
                          "frac_of_batched": round(batched_ms / lms, 3), "verified_against_integer_model": lok, "verified_slots": 8192 * 10 * len(chans),
                          "pattern": "PoolLayer.Apply: per (map, corner) [cn_ct_alloc + cn_encrypt(zero) per padded tap] + cn_scalar_dot (K = 25 real handles) + "
                                     "cn_add_plain + cn_free, ReleaseTemp: cn_free per zero encryption; SquareActivation: per column cn_mul_relin(count 1); every "
-                                    "ciphertext its own handle; 2 x (2855 + 3 x 645) calls per batch; cn_set_option(defer, 1); threads = Defaults.ThreadCount",
+                                    "ciphertext its own handle; 2 x (2855 + 3 x 645) calls per batch; cn_set_option(defer, 1); threads = Defaults.ThreadCount = processor count "
+                                    "(visible CPUs %d, cgroup quota %s)" % (effective_cores()[1], effective_cores()[2]),
                          "skipped_taps": {"value": round(8192e3 / ums, 1), "ms_per_step": round(ums, 2), "threads": 4, "frac_of_batched": round(batched_ms / ums, 3),
                                           "words_identical_to_batched": bool(all(np.array_equal(a, b) for a, b in zip(uwords, ref_words)))}}
         except Exception as ex:
@@ -594,7 +624,7 @@ def main():
                                              "unit": "GB/s", "frac": round(nbytes / (dt / args.steps) / 8e12, 4)})(
                    2 * (784 + 845 + 2 * 845 + 845 + 100 + 2 * 100 + 100 + 10) * 2 * g.k * g.n * 8)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1, layers)
+            out["cpu_baseline"] = cpu_baseline(effective_cores()[0], layers)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

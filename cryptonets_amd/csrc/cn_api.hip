@@ -30,7 +30,7 @@ struct DOp {
 struct DeferQueue {
     std::vector<DOp> ops;
     std::vector<uint64_t> addr, wt;
-    struct Haz { int32_t w = -1, r = -1, wop = -1; uint32_t readers = 0; };   // level of the last writer / deepest reader since / index of the writing op / readers since
+    struct Haz { int32_t w = -1, r = -1, wop = -1; uint32_t readers = 0; int32_t hd = 0; };   // level of the last writer / deepest reader since / index of the writing op / readers since / heavy depth of the value (defer_push)
     // address -> hazard record: open addressing, cleared by bumping the epoch (a dense-layer call touches 845 records)
     struct HazMap {
         struct E { const uint64_t *key = nullptr; uint32_t epoch = 0; Haz v; };
@@ -1532,20 +1532,16 @@ extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t co
 // full, and before every entry point that is not deferrable (cn_sync, downloads, rotations, key changes ...).  Results are the same
 // words as the immediate calls - every operation is exact modular arithmetic, batching changes no value.  Errors of a flush (HIP
 // failures) surface at the call that triggered it; argument errors are still reported by the call that made them.
-// A flush is triggered by demand (any entry point that needs results), by a full queue, and - so that the device does not wait for the
-// callers - whenever the context's stream has RUN DRY while at least DEFER_FLUSH_MIN calls are queued (looked at every DEFER_POLL calls:
-// one hipStreamQuery).  While the device is busy the queue keeps growing across layers and levels: the launches get bigger, never
-// smaller.  (Rounds 2 / 3a flushed "when a deeper dependency level opens and 64 calls wait" - a stand-in for "the previous layer is
-// complete" that broke once a layer had dependent calls of its own: with the literal padded taps (encryption -> scalar product -> plain
-// addition per item) several caller threads interleave the levels and the layer was cut into dozens of small launches: 0.47 of the
-// batched rate at 4-32 threads against 0.84 at one.)
-static const size_t DEFER_FLUSH_MIN = 256, DEFER_POLL = 64, DEFER_MAX_OPS = 32768;
-static bool stream_idle(cn_ctx *ctx) {
-    const hipError_t e = hipStreamQuery(ctx->stream);
-    if (e == hipSuccess) return true;
-    (void)hipGetLastError();                                   // hipErrorNotReady is reported through the sticky error as well
-    return false;
-}
+// A flush is triggered by demand (any entry point that needs results), by a full queue, and at LAYER BOUNDARIES, so that the device works on
+// one layer while the callers queue the next.  A boundary is recognised by the "heavy depth" of a value: 0 for anything that was not
+// produced by a queued call, and for fresh encryptions; a scalar product (DenseMatrixBySparseVectorMultiply) or a Multiply + Relinearize
+// produces depth 1 + the deepest of its inputs, additions pass the depth of their inputs on.  A heavy call that would reach depth 2 reads
+// the result of another queued heavy call: the layer that produced it is complete (its callers have returned) - everything queued is
+// launched, if at least DEFER_FLUSH_MIN calls wait.  (Round 2 used the plain dependency level for this; with the literal padded taps -
+// encryption -> scalar product -> plain addition inside ONE layer - several caller threads interleave those levels and the layer was cut
+// into dozens of small launches: 0.47 of the batched rate at 4-32 threads against 0.84 at one.  Flushing whenever the stream had run dry
+// instead cut the first layers into 256-call pieces and lost the bias folding: 0.85 against 0.93.)
+static const size_t DEFER_FLUSH_MIN = 64, DEFER_MAX_OPS = 32768;
 static DeferQueue *cn_defer_new() { return new DeferQueue(); }
 static void cn_defer_delete(DeferQueue *q) { delete q; }
 static bool cn_defer_pending(cn_ctx *ctx) { return ctx->dq && !ctx->dq->ops.empty(); }
@@ -1565,8 +1561,12 @@ static int32_t defer_level(DeferQueue *q, const uint64_t *const *ins, uint32_t n
 static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t nin) {
     DeferQueue *q = ctx->dq;
     int32_t lv = defer_level(q, ins, nin, op.out);
-    if (q->ops.size() >= DEFER_MAX_OPS || (q->ops.size() >= DEFER_FLUSH_MIN && q->ops.size() % DEFER_POLL == 0 && stream_idle(ctx))) {
-        // the device has nothing left to do (or the queue is full): launch what is queued, the callers go on queueing behind it
+    const bool heavy = op.type == DOP_GEMM1 || op.type == DOP_MULRELIN;
+    int32_t hd = 0;
+    for (uint32_t i = 0; i < nin; i++) if (ins[i]) { const DeferQueue::Haz *h = q->haz.find(ins[i]); if (h) hd = std::max(hd, h->hd); }
+    hd += heavy ? 1 : 0;
+    if (q->ops.size() >= DEFER_MAX_OPS || (heavy && hd >= 2 && q->ops.size() >= DEFER_FLUSH_MIN)) {
+        // a layer boundary (or a full queue): launch what is queued, the callers go on queueing the next layer behind it
         std::vector<uint64_t> ta, tw;
         if (op.type == DOP_GEMM1) {                     // the terms of this call sit at the end of the term arrays: keep them over the flush
             ta.assign(q->addr.begin() + op.terms, q->addr.end()); tw.assign(q->wt.begin() + op.terms, q->wt.end());
@@ -1574,7 +1574,7 @@ static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t 
         }
         CHECK(cn_defer_flush(ctx));
         if (op.type == DOP_GEMM1) { op.terms = 0; q->addr = ta; q->wt = tw; }
-        lv = 0;
+        lv = 0; hd = heavy ? 1 : 0;
     }
     op.level = lv;
     const int32_t me = (int32_t)q->ops.size();
@@ -1584,7 +1584,7 @@ static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t 
         h.r = std::max(h.r, lv); h.readers++;
     }
     DeferQueue::Haz &ho = q->haz[op.out];
-    ho.w = lv; ho.r = -1; ho.wop = me; ho.readers = 0;
+    ho.w = lv; ho.r = -1; ho.wop = me; ho.readers = 0; ho.hd = hd;
     q->maxlevel = std::max(q->maxlevel, lv);
     q->ops.push_back(op);
     return 0;

@@ -28,6 +28,19 @@ class EMatrixFormat(enum.Enum):
     RowMajor = 1
 
 
+
+# LITERAL = True: the matrix- and layer-level conveniences of this mirror (RowsDotProduct, MulColumnsByPlain, the batched LLPoolLayer /
+# MulManySparse forms) are switched off and every layer takes the per-vector path the reference's UNCHANGED files take - one
+# AtomicSealBfvEncryptedVector method call per row / column / map (EncryptedSealBfvMatrix.cs:79-120, LLPoolLayer.cs, LLInterleaveLayer.cs,
+# LLDenseLayer.cs).  That is the call sequence the C# twin receives; tools/call_trace.py records it at the C ABI and
+# tools/replay_call_trace.cpp replays it from native code (bench.py --workload lola: `unchanged_caller`).  Same ciphertext words.
+LITERAL = bool(int(os.environ.get("CN_LITERAL_CALLS", "0")))
+
+
+def set_literal(on):
+    global LITERAL
+    LITERAL = bool(on)
+
 class ClientCrypto:
     """The client-side SEAL objects of AtomicSealBfvEncryptedEnvironment.SetKeys (AtomicSealBfvVector.cs:62-74):
     KeyGenerator / Encryptor / Decryptor for ONE plaintext modulus."""
@@ -1176,7 +1189,7 @@ class EncryptedSealBfvMatrix:
         if self.Format != EMatrixFormat.ColumnMajor:
             raise Exception("Expecting ColumnMajor matrix")
         cols = self.leVectors
-        ok = all(c.IsEncrypted and c.Format == EVectorFormat.dense and all(a.encData.count == 1 for a in c.eVectors) and c.Dim == cols[0].Dim
+        ok = (not LITERAL) and all(c.IsEncrypted and c.Format == EVectorFormat.dense and all(a.encData.count == 1 for a in c.eVectors) and c.Dim == cols[0].Dim
                  for c in cols) and (not plain.IsEncrypted) and plain.Format == EVectorFormat.dense and plain.Dim == cols[0].Dim \
             and all(a.plainDense is not None and a.plainDense.count == 1 and not a.plainZero[0] for a in plain.eVectors)
         if not ok:
@@ -1222,7 +1235,7 @@ class EncryptedSealBfvMatrix:
         return cache[i]
 
     def _can_batch_rows(self, v):
-        return (self.Format == EMatrixFormat.RowMajor and v.IsEncrypted and v.Format == EVectorFormat.dense
+        return (not LITERAL and self.Format == EMatrixFormat.RowMajor and v.IsEncrypted and v.Format == EVectorFormat.dense
                 and all(a.encData.count == 1 for a in v.eVectors)
                 and all((not r.IsEncrypted) and r.Format == EVectorFormat.dense and r.Dim == v.Dim
                         and all(a.plainDense is not None and a.plainDense.count == 1 and not a.plainZero[0] for a in r.eVectors)

@@ -700,7 +700,8 @@ class LLPoolLayer(BaseLayer):
             vec.RegisterScale(vec.Scale * m.ColumnCount)
             return self.Factory.GetMatrix([vec], EMatrixFormat.ColumnMajor, CopyVectors=False)
         maps, K = len(self.biasVectors), m.ColumnCount
-        batched = (hasattr(m, "leVectors") and all(c.IsEncrypted and c.Format == EVectorFormat.dense for c in m.leVectors)
+        from . import hewrapper as _hw
+        batched = (not _hw.LITERAL and hasattr(m, "leVectors") and all(c.IsEncrypted and c.Format == EVectorFormat.dense for c in m.leVectors)
                    and all(a.encData.count == 1 for c in m.leVectors for a in c.eVectors) and all(any(w) for w in self.weightInts))
         if batched:
             # the `maps` (Mul + Add) pairs as ONE scalar GEMM with dense bias plaintexts per plaintext prime, planned once

@@ -242,3 +242,44 @@ def test_failed_recording_leaves_the_contexts_usable():
     assert np.array_equal(sq.Decrypt(env), np.ones((4, 40)))
     sq2 = m.ElementWiseMultiply(m, env)
     assert np.array_equal(sq2.Decrypt(env), np.arange(8, dtype=float).reshape(4, 2) ** 2)
+
+
+@pytest.mark.parametrize("backend", [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_lola_literal_call_sequence_gives_the_same_words(backend):
+    """hewrapper.LITERAL: every layer takes the per-vector path of the reference's unchanged files (one DotProduct per row, one
+    PointwiseMultiply per column, one Mul + Add per map) instead of this mirror's batched conveniences - the call sequence the C# twin
+    receives.  Same input ciphertexts -> the SAME output ciphertext words, and far more evaluator calls."""
+    from cryptonets_amd import hewrapper
+    primes = PRIMES if backend == "gpu" else PRIMES[:1]
+    Factory = make_factory(backend, primes=primes, n=8192, galois=True)
+    env = Factory.AllocateComputationEnv()
+    net = lola(Factory, image(11))
+    net.PrepareNetwork()
+    layers = list(networks._chain(net))[::-1]
+    enc = layers[1].Apply(layers[0].GetNext())
+
+    def run():
+        m = enc
+        for L in layers[2:]:
+            m2 = L.Apply(m)
+            if m2 is not m and m is not enc:
+                m.Dispose()
+            m = m2
+        col = m.GetColumn(0)
+        words = [e.ctx.ct_download(a.encData.h, a.encData.first, a.encData.count) for a, e in zip(col.eVectors, env.Environments)]
+        m.Dispose()
+        return words
+    stats = lambda: sum(e.ctx.stats()["kernel_launches"] for e in env.Environments) if backend == "gpu" else 0
+    s0 = stats()
+    batched = run()
+    s1 = stats()
+    hewrapper.set_literal(True)
+    try:
+        literal = run()
+    finally:
+        hewrapper.set_literal(False)
+    s2 = stats()
+    for a, b in zip(batched, literal):
+        assert np.array_equal(a, b)
+    if backend == "gpu":
+        assert s2 - s1 > s1 - s0                    # the per-vector sequence is made of more, smaller launches

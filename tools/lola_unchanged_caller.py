@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""The UNCHANGED caller of the LoLa networks through the C ABI: the per-call sequence the reference's unchanged EncryptedSealBfvMatrix /
+LL*Layer files issue (one AtomicSealBfvEncryptedVector method per row / column / map - `hewrapper.LITERAL`), recorded once
+(tools/call_trace.py) and replayed from C++ (tools/replay_call_trace.cpp), next to the same for this mirror's batched conveniences.
+
+    python tools/lola_unchanged_caller.py [LoLa|LoLaSmall] [--reps 20]
+
+Prints one JSON object per (call pattern, host) with ms per image; every replayed result is decrypted and compared with the exact integer
+logits of the recorded image.  (bench.py --workload lola carries the same figures as `unchanged_caller`.)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _apply_chain(layers, enc):
+    """the evaluated layers of one inference (encrypted input -> encrypted logits), intermediates disposed like BaseLayer.GetNext does"""
+    m = enc
+    for L in layers[2:]:
+        m2 = L.Apply(m)
+        if m2 is not m:
+            m.Dispose()
+        m = m2
+    return m
+
+
+def measure(name="LoLa", reps=20, device=0, image_seed=1234):
+    import call_trace
+    from cryptonets_amd import cryptonets_mnist as cm, hewrapper, networks
+    from cryptonets_amd.distributed import crt_join_over_ranks
+    from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
+    parms = dict(networks.FACTORY_PARAMETERS[name], device=device)
+    primes = list(parms["primes"])
+    w = dict(zip(("Weights_0", "Weights_1", "Biases_2", "Weights_3", "Biases_3"), cm.reference_weights()))
+    img = cm.synthetic_images(1, seed=image_seed)[0]
+    tsv = "/tmp/lola_unchanged_%d.tsv" % os.getpid()
+    with open(tsv, "w") as f:
+        for _ in range(64):
+            f.write("7\t784\t" + "\t".join("%d:%d" % (i, int(img[i])) for i in np.nonzero(img)[0]) + "\n")
+    Factory = EncryptedSealBfvFactory(**parms)
+    env = Factory.AllocateComputationEnv()
+    reader = networks.lola_reader(name, tsv, Factory=Factory)
+    net = networks.LOLA_NETWORKS[name](Factory, reader, w)
+    net.PrepareNetwork()
+    layers = list(networks._chain(net))[::-1]
+    ctxs = [e.ctx for e in env.Environments]
+    M = 1
+    for p in primes:
+        M *= p
+    want = [int(v) for v in cm.centred(cm.int_logits(w, img), M)]
+
+    def fresh():
+        return layers[1].Apply(layers[0].GetNext())
+
+    def sync():
+        for c in ctxs:
+            c.sync()
+
+    def logits_of_handles(handles):
+        res = {}
+        for p, c, h in zip(primes, ctxs, handles):
+            ph = c.pt_alloc(1)
+            c.decrypt(h, 0, 1, ph, 0)
+            res[p] = np.asarray(c.decode_batch(ph, 0, 1)[0][:10], dtype=object)
+            c.free(ph)
+        return [int(v) for v in crt_join_over_ranks(res, primes, None)]
+
+    rows = []
+    for literal in (False, True):
+        hewrapper.set_literal(literal)
+        try:
+            for _ in range(2):                                     # warm: masks / plaintext forms cached, arenas sized, pool filled
+                _apply_chain(layers, fresh()).Dispose()
+            sync()
+            encs = [fresh() for _ in range(reps)]
+            sync()
+            t0 = time.perf_counter()
+            outs = []
+            for e in encs:
+                outs.append(_apply_chain(layers, e))
+                sync()
+            py_ms = 1e3 * (time.perf_counter() - t0) / reps
+            ok = all(logits_of_handles([a.encData.h for a in o.GetColumn(0).eVectors]) == want for o in outs[-2:])
+            for o in outs:
+                o.Dispose()
+            label = "unchanged per-call sequence (hewrapper.LITERAL)" if literal else "batched conveniences of the mirror (RowsDotProduct, MulColumnsByPlain, MulManySparse)"
+            rows.append(dict(pattern=label, host="python mirror (ctypes)", ms_per_image=round(py_ms, 2), logits_exact=bool(ok)))
+            # ---- record one inference at the C ABI, replay it from C++
+            enc = fresh()
+            sync()
+            recs = [call_trace.Recorder(c).start() for c in ctxs]
+            try:
+                out = _apply_chain(layers, enc)
+            finally:
+                for r in recs:
+                    r.stop()
+            col = out.GetColumn(0)
+            rids = [r.ids[int(a.encData.h)] for r, a in zip(recs, col.eVectors)]
+            assert all(a.encData.count == 1 and a.encData.first == 0 and rid[0] == "new" for a, rid in zip(col.eVectors, rids))
+            calls = [len(r.records) for r in recs]
+            out.Dispose()
+            for mode, host in ((0, "C++ replay, one host thread, contexts call by call"), (1, "C++ replay, one thread per plaintext prime, joined after every call"),
+                               (2, "C++ replay, one free-running thread per plaintext prime")):
+                ms, handles = call_trace.replay(recs, reps, mode, rids, warmup=2)
+                ok = logits_of_handles(handles) == want
+                for c, h in zip(ctxs, handles):
+                    c.free(h)
+                rows.append(dict(pattern=label, host=host, ms_per_image=round(ms, 2), logits_exact=bool(ok), calls_per_prime=calls[0]))
+        finally:
+            hewrapper.set_literal(False)
+    return rows
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("network", nargs="?", default="LoLa")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    for r in measure(a.network, a.reps):
+        print(json.dumps(r))
