@@ -2,6 +2,7 @@
 #include "cn_runtime.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <sched.h>
 
 static thread_local char g_err[512] = "";
@@ -32,12 +33,49 @@ extern "C" const char *cn_last_error(void) { return g_err; }
 #include <unistd.h>
 static const int MAX_SPINNERS = 3;
 static long futex(std::atomic<int> *addr, int op, int val, const struct timespec *to) { return syscall(SYS_futex, reinterpret_cast<int *>(addr), op, val, to, nullptr, 0); }
+// Owner bias: a caller thread issues BURSTS of calls (one work item of PoolLayer.Apply is alloc + scalar product + alloc + plain addition + free,
+// plus an alloc + encryption per padded tap: 5-15 calls a few hundred nanoseconds apart).  Every critical section works on the same few
+// cache lines (queue tails, hazard table, handle table, counters); if the lock changes hands between two calls of a burst those lines
+// cross the chip twice per call.  So for `grace` TSC cycles after a release the lock can only be re-taken by the thread that released it;
+// everybody else keeps waiting.  The owner's next call finds the lock and the data in its own cache; when it does not come back (the item
+// is finished) the others lose the grace period once per item.  A thread that re-acquires more than MAX_BURST times in a row loses the
+// privilege for one hand-over (no starvation by a polling loop).  CN_LOCK_GRACE_NS sets the period (default 400; 0 = off).
+#include <x86intrin.h>
+static const uint32_t MAX_BURST = 256;
+static std::atomic<uint32_t> g_next_tid{1};
+static thread_local uint32_t t_tid = 0;
+static uint32_t my_tid() { if (!t_tid) t_tid = g_next_tid.fetch_add(1, std::memory_order_relaxed); return t_tid; }
+static uint64_t grace_cycles() {
+    static const uint64_t g = [] {
+        const char *e = getenv("CN_LOCK_GRACE_NS");
+        const double ns = e ? atof(e) : 400.0;
+        if (ns <= 0) return (uint64_t)0;
+        struct timespec a, b;                                          // TSC cycles per nanosecond, measured over ~2 ms
+        clock_gettime(CLOCK_MONOTONIC, &a); const uint64_t c0 = __rdtsc();
+        do clock_gettime(CLOCK_MONOTONIC, &b); while ((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec) < 2000000);
+        const uint64_t c1 = __rdtsc();
+        const double per_ns = (double)(c1 - c0) / (double)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec));
+        return (uint64_t)(ns * per_ns);
+    }();
+    return g;
+}
+bool CnMutex::try_take(uint32_t me) {
+    if (held.load(std::memory_order_relaxed)) return false;
+    const uint64_t g = grace_cycles();
+    if (g && last_owner.load(std::memory_order_relaxed) != me && burst.load(std::memory_order_relaxed) < MAX_BURST &&
+        __rdtsc() - released_at.load(std::memory_order_relaxed) < g) return false;                 // the releasing thread may still come back
+    if (held.exchange(1, std::memory_order_acquire)) return false;
+    if (last_owner.load(std::memory_order_relaxed) == me) burst.fetch_add(1, std::memory_order_relaxed);
+    else { last_owner.store(me, std::memory_order_relaxed); burst.store(0, std::memory_order_relaxed); }
+    return true;
+}
 void CnMutex::lock(Node &) {
-    if (!held.load(std::memory_order_relaxed) && !held.exchange(1, std::memory_order_acquire)) return;
+    const uint32_t me = my_tid();
+    if (try_take(me)) return;
     for (;;) {
         if (spinners.fetch_add(1, std::memory_order_acq_rel) < MAX_SPINNERS) {
             for (int spins = 0;; spins++) {
-                if (!held.load(std::memory_order_relaxed) && !held.exchange(1, std::memory_order_acquire)) { spinners.fetch_sub(1, std::memory_order_acq_rel); return; }
+                if (try_take(me)) { spinners.fetch_sub(1, std::memory_order_acq_rel); return; }
                 if (spins < 64) __builtin_ia32_pause(); else sched_yield();
             }
         }
@@ -46,16 +84,17 @@ void CnMutex::lock(Node &) {
         sleepers.fetch_add(1, std::memory_order_acq_rel);
         if (!held.load(std::memory_order_acquire)) {                        // freed meanwhile: do not sleep on a free lock
             sleepers.fetch_sub(1, std::memory_order_acq_rel);
-            if (!held.exchange(1, std::memory_order_acquire)) return;
+            if (try_take(me)) return;
             continue;
         }
         const struct timespec to = {0, 2000000};                            // 2 ms backstop (a wake-up skipped because a spinner existed that then left)
         futex(&wake_seq, FUTEX_WAIT_PRIVATE, seq, &to);
         sleepers.fetch_sub(1, std::memory_order_acq_rel);
-        if (!held.load(std::memory_order_relaxed) && !held.exchange(1, std::memory_order_acquire)) return;
+        if (try_take(me)) return;
     }
 }
 void CnMutex::unlock(Node &) {
+    if (grace_cycles()) released_at.store(__rdtsc(), std::memory_order_relaxed);
     held.store(0, std::memory_order_release);
     if (sleepers.load(std::memory_order_acquire) > 0 && spinners.load(std::memory_order_acquire) == 0) {
         wake_seq.fetch_add(1, std::memory_order_acq_rel);

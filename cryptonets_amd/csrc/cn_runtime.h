@@ -77,6 +77,9 @@ private:
     std::atomic<int> held{0};
     std::atomic<int> spinners{0};      // waiters that spin; the others sleep on wake_seq (cn_host.cpp)
     std::atomic<int> sleepers{0}, wake_seq{0};
+    std::atomic<uint32_t> last_owner{0}, burst{0};   // owner bias (cn_host.cpp): who released last, how many times in a row it re-acquired
+    std::atomic<uint64_t> released_at{0};            // TSC of the last release
+    bool try_take(uint32_t me);
 };
 struct CnGuard {
     CnMutex &m; CnMutex::Node n;

@@ -62,48 +62,29 @@ namespace HEWrapper
         public void Dispose() { Free(); GC.SuppressFinalize(this); }
     }
 
-    /// <summary>SEAL 3.2 objects <-> u64 words.  A SEAL Ciphertext is [poly][limb][N] u64 words (the layout of include/cnhip.h); its
-    /// Save() stream is  parms_id (4 x u64) | is_ntt_form (u8) | size, poly_modulus_degree, coeff_mod_count (u64 each) | scale (f64) |
-    /// word count (u64) | words  - 73 header bytes (SEAL 3.2 ciphertext.cpp).  Reading goes through Save() when that layout checks out and
-    /// through the public indexer otherwise; writing composes the same stream for Load().</summary>
+    /// <summary>SEAL 3.2 objects <-> u64 words.  A SEAL Ciphertext is [poly][limb][N] u64 words (the layout of include/cnhip.h).  Words are
+    /// read and written through the PUBLIC indexer of Ciphertext (`this[ulong]` get / set, UInt64Count, Resize) - the members SEALNet's own
+    /// Save / Load are written with; every SEALNet member this file touches is listed, with its source, in integration/SEALNET_MANIFEST.json
+    /// (checked by tests/test_integration_cs.py).  (Round 2 read the words out of the Save() stream behind an assumed 73-byte header: no
+    /// faster - SEALNet's Save walks the same indexer - and not backed by anything in this repository; removed.)</summary>
     public static class SealInterop
     {
-        const int CtHeader = 73;
         public static ulong[] Words(Ciphertext c)
         {
             ulong count = c.UInt64Count;
             var w = new ulong[count];
-            using (var mem = new MemoryStream())
-            {
-                c.Save(mem);
-                if ((ulong)mem.Length == CtHeader + 8 * count)
-                {
-                    Buffer.BlockCopy(mem.GetBuffer(), CtHeader, w, 0, (int)(8 * count));
-                    return w;
-                }
-            }
-            for (ulong i = 0; i < count; i++) w[i] = c[i];          // layout differs from the documented one: the (slow) public indexer
+            for (ulong i = 0; i < count; i++) w[i] = c[i];
             return w;
         }
         public static Ciphertext ToCiphertext(ulong[] words, AtomicSealBfvEncryptedEnvironment env, bool nttForm = false)
         {
             ulong n = env.parameters.PolyModulusDegree, k = (ulong)env.parameters.CoeffModulus.Count();
             ulong size = (ulong)words.Length / (n * k);
-            using (var mem = new MemoryStream())
-            using (var bw = new BinaryWriter(mem))
-            {
-                foreach (var b in env.context.FirstParmsId.Block) bw.Write(b);
-                bw.Write((byte)(nttForm ? 1 : 0));
-                bw.Write(size); bw.Write(n); bw.Write(k); bw.Write(1.0); bw.Write((ulong)words.Length);
-                var bytes = new byte[8 * words.Length];
-                Buffer.BlockCopy(words, 0, bytes, 0, bytes.Length);
-                bw.Write(bytes);
-                bw.Flush();
-                mem.Position = 0;
-                var c = new Ciphertext(env.context, env.memoryPool);
-                c.Load(env.context, mem);
-                return c;
-            }
+            var c = new Ciphertext(env.context, env.memoryPool);
+            c.Resize(env.context, env.context.FirstParmsId, size);
+            c.IsNTTForm = nttForm;
+            for (ulong i = 0; i < (ulong)words.Length; i++) c[i] = words[i];
+            return c;
         }
         /// <summary>N coefficients of a BatchEncoded plaintext (shorter plaintexts are zero padded)</summary>
         public static ulong[] Coeffs(Plaintext p, uint n)
@@ -153,6 +134,8 @@ namespace HEWrapper
         public static int DefaultDeviceIndex = 0;
         public static bool DeferredSubmission = true;
         int decompositionBitCount, galoisDecompositionBitCount;
+        long encryptNonce;                        // nonce of the next device encryption (any value, never reused under one sampler key)
+        public ulong NextNonce() { return (ulong)Interlocked.Increment(ref encryptNonce); }
 
         public AtomicSealBfvEncryptedEnvironment() { }
         public AtomicSealBfvEncryptedEnvironment(AtomicSealBfvEncryptedEnvironment p)
@@ -160,14 +143,27 @@ namespace HEWrapper
             parameters = p.parameters; context = p.context; builder = p.builder; relinKeys = p.relinKeys; secretKey = p.secretKey;
             publicKey = p.publicKey; evaluator = p.evaluator; encryptor = p.encryptor; decryptor = p.decryptor; galoisKeys = p.galoisKeys;
             PlainZero = p.PlainZero; ParentFactory = p.ParentFactory; plainmodulusValue = p.plainmodulusValue;
-            device = p.device;
+            device = p.device;                    // (device encryptions of a copy draw their nonces from the parent: see EncryptZeroInto)
+            nonceSource = p.nonceSource ?? p;
         }
+        AtomicSealBfvEncryptedEnvironment nonceSource = null;
+        public ulong DeviceNonce() { return (nonceSource ?? this).NextNonce(); }
 
         /// <summary>uploads the PUBLIC evaluation keys into HBM (cn_set_relin_key / cn_set_galois_key); the secret key stays on the host</summary>
         void CreateDevice(int dbc, int gdbc)
         {
             decompositionBitCount = dbc; galoisDecompositionBitCount = gdbc;
             device = new CnDevice(parameters, dbc, gdbc, DefaultDeviceIndex, DeferredSubmission);
+            // the PUBLIC key goes to the device too: zero vectors (PoolLayer.ElementAt encrypts one per padded convolution tap, PoolLayer.cs:67-80;
+            // the IsZero branches of the multiply-by-plain methods) are encrypted there - cn_encrypt(pt = 0), queued and batched like the
+            // evaluator calls - instead of SEAL Encrypt on the host + a 640 KiB upload each.  PublicKey.Data is a size-2 NTT-form Ciphertext:
+            // [2][k][N] words, the layout of cn_set_public_key.  The sampler's 256-bit key comes from the OS.
+            var pkw = SealInterop.Words(publicKey.Data);
+            CnHip.Check(CnHip.cn_set_public_key(device.Ctx, pkw, (UIntPtr)pkw.Length));
+            var rngKey = new byte[32];
+            using (var osRng = System.Security.Cryptography.RandomNumberGenerator.Create()) osRng.GetBytes(rngKey);
+            CnHip.Check(CnHip.cn_set_rng_key(device.Ctx, rngKey));
+            encryptNonce = BitConverter.ToInt64(rngKey, 0) ^ DateTime.UtcNow.Ticks;
             // RelinKeys.Data[0]: the key that takes a size-3 ciphertext to size 2 (relinearize_one_step)
             var rk = SealInterop.KeySwitchKey(relinKeys.Data.First());
             CnHip.Check(CnHip.cn_set_relin_key(device.Ctx, rk, (UIntPtr)rk.Length, 0));
@@ -499,13 +495,11 @@ namespace HEWrapper
             OperationsCount.Add(ref OperationsCount.PlainMultiplication, (int)n);
             return t;
         }
+        /// <summary>a fresh encryption of zero into block `index`, made ON THE DEVICE with the public key (cn_encrypt, pt = 0): deferrable, no
+        /// host encryption, no upload</summary>
         void EncryptZeroInto(AtomicSealBfvEncryptedEnvironment eenv, uint index)
         {
-            using (var c = new Ciphertext(eenv.context, eenv.memoryPool))
-            {
-                eenv.encryptor.Encrypt(eenv.PlainZero, c, eenv.memoryPool);
-                CnHip.Check(CnHip.cn_ct_upload(eenv.device.Ctx, enc.Handle, index, 1, SealInterop.Words(c)));
-            }
+            CnHip.Check(CnHip.cn_encrypt(eenv.device.Ctx, 0, 0, 0, enc.Handle, index, 1, eenv.DeviceNonce()));
             OperationsCount.Add(ref OperationsCount.Encryption, 1);
         }
 
@@ -877,6 +871,16 @@ namespace HEWrapper
         {
             owner = eenv;
             enc = new CnBuffer(eenv.device, (uint)plain.Length);
+            if (plain.All(p => p.IsZero))
+            {
+                // an all-zero vector (PoolLayer.ElementAt for a padded tap: Factory.GetEncryptedVector(zeros), PoolLayer.cs:67-80): nothing secret
+                // goes in, the public key is on the device - one queued cn_encrypt instead of SEAL Encrypt + upload per block
+                CnHip.Check(CnHip.cn_encrypt(eenv.device.Ctx, 0, 0, 0, enc.Handle, 0, enc.Count, eenv.DeviceNonce()));
+                foreach (var p in plain) p.Dispose();
+                plainData = null;
+                OperationsCount.Add(ref OperationsCount.Encryption, plain.Length);
+                return;
+            }
             int ctw = eenv.device.CtWords();
             var words = new ulong[plain.Length * ctw];
             using (var c = new Ciphertext(eenv.context, eenv.memoryPool))

@@ -123,6 +123,9 @@ def replay_layers(chans, layers):
     return out
 
 
+LAST_LAUNCHES = None
+
+
 def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False):
     """images/s of the unchanged caller on the inputs resident in chans[p].h_in; returns (ms per batch, output words [primes][O][...]).
     literal_taps: padded taps are fresh encryptions of zero (PoolLayer.cs:67-80) - the words then differ from the batched path's (fresh
@@ -135,17 +138,20 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
         g.set_option("defer", int(defer))
         g.sync()
     words = None
+    global LAST_LAUNCHES
     try:
         for it in range(warmup + steps):
             if it == warmup:
                 for g in ctxs:
                     g.sync()
+                launches0 = sum(g.stats()["kernel_launches"] for g in ctxs)
                 t0 = time.perf_counter()
             out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000)
             if it == warmup + steps - 1:
                 for g in ctxs:
                     g.sync()
                 dt = time.perf_counter() - t0
+                LAST_LAUNCHES = (sum(g.stats()["kernel_launches"] for g in ctxs) - launches0) / steps       # how finely the queue was cut
                 words = [np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[p]]) for p, g in enumerate(ctxs)]
             for p, g in enumerate(ctxs):                 # Decrypt + Dispose of the result matrix
                 for h in out[p]:
@@ -217,13 +223,13 @@ def main():
         ms, words = measure(chans, layers, t, args.steps)
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
         rows.append(dict(caller="unchanged (per-ciphertext calls), deferred submission", threads=t, ms_per_batch=round(ms, 2),
-                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same))
+                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES))
     for t in [int(x) for x in args.literal_threads.split(",") if x]:
         ms, words = measure(chans, layers, t, args.steps, literal_taps=True)
         dec = decrypt_outputs(chans, words)
         same = all(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t)) for d, ch in zip(dec, chans))
         rows.append(dict(caller="unchanged, padded taps as fresh encryptions of zero (PoolLayer.ElementAt), deferred submission", threads=t, ms_per_batch=round(ms, 2),
-                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same,
+                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES,
                          note="words_identical here = every decrypted slot of every output equals the integer model (fresh randomness: words cannot match)"))
     if args.immediate:
         ms, words = measure(chans, layers, 8, 1, warmup=1, defer=False)
