@@ -5,8 +5,11 @@
 // constructors and CRT helpers work as they are.  This subclass only adds what a GPU deployment has to choose:
 //   * which device(s) the plaintext-prime channels live on (one context per prime; round-robin over `devices`),
 //   * deferred submission (on by default: the layers' per-ciphertext calls are merged into batched launches by libcnhip),
-//   * the caller thread count: the reference uses Environment.ProcessorCount threads per ParallelProcessInEnv (Defaults.cs) to keep CPU cores
-//     busy with SEAL arithmetic; here the threads only enqueue work, so more than a few add lock traffic and nothing else,
+//   * optionally a cap on the caller thread count.  The reference uses Environment.ProcessorCount threads per ParallelProcessInEnv
+//     (Defaults.cs) to keep CPU cores busy with SEAL arithmetic; here the threads only enqueue work.  libcnhip no longer needs the cap -
+//     its context lock keeps at most four threads awake and biased to the thread that holds it (round 3: flat from 1 to 256 caller
+//     threads) - so a program that keeps `new EncryptedSealBfvFactory(...)` and the default thread count behaves the same; the cap
+//     (callerThreads > 0) only saves the program its own thread start-up,
 //   * replicas on other GPUs for independent batches: same SEAL keys, evaluation keys copied with ONE RCCL broadcast per key over xGMI
 //     (cn_ctx_broadcast_keys) - no ciphertext ever crosses GPUs (SURVEY.md section 8e).
 // Not compiled in this repository (no .NET toolchain in the build image); see INTEGRATION.md.
@@ -19,8 +22,9 @@ namespace HEWrapper
 {
     public class GpuSealBfvFactory : EncryptedSealBfvFactory
     {
-        /// <summary>threads that issue evaluator calls; the reference's default (ProcessorCount) is capped here</summary>
-        public const int DefaultCallerThreads = 4;
+        /// <summary>threads that issue evaluator calls: 0 = leave Defaults.ThreadCount as the program set it (the reference's default is
+        /// Environment.ProcessorCount); the library takes any count</summary>
+        public const int DefaultCallerThreads = 0;
 
         public static int DeviceCount { get { return CnHip.cn_device_count(); } }
 
