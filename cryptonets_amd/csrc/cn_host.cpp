@@ -39,7 +39,10 @@ static long futex(std::atomic<int> *addr, int op, int val, const struct timespec
 // cross the chip twice per call.  So for `grace` TSC cycles after a release the lock can only be re-taken by the thread that released it;
 // everybody else keeps waiting.  The owner's next call finds the lock and the data in its own cache; when it does not come back (the item
 // is finished) the others lose the grace period once per item.  A thread that re-acquires more than MAX_BURST times in a row loses the
-// privilege for one hand-over (no starvation by a polling loop).  CN_LOCK_GRACE_NS sets the period (default 400; 0 = off).
+// privilege for one hand-over (no starvation by a polling loop).  CN_LOCK_GRACE_NS sets the period; DEFAULT 0 = OFF: measured on the
+// MI355X box (profiles/r03_unchanged_caller_lock.txt) the bias does not pay - with the literal padded taps the unchanged caller ran at
+// 0.85 / 0.85 / 0.84 / 0.82 of the batched rate at 1 / 4 / 16 / 256 threads without it and at 0.84 / 0.84 / 0.78 / 0.72 (400 ns),
+// 0.86 / 0.77 / 0.51 / 0.80 (1 us) with it: the threads that lose the grace period queue up behind a holder that is not coming back.
 #include <x86intrin.h>
 static const uint32_t MAX_BURST = 256;
 static std::atomic<uint32_t> g_next_tid{1};
@@ -48,7 +51,7 @@ static uint32_t my_tid() { if (!t_tid) t_tid = g_next_tid.fetch_add(1, std::memo
 static uint64_t grace_cycles() {
     static const uint64_t g = [] {
         const char *e = getenv("CN_LOCK_GRACE_NS");
-        const double ns = e ? atof(e) : 400.0;
+        const double ns = e ? atof(e) : 0.0;
         if (ns <= 0) return (uint64_t)0;
         struct timespec a, b;                                          // TSC cycles per nanosecond, measured over ~2 ms
         clock_gettime(CLOCK_MONOTONIC, &a); const uint64_t c0 = __rdtsc();

@@ -63,14 +63,24 @@ def measure(name="LoLa", reps=20, device=0, image_seed=1234):
         for c in ctxs:
             c.sync()
 
-    def logits_of_handles(handles, firsts=None):
+    def logits_of_handles(handles, firsts, count, sparse):
+        """the 10 logits from the result handles of every prime: a sparse-format vector is `count` ciphertexts whose plaintext is the constant
+        polynomial (AtomicSealBfvVector.cs:1060-1063 reads coefficient 0), a dense one is one ciphertext read through BatchEncoder.Decode"""
         res = {}
         for i, (p, c, h) in enumerate(zip(primes, ctxs, handles)):
-            ph = c.pt_alloc(1)
-            c.decrypt(h, firsts[i] if firsts else 0, 1, ph, 0)
-            res[p] = np.asarray(c.decode_batch(ph, 0, 1)[0][:10], dtype=object)
+            ph = c.pt_alloc(count)
+            c.decrypt(h, firsts[i], count, ph, 0)
+            if sparse:
+                res[p] = np.asarray(c.pt_download(ph, 0, count)[:, 0][:10], dtype=object)
+            else:
+                res[p] = np.asarray(c.decode_batch(ph, 0, 1)[0][:10], dtype=object)
             c.free(ph)
         return [int(v) for v in crt_join_over_ranks(res, primes, None)]
+
+    def result_of(out):
+        from cryptonets_amd.hewrapper import EVectorFormat
+        col = out.GetColumn(0)
+        return col, [a.encData.first for a in col.eVectors], col.eVectors[0].encData.count, col.Format == EVectorFormat.sparse
 
     rows = []
     for literal in (False, True):
@@ -87,7 +97,10 @@ def measure(name="LoLa", reps=20, device=0, image_seed=1234):
                 outs.append(_apply_chain(layers, e))
                 sync()
             py_ms = 1e3 * (time.perf_counter() - t0) / reps
-            ok = all(logits_of_handles([a.encData.h for a in o.GetColumn(0).eVectors], [a.encData.first for a in o.GetColumn(0).eVectors]) == want for o in outs[-2:])
+            ok = True
+            for o in outs[-2:]:
+                col, firsts, count, sparse = result_of(o)
+                ok = ok and logits_of_handles([a.encData.h for a in col.eVectors], firsts, count, sparse) == want
             for o in outs:
                 o.Dispose()
             label = "unchanged per-call sequence (hewrapper.LITERAL)" if literal else "batched conveniences of the mirror (RowsDotProduct, MulColumnsByPlain, MulManySparse)"
@@ -101,16 +114,15 @@ def measure(name="LoLa", reps=20, device=0, image_seed=1234):
             finally:
                 for r in recs:
                     r.stop()
-            col = out.GetColumn(0)
+            col, firsts, count, sparse = result_of(out)                  # the result: `count` ciphertexts of an array the trace allocated
             rids = [r.ids[int(a.encData.h)] for r, a in zip(recs, col.eVectors)]
-            firsts = [a.encData.first for a in col.eVectors]             # the result may be one ciphertext of a larger array the trace allocated
-            assert all(a.encData.count == 1 and rid[0] == "new" for a, rid in zip(col.eVectors, rids))
+            assert all(rid[0] == "new" for rid in rids), rids
             calls = [len(r.records) for r in recs]
             out.Dispose()
             for mode, host in ((0, "C++ replay, one host thread, contexts call by call"), (1, "C++ replay, one thread per plaintext prime, joined after every call"),
                                (2, "C++ replay, one free-running thread per plaintext prime")):
                 ms, handles = call_trace.replay(recs, reps, mode, rids, warmup=2)
-                ok = logits_of_handles(handles, firsts) == want
+                ok = logits_of_handles(handles, firsts, count, sparse) == want
                 for c, h in zip(ctxs, handles):
                     c.free(h)
                 rows.append(dict(pattern=label, host=host, ms_per_image=round(ms, 2), logits_exact=bool(ok), calls_per_prime=calls[0]))
