@@ -18,7 +18,8 @@ static DeferQueue *cn_defer_new();
 static void cn_defer_delete(DeferQueue *q);
 static int cn_defer_flush(cn_ctx *ctx);
 static bool cn_defer_pending(cn_ctx *ctx);
-enum { DOP_GEMM1 = 0, DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN, DOP_MULRELIN, DOP_ENCRYPT, DOP_TYPES };
+enum { DOP_GEMM1 = 0, DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN, DOP_MULRELIN, DOP_ENCRYPT,
+       DOP_COPY, DOP_MULPLAIN, DOP_ROT, DOP_ROTADD, DOP_COLS, DOP_COLSADD, DOP_SUMSLOTS, DOP_TYPES };      // DOP_COPY .. : staged (gather / batched call / scatter) at flush time
 struct DOp {
     int type; int32_t level;
     uint64_t *out;                 // output ciphertext (size 2)
@@ -26,6 +27,7 @@ struct DOp {
     uint32_t K; size_t terms;      // GEMM1: K (address, weight) pairs from DeferQueue::addr / ::wt [terms ..)
     const uint64_t *bias;          // GEMM1: plaintext polynomial added to the result (an AddPlain folded in at flush time), or null
     uint64_t nonce = 0, item = 0;  // ENCRYPT: the call's seed and the sampler item of this ciphertext (a = plaintext polynomial or null)
+    int64_t arg = 0;               // staged kinds: rotation steps (ROT, ROTADD) / slot count (SUMSLOTS); MULPLAIN: b = plaintext polynomial; ROTADD / COLSADD: b = accumulator
 };
 struct DeferQueue {
     std::vector<DOp> ops;
@@ -70,6 +72,10 @@ static bool in_slab(cn_ctx *ctx, const void *p) {
     for (const Slab &s : slabs_of(ctx)) if ((const char *)p >= s.base && (const char *)p < s.base + s.bytes) return true;
     return false;
 }
+static bool deferring(cn_ctx *ctx);
+static int defer_staged(cn_ctx *ctx, int type, Buffer *A, uint32_t ai, Buffer *B, uint32_t bi, const uint64_t *plain, uint32_t pstride_words, Buffer *O, uint32_t oi,
+                        uint32_t count, int64_t arg);
+static const uint32_t DEFER_STAGED_MAX = 4;       // per-ciphertext callers: calls on up to this many ciphertexts are queued, larger ones run at once
 static void pool_flush(cn_ctx *ctx);
 static int free_gemm_plan(cn_ctx *ctx, Buffer &b);
 static int free_graph(cn_ctx *ctx, Buffer &b);
@@ -214,7 +220,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
-    if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD")) != 0;
+    if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD"));
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -251,7 +257,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     delete &slabs_of(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
-    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map);
+    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map); (void)hipFree(ctx->stage);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     (void)hipStreamDestroy(ctx->stream);
@@ -265,7 +271,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
-    if (!strcmp(name, "ks_xcd")) { ctx->ks_xcd = value != 0; return 0; }
+    if (!strcmp(name, "ks_xcd")) { ctx->ks_xcd = value; return 0; }              // 0 (ct, limb) order, 1 the limbs of a ciphertext on one XCD, 2 limb-major
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
@@ -593,8 +599,12 @@ extern "C" int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t 
 }
 extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values) { return cn_decode_batch(ctx, pt, pi, 1, values); }
 extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) {
-    LOCK;
+    LOCK_ONLY;
     Buffer *s = ctx->bufs.find(src), *d = ctx->bufs.find(dst);
+    if (deferring(ctx) && s && d && s->kind == 0 && d->kind == 0 && s->size == 2 && d->size == 2 && count && count <= DEFER_STAGED_MAX &&
+        range_ok(s, sfirst, count) && range_ok(d, dfirst, count) && !(s == d && sfirst < dfirst + count && dfirst < sfirst + count))
+        return defer_staged(ctx, DOP_COPY, s, sfirst, nullptr, 0, nullptr, 0, d, dfirst, count, 0);
+    CHECK(cn_defer_flush(ctx));
     if (!s || !d) return fail(CN_ERR_ARG, "invalid handle");
     if (s->kind != d->kind || s->item_words != d->item_words) return fail(CN_ERR_ARG, "copy between different buffer shapes");
     if (!range_ok(s, sfirst, count) || !range_ok(d, dfirst, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -727,7 +737,14 @@ static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buf
     return 0;
 }
 extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pstride, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    LOCK_ONLY; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
+    if (deferring(ctx) && count && count <= DEFER_STAGED_MAX && A->size == 2) {       // the per-row MultiplyPlain of an unchanged caller: queued, rows merged at flush
+        if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1)) return fail(CN_ERR_ARG, "index out of range");
+        for (uint32_t c = 0; c < (pstride ? count : 1u); c++) if (P->pt_zero[pi + c * pstride]) return fail(CN_ERR_ZERO, "plain cannot be zero");
+        if (A == O && ai != oi && ai < oi + count && oi < ai + count) return fail(CN_ERR_ARG, "multiply_plain: input and output ranges overlap partially (use the same range or disjoint ranges)");
+        return defer_staged(ctx, DOP_MULPLAIN, A, ai, nullptr, 0, P->d + (size_t)pi * ctx->hc.n, pstride * ctx->hc.n, O, oi, count, 0);
+    }
+    CHECK(cn_defer_flush(ctx));
     return mul_plain_impl(ctx, A, ai, false, P, pi, pstride, O, oi, count);
 }
 static uint64_t lift_scalar(const DevConsts &hc, uint64_t w, uint32_t j) { return w >= hc.t_half ? w + hc.lift_inc[j] : w; }
@@ -1055,7 +1072,8 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     KsArgs a{target, tstride, add0, add1, astride, key.d, out, cnt, galois, extra, xstride,
              key.f64 ? (bits >= 50 ? 1u : (1u << std::min(10, 50 - bits))) : 0xffffffffu,     // lazy FP64 accumulators: |term| <= 2.1 q, sum below 2^52
              0, out_tab};
-    if (ctx->ks_xcd) a.xcd_cts = cnt & ~7u;
+    if (ctx->ks_xcd == 1) a.xcd_cts = cnt & ~7u;
+    else if (ctx->ks_xcd == 2) a.xcd_cts = 0x80000000u;
     const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;                // register-radix kernels available
     if (rr && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * k <= KS_WIDE_MAX_BLOCKS))) {
         // N = 16384: 1024-thread workgroups cannot hold two accumulator sets without spilling -> per-digit only
@@ -1169,13 +1187,17 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
     if (acc) ctx->st.Addition += count;
     return 0;
 }
-extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t elt, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(I, in, 2); GETCT(O, out, 2);
+static int galois_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, uint64_t elt, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
     return do_galois(ctx, I->d + ii * I->item_words, elt, O->d + oi * O->item_words, tmp, count);
+}
+static bool galois_key_present(cn_ctx *ctx, uint64_t elt) { auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
+extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t elt, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK; GETCT(I, in, 2); GETCT(O, out, 2);
+    return galois_impl(ctx, I, ii, elt, O, oi, count);
 }
 // Evaluator::rotate_internal: direct key if present, otherwise non-adjacent-form decomposition
 static bool has_direct_key(cn_ctx *ctx, int steps) {
@@ -1199,8 +1221,7 @@ static int rotate_rec(cn_ctx *ctx, uint64_t *cur, int steps, uint64_t *tmp, uint
     }
     return 0;
 }
-extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(I, in, 2); GETCT(O, out, 2);
+static int rotate_rows_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
@@ -1209,6 +1230,30 @@ extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps,
     if (steps != 0 && has_direct_key(ctx, steps)) return do_galois(ctx, i, cn_galois_elt_from_step(ctx, steps), o, tmp, count);   // one hop: no staging copy
     if (o != i) HIPCHK(hipMemcpyAsync(o, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return rotate_rec(ctx, o, steps, tmp, count);
+}
+// can RotateRows(steps) run with the keys this context holds (direct key, or every hop of the NAF decomposition)?  Queued rotations are
+// checked when they are queued, like every other argument.
+static int rotate_check(cn_ctx *ctx, int steps) {
+    if (steps == 0) return 0;
+    const uint64_t elt = cn_galois_elt_from_step(ctx, steps);
+    if (!elt) return fail(CN_ERR_ARG, "step count too large");
+    if (galois_key_present(ctx, elt)) return 0;
+    std::vector<int> naf;
+    bool sign = steps < 0; int v = std::abs(steps);
+    for (int i = 0; v; i++) { int zi = (v & 1) ? 2 - (v & 3) : 0; v = (v - zi) >> 1; if (zi) naf.push_back((sign ? -zi : zi) * (1 << i)); }
+    if (naf.size() == 1) return fail(CN_ERR_NOKEY, "Galois key not present");
+    for (int s2 : naf) { if ((uint32_t)std::abs(s2) == ctx->hc.n / 2) continue; CHECK(rotate_check(ctx, s2)); }
+    return 0;
+}
+extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count) {
+    LOCK_ONLY; GETCT(I, in, 2); GETCT(O, out, 2);
+    if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
+        if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+        CHECK(rotate_check(ctx, steps));
+        return defer_staged(ctx, DOP_ROT, I, ii, nullptr, 0, nullptr, 0, O, oi, count, steps);
+    }
+    CHECK(cn_defer_flush(ctx));
+    return rotate_rows_impl(ctx, I, ii, steps, O, oi, count);
 }
 // out = acc + RotateRows(in, steps): the rotate-and-add step of SumAllSlots (AtomicSealBfvVector.cs:862-868) with the addition
 // fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
@@ -1245,11 +1290,23 @@ static int rotate_columns_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, Buffer *
     return do_galois(ctx, I->d + ii * I->item_words, 2ull * ctx->hc.n - 1, O->d + oi * O->item_words, tmp, count, A->d + ai * A->item_words);
 }
 extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    LOCK_ONLY; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
+        if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+        CHECK(rotate_check(ctx, steps));
+        return defer_staged(ctx, DOP_ROTADD, I, ii, A, ai, nullptr, 0, O, oi, count, steps);
+    }
+    CHECK(cn_defer_flush(ctx));
     return rotate_rows_add_impl(ctx, I, ii, steps, A, ai, O, oi, count);
 }
 extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
-    LOCK; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    LOCK_ONLY; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
+    if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
+        if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+        if (!galois_key_present(ctx, 2ull * ctx->hc.n - 1)) return fail(CN_ERR_NOKEY, "Galois key not present");
+        return defer_staged(ctx, DOP_COLSADD, I, ii, A, ai, nullptr, 0, O, oi, count, 0);
+    }
+    CHECK(cn_defer_flush(ctx));
     return rotate_columns_add_impl(ctx, I, ii, A, ai, O, oi, count);
 }
 // SumAllSlots(length) of AtomicSealBfvVector.cs:888-935 on `count` single-block ciphertexts at once, in place: the column swap when
@@ -1262,9 +1319,17 @@ static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count
     return 0;
 }
 extern "C" int cn_sum_slots(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint32_t length) {
-    LOCK; GETCT(H, h, 2);
+    LOCK_ONLY; GETCT(H, h, 2);
     if (!range_ok(H, first, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
+    if (deferring(ctx) && count <= DEFER_STAGED_MAX) {
+        const uint32_t n = ctx->hc.n, half = n / 2;
+        uint32_t len = length ? length : n;
+        if (len >= half) { if (!galois_key_present(ctx, 2ull * n - 1)) return fail(CN_ERR_NOKEY, "Galois key not present"); len = half; }
+        for (uint32_t st = 1; st < len; st *= 2) CHECK(rotate_check(ctx, -(int)st));
+        return defer_staged(ctx, DOP_SUMSLOTS, H, first, nullptr, 0, nullptr, 0, H, first, count, length);
+    }
+    CHECK(cn_defer_flush(ctx));
     return sum_slots_impl(ctx, H, first, count, length);
 }
 // out[r] = SumAllSlots(v * pt[r], length) for r < rows: every row of a plaintext matrix against ONE packed ciphertext
@@ -1278,7 +1343,14 @@ extern "C" int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle 
     return sum_slots_impl(ctx, O, oi, rows, length);
 }
 extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
-    return cn_apply_galois(ctx, in, ii, 2ull * ctx->hc.n - 1, out, oi, count);
+    LOCK_ONLY; GETCT(I, in, 2); GETCT(O, out, 2);
+    if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
+        if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+        if (!galois_key_present(ctx, 2ull * ctx->hc.n - 1)) return fail(CN_ERR_NOKEY, "Galois key not present");
+        return defer_staged(ctx, DOP_COLS, I, ii, nullptr, 0, nullptr, 0, O, oi, count, 0);
+    }
+    CHECK(cn_defer_flush(ctx));
+    return galois_impl(ctx, I, ii, 2ull * ctx->hc.n - 1, O, oi, count);
 }
 
 // ---------------------------------------------------------------- client side on the device
@@ -1701,6 +1773,111 @@ static int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all
     return 0;
 }
 
+// ---- staged kinds (DOP_COPY .. DOP_SUMSLOTS): the per-ciphertext calls of an unchanged LoLa-style caller - one MultiplyPlain, SumAllSlots,
+// RotateRows(AndAdd) per matrix row (EncryptedSealBfvMatrix.cs:79-120: `leVectors[row].DotProduct(v)` in a loop over the rows, LLInterleaveLayer:
+// one PointwiseMultiply per column).  The rows are independent, so the queue puts row r's k-th call and row r''s k-th call on the same
+// level; at flush all calls of one level, kind and parameter (rotation steps / slot count) are executed as ONE batched call of the same
+// implementation the batched entry points use: their operand ciphertexts are gathered into a contiguous staging array (one table-driven
+// copy launch), the batched implementation runs on it, the results are scattered to the callers' arrays (one more copy launch).  The
+// copies move 2 x 640 KiB per ciphertext and call - microseconds against the key switches they let merge (13 rows of LoLa's dense
+// layer: 13 x 10 single-ciphertext key switches become 10 key switches of 13 ciphertexts).  Same words: the batched implementations
+// are bit-identical to their count-1 selves (tests/test_deferred.py, tests/test_lola.py).
+struct Tab2 { const NTT_GLOBAL uint64_t *src; NTT_GLOBAL uint64_t *dst; };
+__global__ void k_copy_tab(const Tab2 *__restrict__ tab, uint32_t pairs_per_item) {          // grid (chunks, items); 16 B per thread
+    const Tab2 t = tab[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));          // (a plain vector type: assignable through a global-address-space pointer)
+    if (i < pairs_per_item) reinterpret_cast<NTT_GLOBAL v2u64 *>(t.dst)[i] = reinterpret_cast<const NTT_GLOBAL v2u64 *>(t.src)[i];
+}
+static int ensure_stage(cn_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->stage_cap) return 0;
+    if (ctx->capturing || ctx->graphs_alive) return fail(CN_ERR_ARG, "the staging arena would have to grow while a graph is recorded / alive");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->stage) HIPCHK(hipFree(ctx->stage));
+    ctx->stage = nullptr; ctx->stage_cap = 0;
+    const size_t want = bytes + (bytes >> 2) + (1 << 20);
+    HIPCHK(hipMalloc((void **)&ctx->stage, want));
+    ctx->stage_cap = want;
+    return 0;
+}
+// host table -> device (a block the context keeps alive until the stream has drained, like upload_tmp), then one copy launch
+static int copy_by_table(cn_ctx *ctx, const std::vector<Tab2> &tab, Tab2 *dtab, uint32_t words_per_item) {
+    if (tab.empty()) return 0;
+    if (!ctx->staged.empty() && hipStreamQuery(ctx->stream) == hipSuccess) ctx->staged.clear();
+    (void)hipGetLastError();
+    ctx->staged.emplace_back(new char[tab.size() * sizeof(Tab2)]);
+    memcpy(ctx->staged.back().get(), tab.data(), tab.size() * sizeof(Tab2));
+    HIPCHK(hipMemcpyAsync(dtab, ctx->staged.back().get(), tab.size() * sizeof(Tab2), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t pairs = words_per_item / 2;
+    hipLaunchKernelGGL(k_copy_tab, dim3((pairs + 255) / 256, (unsigned)tab.size()), dim3(256), 0, ctx->stream, dtab, pairs);
+    HIPCHK(hipGetLastError()); launch_count(ctx);
+    return 0;
+}
+static int flush_staged_group(cn_ctx *ctx, const std::vector<const DOp *> &all, int type) {
+    if (type == DOP_COPY) {                                  // Ciphertext copies: the table copy is the operation
+        CHECK(ensure_stage(ctx, al(all.size() * sizeof(Tab2))));
+        std::vector<Tab2> tab(all.size());
+        for (size_t i = 0; i < all.size(); i++) tab[i] = {(const NTT_GLOBAL uint64_t *)all[i]->a, (NTT_GLOBAL uint64_t *)all[i]->out};
+        return copy_by_table(ctx, tab, (Tab2 *)ctx->stage, (uint32_t)ctx->ctw2);
+    }
+    std::map<int64_t, std::vector<const DOp *>> by_arg;      // one batched call per parameter value (rotation steps, slot count)
+    for (const DOp *op : all) by_arg[op->arg].push_back(op);
+    const uint32_t n = ctx->hc.n; const size_t ctw = ctx->ctw2;
+    for (auto &kv : by_arg) {
+        const std::vector<const DOp *> &ops = kv.second;
+        const uint32_t cnt = (uint32_t)ops.size();
+        const bool has_b = type == DOP_ROTADD || type == DOP_COLSADD, has_p = type == DOP_MULPLAIN, in_place = type == DOP_SUMSLOTS;
+        const size_t tabs = al(3 * cnt * sizeof(Tab2)) + al(cnt * sizeof(Tab2)), ctb = al(cnt * ctw * 8);
+        CHECK(ensure_stage(ctx, tabs + ctb * (1 + (has_b ? 1 : 0) + (in_place ? 0 : 1)) + (has_p ? al((size_t)cnt * n * 8) : 0)));
+        char *base = ctx->stage;
+        Tab2 *t_in = (Tab2 *)base, *t_pt = t_in + 2 * cnt, *t_out = (Tab2 *)(base + al(3 * cnt * sizeof(Tab2)));
+        uint64_t *A = (uint64_t *)(base + tabs), *B = has_b ? A + ctb / 8 : nullptr;
+        uint64_t *O = in_place ? A : A + (ctb / 8) * (has_b ? 2 : 1), *P = has_p ? O + ctb / 8 : nullptr;
+        std::vector<Tab2> gin, gpt, gout(cnt);
+        for (uint32_t i = 0; i < cnt; i++) {
+            gin.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->a, (NTT_GLOBAL uint64_t *)(A + (size_t)i * ctw)});
+            if (has_b) gin.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)(B + (size_t)i * ctw)});
+            if (has_p) gpt.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)(P + (size_t)i * n)});
+            gout[i] = {(const NTT_GLOBAL uint64_t *)(O + (size_t)i * ctw), (NTT_GLOBAL uint64_t *)ops[i]->out};
+        }
+        CHECK(copy_by_table(ctx, gin, t_in, (uint32_t)ctw));
+        if (has_p) CHECK(copy_by_table(ctx, gpt, t_pt, n));
+        Buffer fa, fb, fo, fp;
+        auto fake = [&](Buffer &b, int kind, uint64_t *d, size_t item) { b.kind = kind; b.count = cnt; b.size = kind == 0 ? 2 : 1; b.d = d; b.item_words = item; };
+        fake(fa, 0, A, ctw); fake(fb, 0, B, ctw); fake(fo, 0, O, ctw); fake(fp, 1, P, n);
+        if (has_p) fp.pt_zero.assign(cnt, 0);                 // zero plaintexts were refused when the calls were queued
+        int rc = 0;
+        switch (type) {
+        case DOP_MULPLAIN: rc = mul_plain_impl(ctx, &fa, 0, false, &fp, 0, 1, &fo, 0, cnt); break;
+        case DOP_ROT: rc = rotate_rows_impl(ctx, &fa, 0, (int)kv.first, &fo, 0, cnt); break;
+        case DOP_ROTADD: rc = rotate_rows_add_impl(ctx, &fa, 0, (int)kv.first, &fb, 0, &fo, 0, cnt); break;
+        case DOP_COLS: rc = galois_impl(ctx, &fa, 0, 2ull * n - 1, &fo, 0, cnt); break;
+        case DOP_COLSADD: rc = rotate_columns_add_impl(ctx, &fa, 0, &fb, 0, &fo, 0, cnt); break;
+        case DOP_SUMSLOTS: rc = sum_slots_impl(ctx, &fa, 0, cnt, (uint32_t)kv.first); break;
+        default: rc = fail(CN_ERR_ARG, "internal: staged kind %d", type);
+        }
+        CHECK(rc);
+        CHECK(copy_by_table(ctx, gout, t_out, (uint32_t)ctw));
+    }
+    return 0;
+}
+// queue `count` per-ciphertext operations of a staged kind (arguments were checked by the caller)
+static int defer_staged(cn_ctx *ctx, int type, Buffer *A, uint32_t ai, Buffer *B, uint32_t bi, const uint64_t *plain, uint32_t pstride_words, Buffer *O, uint32_t oi,
+                        uint32_t count, int64_t arg) {
+    for (uint32_t c = 0; c < count; c++) {
+        const uint64_t *pa = A->d + (size_t)(ai + c) * A->item_words, *pb = B ? B->d + (size_t)(bi + c) * B->item_words : nullptr;
+        DOp op{type, 0, O->d + (size_t)(oi + c) * O->item_words, pa, plain ? plain + (size_t)c * pstride_words : pb, 0, 0, nullptr};
+        op.arg = arg;
+        const uint64_t *ins[2] = {pa, pb};
+        CHECK(defer_push(ctx, op, ins, 2));
+    }
+    switch (type) {
+    case DOP_MULPLAIN: ctx->st.PlainMultiplication += 0; break;          // (counted by the batched implementation at flush time)
+    default: break;
+    }
+    return 0;
+}
+
 // all queued Encryptor.Encrypt calls of one level: one sampling / transform / tail launch chain over a table
 static int flush_encrypt_group(cn_ctx *ctx, const std::vector<const DOp *> &ops) {
     std::vector<EncTab> tab(ops.size());
@@ -1770,6 +1947,7 @@ static int cn_defer_flush(cn_ctx *ctx) {
             }
             for (int t : {DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN}) if (!rc && !by_type[t].empty()) rc = flush_elementwise_group(ctx, by_type[t], t);
             if (!rc && !by_type[DOP_ENCRYPT].empty()) rc = flush_encrypt_group(ctx, by_type[DOP_ENCRYPT]);
+            for (int t = DOP_COPY; t <= DOP_SUMSLOTS; t++) if (!rc && !by_type[t].empty()) rc = flush_staged_group(ctx, by_type[t], t);
             if (!rc && !by_type[DOP_MULRELIN].empty()) rc = flush_mulrelin_group(ctx, by_type[DOP_MULRELIN]);
         }
     }

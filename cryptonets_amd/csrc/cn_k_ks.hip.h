@@ -71,8 +71,11 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
     // dispatch rule; a speed assumption only), so the k workgroups of ONE ciphertext are given block ids of one residue class: they
     // follow each other on one XCD and the k - 1 later ones find the ciphertext's source limbs in THAT XCD's L2 instead of fetching
     // them through k different L2s.  Bijective: b -> (x = b % 8, s = b / 8) -> ct = 8 (s / k) + x, j = s % k.
+    // xcd_cts = 0x80000000: limb-major order (all ciphertexts of output limb 0, then limb 1, ...): every XCD works on ONE key slice
+    // (3.2 MiB at N = 8192, k = 5) at a time, which then stays in its 4 MiB L2; the source limbs are fetched once per output limb instead.
     uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
-    if (blockIdx.x < xcd_cts * k) { const uint32_t x = blockIdx.x & 7, sl = blockIdx.x >> 3; ct = 8 * (sl / k) + x; j = sl % k; }
+    if (xcd_cts & 0x80000000u) { const uint32_t cnt = gridDim.x / k; j = blockIdx.x / cnt; ct = blockIdx.x % cnt; }
+    else if (blockIdx.x < xcd_cts * k) { const uint32_t x = blockIdx.x & 7, sl = blockIdx.x >> 3; ct = 8 * (sl / k) + x; j = sl % k; }
     const DMod qm = C->q[j];
     const uint64_t q = qm.q;
     const ArCtx<AR> A(C, j);

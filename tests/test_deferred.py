@@ -404,3 +404,109 @@ def test_literal_padded_taps_in_the_unchanged_caller(rng):
         g.free(int(h))
     assert g.live_handles() == live
     g.close()
+
+
+def _rot_program(g, cts, pts, seed, defer):
+    """A per-ciphertext program of the LoLa kind: MultiplyPlain, rotations (direct key, NAF-decomposed, in place), rotate-and-add, column swaps,
+    SumAllSlots, copies, mixed with additions and squarings; every ciphertext its own handle; independent chains side by side (the rows of a
+    matrix) so that the queue finds calls to merge."""
+    rng = np.random.default_rng(seed)
+    g.set_option("defer", int(defer))
+    hs = []
+    for c in cts:
+        h = g.ct_alloc(1)
+        g.ct_upload(h, 0, c[None, :])
+        hs.append(h)
+    ph = g.pt_alloc(len(pts))
+    g.pt_upload(ph, 0, pts)
+    steps_pool = [1, -1, 2, -4, 5, -3, 8]                    # 5 and -3 have no direct key: NAF hops
+    for step in range(70):
+        kind = int(rng.integers(0, 9))
+        a, b = (int(x) for x in rng.integers(0, len(hs), size=2))
+        if kind == 0:
+            out = g.ct_alloc(1)
+            g.mul_plain(hs[a], 0, ph, int(rng.integers(0, len(pts))), out, 0)
+            hs.append(out)
+        elif kind == 1:
+            out = g.ct_alloc(1)
+            g.rotate_rows(hs[a], 0, steps_pool[int(rng.integers(0, len(steps_pool)))], out, 0)
+            hs.append(out)
+        elif kind == 2:                                       # in place
+            g.rotate_rows(hs[a], 0, steps_pool[int(rng.integers(0, 4))], hs[a], 0)
+        elif kind == 3:                                       # agg = agg + rot(x): AtomicSealBfvVector.cs:862-868
+            g.rotate_rows_add(hs[a], 0, -int(2 ** rng.integers(0, 4)), hs[b], 0, hs[b], 0)
+        elif kind == 4:
+            out = g.ct_alloc(1)
+            g.rotate_columns(hs[a], 0, out, 0)
+            hs.append(out)
+        elif kind == 5:
+            g.sum_slots(hs[a], 0, 1, int(2 ** rng.integers(1, 6)))
+        elif kind == 6 and a != b:
+            g.copy(hs[a], 0, hs[b], 0, 1)
+        elif kind == 7:
+            out = g.ct_alloc(1)
+            g.add(hs[a], 0, hs[b], 0, out, 0)
+            hs.append(out)
+        elif kind == 8 and len(hs) > 8:
+            g.free(hs.pop(a))
+    pending = g.get_option("pending_calls")
+    words = [g.ct_download(h, 0, 1)[0] for h in hs]
+    for h in hs:
+        g.free(h)
+    g.free(ph)
+    g.set_option("defer", 0)
+    return words, pending
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_deferred_rotations_and_plain_products_equal_immediate(name, rng):
+    """the staged kinds of the queue (gather -> batched implementation -> scatter at flush time): MultiplyPlain, RotateRows(AndAdd),
+    RotateColumns, SumAllSlots, copies - the calls an unchanged LoLa-style caller makes per matrix row - against the immediate calls"""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    cts = _fresh(o, rng, 6)
+    pts = np.stack([o.encode(rng.integers(1, 9, size=o.n, dtype=np.uint64)) for _ in range(3)])
+    for seed in (11, 12):
+        now, _ = _rot_program(g, cts, pts, seed, defer=False)
+        later, pending = _rot_program(g, cts, pts, seed, defer=True)
+        assert pending > 20                                  # the program really was queued
+        assert len(now) == len(later)
+        for x, y in zip(now, later):
+            assert np.array_equal(x, y)
+    # and against the oracle: a MultiplyPlain + SumAllSlots row pair queued side by side
+    g.set_option("defer", 1)
+    try:
+        hs = []
+        for c in cts[:2]:
+            h = g.ct_alloc(1)
+            g.ct_upload(h, 0, c[None, :])
+            hs.append(h)
+        ph = g.pt_alloc(2)
+        g.pt_upload(ph, 0, pts[:2])
+        outs = [g.ct_alloc(1), g.ct_alloc(1)]
+        for r in range(2):
+            g.mul_plain(hs[r], 0, ph, r, outs[r], 0)
+            g.rotate_rows_add(outs[r], 0, -2, outs[r], 0, outs[r], 0)
+        assert g.get_option("pending_calls") == 4
+        for r in range(2):
+            t = o.multiply_plain(cts[r], pts[r])
+            want = o.add(t, o.rotate_rows(t, -2))
+            assert np.array_equal(g.ct_download(outs[r], 0, 1)[0], want)
+        for h in hs + outs + [ph]:
+            g.free(h)
+    finally:
+        g.set_option("defer", 0)
+    from cryptonets_amd._native import CnError
+    g.set_option("defer", 1)
+    try:
+        h = g.ct_alloc(1)
+        g.ct_upload(h, 0, cts[0][None, :])
+        with pytest.raises(CnError):
+            g.rotate_rows(h, 0, o.n, h, 0)                   # step count too large: refused when queued, not at flush time
+        zp = g.pt_alloc(1)
+        g.encode(np.zeros(4, dtype=np.uint64), zp, 0)
+        with pytest.raises(CnError):
+            g.mul_plain(h, 0, zp, 0, h, 0)                   # "plain cannot be zero": likewise
+        g.free(h), g.free(zp)
+    finally:
+        g.set_option("defer", 0)

@@ -875,7 +875,7 @@ def test_key_switch_xcd_placement_is_only_a_placement(name, rng):
     rot = np.stack([o.rotate_rows(c, 1) for c in cts])
     try:
         g.set_option("ks_wide", 0)
-        for xcd in (1, 0):
+        for xcd in (1, 2, 0):
             g.set_option("ks_xcd", xcd)
             g.mul_relin(h, 0, h, 0, out, 0, 19)
             assert np.array_equal(g.ct_download(out, 0, 19), want), xcd

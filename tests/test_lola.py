@@ -283,3 +283,17 @@ def test_lola_literal_call_sequence_gives_the_same_words(backend):
         assert np.array_equal(a, b)
     if backend == "gpu":
         assert s2 - s1 > s1 - s0                    # the per-vector sequence is made of more, smaller launches
+        # ... unless the library merges them: with deferred submission the rows' calls are queued and launched level by level as batched calls
+        for e in env.Environments:
+            e.ctx.set_option("defer", 1)
+        hewrapper.set_literal(True)
+        try:
+            deferred = run()
+        finally:
+            hewrapper.set_literal(False)
+            for e in env.Environments:
+                e.ctx.set_option("defer", 0)
+        s3 = stats()
+        for a, b in zip(batched, deferred):
+            assert np.array_equal(a, b)
+        assert s3 - s2 < (s2 - s1) // 2             # the queue gave most of the launches back

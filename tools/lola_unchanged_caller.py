@@ -119,13 +119,24 @@ def measure(name="LoLa", reps=20, device=0, image_seed=1234):
             assert all(rid[0] == "new" for rid in rids), rids
             calls = [len(r.records) for r in recs]
             out.Dispose()
-            for mode, host in ((0, "C++ replay, one host thread, contexts call by call"), (1, "C++ replay, one thread per plaintext prime, joined after every call"),
-                               (2, "C++ replay, one free-running thread per plaintext prime")):
-                ms, handles = call_trace.replay(recs, reps, mode, rids, warmup=2)
-                ok = logits_of_handles(handles, firsts, count, sparse) == want
-                for c, h in zip(ctxs, handles):
-                    c.free(h)
-                rows.append(dict(pattern=label, host=host, ms_per_image=round(ms, 2), logits_exact=bool(ok), calls_per_prime=calls[0]))
+            for defer in ((0, 1) if literal else (0,)):
+                # defer = 1: libcnhip's deferred submission (what the C# twin switches on): the per-row calls are queued and merged level by level
+                for c in ctxs:
+                    c.set_option("defer", defer)
+                try:
+                    for mode, host in ((0, "C++ replay, one host thread, contexts call by call"), (1, "C++ replay, one thread per plaintext prime, joined after every call"),
+                                       (2, "C++ replay, one free-running thread per plaintext prime")):
+                        l0 = sum(c.stats()["kernel_launches"] for c in ctxs)
+                        ms, handles = call_trace.replay(recs, reps, mode, rids, warmup=2)
+                        launches = (sum(c.stats()["kernel_launches"] for c in ctxs) - l0) / (reps + 2) / len(ctxs)
+                        ok = logits_of_handles(handles, firsts, count, sparse) == want
+                        for c, h in zip(ctxs, handles):
+                            c.free(h)
+                        rows.append(dict(pattern=label + (", deferred submission" if defer else ""), host=host, ms_per_image=round(ms, 2), logits_exact=bool(ok),
+                                         calls_per_prime=calls[0], launches_per_prime=round(launches, 1)))
+                finally:
+                    for c in ctxs:
+                        c.set_option("defer", 0)
         finally:
             hewrapper.set_literal(False)
     return rows
