@@ -282,7 +282,6 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import lola_unchanged_caller
                 rows = lola_unchanged_caller.measure(name, reps=max(5, min(20, args.steps)), device=local)
-                pick = lambda pat, host: [r for r in rows if r["pattern"].startswith(pat) and r["pattern"].endswith("deferred submission") == pat.endswith("!") and r["host"].startswith(host)][0]
                 sel = lambda lit, dfr, host: [r for r in rows if r["pattern"].startswith("unchanged") == lit and r["pattern"].endswith("deferred submission") == dfr and r["host"].startswith(host)][0]
                 lit, imm, bat = sel(True, True, "C++ replay, one host thread"), sel(True, False, "C++ replay, one host thread"), sel(False, False, "C++ replay, one host thread")
                 out["unchanged_caller"] = {"ms_per_image": lit["ms_per_image"], "logits_exact": lit["logits_exact"], "calls_per_prime": lit["calls_per_prime"],

@@ -220,6 +220,10 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->pool_max = (size_t)((env ? atof(env) : 8.0) * (double)(1ull << 30));
     c->legacy_ntt = getenv("CN_LEGACY_NTT") && atoi(getenv("CN_LEGACY_NTT"));
     c->ks_tight = getenv("CN_KS_TIGHT") && atoi(getenv("CN_KS_TIGHT"));
+    // fused key switch, workgroup order: limb-major up to N = 8192 (one key slice per XCD L2 at a time: 2.34 GiB fetched per 845-ciphertext launch
+    // against 3.99 GiB in (ciphertext, limb) order and 3.0 GiB with the limbs of a ciphertext on one XCD, same kernel time -
+    // profiles/r03_pmc_keyswitch_orders.txt); (ciphertext, limb) order at N = 16384, where limb-major measured 30 % slower in round 1
+    c->ks_xcd = c->hc.logn <= 13 ? 2 : 0;
     if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD"));
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
@@ -1607,7 +1611,8 @@ extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t co
 // A flush is triggered by demand (any entry point that needs results), by a full queue, and at LAYER BOUNDARIES, so that the device works on
 // one layer while the callers queue the next.  A boundary is recognised by the "heavy depth" of a value: 0 for anything that was not
 // produced by a queued call, and for fresh encryptions; a scalar product (DenseMatrixBySparseVectorMultiply) or a Multiply + Relinearize
-// produces depth 1 + the deepest of its inputs, additions pass the depth of their inputs on.  A heavy call that would reach depth 2 reads
+// (and every rotation / SumAllSlots: the kinds that end in a key switch) produces depth 1 + the deepest of its inputs; additions, plaintext
+// products and copies pass the depth of their inputs on.  A heavy call that would reach depth 2 reads
 // the result of another queued heavy call: the layer that produced it is complete (its callers have returned) - everything queued is
 // launched, if at least DEFER_FLUSH_MIN calls wait.  (Round 2 used the plain dependency level for this; with the literal padded taps -
 // encryption -> scalar product -> plain addition inside ONE layer - several caller threads interleave those levels and the layer was cut
@@ -1633,7 +1638,7 @@ static int32_t defer_level(DeferQueue *q, const uint64_t *const *ins, uint32_t n
 static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t nin) {
     DeferQueue *q = ctx->dq;
     int32_t lv = defer_level(q, ins, nin, op.out);
-    const bool heavy = op.type == DOP_GEMM1 || op.type == DOP_MULRELIN;
+    const bool heavy = op.type == DOP_GEMM1 || op.type == DOP_MULRELIN || (op.type >= DOP_ROT && op.type <= DOP_SUMSLOTS);      // every kind that ends in a key switch, and the GEMMs
     int32_t hd = 0;
     for (uint32_t i = 0; i < nin; i++) if (ins[i]) { const DeferQueue::Haz *h = q->haz.find(ins[i]); if (h) hd = std::max(hd, h->hd); }
     hd += heavy ? 1 : 0;

@@ -873,6 +873,7 @@ def test_key_switch_xcd_placement_is_only_a_placement(name, rng):
     h, out = up(g, cts), g.ct_alloc(19)
     want = o.mul_relin_batch(cts, cts)
     rot = np.stack([o.rotate_rows(c, 1) for c in cts])
+    default_order = g.get_option("ks_xcd")
     try:
         g.set_option("ks_wide", 0)
         for xcd in (1, 2, 0):
@@ -883,5 +884,5 @@ def test_key_switch_xcd_placement_is_only_a_placement(name, rng):
             assert np.array_equal(g.ct_download(out, 0, 19), rot), xcd
     finally:
         g.set_option("ks_wide", -1)
-        g.set_option("ks_xcd", 0)
+        g.set_option("ks_xcd", default_order)
     g.free(h), g.free(out)
