@@ -135,7 +135,11 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
     if ((sz) && var->size != (uint32_t)(sz)) return fail(CN_ERR_ARG, "ciphertext size mismatch for " #h)
 #define GETPT(var, h) Buffer *var = getbuf(ctx, h, 1); if (!var) return fail(CN_ERR_ARG, "invalid plaintext handle " #h)
 // every entry point takes the context lock; all but the deferrable ones (cn_defer.hip) first drain the queue of deferred calls
-#define LOCK_ONLY CnGuard lk_(ctx->mu); CHECK(use(ctx))
+// (the function bodies that start with LOCK / LOCK_ONLY run inside CnMutex::run - see API_BODY below: under the context lock, on the calling
+// thread or, when the lock is held, on the holder's thread)
+#define LOCK_ONLY CHECK(use(ctx))
+#define API_BODY return ctx->mu.run([&]() -> int {
+#define API_END });
 #define LOCK LOCK_ONLY; CHECK(cn_defer_flush(ctx))
 
 #define launch_count cn_launch_count
@@ -269,7 +273,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     delete ctx;
     return 0;
 }
-extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
+extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BODY
     LOCK;
     if (!name) return fail(CN_ERR_ARG, "null option name");
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
@@ -284,9 +288,9 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     return fail(CN_ERR_ARG, "unknown option %s", name);
-}
+API_END }
 // read-back of the switches and of choices the library made (tests, diagnostics)
-extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) {
+extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BODY
     LOCK_ONLY;
     if (!name || !value) return fail(CN_ERR_ARG, "null argument");
     if (!strcmp(name, "f64")) *value = ctx->use_f64;
@@ -303,24 +307,31 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) {
     else if (!strcmp(name, "pending_calls")) *value = (int)ctx->dq->ops.size();
     else return fail(CN_ERR_ARG, "unknown option %s", name);
     return 0;
-}
+API_END }
 #define NOT_CAPTURING(what) do { if (ctx->capturing) return fail(CN_ERR_ARG, what " is not possible while a graph is recorded (cn_graph_begin .. cn_graph_end)"); } while (0)
-extern "C" int cn_sync(cn_ctx *ctx) { LOCK; NOT_CAPTURING("cn_sync"); HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; }
+extern "C" int cn_sync(cn_ctx *ctx) { API_BODY LOCK; NOT_CAPTURING("cn_sync"); HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->staged.clear(); return 0; API_END }
 extern "C" void *cn_stream(cn_ctx *ctx) { return (void *)ctx->stream; }
 // ctx's later work waits (on the device) for other's earlier work.  The two locks are taken one after the other, never together.
-extern "C" int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other) {
-    if (!ctx || !other) return fail(CN_ERR_ARG, "null argument");
-    if (ctx == other) return 0;
+extern "C" int cn_ctx_wait_for(cn_ctx *ctx_, cn_ctx *other) {
+    if (!ctx_ || !other) return fail(CN_ERR_ARG, "null argument");
+    if (ctx_ == other) return 0;
     hipEvent_t ev = nullptr;
     {
-        cn_ctx *c0 = ctx; ctx = other;                    // (the macros name the context `ctx`)
-        { LOCK; NOT_CAPTURING("cn_ctx_wait_for"); if (!ctx->ev_order) HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
-          HIPCHK(hipEventRecord(ctx->ev_order, ctx->stream)); ev = ctx->ev_order; }
-        ctx = c0;
+        cn_ctx *ctx = other;                                  // (the macros name the context `ctx`)
+        const int rc = ctx->mu.run([&]() -> int {
+            LOCK; NOT_CAPTURING("cn_ctx_wait_for");
+            if (!ctx->ev_order) HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ctx->ev_order, ctx->stream)); ev = ctx->ev_order;
+            return 0;
+        });
+        if (rc) return rc;
     }
-    LOCK; NOT_CAPTURING("cn_ctx_wait_for");
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
-    return 0;
+    cn_ctx *ctx = ctx_;
+    return ctx->mu.run([&]() -> int {
+        LOCK; NOT_CAPTURING("cn_ctx_wait_for");
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
+        return 0;
+    });
 }
 extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ? ctx->hc.gk_tot : ctx->hc.rl_tot) * ctx->ctw2; }
 
@@ -346,14 +357,14 @@ static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count
     }
     return 0;
 }
-extern "C" int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_dev) {
+extern "C" int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_dev) { API_BODY
     LOCK; NOT_CAPTURING("cn_set_relin_key"); return set_key(ctx, ctx->rlk, words, count, cn_key_words(ctx, 0), is_dev);
-}
-extern "C" int cn_set_galois_key(cn_ctx *ctx, uint64_t elt, const uint64_t *words, size_t count, int is_dev) {
+API_END }
+extern "C" int cn_set_galois_key(cn_ctx *ctx, uint64_t elt, const uint64_t *words, size_t count, int is_dev) { API_BODY
     LOCK; NOT_CAPTURING("cn_set_galois_key");
     if (!(elt & 1) || elt >= 2ull * ctx->hc.n) return fail(CN_ERR_ARG, "invalid Galois element");
     return set_key(ctx, ctx->gk[elt], words, count, cn_key_words(ctx, 1), is_dev);
-}
+API_END }
 extern "C" int cn_has_galois_key(cn_ctx *ctx, uint64_t elt) { CnGuard lk(ctx->mu); auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
 extern "C" uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps) {
     uint64_t n = ctx->hc.n, m = 2 * n;
@@ -424,11 +435,11 @@ static int alloc_buf(cn_ctx *ctx, int kind, uint32_t count, uint32_t size, cn_ha
     *out = ctx->bufs.insert(std::move(b));
     return 0;
 }
-extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) {
+extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) { API_BODY
     LOCK_ONLY; if (size < 2 || size > 3) return fail(CN_ERR_ARG, "ciphertext size must be 2 or 3"); return alloc_buf(ctx, 0, count, size, out);
-}
-extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { LOCK_ONLY; return alloc_buf(ctx, 1, count, 1, out); }
-extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
+API_END }
+extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { API_BODY LOCK_ONLY; return alloc_buf(ctx, 1, count, 1, out); API_END }
+extern "C" int cn_free(cn_ctx *ctx, cn_handle h) { API_BODY
     LOCK_ONLY;
     Buffer *it = ctx->bufs.find(h);
     if (!it) return fail(CN_ERR_ARG, "invalid handle");
@@ -438,7 +449,7 @@ extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
     else CHECK(dev_release(ctx, it->d, it->item_words * 8 * it->count));
     ctx->bufs.erase(h);
     return 0;
-}
+API_END }
 // ---- captured sequences: the launch-bound chains of small kernels of a single-image inference (LoLa: ~235 launches per plaintext
 // prime) are recorded once on the context stream and replayed with one hipGraphLaunch - no per-launch host work, dependent kernels
 // back to back on the device.  Recording rules: the same sequence must have run once before (so that every temporary comes out of
@@ -455,14 +466,14 @@ static int free_graph(cn_ctx *ctx, Buffer &b) {
     ctx->graphs_alive--;
     return 0;
 }
-extern "C" int cn_graph_begin(cn_ctx *ctx) {
+extern "C" int cn_graph_begin(cn_ctx *ctx) { API_BODY
     LOCK; NOT_CAPTURING("cn_graph_begin");
     ctx->cap_staged.clear(); ctx->cap_allocs.clear();
     HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
     ctx->capturing = true;
     return 0;
-}
-extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) {
+API_END }
+extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) { API_BODY
     LOCK;
     if (!ctx->capturing) return fail(CN_ERR_ARG, "cn_graph_end without cn_graph_begin");
     ctx->capturing = false;
@@ -490,31 +501,31 @@ extern "C" int cn_graph_end(cn_ctx *ctx, cn_handle *graph) {
     ctx->graphs_alive++;
     *graph = ctx->bufs.insert(std::move(b));
     return 0;
-}
-extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) {
+API_END }
+extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) { API_BODY
     LOCK; NOT_CAPTURING("cn_graph_launch");
     Buffer *b = getbuf(ctx, graph, 3);
     if (!b || !b->cg) return fail(CN_ERR_ARG, "invalid graph handle");
     HIPCHK(hipGraphLaunch(b->cg->exec, ctx->stream));
     ctx->st.kernel_launches += 1;
     return 0;
-}
+API_END }
 extern "C" int cn_live_handles(cn_ctx *ctx) { CnGuard lk(ctx->mu); return (int)ctx->bufs.size(); }
-extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
+extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) { API_BODY
     LOCK; NOT_CAPTURING("cn_ct_upload"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(b->d + first * b->item_words, host, count * b->item_words * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
-extern "C" int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) {
+API_END }
+extern "C" int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) { API_BODY
     LOCK; NOT_CAPTURING("cn_ct_download"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(host, b->d + first * b->item_words, count * b->item_words * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
-extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) {
+API_END }
+extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) { API_BODY
     LOCK; NOT_CAPTURING("cn_pt_upload"); GETPT(b, h);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     const uint32_t n = ctx->hc.n; const uint64_t t = ctx->hc.t.q;
@@ -526,14 +537,14 @@ extern "C" int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t c
     HIPCHK(hipMemcpyAsync(b->d + (size_t)first * n, host, (size_t)count * n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
-extern "C" int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) {
+API_END }
+extern "C" int cn_pt_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host) { API_BODY
     LOCK; NOT_CAPTURING("cn_pt_download"); GETPT(b, h);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
     HIPCHK(hipMemcpyAsync(host, b->d + (size_t)first * ctx->hc.n, (size_t)count * ctx->hc.n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
+API_END }
 // BatchEncoder.Encode / Decode of `count` plaintexts with ONE upload, one scatter launch and one batched (I)NTT mod t: the slot order is
 // SEAL's index map (matrix rows -> bit-reversed coefficient positions), kept on the device
 __global__ void k_encode_scatter(const uint64_t *__restrict__ values, uint32_t nvalues, const uint32_t *__restrict__ index_map, uint64_t *__restrict__ out, uint32_t n) {
@@ -551,7 +562,7 @@ static int ensure_index_map(cn_ctx *ctx) {
     return 0;
 }
 // BatchEncoder.Encode: values [count][nvalues] (slot order, each < t; slots beyond nvalues are zero) -> plaintexts pt[pi .. pi + count)
-extern "C" int cn_encode_batch(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, uint32_t count, cn_handle pt, uint32_t pi) {
+extern "C" int cn_encode_batch(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, uint32_t count, cn_handle pt, uint32_t pi) { API_BODY
     LOCK; NOT_CAPTURING("cn_encode"); GETPT(b, pt);
     if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
     const uint32_t n = ctx->hc.n;
@@ -580,10 +591,10 @@ extern "C" int cn_encode_batch(cn_ctx *ctx, const uint64_t *values, uint32_t nva
     CHECK(cn_run_ntt(ctx, d, count, ctx->hc.k + ctx->hc.kb, 1, 1));
     for (uint32_t c = 0; c < count; c++) b->pt_zero[pi + c] = zero[c];
     return 0;
-}
+API_END }
 extern "C" int cn_encode(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, cn_handle pt, uint32_t pi) { return cn_encode_batch(ctx, values, nvalues, 1, pt, pi); }
 // BatchEncoder.Decode: plaintexts pt[pi .. pi + count) -> values [count][N] in slot order
-extern "C" int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t count, uint64_t *values) {
+extern "C" int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t count, uint64_t *values) { API_BODY
     LOCK; NOT_CAPTURING("cn_decode"); GETPT(b, pt);
     if (!ctx->hc.batching) return fail(CN_ERR_ARG, "plain modulus does not support batching");
     const uint32_t n = ctx->hc.n;
@@ -600,9 +611,9 @@ extern "C" int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t 
     HIPCHK(hipMemcpyAsync(values, slots, words * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
+API_END }
 extern "C" int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values) { return cn_decode_batch(ctx, pt, pi, 1, values); }
-extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) {
+extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count) { API_BODY
     LOCK_ONLY;
     Buffer *s = ctx->bufs.find(src), *d = ctx->bufs.find(dst);
     if (deferring(ctx) && s && d && s->kind == 0 && d->kind == 0 && s->size == 2 && d->size == 2 && count && count <= DEFER_STAGED_MAX &&
@@ -615,7 +626,7 @@ extern "C" int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle ds
     HIPCHK(hipMemcpyAsync(d->d + dfirst * d->item_words, s->d + sfirst * s->item_words, count * s->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (s->kind == 1) for (uint32_t i = 0; i < count; i++) d->pt_zero[dfirst + i] = s->pt_zero[sfirst + i];
     return 0;
-}
+API_END }
 extern "C" int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes) {
     CnGuard lk(ctx->mu);
     Buffer *it = ctx->bufs.find(h);
@@ -642,20 +653,20 @@ static bool deferring(cn_ctx *ctx);
 static int defer_addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op);
 static int defer_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count);
 static int defer_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out, uint32_t oi, uint32_t count);
-extern "C" int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
+extern "C" int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY;
     if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, 0); if (rc <= 0) return rc; }      // > 0: not deferrable (size-3 operands)
     CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 0)); ctx->st.Addition += count; return 0;
-}
-extern "C" int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
+API_END }
+extern "C" int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY;
     if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, 1); if (rc <= 0) return rc; }
     CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 1)); ctx->st.Subtraction += count; return 0;
-}
-extern "C" int cn_negate(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+API_END }
+extern "C" int cn_negate(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK; return addsub(ctx, a, ai, a, ai, out, oi, count, 2);
-}
-extern "C" int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint32_t n_idx, cn_handle out, uint32_t oi) {
+API_END }
+extern "C" int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint32_t n_idx, cn_handle out, uint32_t oi) { API_BODY
     LOCK; GETCT(I, in, 0); GETCT(O, out, I->size);
     if (!n_idx || !idx) return fail(CN_ERR_ARG, "AddMany of an empty list");
     for (uint32_t i = 0; i < n_idx; i++) if (idx[i] >= I->count) return fail(CN_ERR_ARG, "index out of range");
@@ -668,8 +679,8 @@ extern "C" int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint3
     HIPCHK(hipGetLastError()); launch_count(ctx);
     ctx->st.AddMany += 1; ctx->st.AddManyItemCount += n_idx;
     return 0;
-}
-extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) {
+API_END }
+extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY;
     if (deferring(ctx)) { int rc = defer_add_plain(ctx, a, ai, pt, pi, subtract, out, oi, count); if (rc <= 0) return rc; }
     CHECK(cn_defer_flush(ctx));
@@ -682,7 +693,7 @@ extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
     HIPCHK(hipGetLastError()); launch_count(ctx);
     if (subtract) ctx->st.PlainSubtraction += count; else ctx->st.PlainAddition += count;
     return 0;
-}
+API_END }
 // out[c] = a[c * (a_bcast ? 0 : 1)] * pt[c * pstride]; a_bcast: ONE ciphertext against `count` plaintexts (row-dot batches)
 // Dense MultiplyPlain in two launches (k_lift_ntt, k_mul_plain_fused); ranges / zero plaintexts were checked by the caller
 static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
@@ -740,7 +751,7 @@ static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buf
     ctx->st.PlainMultiplication += count;
     return 0;
 }
-extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pstride, cn_handle out, uint32_t oi, uint32_t count) {
+extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, uint32_t pstride, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY; GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
     if (deferring(ctx) && count && count <= DEFER_STAGED_MAX && A->size == 2) {       // the per-row MultiplyPlain of an unchanged caller: queued, rows merged at flush
         if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1)) return fail(CN_ERR_ARG, "index out of range");
@@ -750,9 +761,9 @@ extern "C" int cn_mul_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
     }
     CHECK(cn_defer_flush(ctx));
     return mul_plain_impl(ctx, A, ai, false, P, pi, pstride, O, oi, count);
-}
+API_END }
 static uint64_t lift_scalar(const DevConsts &hc, uint64_t w, uint32_t j) { return w >= hc.t_half ? w + hc.lift_inc[j] : w; }
-extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars, uint32_t sstride, cn_handle out, uint32_t oi, uint32_t count) {
+extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars, uint32_t sstride, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK; GETCT(A, a, 0); GETCT(O, out, A->size);
     if (!range_ok(A, ai, count) || !range_ok(O, oi, count) || !scalars) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
@@ -772,7 +783,7 @@ extern "C" int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64
     HIPCHK(hipGetLastError()); launch_count(ctx);
     ctx->st.PlainMultiplication += count;
     return 0;
-}
+API_END }
 
 // HOT LOOP A
 // weight tiles of a planned GEMM in kernel layout; row(g, m): the K weights (residues mod t) of member m of group g, or null
@@ -950,7 +961,7 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
     return 0;
 }
 extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
-                              const int32_t *bias_idx, cn_handle out, uint32_t oi) {
+                              const int32_t *bias_idx, cn_handle out, uint32_t oi) { API_BODY
     LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
     Buffer *BP = bias_pt ? getbuf(ctx, bias_pt, 1) : nullptr;
     GemmPlan P;
@@ -958,10 +969,10 @@ extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, con
     CHECK(ensure_scratch(ctx, al(P.host.size())));
     char *tables; CHECK(upload_tmp(ctx, P.host.data(), P.host.size(), &tables));
     return run_gemm_plan(ctx, P, tables, I, OB, oi);
-}
+API_END }
 // Plan once, apply per inference: the weight tiles and gather tables stay in HBM (cn_free releases the plan).
 extern "C" int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt, const int32_t *bias_idx,
-                                   cn_handle *plan) {
+                                   cn_handle *plan) { API_BODY
     LOCK; NOT_CAPTURING("cn_gemm_plan_create");
     if (!plan) return fail(CN_ERR_ARG, "null argument");
     Buffer *BP = bias_pt ? getbuf(ctx, bias_pt, 1) : nullptr;
@@ -973,13 +984,13 @@ extern "C" int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64
     Buffer b; b.kind = 2; b.count = O; b.size = 0; b.d = nullptr; b.item_words = 0; b.plan = P;
     *plan = ctx->bufs.insert(std::move(b));
     return 0;
-}
-extern "C" int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi) {
+API_END }
+extern "C" int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi) { API_BODY
     LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
     Buffer *PB = getbuf(ctx, plan, 2);
     if (!PB || !PB->plan) return fail(CN_ERR_ARG, "invalid scalar GEMM plan handle");
     return run_gemm_plan(ctx, *PB->plan, PB->plan->dev, I, OB, oi);
-}
+API_END }
 
 // ---------------------------------------------------------------- BEHZ multiply / key switching
 // tensor product fused into the inverse transform (register-radix sizes only); returns false when the caller must fall back
@@ -1123,7 +1134,7 @@ static uint32_t chunk_for(cn_ctx *ctx, size_t per_ct, uint32_t count) {
     return (uint32_t)std::min<size_t>(c, count);
 }
 
-extern "C" int cn_multiply(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out3, uint32_t oi, uint32_t count) {
+extern "C" int cn_multiply(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out3, uint32_t oi, uint32_t count) { API_BODY
     LOCK; GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out3, 3);
     if (!range_ok(A, ai, count) || !range_ok(B, bi, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
@@ -1136,8 +1147,8 @@ extern "C" int cn_multiply(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, u
         CHECK(do_multiply(ctx, pa + s * A->item_words, 1, pb + s * B->item_words, 1, O->d + (oi + s) * O->item_words, c));
     }
     return 0;
-}
-extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
+API_END }
+extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK; GETCT(I, in3, 3); GETCT(O, out, 2);
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!ctx->rlk.d) return fail(CN_ERR_NOKEY, "relinearization keys not set");
@@ -1147,9 +1158,9 @@ extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle
     CHECK(do_keyswitch(ctx, p + 2 * kn, 3 * kn, p, p + kn, 3 * kn, ctx->rlk, O->d + oi * O->item_words, count, 0));
     ctx->st.Relinarization += count;
     return 0;
-}
+API_END }
 extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out,
-                            uint32_t oi, uint32_t count) {
+                            uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY;
     if (deferring(ctx)) return defer_mul_relin(ctx, a, ai, astride, b, bi, bstride, out, oi, count);
     CHECK(cn_defer_flush(ctx));
@@ -1172,7 +1183,7 @@ extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astr
     }
     ctx->st.Relinarization += count;
     return 0;
-}
+API_END }
 
 // ---------------------------------------------------------------- rotations
 // in/out device pointers to size-2 ciphertext arrays; tmp holds count size-2 ciphertexts
@@ -1199,10 +1210,10 @@ static int galois_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, uint64_t elt, Buffer
     return do_galois(ctx, I->d + ii * I->item_words, elt, O->d + oi * O->item_words, tmp, count);
 }
 static bool galois_key_present(cn_ctx *ctx, uint64_t elt) { auto it = ctx->gk.find(elt); return it != ctx->gk.end() && it->second.d; }
-extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t elt, cn_handle out, uint32_t oi, uint32_t count) {
+extern "C" int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t elt, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK; GETCT(I, in, 2); GETCT(O, out, 2);
     return galois_impl(ctx, I, ii, elt, O, oi, count);
-}
+API_END }
 // Evaluator::rotate_internal: direct key if present, otherwise non-adjacent-form decomposition
 static bool has_direct_key(cn_ctx *ctx, int steps) {
     uint64_t elt = cn_galois_elt_from_step(ctx, steps);
@@ -1249,7 +1260,7 @@ static int rotate_check(cn_ctx *ctx, int steps) {
     for (int s2 : naf) { if ((uint32_t)std::abs(s2) == ctx->hc.n / 2) continue; CHECK(rotate_check(ctx, s2)); }
     return 0;
 }
-extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count) {
+extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY; GETCT(I, in, 2); GETCT(O, out, 2);
     if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
         if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -1258,7 +1269,7 @@ extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps,
     }
     CHECK(cn_defer_flush(ctx));
     return rotate_rows_impl(ctx, I, ii, steps, O, oi, count);
-}
+API_END }
 // out = acc + RotateRows(in, steps): the rotate-and-add step of SumAllSlots (AtomicSealBfvVector.cs:862-868) with the addition
 // fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
 static int rotate_rows_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
@@ -1293,7 +1304,7 @@ static int rotate_columns_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, Buffer *
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
     return do_galois(ctx, I->d + ii * I->item_words, 2ull * ctx->hc.n - 1, O->d + oi * O->item_words, tmp, count, A->d + ai * A->item_words);
 }
-extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
     if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
         if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -1302,8 +1313,8 @@ extern "C" int cn_rotate_rows_add(cn_ctx *ctx, cn_handle in, uint32_t ii, int st
     }
     CHECK(cn_defer_flush(ctx));
     return rotate_rows_add_impl(ctx, I, ii, steps, A, ai, O, oi, count);
-}
-extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) {
+API_END }
+extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle acc, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY; GETCT(I, in, 2); GETCT(A, acc, 2); GETCT(O, out, 2);
     if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
         if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -1312,7 +1323,7 @@ extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_
     }
     CHECK(cn_defer_flush(ctx));
     return rotate_columns_add_impl(ctx, I, ii, A, ai, O, oi, count);
-}
+API_END }
 // SumAllSlots(length) of AtomicSealBfvVector.cs:888-935 on `count` single-block ciphertexts at once, in place: the column swap when
 // length >= N/2, then log2 rotate-and-add steps (RotateRows(-2^s) + AddInplace).  length 0 = all N slots.
 static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count, uint32_t length) {
@@ -1322,7 +1333,7 @@ static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count
     for (uint32_t steps = 1; steps < len; steps *= 2) CHECK(rotate_rows_add_impl(ctx, H, first, -(int)steps, H, first, H, first, count));
     return 0;
 }
-extern "C" int cn_sum_slots(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint32_t length) {
+extern "C" int cn_sum_slots(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint32_t length) { API_BODY
     LOCK_ONLY; GETCT(H, h, 2);
     if (!range_ok(H, first, count)) return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
@@ -1335,18 +1346,18 @@ extern "C" int cn_sum_slots(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t c
     }
     CHECK(cn_defer_flush(ctx));
     return sum_slots_impl(ctx, H, first, count, length);
-}
+API_END }
 // out[r] = SumAllSlots(v * pt[r], length) for r < rows: every row of a plaintext matrix against ONE packed ciphertext
 // (EncryptedSealBfvMatrix.Mul row-major, EncryptedSealBfvMatrix.cs:79-120 -> DotProduct, AtomicSealBfvVector.cs:963-977).
-extern "C" int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle pt, uint32_t pi, uint32_t rows, uint32_t length, cn_handle out, uint32_t oi) {
+extern "C" int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle pt, uint32_t pi, uint32_t rows, uint32_t length, cn_handle out, uint32_t oi) { API_BODY
     LOCK; GETCT(V, v, 2); GETCT(O, out, 2); GETPT(P, pt);
     if (!rows) return 0;
     if (V == O && vi >= oi && vi < oi + rows) return fail(CN_ERR_ARG, "row-dot batch cannot overwrite its input");
     CHECK(mul_plain_impl(ctx, V, vi, true, P, pi, 1, O, oi, rows));
     if (length == 1) return 0;
     return sum_slots_impl(ctx, O, oi, rows, length);
-}
-extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) {
+API_END }
+extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY; GETCT(I, in, 2); GETCT(O, out, 2);
     if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
         if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -1355,7 +1366,7 @@ extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_hand
     }
     CHECK(cn_defer_flush(ctx));
     return galois_impl(ctx, I, ii, 2ull * ctx->hc.n - 1, O, oi, count);
-}
+API_END }
 
 // ---------------------------------------------------------------- client side on the device
 static int set_plain_key(cn_ctx *ctx, uint64_t **slot, const uint64_t *words, size_t count, size_t expect) {
@@ -1365,10 +1376,10 @@ static int set_plain_key(cn_ctx *ctx, uint64_t **slot, const uint64_t *words, si
     HIPCHK(hipMemcpy(*slot, words, expect * 8, hipMemcpyHostToDevice));
     return 0;
 }
-extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; NOT_CAPTURING("cn_set_public_key"); return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2); }
-extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { LOCK; NOT_CAPTURING("cn_set_secret_key"); return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); }
+extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count) { API_BODY LOCK; NOT_CAPTURING("cn_set_public_key"); return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2); API_END }
+extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { API_BODY LOCK; NOT_CAPTURING("cn_set_secret_key"); return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); API_END }
 // which: 0 relin, 1 galois(elt), 2 public, 3 secret.  Exports u64 residues (FP64-form keys are converted back).
-extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, size_t count) {
+extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, size_t count) { API_BODY
     LOCK; NOT_CAPTURING("cn_get_key");
     const uint64_t *src = nullptr; size_t words = 0; bool f64 = false;
     if (which == 0) { src = ctx->rlk.d; words = cn_key_words(ctx, 0); f64 = ctx->rlk.f64; }
@@ -1381,7 +1392,7 @@ extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, 
     HIPCHK(hipMemcpy(host, src, words * 8, hipMemcpyDeviceToHost));
     if (f64) for (size_t i = 0; i < words; i++) { double d; memcpy(&d, &host[i], 8); host[i] = (uint64_t)d; }
     return 0;
-}
+API_END }
 static RngKey rng_key_of(const cn_ctx *ctx) { RngKey k; memcpy(k.k, ctx->rng_key, sizeof k.k); return k; }
 // `polys` polynomials [polys][k][N] of residues: kind 0 ternary, 1 clipped normal (both drawn ONCE per coefficient into an int8 array in
 // scratch - the caller's ensure_scratch leaves room for polys * N bytes - and expanded to the k limbs), 2 uniform per limb
@@ -1435,10 +1446,10 @@ static int adopt_ksk(cn_ctx *ctx, KsKey &slot, uint64_t *dev, size_t words) {   
     return 0;
 }
 // sampler key material: the 256-bit ChaCha20 key of every block keygen / encrypt draw from now on (cn_set_rng_salt: its first 64 bits)
-extern "C" int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt) { LOCK; ctx->rng_key[0] = (uint32_t)salt; ctx->rng_key[1] = (uint32_t)(salt >> 32); return 0; }
+extern "C" int cn_set_rng_salt(cn_ctx *ctx, uint64_t salt) { API_BODY LOCK; ctx->rng_key[0] = (uint32_t)salt; ctx->rng_key[1] = (uint32_t)(salt >> 32); return 0; API_END }
 // known-answer hook: the generator's block for (key, counter words 12-13, nonce words 14-15) - RFC 7539 section 2.3.2 is reproduced with
 // counter = 0x09000000'00000001, nonce = 0x00000000'4a000000 (tests/test_gpu_client.py)
-extern "C" int cn_rng_selftest(cn_ctx *ctx, const uint8_t *key32, uint64_t counter, uint64_t nonce, uint32_t *out16) {
+extern "C" int cn_rng_selftest(cn_ctx *ctx, const uint8_t *key32, uint64_t counter, uint64_t nonce, uint32_t *out16) { API_BODY
     LOCK; NOT_CAPTURING("cn_rng_selftest");
     if (!key32 || !out16) return fail(CN_ERR_ARG, "null argument");
     RngKey k; memcpy(k.k, key32, 32);
@@ -1449,16 +1460,16 @@ extern "C" int cn_rng_selftest(cn_ctx *ctx, const uint8_t *key32, uint64_t count
     HIPCHK(hipMemcpyAsync(out16, d, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
-extern "C" int cn_set_rng_key(cn_ctx *ctx, const uint8_t *key32) {
+API_END }
+extern "C" int cn_set_rng_key(cn_ctx *ctx, const uint8_t *key32) { API_BODY
     LOCK;
     if (!key32) return fail(CN_ERR_ARG, "null argument");
     memcpy(ctx->rng_key, key32, 32);
     return 0;
-}
+API_END }
 // KeyGenerator (AtomicSealBfvVector.cs:62-74,163-173 runs it inside SEAL): secret, public, relinearisation and the default Galois
 // key set (2N-1, 3^(2^i), 3^(-2^i)) generated on the device from the ChaCha20 sampler.
-extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
+extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) { API_BODY
     LOCK; NOT_CAPTURING("cn_keygen");
     const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
     if (!ctx->sk) HIPCHK(hipMalloc((void **)&ctx->sk, kn * 8));
@@ -1502,7 +1513,7 @@ extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) {
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
+API_END }
 // Encryptor.Encrypt (AtomicSealBfvVector.cs:1211,1227): (pk0 u + e1 + Delta m [+ r_t(q)], pk1 u + e2); pt = 0 encrypts zero.
 // tab != null: `cnt` encryptions whose outputs / plaintexts / nonces / items come from the table (host copy `htab`), else dense out / ptd
 static int encrypt_chain(cn_ctx *ctx, uint32_t cnt, const uint64_t *ptd, uint32_t pt_stride_words, uint64_t *out, uint64_t seed, const EncTab *htab) {
@@ -1527,7 +1538,7 @@ static int encrypt_chain(cn_ctx *ctx, uint32_t cnt, const uint64_t *ptd, uint32_
     return 0;
 }
 static int defer_encrypt(cn_ctx *ctx, const uint64_t *ptd, uint32_t pt_stride_words, Buffer *O, uint32_t oi, uint32_t count, uint64_t seed);
-extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) {
+extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) { API_BODY
     LOCK_ONLY; NOT_CAPTURING("cn_encrypt (a replayed graph would reuse its randomness)"); GETCT(O, out, 2);
     if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
     if (!range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -1539,7 +1550,7 @@ extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_st
     if (deferring(ctx) && count <= 4) return defer_encrypt(ctx, ptd, pt_stride ? ctx->hc.n : 0, O, oi, count, seed);
     CHECK(cn_defer_flush(ctx));
     return encrypt_chain(ctx, count, ptd, pt_stride ? ctx->hc.n : 0, O->d + oi * O->item_words, seed, nullptr);
-}
+API_END }
 #define DISPATCH_K2(fn, ...) switch (ctx->hc.k) { \
     case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; \
     case 5: fn<5>(__VA_ARGS__); break; case 6: fn<6>(__VA_ARGS__); break; case 7: fn<7>(__VA_ARGS__); break; case 8: fn<8>(__VA_ARGS__); break; \
@@ -1567,7 +1578,7 @@ static int decrypt_phase(cn_ctx *ctx, Buffer *I, uint32_t ci, uint32_t count, ui
     return cn_run_ntt(ctx, acc, count * k, 0, k, 1);
 }
 // Decryptor.Decrypt (AtomicSealBfvVector.cs:1042,1085): m = round(t (c0 + c1 s + c2 s^2) / q) mod t
-extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi) {
+extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi) { API_BODY
     LOCK; GETCT(I, ct, 0); GETPT(P, pt_out);
     if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
     if (!ctx->hc.inv_g_t) return fail(CN_ERR_ARG, "device decryption needs a prime plain modulus");
@@ -1579,9 +1590,9 @@ extern "C" int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count
     HIPCHK(hipGetLastError()); launch_count(ctx);
     for (uint32_t c = 0; c < count; c++) P->pt_zero[pi + c] = 0;      // unknown: treated as non-zero
     return 0;
-}
+API_END }
 // Decryptor.InvariantNoiseBudget (CryptoTracker.cs:41-52): the residues of t (c0 + c1 s + c2 s^2) mod q, [count][k][N] to the host
-extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, uint64_t *host) {
+extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, uint64_t *host) { API_BODY
     LOCK; NOT_CAPTURING("cn_noise_poly"); GETCT(I, ct, 0);
     if (!ctx->sk) return fail(CN_ERR_NOKEY, "secret key not set");
     if (!host || !range_ok(I, ci, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -1593,7 +1604,7 @@ extern "C" int cn_noise_poly(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t co
     HIPCHK(hipMemcpyAsync(host, acc, (size_t)count * ctx->hc.k * ctx->hc.n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
-}
+API_END }
 
 
 // ---------------------------------------------------------------- deferred submission of per-ciphertext calls
@@ -1965,7 +1976,7 @@ static int cn_defer_flush(cn_ctx *ctx) {
 static bool deferring(cn_ctx *ctx) { return ctx->defer && !ctx->capturing; }
 
 /* DenseMatrixBySparseVectorMultiply for ONE output block whose K input ciphertexts are separate objects (see include/cnhip.h) */
-extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi) {
+extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi) { API_BODY
     LOCK_ONLY; GETCT(O, out, 2);
     if (!K || !in || !w) return fail(CN_ERR_ARG, "empty scalar product");
     if (oi >= O->count) return fail(CN_ERR_ARG, "index out of range");
@@ -1996,7 +2007,7 @@ extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *i
     ctx->st.PlainMultiplication += nnz; ctx->st.Addition += nnz - 1;
     if (!deferring(ctx)) return cn_defer_flush(ctx);
     return 0;
-}
+API_END }
 
 // ---- the deferrable forms of the per-ciphertext entry points (arguments are checked now, the work is queued)
 static int defer_addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op) {
@@ -2163,14 +2174,14 @@ static int raw_ntt(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse) 
     if (base != 0 && base != 1) return fail(CN_ERR_ARG, "base must be 0 (q) or 1 (Bsk)");
     return cn_run_ntt(ctx, (uint64_t *)p, limbs, base ? ctx->hc.k : 0, base ? ctx->hc.kb : ctx->hc.k, inverse);
 }
-extern "C" int cn_ntt_forward(cn_ctx *ctx, void *p, uint32_t limbs, int base) { LOCK; return raw_ntt(ctx, p, limbs, base, 0); }
-extern "C" int cn_ntt_inverse(cn_ctx *ctx, void *p, uint32_t limbs, int base) { LOCK; return raw_ntt(ctx, p, limbs, base, 1); }
-extern "C" int cn_ct_ntt(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, int inverse) {
+extern "C" int cn_ntt_forward(cn_ctx *ctx, void *p, uint32_t limbs, int base) { API_BODY LOCK; return raw_ntt(ctx, p, limbs, base, 0); API_END }
+extern "C" int cn_ntt_inverse(cn_ctx *ctx, void *p, uint32_t limbs, int base) { API_BODY LOCK; return raw_ntt(ctx, p, limbs, base, 1); API_END }
+extern "C" int cn_ct_ntt(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, int inverse) { API_BODY
     LOCK; GETCT(B, h, 0);
     if (!range_ok(B, first, count)) return fail(CN_ERR_ARG, "index out of range");
     return raw_ntt(ctx, B->d + first * B->item_words, count * B->size * ctx->hc.k, 0, inverse);
-}
-extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse, int iters, float *ms) {
+API_END }
+extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int inverse, int iters, float *ms) { API_BODY
     LOCK; NOT_CAPTURING("cn_ntt_time");
     if (iters < 1 || !ms) return fail(CN_ERR_ARG, "bad arguments");
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -2180,11 +2191,11 @@ extern "C" int cn_ntt_time(cn_ctx *ctx, void *p, uint32_t limbs, int base, int i
     float t = 0; HIPCHK(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
     *ms = t / iters;
     return 0;
-}
+API_END }
 // ns per wave-instruction per SIMD RIGHT NOW (same occupancy as the fused key switch: 512-thread workgroups, one per CU, two waves per
 // SIMD), over `launches` launches.  kind 0: FP64 (8 independent chains of the 6-instruction modular multiply per thread, `iters` x 48
 // instructions); kind 1: full-rate 32-bit VALU (4 chains x 6 instructions, `iters` x 24)
-extern "C" int cn_valu_issue_time(cn_ctx *ctx, int kind, int iters, int launches, float *ns_per_instr) {
+extern "C" int cn_valu_issue_time(cn_ctx *ctx, int kind, int iters, int launches, float *ns_per_instr) { API_BODY
     LOCK; NOT_CAPTURING("cn_valu_issue_time");
     if (iters < 1 || launches < 1 || !ns_per_instr || kind < 0 || kind > 1) return fail(CN_ERR_ARG, "bad arguments");
     int cus = 0;
@@ -2208,17 +2219,17 @@ extern "C" int cn_valu_issue_time(cn_ctx *ctx, int kind, int iters, int launches
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ns_per_instr = ms * 1e6f / ((float)launches * 2.0f * (float)iters * (kind == 0 ? 48.0f : 24.0f));       // 2 waves per SIMD
     return 0;
-}
-extern "C" int cn_event_time_begin(cn_ctx *ctx) { LOCK; HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return 0; }
-extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) {
+API_END }
+extern "C" int cn_event_time_begin(cn_ctx *ctx) { API_BODY LOCK; HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return 0; API_END }
+extern "C" int cn_event_time_end(cn_ctx *ctx, float *ms) { API_BODY
     LOCK; NOT_CAPTURING("cn_event_time_end");
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream)); HIPCHK(hipEventSynchronize(ctx->ev1));
     HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return 0;
-}
-extern "C" int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset) {
+API_END }
+extern "C" int cn_stats_get(cn_ctx *ctx, cn_stats *out, int reset) { API_BODY
     LOCK;                                        // queued calls are launched first: Multiplication is counted by the batched multiply at flush time
     if (out) *out = ctx->st;
     if (reset) ctx->st = cn_stats{};
     return 0;
-}
+API_END }

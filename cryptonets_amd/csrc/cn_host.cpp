@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <sched.h>
 
 static thread_local char g_err[512] = "";
@@ -11,6 +12,8 @@ int cn_fail(int code, const char *fmt, ...) {
     return code;
 }
 extern "C" const char *cn_last_error(void) { return g_err; }
+static void err_copy_out(char *dst, size_t n) { snprintf(dst, n, "%s", g_err); }
+static void err_set(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 
 // The context lock.  The reference calls the wrapper from Defaults.ThreadCount = Environment.ProcessorCount threads (HE Wrapper/Defaults.cs,
 // Utils.cs:46-88) - 256 on the bench box - and every call is a few hundred nanoseconds of bookkeeping under this lock: the work is
@@ -103,4 +106,49 @@ void CnMutex::unlock(Node &) {
         wake_seq.fetch_add(1, std::memory_order_acq_rel);
         futex(&wake_seq, FUTEX_WAKE_PRIVATE, 1, nullptr);
     }
+}
+
+// ---- combining (CnMutex::run, cn_runtime.h)
+bool CnMutex::try_take_me() { return try_take(my_tid()); }
+bool CnMutex::combining() { static const bool on = !(getenv("CN_LOCK_COMBINE") && atoi(getenv("CN_LOCK_COMBINE")) == 0); return on; }
+void CnMutex::release() { Node n; unlock(n); }
+// executes every published request (oldest first), a bounded number of rounds; the caller holds the lock
+void CnMutex::serve() {
+    char saved[sizeof g_err]; bool have_saved = false;
+    for (int round = 0; round < 256; round++) {
+        CnReq *list = pending.exchange(nullptr, std::memory_order_acquire);
+        if (!list) break;
+        if (!have_saved) { memcpy(saved, g_err, sizeof g_err); have_saved = true; }       // this thread's own cn_last_error() survives the service
+        CnReq *rev = nullptr;
+        while (list) { CnReq *nx = list->next; list->next = rev; rev = list; list = nx; }
+        while (rev) {
+            CnReq *nx = rev->next;                              // (the request may vanish the moment it is marked done)
+            const int rc = rev->fn(rev->arg);
+            rev->rc = rc;
+            if (rc) err_copy_out(rev->err, sizeof rev->err);     // the message was written on THIS thread: hand it to the caller
+            const int asleep = rev->asleep.load(std::memory_order_acquire);
+            std::atomic<int> *flag = &rev->done;
+            flag->store(1, std::memory_order_release);
+            if (asleep) futex(flag, FUTEX_WAKE_PRIVATE, 1, nullptr);
+            rev = nx;
+        }
+    }
+    if (have_saved) memcpy(g_err, saved, sizeof g_err);
+}
+int CnMutex::submit(CnReq &r) {
+    r.next = pending.load(std::memory_order_relaxed);
+    while (!pending.compare_exchange_weak(r.next, &r, std::memory_order_release, std::memory_order_relaxed)) {}
+    const uint32_t me = my_tid();
+    for (int spins = 0;; spins++) {
+        if (r.done.load(std::memory_order_acquire)) break;
+        if (try_take(me)) { serve(); release(); continue; }     // every request taken by an earlier holder was completed before it released: mine is done now
+        if (spins < 256) __builtin_ia32_pause();
+        else {                                                   // sleep on the request itself; woken by the thread that serves it (50 us backstop)
+            r.asleep.store(1, std::memory_order_release);
+            if (!r.done.load(std::memory_order_acquire)) { const struct timespec to = {0, 50000}; futex(&r.done, FUTEX_WAIT_PRIVATE, 0, &to); }
+            r.asleep.store(0, std::memory_order_relaxed);
+        }
+    }
+    if (r.rc) err_set(r.err);
+    return r.rc;
 }

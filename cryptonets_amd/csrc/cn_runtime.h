@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -68,18 +69,45 @@ struct KsKey { uint64_t *d; bool owned; bool f64; };   // f64: words converted t
 // hundred nanoseconds of bookkeeping (handle table, deferred-operation queue): a futex mutex hands every contended acquisition through
 // the kernel, so waiters spin (and yield when the wait gets long).
 // Spin lock (cn_host.cpp): the critical sections are short, waiters spin briefly and then yield.
+// A request published by a thread that found the lock held: the holder executes it (combining) and reports back through it.
+struct CnReq {
+    int (*fn)(void *) = nullptr; void *arg = nullptr; int rc = 0;
+    std::atomic<int> done{0}, asleep{0};
+    CnReq *next = nullptr;
+    char err[256];
+};
 class CnMutex {
 public:
     struct Node {};           // (per-acquisition state of a queue lock; the current lock needs none)
     void lock(Node &n);
     void unlock(Node &n);
+    // Run f() under the lock: on this thread when the lock is free - and then ALSO every request other threads published meanwhile - or,
+    // when it is held, on the holder's thread (the request is published, this thread waits for its completion).  The calls of an
+    // unchanged CryptoNets layer are a few hundred nanoseconds of bookkeeping on the same few cache lines (queue tails, hazard table,
+    // handle table, counters), issued from Defaults.ThreadCount threads: executed by whoever holds the lock, those lines stay in ONE
+    // core's cache instead of crossing the chip (or the socket) with every call.  f must not call into the same context again.
+    template <class F> int run(F &&f) {
+        if (!combining()) { Node n; lock(n); const int rc = f(); unlock(n); return rc; }      // CN_LOCK_COMBINE=0: plain acquisition (A/B)
+        if (try_take_me()) { const int rc = f(); serve(); release(); return rc; }
+        typedef typename std::remove_reference<F>::type Fn;
+        CnReq r;
+        r.fn = [](void *p) -> int { return (*static_cast<Fn *>(p))(); };
+        r.arg = (void *)&f; r.err[0] = 0;
+        return submit(r);
+    }
 private:
     std::atomic<int> held{0};
     std::atomic<int> spinners{0};      // waiters that spin; the others sleep on wake_seq (cn_host.cpp)
     std::atomic<int> sleepers{0}, wake_seq{0};
     std::atomic<uint32_t> last_owner{0}, burst{0};   // owner bias (cn_host.cpp): who released last, how many times in a row it re-acquired
     std::atomic<uint64_t> released_at{0};            // TSC of the last release
+    std::atomic<CnReq *> pending{nullptr};           // published requests (a stack; served oldest first)
     bool try_take(uint32_t me);
+    bool try_take_me();
+    static bool combining();
+    void release();
+    void serve();
+    int submit(CnReq &r);
 };
 struct CnGuard {
     CnMutex &m; CnMutex::Node n;

@@ -14,4 +14,4 @@ def test_context_lock_stress():
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()
     lines = r.stdout.decode().splitlines()
-    assert len(lines) == 5 and all("counter" in ln for ln in lines)
+    assert len(lines) == 15 and all("counter" in ln and " bad 0 " in ln for ln in lines)
