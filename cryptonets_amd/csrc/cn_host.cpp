@@ -110,7 +110,12 @@ void CnMutex::unlock(Node &) {
 
 // ---- combining (CnMutex::run, cn_runtime.h)
 bool CnMutex::try_take_me() { return try_take(my_tid()); }
-bool CnMutex::combining() { static const bool on = !(getenv("CN_LOCK_COMBINE") && atoi(getenv("CN_LOCK_COMBINE")) == 0); return on; }
+// Combining is OFF by default (CN_LOCK_COMBINE=1 switches it on): measured on the MI355X box (profiles/r03_unchanged_caller_combining.txt) it LOST -
+// the unchanged CryptoNets caller ran at 0.92 / 0.77 / 0.58 / 0.57 / 0.47 of the batched rate at 1 / 4 / 16 / 64 / 256 threads with it
+// against 0.95 / 0.92 / 0.94 / 0.91 / 0.92 with the plain lock in the same visit: a thread whose request is executed by somebody else still
+// has to notice, and a caller thread issues its 5-15 calls per work item one after the other - every one of them then pays a hand-back
+// (a cache line pulled across, or a futex wake-up) where the plain lock lets it run its own short critical section as soon as the lock is free.
+bool CnMutex::combining() { static const bool on = getenv("CN_LOCK_COMBINE") && atoi(getenv("CN_LOCK_COMBINE")) != 0; return on; }
 void CnMutex::release() { Node n; unlock(n); }
 // executes every published request (oldest first), a bounded number of rounds; the caller holds the lock
 void CnMutex::serve() {

@@ -81,13 +81,12 @@ public:
     struct Node {};           // (per-acquisition state of a queue lock; the current lock needs none)
     void lock(Node &n);
     void unlock(Node &n);
-    // Run f() under the lock: on this thread when the lock is free - and then ALSO every request other threads published meanwhile - or,
-    // when it is held, on the holder's thread (the request is published, this thread waits for its completion).  The calls of an
-    // unchanged CryptoNets layer are a few hundred nanoseconds of bookkeeping on the same few cache lines (queue tails, hazard table,
-    // handle table, counters), issued from Defaults.ThreadCount threads: executed by whoever holds the lock, those lines stay in ONE
-    // core's cache instead of crossing the chip (or the socket) with every call.  f must not call into the same context again.
+    // Run f() under the lock.  Default: plain acquisition.  With CN_LOCK_COMBINE=1 (an experiment that is kept switchable, measured slower -
+    // cn_host.cpp): on this thread when the lock is free - and then ALSO every request other threads published meanwhile - or, when it is
+    // held, on the holder's thread (the request is published, this thread waits for its completion), so that the few cache lines every call
+    // works on (queue tails, hazard table, handle table, counters) stay in one core's cache.  f must not call into the same context again.
     template <class F> int run(F &&f) {
-        if (!combining()) { Node n; lock(n); const int rc = f(); unlock(n); return rc; }      // CN_LOCK_COMBINE=0: plain acquisition (A/B)
+        if (!combining()) { Node n; lock(n); const int rc = f(); unlock(n); return rc; }
         if (try_take_me()) { const int rc = f(); serve(); release(); return rc; }
         typedef typename std::remove_reference<F>::type Fn;
         CnReq r;
