@@ -106,21 +106,39 @@ template <class T> static T *salloc(cn_ctx *c, size_t count) {
 // Small host tables (gather indices, weight tiles) travel with an asynchronous copy on the context stream.  The caller's buffer is
 // usually a local std::vector, so the bytes are first moved into a staging block the context keeps alive until the stream has
 // drained (checked lazily) - the copy never reads memory that has gone out of scope, whatever the runtime does with pageable sources.
+// Host side of the small uploads: a ring of PINNED memory per context.  hipMemcpyAsync from pageable memory is staged by the runtime and
+// holds the calling thread for ~10 us a piece; a flush of queued LoLa calls uploads a few hundred small tables.  A block of the ring is
+// reused only after the stream has passed it: the ring synchronises once per lap.
+static char *pin_block(cn_ctx *c, size_t bytes) {
+    const size_t cap = 8u << 20;
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes > cap / 2) return nullptr;
+    if (!c->pin) { if (hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pin = nullptr; return nullptr; } c->pin_off = 0; }
+    if (c->pin_off + bytes > cap) { if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr; c->pin_off = 0; }
+    char *p = c->pin + c->pin_off;
+    c->pin_off += bytes;
+    return p;
+}
+static int upload_bytes(cn_ctx *c, const void *host, size_t bytes, void *dev) {
+    if (!c->capturing) {
+        if (char *p = pin_block(c, bytes)) {
+            memcpy(p, host, bytes);
+            HIPCHK(hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, c->stream));
+            return 0;
+        }
+    }
+    std::vector<std::unique_ptr<char[]>> &keep = c->capturing ? c->cap_staged : c->staged;      // a recorded upload reads its host block at EVERY launch
+    if (!c->capturing && !keep.empty() && hipStreamQuery(c->stream) == hipSuccess) keep.clear();
+    (void)hipGetLastError();                                   // hipStreamQuery reports hipErrorNotReady through the sticky error as well
+    keep.emplace_back(new char[bytes]);
+    memcpy(keep.back().get(), host, bytes);
+    HIPCHK(hipMemcpyAsync(dev, keep.back().get(), bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
 template <class T> static int upload_tmp(cn_ctx *c, const T *host, size_t count, T **dev) {
     *dev = salloc<T>(c, count);
     if (!*dev) return fail(CN_ERR_HIP, "internal: scratch exhausted");
-    if (c->capturing) {                                        // the upload becomes a graph node that reads the host block at EVERY launch
-        c->cap_staged.emplace_back(new char[count * sizeof(T)]);
-        memcpy(c->cap_staged.back().get(), host, count * sizeof(T));
-        HIPCHK(hipMemcpyAsync(*dev, c->cap_staged.back().get(), count * sizeof(T), hipMemcpyHostToDevice, c->stream));
-        return 0;
-    }
-    if (!c->staged.empty() && hipStreamQuery(c->stream) == hipSuccess) c->staged.clear();
-    (void)hipGetLastError();                                   // hipStreamQuery reports hipErrorNotReady through the sticky error as well
-    c->staged.emplace_back(new char[count * sizeof(T)]);
-    memcpy(c->staged.back().get(), host, count * sizeof(T));
-    HIPCHK(hipMemcpyAsync(*dev, c->staged.back().get(), count * sizeof(T), hipMemcpyHostToDevice, c->stream));
-    return 0;
+    return upload_bytes(c, host, count * sizeof(T), *dev);
 }
 static Buffer *getbuf(cn_ctx *c, cn_handle h, int kind) {
     Buffer *b = c->bufs.find(h);
@@ -265,7 +283,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     delete &slabs_of(ctx);
     if (ctx->rlk.owned) (void)hipFree(ctx->rlk.d);
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
-    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map); (void)hipFree(ctx->stage);
+    (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map); (void)hipFree(ctx->stage); if (ctx->pin) (void)hipHostFree(ctx->pin);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     (void)hipStreamDestroy(ctx->stream);
@@ -1622,8 +1640,7 @@ API_END }
 // A flush is triggered by demand (any entry point that needs results), by a full queue, and at LAYER BOUNDARIES, so that the device works on
 // one layer while the callers queue the next.  A boundary is recognised by the "heavy depth" of a value: 0 for anything that was not
 // produced by a queued call, and for fresh encryptions; a scalar product (DenseMatrixBySparseVectorMultiply) or a Multiply + Relinearize
-// (and every rotation / SumAllSlots: the kinds that end in a key switch) produces depth 1 + the deepest of its inputs; additions, plaintext
-// products and copies pass the depth of their inputs on.  A heavy call that would reach depth 2 reads
+// produces depth 1 + the deepest of its inputs; additions, plaintext products, rotations and copies pass the depth of their inputs on.  A heavy call that would reach depth 2 reads
 // the result of another queued heavy call: the layer that produced it is complete (its callers have returned) - everything queued is
 // launched, if at least DEFER_FLUSH_MIN calls wait.  (Round 2 used the plain dependency level for this; with the literal padded taps -
 // encryption -> scalar product -> plain addition inside ONE layer - several caller threads interleave those levels and the layer was cut
@@ -1649,7 +1666,8 @@ static int32_t defer_level(DeferQueue *q, const uint64_t *const *ins, uint32_t n
 static int defer_push(cn_ctx *ctx, DOp op, const uint64_t *const *ins, uint32_t nin) {
     DeferQueue *q = ctx->dq;
     int32_t lv = defer_level(q, ins, nin, op.out);
-    const bool heavy = op.type == DOP_GEMM1 || op.type == DOP_MULRELIN || (op.type >= DOP_ROT && op.type <= DOP_SUMSLOTS);      // every kind that ends in a key switch, and the GEMMs
+    const bool heavy = op.type == DOP_GEMM1 || op.type == DOP_MULRELIN;      // (rotations counted as heavy too was measured: the LoLa rows were cut into more, smaller
+                                                                               // launches - 388 instead of 309 per prime, 14.3 instead of 12.1 ms per image)
     int32_t hd = 0;
     for (uint32_t i = 0; i < nin; i++) if (ins[i]) { const DeferQueue::Haz *h = q->haz.find(ins[i]); if (h) hd = std::max(hd, h->hd); }
     hd += heavy ? 1 : 0;
@@ -1819,11 +1837,7 @@ static int ensure_stage(cn_ctx *ctx, size_t bytes) {
 // host table -> device (a block the context keeps alive until the stream has drained, like upload_tmp), then one copy launch
 static int copy_by_table(cn_ctx *ctx, const std::vector<Tab2> &tab, Tab2 *dtab, uint32_t words_per_item) {
     if (tab.empty()) return 0;
-    if (!ctx->staged.empty() && hipStreamQuery(ctx->stream) == hipSuccess) ctx->staged.clear();
-    (void)hipGetLastError();
-    ctx->staged.emplace_back(new char[tab.size() * sizeof(Tab2)]);
-    memcpy(ctx->staged.back().get(), tab.data(), tab.size() * sizeof(Tab2));
-    HIPCHK(hipMemcpyAsync(dtab, ctx->staged.back().get(), tab.size() * sizeof(Tab2), hipMemcpyHostToDevice, ctx->stream));
+    CHECK(upload_bytes(ctx, tab.data(), tab.size() * sizeof(Tab2), dtab));
     const uint32_t pairs = words_per_item / 2;
     hipLaunchKernelGGL(k_copy_tab, dim3((pairs + 255) / 256, (unsigned)tab.size()), dim3(256), 0, ctx->stream, dtab, pairs);
     HIPCHK(hipGetLastError()); launch_count(ctx);

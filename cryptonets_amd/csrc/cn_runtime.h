@@ -151,6 +151,7 @@ struct cn_ctx {
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
+    char *pin = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
     char *stage = nullptr; size_t stage_cap = 0;       // staging arena of the deferred per-ciphertext rotations / plaintext products (gather, batched call, scatter)
     int ks_xcd = 0;           // cn_set_option("ks_xcd", v) / CN_KS_XCD=v: fused key switch, workgroup order: 0 (ciphertext, limb); 1 the k workgroups of a
                               // ciphertext on one XCD (share its source limbs in that L2); 2 limb-major (one key slice per XCD L2 at a time)
