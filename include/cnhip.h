@@ -68,12 +68,17 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * "gemm_mfma" = 1 (default) runs wide scalar GEMMs (cn_scalar_gemm / cn_scalar_dot batches with >= 16 outputs) on the int8 matrix
  * cores.  All variants produce identical words. */
 /* "defer" = 1: DEFERRED SUBMISSION for callers that issue one evaluator call per ciphertext from many threads - the unchanged
- * NeuralNetworks layers of the reference (PoolLayer.cs:113-121,182,214; EncryptedSealBfvMatrix.cs:140-154; Utils.cs:46-88).  cn_scalar_dot,
- * cn_add, cn_sub, cn_add_plain and cn_mul_relin are then queued with their operand addresses, ordered by data dependence, and
- * launched as batched kernels (all pending calls of one dependency level and kind = one launch) when a deeper level opens, when the
- * queue is full, or when any other entry point (cn_sync, downloads, rotations ...) needs the results.  Same words as immediate calls;
- * argument errors are reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle
- * with pending readers is safe (the array returns to the pool after the flush). */
+ * NeuralNetworks layers of the reference (PoolLayer.cs:67-80,113-121,182,214; EncryptedSealBfvMatrix.cs:79-120,140-154; LLInterleaveLayer.cs;
+ * Utils.cs:46-88).  cn_scalar_dot, cn_add, cn_sub, cn_add_plain, cn_mul_relin, cn_encrypt and - on up to 4 ciphertexts per call - cn_mul_plain,
+ * cn_rotate_rows(_add), cn_rotate_columns(_add), cn_sum_slots, cn_copy are then queued with their operand addresses, ordered by data dependence,
+ * and launched as batched kernels (all pending calls of one dependency level, kind and parameter = one launch chain) at layer boundaries (a
+ * scalar product or multiplication that reads the queued result of another one), when the queue is full, or when any other entry point
+ * (cn_sync, downloads, ...) needs the results.  Same words as immediate calls; argument errors (ranges, zero plaintexts, missing Galois keys) are
+ * reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle with pending readers is safe
+ * (the array returns to the pool after the flush).
+ * "ks_xcd": workgroup order of the fused key switch - 0 (ciphertext, limb), 1 the limbs of a ciphertext on one XCD, 2 limb-major (default up to
+ * N = 8192: one key slice per XCD L2 at a time).  Environment: CN_LOCK_GRACE_NS / CN_LOCK_COMBINE switch the two context-lock experiments that
+ * are kept but off (cn_host.cpp). */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* reads a switch back, or a choice the library made: "behz_small_base" (1: auxiliary primes below 2^49 - the FP64 kernels - k+1 of them,
  * or k+2 where k+1 are too few (N = 16384); 0: SEAL's 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not
