@@ -965,6 +965,9 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
     if (!range_ok(OB, oi, P.O)) return fail(CN_ERR_ARG, "output index out of range");
     if (I == OB) return fail(CN_ERR_ARG, "scalar GEMM cannot run in place");
     if (P.max_in > I->count) return fail(CN_ERR_ARG, "input index out of range");
+    // Evaluator::multiply_plain / add take ciphertexts of any size: size 3 = products that have not been relinearized yet (the sum of weighted
+    // products is then relinearized once per OUTPUT instead of once per input)
+    if (I->size != OB->size || I->size < 2 || I->size > 3) return fail(CN_ERR_ARG, "scalar GEMM: input and output ciphertext sizes must match (2 or 3)");
     const uint64_t *bias = nullptr;
     if (P.has_bias) {
         Buffer *BP = getbuf(ctx, P.bias_pt, 1);
@@ -972,7 +975,7 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
         bias = BP->d;
     }
     GemmLaunch gl{P.small, P.two, false, P.MT, I->d, tables, tables + P.off_w, tables + P.off_oidx, bias, tables + P.off_bidx, OB->d,
-                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps};
+                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps, I->size};
     CHECK(P.mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl));
     ctx->st.PlainMultiplication += P.nnz; ctx->st.Addition += P.nnz - P.O;
     if (P.has_bias) ctx->st.PlainAddition += P.O;
@@ -980,7 +983,7 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
 }
 extern "C" int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, cn_handle bias_pt,
                               const int32_t *bias_idx, cn_handle out, uint32_t oi) { API_BODY
-    LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
+    LOCK; GETCT(I, in, 0); GETCT(OB, out, 0);
     Buffer *BP = bias_pt ? getbuf(ctx, bias_pt, 1) : nullptr;
     GemmPlan P;
     CHECK(build_gemm_plan(ctx, idx, W, O, K, BP, bias_pt, bias_idx, P));
@@ -1004,7 +1007,7 @@ extern "C" int cn_gemm_plan_create(cn_ctx *ctx, const int32_t *idx, const uint64
     return 0;
 API_END }
 extern "C" int cn_gemm_plan_apply(cn_ctx *ctx, cn_handle plan, cn_handle in, cn_handle out, uint32_t oi) { API_BODY
-    LOCK; GETCT(I, in, 2); GETCT(OB, out, 2);
+    LOCK; GETCT(I, in, 0); GETCT(OB, out, 0);
     Buffer *PB = getbuf(ctx, plan, 2);
     if (!PB || !PB->plan) return fail(CN_ERR_ARG, "invalid scalar GEMM plan handle");
     return run_gemm_plan(ctx, *PB->plan, PB->plan->dev, I, OB, oi);

@@ -30,10 +30,10 @@ template <int MT, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const uint64_t *__restrict__ Wl,
                                                      const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                      uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase) {
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
-    const uint32_t n = C->n, k = C->k, limbs = 2 * k;
+    const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
     uint32_t chunk, limb, mt, g;
     gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
@@ -110,10 +110,10 @@ template <int MT, int NL, int LW, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const double *__restrict__ Wd,
                                                          const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase) {
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
-    const uint32_t n = C->n, k = C->k, limbs = 2 * k;
+    const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
     uint32_t chunk, limb, mt, g;
     gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
@@ -270,12 +270,12 @@ template <int P, bool ABS>
 __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const int8_t *__restrict__ Wf,
                                                              const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                              uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t G, uint32_t M, uint32_t mtiles,
-                                                             uint32_t ksteps, uint32_t obase) {
+                                                             uint32_t ksteps, uint32_t obase, uint32_t polys) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     constexpr int ND = 6, D = ND + P - 1;
     __shared__ __align__(16) uint32_t frag[2][ND][64][4];          // [buffer][digit plane][lane][slot group q]: 12 KiB
-    const uint32_t n = C->n, k = C->k, limbs = 2 * k, ctiles = n >> 5;
+    const uint32_t n = C->n, k = C->k, limbs = polys * k, ctiles = n >> 5;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     uint32_t b = blockIdx.x;
     const uint32_t ctile = b % ctiles; b /= ctiles;

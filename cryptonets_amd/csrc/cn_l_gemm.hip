@@ -5,17 +5,17 @@
 
 template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
-    const size_t blocks = (size_t)c->chunks * 2 * c->hc.k * mtiles * g.G;
+    const size_t blocks = (size_t)c->chunks * g.polys * c->hc.k * mtiles * g.G;
     hipLaunchKernelGGL((k_scalar_gemm<MT, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const uint64_t *)g.W, g.oidx, g.bias, g.bidx, g.out, c->dc,
-                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase);
+                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys);
 }
 template <int MT, bool ABS> static void launch_f64(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
-    const size_t blocks = (size_t)c->chunks * 2 * c->hc.k * mtiles * g.G;
+    const size_t blocks = (size_t)c->chunks * g.polys * c->hc.k * mtiles * g.G;
     if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase);
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys);
     else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase);
+                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys);
 }
 template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
     if (g.small) {
@@ -42,9 +42,9 @@ int cn_l_gemm(cn_ctx *c, const GemmLaunch &g) { return g.abs ? launch<true>(c, g
 
 template <int P, bool ABS> static void launch_mfma(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mgroups = (g.mtiles + 3) / 4;
-    const size_t blocks = (size_t)g.G * mgroups * 2 * c->hc.k * (c->hc.n / 32);
+    const size_t blocks = (size_t)g.G * mgroups * g.polys * c->hc.k * (c->hc.n / 32);
     hipLaunchKernelGGL((k_scalar_gemm_mfma<P, ABS>), dim3((uint32_t)blocks), dim3(256), 0, c->stream, g.in, g.idx, (const int8_t *)g.W, g.oidx, g.bias, g.bidx, g.out,
-                       c->dc, g.G, g.M, g.mtiles, g.ksteps, g.obase);
+                       c->dc, g.G, g.M, g.mtiles, g.ksteps, g.obase, g.polys);
 }
 template <bool ABS> static int launch_mfma_p(cn_ctx *c, const GemmLaunch &g) {
     switch (g.P) {

@@ -215,6 +215,7 @@ struct GemmLaunch {
     const uint64_t *in; const void *idx; const void *W; const void *oidx; const uint64_t *bias; const void *bidx; uint64_t *out;
     uint32_t G, M, K, lazy, Kp, obase;
     uint32_t P = 0, mtiles = 0, ksteps = 0;          // matrix-core kernel: weight digit planes, 32-row output tiles, 32-term K steps
+    uint32_t polys = 2;                              // ciphertext size of inputs and outputs (3: unrelinearized products)
 };
 int cn_l_gemm(cn_ctx *c, const GemmLaunch &g);
 int cn_l_gemm_mfma(cn_ctx *c, const GemmLaunch &g);   // k_scalar_gemm_mfma: W = weight digit fragments, idx rows of ksteps * 32 entries

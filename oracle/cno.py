@@ -239,12 +239,13 @@ class Oracle:
         W = np.ascontiguousarray(W, dtype=np.uint64)
         O, K = W.shape
         cts = np.ascontiguousarray(cts, dtype=np.uint64)
-        out = np.zeros((O, self.ctw), dtype=np.uint64)
+        size = cts.shape[1] // (self.k * self.n)                     # 3: unrelinearized products (multiply_plain / add on size-3 ciphertexts)
+        out = np.zeros((O, cts.shape[1]), dtype=np.uint64)
         ip = None
         if idx is not None:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
             ip = idx.ctypes.data_as(C.POINTER(C.c_int32))
-        rc = self.L.cno_scalar_gemm(self.h, _p(cts), ip, _p(W), O, K, _p(out))
+        rc = self.L.cno_scalar_gemm_sized(self.h, _p(cts), size, ip, _p(W), O, K, _p(out))
         if rc:
             raise ValueError("scalar_gemm: an output had no non-zero term")
         return out
@@ -260,7 +261,7 @@ class Oracle:
         cts = np.ascontiguousarray(cts, dtype=np.uint64)
         plains = np.ascontiguousarray(plains, dtype=np.uint64)
         out = np.zeros_like(cts)
-        rc = self.L.cno_add_plain_batch(self.h, _p(cts), _p(plains), plains.shape[1], cts.shape[0], _p(out))
+        rc = self.L.cno_add_plain_batch_sized(self.h, _p(cts), cts.shape[1] // (self.k * self.n), _p(plains), plains.shape[1], cts.shape[0], _p(out))
         if rc:
             raise ValueError("add_plain_batch failed")
         return out

@@ -754,22 +754,25 @@ int cno_rotate_columns(const cno_ctx *c, const uint64_t *in2, uint64_t *out2) { 
  * each term = MultiplyPlain (monomial path) into a temp then Add, zero weights skipped
  * (`:468`), idx<0 = padded tap (encryption of zero contributes nothing numerically
  * beyond its own noise; the reference feeds fresh Enc(0), we skip it).            */
-int cno_scalar_gemm(const cno_ctx *c, const uint64_t *in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, uint64_t *out) {
-    uint32_t n = c->n, k = c->k; size_t ctw = 2 * (size_t)k * n; int err = 0;
+int cno_scalar_gemm_sized(const cno_ctx *c, const uint64_t *in, uint32_t size, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, uint64_t *out) {
+    uint32_t n = c->n, k = c->k; size_t ctw = (size_t)size * k * n; int err = 0;          /* size 3: Evaluator::multiply_plain / add on unrelinearized products */
     #pragma omp parallel for schedule(dynamic)
     for (uint32_t o = 0; o < O; o++) {
         uint64_t *tmp = malloc(8 * ctw), *acc = out + (size_t)o * ctw; int first = 1;
         for (uint32_t kk = 0; kk < K; kk++) {
             uint64_t w = W[(size_t)o * K + kk]; int32_t id = idx ? idx[(size_t)o * K + kk] : (int32_t)kk;
             if (w == 0 || id < 0) continue;
-            cno_multiply_plain(c, in + (size_t)id * ctw, 2, &w, 1, first ? acc : tmp);
-            if (!first) cno_add(c, acc, 2, tmp, 2, acc);
+            cno_multiply_plain(c, in + (size_t)id * ctw, size, &w, 1, first ? acc : tmp);
+            if (!first) cno_add(c, acc, size, tmp, size, acc);
             first = 0;
         }
         if (first) { err = -3; memset(acc, 0, 8 * ctw); }
         free(tmp);
     }
     return err;
+}
+int cno_scalar_gemm(const cno_ctx *c, const uint64_t *in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, uint64_t *out) {
+    return cno_scalar_gemm_sized(c, in, 2, idx, W, O, K, out);
 }
 /* HOT LOOP B: PointwiseMultiply on encrypted blocks = Multiply + Relinearize
  * (`AtomicSealBfvVector.cs:839-840`), count ciphertexts. */
@@ -785,11 +788,14 @@ int cno_mul_relin_batch(const cno_ctx *c, const uint64_t *a, const uint64_t *b, 
     return 0;
 }
 /* batched add_plain of one dense plaintext per ciphertext (bias add, `:1019`) */
-int cno_add_plain_batch(const cno_ctx *c, const uint64_t *cts, const uint64_t *plains, uint32_t pcount, uint32_t count, uint64_t *out) {
-    size_t ctw = 2 * (size_t)c->k * c->n; int err = 0;
+int cno_add_plain_batch_sized(const cno_ctx *c, const uint64_t *cts, uint32_t size, const uint64_t *plains, uint32_t pcount, uint32_t count, uint64_t *out) {
+    size_t ctw = (size_t)size * c->k * c->n; int err = 0;
     #pragma omp parallel for
-    for (uint32_t i = 0; i < count; i++) { int rc = cno_add_plain(c, cts + i * ctw, 2, plains + (size_t)i * pcount, pcount, 0, out + i * ctw); if (rc) err = rc; }
+    for (uint32_t i = 0; i < count; i++) { int rc = cno_add_plain(c, cts + i * ctw, size, plains + (size_t)i * pcount, pcount, 0, out + i * ctw); if (rc) err = rc; }
     return err;
+}
+int cno_add_plain_batch(const cno_ctx *c, const uint64_t *cts, const uint64_t *plains, uint32_t pcount, uint32_t count, uint64_t *out) {
+    return cno_add_plain_batch_sized(c, cts, 2, plains, pcount, count, out);
 }
 /* batched forward NTT over limbs (micro-benchmark baseline): limbs cycle through q_0..q_{k-1} */
 void cno_ntt_fwd_batch(const cno_ctx *c, uint64_t *x, uint32_t limbs) {

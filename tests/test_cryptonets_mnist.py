@@ -176,3 +176,41 @@ def test_dense_exact_model_equals_the_term_by_term_model():
         assert np.array_equal(fast, cm.model_mod_p(x, layers, p))
         for s in (0, 1, 47):
             assert [int(v) for v in fast[s]] == [v % p for v in cm.int_logits(w, imgs[s])]
+
+
+@pytest.mark.gpu
+def test_relinearize_late_program_decrypts_to_the_same_logits():
+    """CryptoNetsChannel.forward_relinearize_late (opt-in, NOT the reference's call sequence): squarings leave size-3 products, the dense
+    layers run on them, Relinearize once per dense OUTPUT (110 key switches per channel instead of 945).  Same SEAL operations (their
+    words are pinned per operation in test_gpu_evaluator.py::test_scalar_gemm_on_unrelinearized_products); here the whole batch at
+    BASELINE config 3: every slot of every logit equals the integer model for both plaintext primes, and equals what the reference's
+    sequence decrypts to, while the ciphertext words differ (digit decomposition is not linear)."""
+    from cryptonets_amd._native import Context
+    layers = cm.layer_tables(*weights())
+    x_int = np.rint(cm.synthetic_images(cm.N, seed=9) * cm.NORMALIZATION * cm.INPUT_SCALE).astype(np.int64)
+    for p in cm.PLAIN_PRIMES:
+        g = Context(cm.N, p, dbc=10, gdbc=20, device=0)
+        g.keygen(0x51CE ^ p, galois=False)
+        ch = cm.CryptoNetsChannel(g, layers, cm.constant_plaintext(cm.N))
+        ph = g.pt_alloc(784)
+        g.encode_batch(np.mod(x_int.T, p).astype(np.uint64), ph, 0)
+        g.encrypt(ph, 0, ch.h_in, 0, 784, seed=123)
+        g.free(ph)
+
+        def logits():
+            dh = g.pt_alloc(10)
+            g.decrypt(ch.h5, 0, 10, dh, 0)
+            got = g.decode_batch(dh, 0, 10).T
+            g.free(dh)
+            return got
+
+        ch.forward()
+        ref_words, ref_logits = g.ct_download(ch.h5, 0, 10), logits()
+        g.stats(reset=True)
+        ch.forward_relinearize_late()
+        late_words, late_logits = g.ct_download(ch.h5, 0, 10), logits()
+        assert g.stats()["Relinarization"] == 110                # the reference's spelling (OperationsCount)
+        model = cm.model_mod_p_dense(x_int, layers, p)
+        assert np.array_equal(ref_logits, model) and np.array_equal(late_logits, model)
+        assert not np.array_equal(ref_words, late_words)
+        g.close()

@@ -886,3 +886,45 @@ def test_key_switch_xcd_placement_is_only_a_placement(name, rng):
         g.set_option("ks_wide", -1)
         g.set_option("ks_xcd", default_order)
     g.free(h), g.free(out)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c2", "c3"])
+def test_scalar_gemm_on_unrelinearized_products(name, rng):
+    """Evaluator.MultiplyPlain / Add take ciphertexts of any size: a scalar GEMM over size-3 ciphertexts (products that have not been
+    relinearized) through all three kernels - general weights (128-bit integer accumulation), small signed weights with few outputs
+    (exact FP64) and with >= 16 outputs per gather list (int8 matrix cores) - with a bias (lands in c0 only), then ONE Relinearize per
+    output; words against the oracle running the same sequence; mixed sizes are refused."""
+    from cryptonets_amd._native import CnError
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    n_in = 6
+    vals, cts = enc_batch(o, rng, n_in)
+    prod = np.stack([o.multiply(cts[i], cts[(i + 1) % n_in]) for i in range(n_in)])      # size 3
+    h3 = up(g, prod, size=3)
+    bias_vals = rng.integers(0, o.t, size=2, dtype=np.uint64)
+    bias_plain = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in bias_vals])
+    bh = g.pt_alloc(2)
+    g.pt_upload(bh, 0, bias_plain)
+    half = (o.t - 1) // 2
+    for O, K, wmax in ((7, 4, None), (5, 6, min(1000, half)), (40, 6, min(32000, half))):
+        idx = rng.integers(0, n_in, size=(O, K), dtype=np.int32)
+        idx[:, :] = idx[0]
+        idx[:, 1] = -1
+        if wmax is None:
+            W = rng.integers(1, o.t, size=(O, K), dtype=np.uint64)
+        else:
+            Ws = rng.integers(-wmax, wmax + 1, size=(O, K))
+            Ws[:, 0] = wmax
+            W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
+        bias_idx = (np.arange(O) % 2).astype(np.int32)
+        out3, out2 = g.ct_alloc(O, 3), g.ct_alloc(O)
+        g.scalar_gemm(h3, W, out3, 0, idx=idx, bias_pt=bh, bias_idx=bias_idx)
+        exp3 = o.add_plain_batch(o.scalar_gemm(prod, W, idx), bias_plain[bias_idx])
+        assert np.array_equal(g.ct_download(out3, 0, O, size=3), exp3), (name, O)
+        g.relinearize(out3, 0, out2, 0, O)
+        assert np.array_equal(g.ct_download(out2, 0, O), np.stack([o.relinearize(c) for c in exp3])), (name, O)
+        with pytest.raises(CnError):
+            g.scalar_gemm(h3, W, out2, 0, idx=idx)                        # size-3 inputs into size-2 outputs
+        g.free(out3)
+        g.free(out2)
+    g.free(h3)
+    g.free(bh)
