@@ -147,7 +147,9 @@ int cn_mul_scalar(cn_ctx *ctx, cn_handle a, uint32_t ai, const uint64_t *scalars
  * NeuralNetworks/PoolLayer.cs:113-121,149-229):
  *   out[oi+o] = sum_k W[o*K+k] * in[idx[o*K+k]]  (+ Delta-scaled dense plaintext bias[bias_idx[o]])
  * idx<0 = padded tap (skipped, PoolLayer.cs:68-80); W in [0,t), zero weights skipped (:468);
- * an output whose weights are all zero is an error like SEAL's AddMany of nothing. */
+ * an output whose weights are all zero is an error like SEAL's AddMany of nothing.
+ * `in` and `out` must have the same ciphertext size: 2, or 3 (Evaluator.MultiplyPlain / Add on products that have not been relinearized;
+ * cn_gemm_plan_apply likewise - a plan does not depend on the size). */
 int cn_scalar_gemm(cn_ctx *ctx, cn_handle in, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K,
                    cn_handle bias_pt, const int32_t *bias_idx, cn_handle out, uint32_t oi);
 /* The same product for ONE output whose K input ciphertexts are SEPARATE objects - the form the C# twin of
