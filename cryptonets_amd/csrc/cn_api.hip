@@ -4,6 +4,8 @@
 #include "cn_runtime.h"
 #include "cn_k_elem.hip.h"
 #include <algorithm>
+#include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -197,6 +199,57 @@ template <int EPT> static int set_ks_attr(size_t bytes) {
     return 0;
 }
 
+// ---- a HARDWARE queue of its own for every context.  HIP deals the streams of a process onto at most GPU_MAX_HW_QUEUES (4) hardware queues, the
+// null stream and the runtime's transfer queue take part, and which streams end up together depends on the order in which the process happened to
+// create them.  Two contexts whose streams share a queue run their kernels one after the other: the four plaintext-prime channels of one LoLa
+// inference took 10.0-10.7 ms per image in most processes and 7.5 ms in those where the four streams happened to sit on four queues
+// (profiles/r03_stream_queues.txt; raising GPU_MAX_HW_QUEUES to 8 is no way out: 12 ms).  The runtime offers no query, so the library measures:
+// two 100 us spin kernels, one per stream - together they take 100 us on two queues and 200 us on one.  A new context keeps the first stream
+// that overlaps with the streams of every live context on its device; rejected candidates stay alive until the choice is made (the runtime
+// hands a new stream the least-used queue) and are destroyed then.  CN_STREAM_PROBE=0 takes the first stream as it comes.
+__global__ void k_spin(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();                        // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static std::mutex g_ctx_reg_mu;
+static std::vector<cn_ctx *> g_ctx_reg;
+static bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
+    double best = 1e9;
+    for (int rep = 0; rep < 3 && best > 150e-6; rep++) {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, (uint64_t)10000);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, (uint64_t)10000);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best > 150e-6;
+}
+static int pick_stream(cn_ctx *c) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->stream_tries = 1;
+    const char *env = getenv("CN_STREAM_PROBE");
+    if (env && !atoi(env)) return 0;
+    std::vector<hipStream_t> others;
+    for (cn_ctx *o : g_ctx_reg) if (o->device == c->device) others.push_back(o->stream);
+    if (others.empty()) return 0;
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, (uint64_t)1);          // code object loaded, queue created
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<hipStream_t> rejected;
+    auto collides = [&](hipStream_t s) { for (hipStream_t o : others) if (streams_share_a_queue(s, o)) return true; return false; };
+    hipStream_t first = c->stream;
+    bool found = !collides(c->stream);
+    while (!found && c->stream_tries < 6) {
+        rejected.push_back(c->stream);
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->stream_tries++;
+        found = !collides(c->stream);
+    }
+    if (!found) { rejected.push_back(c->stream); c->stream = first; c->stream_tries = -c->stream_tries; }     // more contexts than queues: as it came
+    for (hipStream_t s : rejected) if (s != c->stream) (void)hipStreamDestroy(s);
+    return 0;
+}
+
 extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc, int device, cn_ctx **out) {
     if (!out || !q) return fail(CN_ERR_ARG, "null argument");
     int ndev = cn_device_count();
@@ -211,7 +264,10 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), c->index_map.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
     c->device = device;
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> reg(g_ctx_reg_mu);
+        CHECK(pick_stream(c));
+    }
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipMalloc((void **)&c->tw, tw.size() * 8));
     HIPCHK(hipMemcpy(c->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
@@ -260,11 +316,16 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     for (int pol = 0; pol < 3; pol++) { CHECK(rr_ops[pol]->set_attrs(c->hc.logn, lds)); CHECK(ks_ops[pol]->set_attrs(c->hc.logn, lds)); }
     c->dq = cn_defer_new();
     c->slabs = new std::vector<Slab>();
+    { std::lock_guard<std::mutex> reg(g_ctx_reg_mu); g_ctx_reg.push_back(c); }
     *out = c;
     return 0;
 }
 extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     if (!ctx) return 0;
+    {
+        std::lock_guard<std::mutex> reg(g_ctx_reg_mu);
+        g_ctx_reg.erase(std::remove(g_ctx_reg.begin(), g_ctx_reg.end(), ctx), g_ctx_reg.end());
+    }
     (void)hipSetDevice(ctx->device);
     {   // queued per-ciphertext calls are launched (their results die with the context, but the arrays parked behind them - cn_free while
         // calls were pending - go back to the pool and are released with it)
@@ -323,6 +384,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
     else if (!strcmp(name, "pending_calls")) *value = (int)ctx->dq->ops.size();
+    else if (!strcmp(name, "stream_tries")) *value = ctx->stream_tries;           // streams created until one had a hardware queue of its own (< 0: none had)
     else return fail(CN_ERR_ARG, "unknown option %s", name);
     return 0;
 API_END }
@@ -1866,15 +1928,25 @@ static int flush_staged_group(cn_ctx *ctx, const std::vector<const DOp *> &all, 
         Tab2 *t_in = (Tab2 *)base, *t_pt = t_in + 2 * cnt, *t_out = (Tab2 *)(base + al(3 * cnt * sizeof(Tab2)));
         uint64_t *A = (uint64_t *)(base + tabs), *B = has_b ? A + ctb / 8 : nullptr;
         uint64_t *O = in_place ? A : A + (ctb / 8) * (has_b ? 2 : 1), *P = has_p ? O + ctb / 8 : nullptr;
-        std::vector<Tab2> gin, gpt, gout(cnt);
+        // an operand whose addresses are equally spaced already IS the array the batched implementation wants (always so for a single call -
+        // 12 rotations by 12 different step counts are 12 groups of one): it is used in place; only scattered operands are gathered
+        auto spaced = [&](auto get, size_t words) { for (uint32_t i = 1; i < cnt; i++) if (get(ops[i]) != get(ops[0]) + (size_t)i * words) return false; return true; };
+        const bool da = spaced([](const DOp *o) { return o->a; }, ctw), db = has_b && spaced([](const DOp *o) { return o->b; }, ctw),
+                   dp = has_p && spaced([](const DOp *o) { return o->b; }, n), dout = spaced([](const DOp *o) { return (const uint64_t *)o->out; }, ctw);
+        std::vector<Tab2> gin, gpt, gout;
         for (uint32_t i = 0; i < cnt; i++) {
-            gin.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->a, (NTT_GLOBAL uint64_t *)(A + (size_t)i * ctw)});
-            if (has_b) gin.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)(B + (size_t)i * ctw)});
-            if (has_p) gpt.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)(P + (size_t)i * n)});
-            gout[i] = {(const NTT_GLOBAL uint64_t *)(O + (size_t)i * ctw), (NTT_GLOBAL uint64_t *)ops[i]->out};
+            if (!da) gin.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->a, (NTT_GLOBAL uint64_t *)(A + (size_t)i * ctw)});
+            if (has_b && !db) gin.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)(B + (size_t)i * ctw)});
+            if (has_p && !dp) gpt.push_back({(const NTT_GLOBAL uint64_t *)ops[i]->b, (NTT_GLOBAL uint64_t *)(P + (size_t)i * n)});
+            if (!dout) gout.push_back({(const NTT_GLOBAL uint64_t *)(O + (size_t)i * ctw), (NTT_GLOBAL uint64_t *)ops[i]->out});
         }
-        CHECK(copy_by_table(ctx, gin, t_in, (uint32_t)ctw));
-        if (has_p) CHECK(copy_by_table(ctx, gpt, t_pt, n));
+        if (in_place && da != dout) return fail(CN_ERR_ARG, "internal: in-place staged call with different operand and result addresses");
+        if (da) A = const_cast<uint64_t *>(ops[0]->a);
+        if (db) B = const_cast<uint64_t *>(ops[0]->b);
+        if (dp) P = const_cast<uint64_t *>(ops[0]->b);
+        if (dout) O = ops[0]->out;
+        if (!gin.empty()) CHECK(copy_by_table(ctx, gin, t_in, (uint32_t)ctw));
+        if (!gpt.empty()) CHECK(copy_by_table(ctx, gpt, t_pt, n));
         Buffer fa, fb, fo, fp;
         auto fake = [&](Buffer &b, int kind, uint64_t *d, size_t item) { b.kind = kind; b.count = cnt; b.size = kind == 0 ? 2 : 1; b.d = d; b.item_words = item; };
         fake(fa, 0, A, ctw); fake(fb, 0, B, ctw); fake(fo, 0, O, ctw); fake(fp, 1, P, n);
@@ -1890,7 +1962,7 @@ static int flush_staged_group(cn_ctx *ctx, const std::vector<const DOp *> &all, 
         default: rc = fail(CN_ERR_ARG, "internal: staged kind %d", type);
         }
         CHECK(rc);
-        CHECK(copy_by_table(ctx, gout, t_out, (uint32_t)ctw));
+        if (!gout.empty()) CHECK(copy_by_table(ctx, gout, t_out, (uint32_t)ctw));
     }
     return 0;
 }
@@ -1970,9 +2042,19 @@ static int cn_defer_flush(cn_ctx *ctx) {
         }
         // ---- launches: level by level, one batched launch per kind (and per term count for the GEMMs)
         const int32_t levels = q->maxlevel + 1;
+        static const bool trace = getenv("CN_DEFER_TRACE") && atoi(getenv("CN_DEFER_TRACE"));       // one line per (flush, level): calls per kind, launches
         for (int32_t lv = 0; lv < levels && !rc; lv++) {
             std::vector<const DOp *> by_type[DOP_TYPES];
             for (size_t x = 0; x < ops.size(); x++) if (!dead[x] && ops[x].level == lv) by_type[ops[x].type].push_back(&ops[x]);
+            const uint64_t l0 = ctx->st.kernel_launches;
+            struct Tr { cn_ctx *c; int32_t lv; uint64_t l0; std::vector<const DOp *> *bt; bool on; ~Tr() {
+                if (!on) return;
+                char line[512]; int o = snprintf(line, sizeof line, "defer %p level %d:", (void *)c, lv);
+                for (int t = 0; t < DOP_TYPES; t++) if (!bt[t].empty()) {
+                    std::map<int64_t, int> args; for (const DOp *op : bt[t]) args[op->arg]++;
+                    o += snprintf(line + o, sizeof line - o, " kind%d x%zu (%zu args)", t, bt[t].size(), args.size());
+                }
+                fprintf(stderr, "%s -> %llu launches\n", line, (unsigned long long)(c->st.kernel_launches - l0)); } } tr{ctx, lv, l0, by_type, trace};
             if (!by_type[DOP_GEMM1].empty()) {
                 std::map<uint32_t, std::vector<const DOp *>> byK;
                 for (const DOp *op : by_type[DOP_GEMM1]) byK[op->K].push_back(op);
