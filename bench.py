@@ -281,15 +281,20 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import lola_unchanged_caller
+                for e in env.Environments:                     # the measured contexts give their hardware queues back (a process has four: cn_api.hip pick_stream)
+                    e.ctx.close()
                 rows = lola_unchanged_caller.measure(name, reps=max(5, min(20, args.steps)), device=local)
                 sel = lambda lit, dfr, host: [r for r in rows if r["pattern"].startswith("unchanged") == lit and r["pattern"].endswith("deferred submission") == dfr and r["host"].startswith(host)][0]
-                lit, imm, bat = sel(True, True, "C++ replay, one host thread"), sel(True, False, "C++ replay, one host thread"), sel(False, False, "C++ replay, one host thread")
+                # host pattern of the reference: ForEveryEncryptedVector runs one Task per plaintext prime and joins them after every vector call
+                # (EncryptedSealBfvVector.cs:225-236) = the rows "one thread per plaintext prime, joined after every call"
+                host = "C++ replay, one thread per plaintext prime, joined"
+                lit, imm, bat = sel(True, True, host), sel(True, False, host), sel(False, False, host)
                 out["unchanged_caller"] = {"ms_per_image": lit["ms_per_image"], "logits_exact": lit["logits_exact"], "calls_per_prime": lit["calls_per_prime"],
                                            "launches_per_prime": lit.get("launches_per_prime"), "every_call_launched_on_its_own_ms": imm["ms_per_image"],
                                            "batched_from_the_same_host_ms": bat["ms_per_image"], "batched_calls_per_prime": bat["calls_per_prime"],
                                            "frac_of_batched": round(bat["ms_per_image"] / lit["ms_per_image"], 3),
                                            "pattern": "the per-call sequence of the reference's unchanged LL layers (one vector method per row / column / map), recorded at the C "
-                                                      "ABI, replayed from C++ with cn_set_option(defer, 1)", "all_rows": rows}
+                                                      "ABI, replayed from C++ (one thread per plaintext prime, joined after every call) with cn_set_option(defer, 1)", "all_rows": rows}
             except Exception as ex:
                 out["unchanged_caller"] = {"error": str(ex)[:300]}
         os.write(result_fd, (json.dumps(out) + "\n").encode())

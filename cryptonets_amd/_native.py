@@ -283,6 +283,8 @@ class Context:
         return h.value
 
     def free(self, h):
+        if self._h is None:                                # context closed: its arrays went with it
+            return
         self._chk(self.L.cn_free(self._h, h))
         self._ct_size.pop(h, None)
 

@@ -231,7 +231,7 @@ static int pick_stream(cn_ctx *c) {
     const char *env = getenv("CN_STREAM_PROBE");
     if (env && !atoi(env)) return 0;
     std::vector<hipStream_t> others;
-    for (cn_ctx *o : g_ctx_reg) if (o->device == c->device) others.push_back(o->stream);
+    for (cn_ctx *o : g_ctx_reg) if (o->device == c->device && !o->capturing) others.push_back(o->stream);      // (a recording stream must not see foreign launches)
     if (others.empty()) return 0;
     hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, (uint64_t)1);          // code object loaded, queue created
     HIPCHK(hipStreamSynchronize(c->stream));

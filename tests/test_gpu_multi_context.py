@@ -116,3 +116,47 @@ def test_bench_gpus_flag_launches_ranks_on_the_gpu_box():
     line = _bench({"BENCH_SELF_LAUNCH": "1"}, "--gpus", "1")
     assert line["n_gpus"] == 1 and line["verified_against_integer_model"] is True
     assert line["launcher"] == "self (torch.distributed.run)" and line["process_group"] == "nccl"
+
+
+_QUEUE_SCRIPT = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %r)
+from cryptonets_amd._native import Context
+hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+dummies = []
+for _ in range(int(sys.argv[1])):                        # an application's own streams, created first
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+    dummies.append(s)
+ctxs = [Context(4096, 65537, dbc=10, gdbc=20, device=0) for _ in range(4)]
+tries = [g.get_option("stream_tries") for g in ctxs]
+rng = np.random.default_rng(5)
+for g in ctxs:
+    g.keygen(99, galois=False)
+    vals = rng.integers(0, g.t, size=(2, g.n), dtype=np.uint64)
+    ph, ch, dh = g.pt_alloc(2), g.ct_alloc(2), g.pt_alloc(2)
+    g.encode_batch(vals, ph, 0)
+    g.encrypt(ph, 0, ch, 0, 2, seed=3)
+    g.mul_relin(ch, 0, ch, 1, ch, 0, 1)
+    g.decrypt(ch, 0, 1, dh, 0)
+    assert np.array_equal(g.decode_batch(dh, 0, 1)[0], (vals[0].astype(object) * vals[1].astype(object) %% g.t).astype(np.uint64))
+fifth = Context(4096, 65537, dbc=10, gdbc=20, device=0)
+print("TRIES", " ".join(str(t) for t in tries), fifth.get_option("stream_tries"))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dummies", [0, 3])
+def test_contexts_of_one_process_get_a_hardware_queue_each(dummies):
+    """HIP deals the streams of a process onto 4 hardware queues in creation order (null stream and transfer queue included); two contexts
+    on one queue run their kernels one after the other (LoLa-MNIST: 10.7 instead of 8.0 ms per image, profiles/r03_stream_queues.txt).
+    cn_ctx_create measures (two spin kernels overlap or do not) and keeps the first stream that overlaps with every live context's:
+    whatever streams the process created before, the four plaintext-prime contexts of a LoLa factory report a successful choice and still
+    evaluate correctly; a fifth context finds no free queue, says so (< 0) and works on the first stream it got.  (Own process: the cached
+    contexts of this test session would occupy the queues.)"""
+    r = subprocess.run([sys.executable, "-c", _QUEUE_SCRIPT % ROOT, str(dummies)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tries = [int(x) for x in [l for l in r.stdout.splitlines() if l.startswith("TRIES")][0].split()[1:]]
+    assert all(t >= 1 for t in tries[:4]), tries
+    assert tries[4] < 0, tries
