@@ -117,6 +117,7 @@ SIGNATURES = {
     "cn_encode_batch": (C.c_int, [_CTX, U64P, _u32, _u32, _H, _u32]),
     "cn_decode_batch": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_copy": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
+    "cn_copy_many": (C.c_int, [_CTX, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _u32, _H, _u32]),
     "cn_device_ptr": (C.c_int, [_CTX, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cn_live_handles": (C.c_int, [_CTX]),
     "cn_add": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
@@ -337,6 +338,12 @@ class Context:
 
     def copy(self, src, sfirst, dst, dfirst, count):
         self._chk(self.L.cn_copy(self._h, src, sfirst, dst, dfirst, count))
+
+    def copy_many(self, srcs, sfirsts, dst, dfirst):
+        """dst[dfirst + i] = srcs[i][sfirsts[i]]: single ciphertexts (or plaintexts) of many arrays into one array with one launch"""
+        hs = np.ascontiguousarray(srcs, dtype=np.uint64)
+        fs = np.ascontiguousarray(sfirsts, dtype=np.uint32)
+        self._chk(self.L.cn_copy_many(self._h, hs.ctypes.data_as(C.POINTER(C.c_uint64)), fs.ctypes.data_as(C.POINTER(C.c_uint32)), len(hs), dst, dfirst))
 
     def device_ptr(self, h):
         p, b = C.c_void_p(), C.c_size_t()

@@ -1983,6 +1983,39 @@ static int defer_staged(cn_ctx *ctx, int type, Buffer *A, uint32_t ai, Buffer *B
     return 0;
 }
 
+// n single ciphertexts (or dense plaintexts) that live in n arrays into consecutive places of one array, ONE launch (see include/cnhip.h)
+extern "C" int cn_copy_many(cn_ctx *ctx, const cn_handle *src, const uint32_t *sfirst, uint32_t n, cn_handle dst, uint32_t dfirst) { API_BODY
+    LOCK_ONLY;
+    if (!n) return 0;
+    if (!src) return fail(CN_ERR_ARG, "null argument");
+    Buffer *d = ctx->bufs.find(dst);
+    if (!d || d->kind > 1) return fail(CN_ERR_ARG, "invalid handle");
+    if (!range_ok(d, dfirst, n)) return fail(CN_ERR_ARG, "index out of range");
+    std::vector<Buffer *> sb(n);
+    for (uint32_t i = 0; i < n; i++) {
+        Buffer *b = ctx->bufs.find(src[i]);
+        const uint32_t f = sfirst ? sfirst[i] : 0;
+        if (!b) return fail(CN_ERR_ARG, "invalid handle");
+        if (b->kind != d->kind || b->item_words != d->item_words) return fail(CN_ERR_ARG, "copy between different buffer shapes");
+        if (!range_ok(b, f, 1)) return fail(CN_ERR_ARG, "index out of range");
+        if (b == d && f >= dfirst && f < dfirst + n && f != dfirst + i) return fail(CN_ERR_ARG, "copy_many: a source lies inside the destination range");
+        sb[i] = b;
+    }
+    if (deferring(ctx) && d->kind == 0 && d->size == 2) {          // queued like n cn_copy calls
+        for (uint32_t i = 0; i < n; i++) CHECK(defer_staged(ctx, DOP_COPY, sb[i], sfirst ? sfirst[i] : 0, nullptr, 0, nullptr, 0, d, dfirst + i, 1, 0));
+        return 0;
+    }
+    CHECK(cn_defer_flush(ctx));
+    CHECK(ensure_stage(ctx, al(n * sizeof(Tab2))));
+    std::vector<Tab2> tab(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t f = sfirst ? sfirst[i] : 0;
+        tab[i] = {(const NTT_GLOBAL uint64_t *)(sb[i]->d + (size_t)f * d->item_words), (NTT_GLOBAL uint64_t *)(d->d + (size_t)(dfirst + i) * d->item_words)};
+        if (d->kind == 1) d->pt_zero[dfirst + i] = sb[i]->pt_zero[f];
+    }
+    return copy_by_table(ctx, tab, (Tab2 *)ctx->stage, (uint32_t)d->item_words);
+API_END }
+
 // all queued Encryptor.Encrypt calls of one level: one sampling / transform / tail launch chain over a table
 static int flush_encrypt_group(cn_ctx *ctx, const std::vector<const DOp *> &ops) {
     std::vector<EncTab> tab(ops.size());

@@ -103,6 +103,9 @@ def _gather(ctx, views):
         return b0.h, [v.first + i for v in views for i in range(v.count)], None
     total = sum(v.count for v in views)
     tmp = _Buf(ctx, "ct", total).view()
+    if not LITERAL and hasattr(ctx, "copy_many"):          # one launch for the whole gather (cn_copy_many) instead of one per vector
+        ctx.copy_many([v.h for v in views for _ in range(v.count)], [v.first + i for v in views for i in range(v.count)], tmp.h, 0)
+        return tmp.h, list(range(total)), tmp
     pos, idx = 0, []
     for v in views:
         ctx.copy(v.h, v.first, tmp.h, pos, v.count)
@@ -417,14 +420,23 @@ class AtomicSealBfvEncryptedVector:
             startBlock = thisShift // blockSize
             endBlock = (thisShift + absShift) // blockSize
             v, v2 = 2 * k, 2 * k + 1
-            ctx.copy(src.h, src.first, work.h, v, 1)
+
+            def rotated(steps):
+                """work[v] = RotateRows(src, steps): the reference copies the ciphertext and rotates the copy in place (LITERAL keeps that)"""
+                if LITERAL or steps == 0:
+                    ctx.copy(src.h, src.first, work.h, v, 1)
+                    if steps != 0:
+                        ctx.rotate_rows(work.h, v, steps, work.h, v, 1)
+                else:
+                    ctx.rotate_rows(src.h, src.first, steps, work.h, v, 1)
             if inBlockShift == 0:
+                rotated(0)
                 lower[startBlock].append(v)
             elif inBlockShift + absShift < half:
-                ctx.rotate_rows(work.h, v, -thisShift, work.h, v, 1)
+                rotated(-thisShift)
                 lower[startBlock].append(v)
             elif inBlockShift >= half:
-                ctx.rotate_rows(work.h, v, -(inBlockShift - half), work.h, v, 1)
+                rotated(-(inBlockShift - half))
                 if startBlock == endBlock:
                     upper[startBlock].append(v)
                 else:
@@ -436,7 +448,7 @@ class AtomicSealBfvEncryptedVector:
                     upper[startBlock].append(v2)
                     lower[endBlock].append(v)
             else:
-                ctx.rotate_rows(work.h, v, -inBlockShift, work.h, v, 1)
+                rotated(-inBlockShift)
                 upperPartSize = inBlockShift + absShift - half
                 if upperPartSize > 0:
                     ctx.copy(work.h, v, work.h, v2, 1)
@@ -761,8 +773,11 @@ class AtomicSealBfvEncryptedVector:
         """AtomicSealBfvVector.cs:1347-1359: first block of every vector becomes one entry of a sparse vector"""
         ctx = env.ctx
         res = _Buf(ctx, "ct", len(encryptedVector)).view()
-        for i, e in enumerate(encryptedVector):
-            ctx.copy(e.encData.h, e.encData.first, res.h, i, 1)
+        if not LITERAL and hasattr(ctx, "copy_many"):
+            ctx.copy_many([e.encData.h for e in encryptedVector], [e.encData.first for e in encryptedVector], res.h, 0)
+        else:
+            for i, e in enumerate(encryptedVector):
+                ctx.copy(e.encData.h, e.encData.first, res.h, i, 1)
         return AtomicSealBfvEncryptedVector._new(Scale=encryptedVector[0].Scale, Dim=len(encryptedVector), Format=EVectorFormat.sparse,
                                                  IsSigned=encryptedVector[0].IsSigned, encData=res)
 

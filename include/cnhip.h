@@ -121,6 +121,12 @@ int cn_decode(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint64_t *values /* N */);
 int cn_encode_batch(cn_ctx *ctx, const uint64_t *values, uint32_t nvalues, uint32_t count, cn_handle pt, uint32_t pi);
 int cn_decode_batch(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t count, uint64_t *values /* [count][N] */);
 int cn_copy(cn_ctx *ctx, cn_handle src, uint32_t sfirst, cn_handle dst, uint32_t dfirst, uint32_t count);
+/* n single ciphertexts (or dense plaintexts) that live in n arrays -> consecutive places of ONE array with one launch:
+ * dst[dfirst + i] = src[i][sfirst[i]] (sfirst NULL = element 0 of every array).  The reference keeps a vector as a list of Ciphertext objects and
+ * has no such call; a host that keeps vectors as arrays uses it where the reference copies element by element (GenerateSparseOfArray,
+ * AtomicSealBfvVector.cs:1347-1359; the column gather in front of DenseMatrixBySparseVectorMultiply): 25 + 10 copy launches of one LoLa image
+ * become 2.  Queued like n cn_copy calls under cn_set_option("defer", 1). */
+int cn_copy_many(cn_ctx *ctx, const cn_handle *src, const uint32_t *sfirst, uint32_t n, cn_handle dst, uint32_t dfirst);
 int cn_device_ptr(cn_ctx *ctx, cn_handle h, void **ptr, size_t *bytes);
 int cn_live_handles(cn_ctx *ctx);                                              /* leak counter */
 

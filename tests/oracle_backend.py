@@ -103,7 +103,7 @@ class OracleBackend:
     # ---- emulation of cn_graph_begin / cn_graph_end / cn_graph_launch for the CPU suite: the compute calls made while recording are
     # logged (and executed), a launch re-executes them on the same handles - what the HIP graph does with the same device addresses.
     # Uploads / downloads / synchronisation are refused while recording, like the library does.
-    _REPLAYED = ("copy", "add", "sub", "add_many", "add_plain", "mul_plain", "mul_scalar", "scalar_gemm", "gemm_apply", "mul_relin", "multiply",
+    _REPLAYED = ("copy", "copy_many", "add", "sub", "add_many", "add_plain", "mul_plain", "mul_scalar", "scalar_gemm", "gemm_apply", "mul_relin", "multiply",
                  "relinearize", "rotate_rows", "rotate_rows_add", "rotate_columns", "rotate_columns_add", "sum_slots", "rowdot_batch")
     _REFUSED = ("sync", "ct_upload", "ct_download", "pt_upload", "pt_download", "encode", "decode", "encode_batch", "decode_batch", "set_relin_key", "set_galois_key")
 
@@ -156,6 +156,10 @@ class OracleBackend:
 
     def copy(self, src, sfirst, dst, dfirst, count):
         self.bufs[dst][dfirst:dfirst + count] = self.bufs[src][sfirst:sfirst + count].copy()
+
+    def copy_many(self, srcs, sfirsts, dst, dfirst):
+        for i, (h, f) in enumerate(zip(srcs, sfirsts)):
+            self.bufs[dst][dfirst + i] = self.bufs[int(h)][int(f)].copy()
 
     def set_relin_key(self, words):
         pass            # the oracle context already holds the keys it generated

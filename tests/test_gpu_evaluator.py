@@ -928,3 +928,44 @@ def test_scalar_gemm_on_unrelinearized_products(name, rng):
         g.free(out2)
     g.free(h3)
     g.free(bh)
+
+
+def test_copy_many_gathers_with_one_launch(rng):
+    """cn_copy_many: single ciphertexts (and dense plaintexts) of many arrays into consecutive places of one array - immediate (one launch) and
+    queued under deferred submission; shape / range / overlap errors"""
+    from cryptonets_amd._native import CnError
+    o, g = get_oracle("tiny", galois=False), get_gpu("tiny", galois=False)
+    vals, cts = enc_batch(o, rng, 6)
+    hs = [up(g, cts[2 * i:2 * i + 2]) for i in range(3)]                 # three arrays of two ciphertexts
+    dst = g.ct_alloc(5)
+    l0 = g.stats()["kernel_launches"]
+    g.copy_many([hs[2], hs[0], hs[1], hs[0]], [1, 0, 1, 1], dst, 1)
+    assert g.stats()["kernel_launches"] - l0 == 1
+    got = g.ct_download(dst, 1, 4)
+    assert np.array_equal(got, np.stack([cts[5], cts[0], cts[3], cts[1]]))
+    g.set_option("defer", 1)
+    try:
+        g.copy_many([hs[1], hs[2]], [0, 0], dst, 0)
+        g.add(dst, 0, dst, 1, dst, 4, 1)                                 # reads a queued copy
+        assert g.get_option("pending_calls") == 3
+        got = g.ct_download(dst, 0, 5)
+    finally:
+        g.set_option("defer", 0)
+    assert np.array_equal(got[0], cts[2]) and np.array_equal(got[1], cts[4]) and np.array_equal(got[4], o.add(cts[2], cts[4]))
+    pv = rng.integers(0, o.t, size=(3, o.n), dtype=np.uint64)
+    ph = [g.pt_alloc(1) for _ in range(3)]
+    for h, v in zip(ph, pv):
+        g.pt_upload(h, 0, v[None, :])
+    pd = g.pt_alloc(3)
+    g.copy_many(ph[::-1], [0, 0, 0], pd, 0)
+    assert np.array_equal(g.pt_download(pd, 0, 3), pv[::-1])
+    with pytest.raises(CnError):
+        g.copy_many([hs[0], ph[0]], [0, 0], dst, 0)                      # plaintext into a ciphertext array
+    with pytest.raises(CnError):
+        g.copy_many([hs[0]], [2], dst, 0)                                # source index out of range
+    with pytest.raises(CnError):
+        g.copy_many([hs[0], hs[1]], [0, 0], dst, 4)                      # destination range out of range
+    with pytest.raises(CnError):
+        g.copy_many([dst, hs[0]], [1, 0], dst, 0)                        # a source inside the destination range
+    for h in hs + ph + [dst, pd]:
+        g.free(h)
