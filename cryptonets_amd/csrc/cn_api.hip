@@ -358,6 +358,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
+    if (!strcmp(name, "ks_perm_fused")) { ctx->ks_perm_fused = value != 0; return 0; }      // rotations of small batches: automorphism inside the key-switch kernels (default 1)
     if (!strcmp(name, "ks_xcd")) { ctx->ks_xcd = value; return 0; }              // 0 (ct, limb) order, 1 the limbs of a ciphertext on one XCD, 2 limb-major
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
@@ -1161,9 +1162,20 @@ static int ensure_ks_part(cn_ctx *ctx, size_t need) {
 // auto: the fused kernel runs cnt*k workgroups.  Up to 32 of them (1-6 ciphertexts) every digit gets its own workgroup; up to 160
 // every source limb does; above that the fused kernel fills the chip by itself.
 static const uint32_t KS_DIGIT_MAX_BLOCKS = 32, KS_WIDE_MAX_BLOCKS = 160;
+// the variant do_keyswitch takes for `cnt` ciphertexts: 0 = the fused kernel, 1 / 2 = two launches (KsArgs::mode)
+static int ks_planned_mode(cn_ctx *ctx, uint32_t cnt, int galois) {
+    const uint32_t k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
+    const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;
+    if (!(rr && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * k <= KS_WIDE_MAX_BLOCKS)))) return 0;
+    // N = 16384: 1024-thread workgroups cannot hold two accumulator sets without spilling -> per-digit only
+    const int mode = ctx->ks_wide == 2 || (ctx->ks_wide < 0 && cnt * k > KS_DIGIT_MAX_BLOCKS && ctx->hc.logn < 14) ? 2 : 1;
+    return (size_t)cnt * (mode == 2 ? k : tot_dig) * ctx->ctw2 * 8 > ctx->smax ? 0 : mode;
+}
+// perm_elt != 0 (two-launch variants only - the caller asks ks_planned_mode first): target / add0 are the c1 / c0 of the ciphertext a rotation
+// READS and the kernels apply the automorphism x -> x^perm_elt while loading them
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                         const KsKey &key, uint64_t *out, uint32_t cnt, int galois, const uint64_t *extra = nullptr, size_t xstride = 0,
-                        uint64_t *const *out_tab = nullptr) {
+                        uint64_t *const *out_tab = nullptr, uint32_t perm_elt = 0) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
@@ -1173,12 +1185,10 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     if (ctx->ks_xcd == 1) a.xcd_cts = cnt & ~7u;
     else if (ctx->ks_xcd == 2) a.xcd_cts = 0x80000000u;
     const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;                // register-radix kernels available
-    if (rr && (ctx->ks_wide > 0 || (ctx->ks_wide < 0 && cnt * k <= KS_WIDE_MAX_BLOCKS))) {
-        // N = 16384: 1024-thread workgroups cannot hold two accumulator sets without spilling -> per-digit only
-        a.mode = ctx->ks_wide == 2 || (ctx->ks_wide < 0 && cnt * k > KS_DIGIT_MAX_BLOCKS && ctx->hc.logn < 14) ? 2 : 1;
-        const size_t need = (size_t)cnt * (a.mode == 2 ? k : tot_dig) * ctx->ctw2 * 8;
-        if (need > ctx->smax) a.mode = 0; else CHECK(ensure_ks_part(ctx, need));
-    }
+    a.mode = ks_planned_mode(ctx, cnt, galois);
+    if (a.mode) CHECK(ensure_ks_part(ctx, (size_t)cnt * (a.mode == 2 ? k : tot_dig) * ctx->ctw2 * 8));
+    a.perm_elt = perm_elt;
+    if (perm_elt && !a.mode) return fail(CN_ERR_ARG, "internal: automorphism inside the fused key switch");
     if (a.mode == 0 && rr && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14) {   // N = 16384 as two 8192-point halves per limb
         CHECK(ensure_ks_part(ctx, (size_t)cnt * ctx->ctw2 * 8));
         ks_ops[bits <= 44 ? POL_F64L : POL_F64]->split14(ctx, a);
@@ -1277,6 +1287,13 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
 
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     uint32_t limbs = count * 2 * ctx->hc.k;
+    // small batches (two-launch key switch): no permutation pass - the key-switch kernels apply the automorphism while they load c1 and c0
+    if (ctx->ks_perm_fused && ks_planned_mode(ctx, count, 1) != 0) {
+        CHECK(do_keyswitch(ctx, in + kn, 2 * kn, in, nullptr, 2 * kn, it->second, out, count, 1, acc, ctx->ctw2, nullptr, (uint32_t)elt));
+        ctx->st.Rotation += count;
+        if (acc) ctx->st.Addition += count;
+        return 0;
+    }
     if (ctx->hc.n >= 1024) hipLaunchKernelGGL(k_galois_lds, dim3(limbs), dim3(std::min<uint32_t>(1024, ctx->hc.n / 4)), (size_t)ctx->hc.n * 8, ctx->stream, in, tmp, ctx->dc, elt);
     else hipLaunchKernelGGL(k_galois, dim3(limbs * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, in, tmp, ctx->dc, ctx->chunks, elt);
     HIPCHK(hipGetLastError()); launch_count(ctx);

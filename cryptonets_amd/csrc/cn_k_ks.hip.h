@@ -244,6 +244,25 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
         __syncthreads();
     }
 }
+// A rotation's automorphism x -> x^elt applied while a two-launch key switch LOADS its operand, instead of a permutation kernel in front of
+// it (k_galois_lds): one dispatch less per rotation - a single-image LoLa chain is ~230 dependent dispatches, 66 of them were this
+// permutation, and the command processor retires ~5 us per dependent dispatch whatever queue it comes from.  The limb is
+// loaded coalesced (coefficient tid + NT r, the first pass' own pattern), written to the exchange image at its destination
+// (i elt mod 2N, negated when it wraps), and read back in the first pass' layout: raw[r] = sigma(a)[pass_index(tid, r)].
+template <int L> NTT_DEV void ks_gather_automorphism(uint64_t (&raw)[16], const uint64_t *limb, uint32_t elt, uint64_t q, void *image, uint32_t tid) {
+    constexpr uint32_t n = 1u << L, NT = NttPlan<L>::NT;
+    uint64_t *s = reinterpret_cast<uint64_t *>(image);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t i = tid + NT * (uint32_t)r, pos = (i * elt) & (2 * n - 1);
+        const uint64_t v = limb[i];
+        s[lds_pos(pos & (n - 1))] = (pos >> L) ? (v ? q - v : 0) : v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) raw[r] = s[lds_pos(pass_index<L, NttPlan<L>::SA, 0>(tid, r))];
+    __syncthreads();                                   // the image is the transform's again
+}
 // Latency variant of the key switch for SMALL batches (LoLa: one image = 1..13 ciphertexts per rotation): the fused kernel above
 // runs count*k workgroups, each pushing all digit transforms through one CU in sequence - 5 busy CUs of 256 at count 1.  Here
 // the digit transforms are spread over the chip and the sum is a second launch:
@@ -253,7 +272,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
 // Same residues as the fused kernel (exact arithmetic in both), HBM traffic 2 * tot * 2kN words per ciphertext more.
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
-                                                                  void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t tot) {
+                                                                  void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t tot, uint32_t perm_elt) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -271,9 +290,15 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
     const size_t kn = (size_t)k * n;
     const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
     T v[16];
+    uint64_t raw[16];
+    if (perm_elt) ks_gather_automorphism<L>(raw, src, perm_elt, C->q[l].q, s, tid);
+    else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(tid, r)];
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        uint64_t t = (src[pass_index<L, SA, 0>(tid, r)] >> sh) & mask;
+        uint64_t t = (raw[r] >> sh) & mask;
         if constexpr (std::is_same<T, uint64_t>::value) { if (mask >= q) t = t >= q ? bred128(t, 0, qm) : t; }
         v[r] = A.load(t);
     }
@@ -297,7 +322,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
 // instead of k (fused) or digits*k (k_ks_digit_mac), and k_ks_sum_intt adds k partials instead of all digits.
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
-                                                                 void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
+                                                                 void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t accmax, uint32_t perm_elt) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -316,7 +341,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
     const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
     const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
     uint64_t raw[16];
-    {
+    if (perm_elt) ks_gather_automorphism<L>(raw, src, perm_elt, C->q[l].q, s, tid);
+    else {
         uint32_t t0 = tid;
         asm volatile("" : "+v"(t0));
 #pragma unroll
@@ -365,7 +391,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__restrict__ part_, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
                                                                  size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, uint32_t tot,
-                                                                 uint32_t accmax, const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab) {
+                                                                 uint32_t accmax, const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab, uint32_t perm_elt) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -392,12 +418,20 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__re
     }
     ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
     const uint64_t *ad = p ? add1 : add0;
+    uint64_t addv[16];
+    if (ad && perm_elt) {                                  // sigma(c0): the whole limb is read (through the image) before a word of the result is written
+        __syncthreads();                                   // everybody has taken its coefficients out of the image
+        ks_gather_automorphism<L>(addv, ad + (size_t)ct * add_stride + (size_t)j * n, perm_elt, qm.q, s, tid);
+    } else if (ad) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) addv[r] = ad[(size_t)ct * add_stride + (size_t)j * n + pass_index<L, SA, 0>(tid, r)];
+    }
     NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const uint32_t e = pass_index<L, SA, 0>(tid, r);
         uint64_t val = A.scaled(v[r]);
-        if (ad) val = addmod(val, ad[(size_t)ct * add_stride + (size_t)j * n + e], qm.q);
+        if (ad) val = addmod(val, addv[r], qm.q);
         if (extra) val = addmod(val, extra[(size_t)ct * ex_stride + (size_t)p * kn + (size_t)j * n + e], qm.q);
         o[e] = val;
     }

@@ -154,6 +154,7 @@ struct cn_ctx {
     char *pin = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
     char *stage = nullptr; size_t stage_cap = 0;       // staging arena of the deferred per-ciphertext rotations / plaintext products (gather, batched call, scatter)
     int ks_xcd = 0;           // cn_set_option("ks_xcd", v) / CN_KS_XCD=v: fused key switch, workgroup order: 0 (ciphertext, limb); 1 the k workgroups of a
+    bool ks_perm_fused = true;                    // rotations through the two-launch key switch apply the automorphism while loading (no k_galois_lds pass)
     int stream_tries = 0;                        // streams created until one had a hardware queue of its own (cn_api.hip: pick_stream)
                               // ciphertext on one XCD (share its source limbs in that L2); 2 limb-major (one key slice per XCD L2 at a time)
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
@@ -187,6 +188,7 @@ struct KsArgs {
     int mode;                 // 0 fused, 1 two launches / workgroup per digit, 2 two launches / workgroup per source limb
     uint64_t *const *out_tab;
     uint32_t xcd_cts = 0;     // fused kernel: ciphertexts (a multiple of 8) placed XCD-aware, see k_keyswitch_rr
+    uint32_t perm_elt = 0;    // two-launch variants: Galois element of a rotation whose automorphism the kernels apply while loading (target / add0 = the UNPERMUTED c1 / c0)
 };
 struct RrOps {                // register-radix kernels of one arithmetic policy; every launcher returns false when the size has no kernel
     int (*set_attrs)(uint32_t logn, size_t lds);
