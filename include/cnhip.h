@@ -76,6 +76,9 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * (cn_sync, downloads, ...) needs the results.  Same words as immediate calls; argument errors (ranges, zero plaintexts, missing Galois keys) are
  * reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle with pending readers is safe
  * (the array returns to the pool after the flush).
+ * "ks_perm_fused" = 1 (default): a rotation of a small batch (two-launch key switch) has no permutation pass - the key-switch kernels apply the
+ * automorphism while they load c1 and c0; 0 = k_galois_lds in front of them.  "stream_tries" (read only): streams cn_ctx_create tried until one had a
+ * hardware queue of its own (< 0: none had; CN_STREAM_PROBE=0 takes the first).
  * "ks_xcd": workgroup order of the fused key switch - 0 (ciphertext, limb), 1 the limbs of a ciphertext on one XCD, 2 limb-major (default up to
  * N = 8192: one key slice per XCD L2 at a time).  Environment: CN_LOCK_GRACE_NS / CN_LOCK_COMBINE switch the two context-lock experiments that
  * are kept but off (cn_host.cpp). */
