@@ -385,6 +385,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
     else if (!strcmp(name, "pending_calls")) *value = (int)ctx->dq->ops.size();
+    else if (!strcmp(name, "ks_perm_fused")) *value = ctx->ks_perm_fused;
     else if (!strcmp(name, "stream_tries")) *value = ctx->stream_tries;           // streams created until one had a hardware queue of its own (< 0: none had)
     else return fail(CN_ERR_ARG, "unknown option %s", name);
     return 0;

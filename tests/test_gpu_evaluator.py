@@ -969,3 +969,39 @@ def test_copy_many_gathers_with_one_launch(rng):
         g.copy_many([dst, hs[0]], [1, 0], dst, 0)                        # a source inside the destination range
     for h in hs + ph + [dst, pd]:
         g.free(h)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4", "c5"])
+def test_rotation_with_and_without_the_permutation_pass(name, rng):
+    """Small batches rotate through the two-launch key switch, whose kernels apply the automorphism while they load c1 / c0
+    (cn_set_option("ks_perm_fused", 1), default) instead of a permutation pass in front of them: same words as with the pass and as the
+    oracle - per digit (1-6 ciphertexts) and per source limb (7-32), multi-hop steps, the column swap, in place, and rotate-and-add with the
+    accumulator in the output's place (the SumAllSlots step)."""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    assert g.get_option("ks_perm_fused") == 1
+    vals, cts = enc_batch(o, rng, 8)
+    h, out = up(g, cts), g.ct_alloc(8)
+    half = o.n // 2
+    try:
+        for count in (1, 3, 8):
+            for steps in (1, -2, 7, -(half - 1)):
+                exp = np.stack([o.rotate_rows(c, steps) for c in cts[:count]])
+                for fused in (1, 0):
+                    g.set_option("ks_perm_fused", fused)
+                    g.rotate_rows(h, 0, steps, out, 0, count)
+                    assert np.array_equal(g.ct_download(out, 0, count), exp), (name, count, steps, fused)
+        for fused in (1, 0):
+            g.set_option("ks_perm_fused", fused)
+            g.rotate_columns(h, 0, out, 0, 2)
+            assert np.array_equal(g.ct_download(out, 0, 2), np.stack([o.rotate_columns(c) for c in cts[:2]]))
+            w = up(g, cts[:2])
+            g.rotate_rows(w, 0, -4, w, 0, 2)                                        # in place
+            assert np.array_equal(g.ct_download(w, 0, 2), np.stack([o.rotate_rows(c, -4) for c in cts[:2]]))
+            g.ct_upload(w, 0, cts[:2])
+            g.rotate_rows_add(w, 0, -1, w, 0, w, 0, 2)                              # x += RotateRows(x, -1), everything in one array
+            assert np.array_equal(g.ct_download(w, 0, 2), np.stack([o.add(c, o.rotate_rows(c, -1)) for c in cts[:2]]))
+            g.free(w)
+    finally:
+        g.set_option("ks_perm_fused", 1)
+    g.free(h)
+    g.free(out)
