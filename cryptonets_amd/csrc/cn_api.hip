@@ -307,6 +307,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
+    if (getenv("CN_GEMM_ORDER")) c->gemm_order = atoi(getenv("CN_GEMM_ORDER"));
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
@@ -358,6 +359,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "f64")) { ctx->use_f64 = value != 0; return 0; }              // affects keys uploaded AFTER the call
     if (!strcmp(name, "legacy_ntt")) { ctx->legacy_ntt = value != 0; return 0; }
     if (!strcmp(name, "ks_tight")) { ctx->ks_tight = value != 0; return 0; }
+    if (!strcmp(name, "gemm_order")) { ctx->gemm_order = value; return 0; }                  // 1 slice-major (default), 0 group-major
     if (!strcmp(name, "ks_perm_fused")) { ctx->ks_perm_fused = value != 0; return 0; }      // rotations of small batches: automorphism inside the key-switch kernels (default 1)
     if (!strcmp(name, "ks_xcd")) { ctx->ks_xcd = value; return 0; }              // 0 (ct, limb) order, 1 the limbs of a ciphertext on one XCD, 2 limb-major
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
@@ -386,6 +388,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
     else if (!strcmp(name, "pending_calls")) *value = (int)ctx->dq->ops.size();
     else if (!strcmp(name, "ks_perm_fused")) *value = ctx->ks_perm_fused;
+    else if (!strcmp(name, "gemm_order")) *value = ctx->gemm_order;
     else if (!strcmp(name, "stream_tries")) *value = ctx->stream_tries;           // streams created until one had a hardware queue of its own (< 0: none had)
     else return fail(CN_ERR_ARG, "unknown option %s", name);
     return 0;
@@ -1039,7 +1042,7 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
         bias = BP->d;
     }
     GemmLaunch gl{P.small, P.two, false, P.MT, I->d, tables, tables + P.off_w, tables + P.off_oidx, bias, tables + P.off_bidx, OB->d,
-                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps, I->size};
+                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps, I->size, (uint32_t)ctx->gemm_order};
     CHECK(P.mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl));
     ctx->st.PlainMultiplication += P.nnz; ctx->st.Addition += P.nnz - P.O;
     if (P.has_bias) ctx->st.PlainAddition += P.O;
@@ -1848,7 +1851,7 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
     CHECK(ensure_scratch(ctx, al(host.size())));
     char *tables; CHECK(upload_tmp(ctx, host.data(), host.size(), &tables));
     GemmLaunch gl{small, two, true, MT, fallback, tables, tables + off_w, tables + off_oidx, nullptr, any_bias ? tables + off_bidx : nullptr, nullptr,
-                  G, M, K, lazy, Kp, 0, WP, (M + 31) / 32, (K + 31) / 32};
+                  G, M, K, lazy, Kp, 0, WP, (M + 31) / 32, (K + 31) / 32, 2, (uint32_t)ctx->gemm_order};
     return mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl);
 }
 static int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, int type) {

@@ -7,7 +7,18 @@
 // input elements; workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles take ids b, b+8, b+16, ...
 // - same XCD, adjacent in time: the K input elements are fetched from HBM once and re-read from that XCD's L2 (dense 845->100:
 // 5 tiles; without this every tile streamed the 528 MB of input ciphertexts again).
-DEV void gemm_block_coords(uint32_t b, uint32_t chunks, uint32_t limbs, uint32_t mtiles, uint32_t G, uint32_t &chunk, uint32_t &limb, uint32_t &mt, uint32_t &g) {
+// order 1 (slice-major): a SLICE = (limb, chunk of 256 coefficients) of every ciphertext is 2 KiB per ciphertext - all 784 inputs of the CryptoNets
+// convolution are 1.5 MiB, which an XCD's 4 MiB L2 holds.  XCD x (blocks b = x mod 8) walks through ALL groups of slice x, then of slice x + 8, ...:
+// every input slice is fetched once per launch, whatever the overlap of the gather lists (5x5 windows at stride 2 share each pixel 6.25 times; in
+// group-major order only the horizontal overlap survived in L2: FETCH_SIZE 2.3 x the input bytes, profiles/r02_pmc_square_gemm.txt).
+DEV void gemm_block_coords(uint32_t b, uint32_t chunks, uint32_t limbs, uint32_t mtiles, uint32_t G, uint32_t &chunk, uint32_t &limb, uint32_t &mt, uint32_t &g, uint32_t order = 0) {
+    if (order == 1) {
+        const uint32_t x = b & 7, r = b >> 3;
+        mt = r % mtiles;
+        const uint32_t rr = r / mtiles, sl = (rr / G) * 8 + x;
+        g = rr % G; chunk = sl % chunks; limb = sl / chunks;
+        return;
+    }
     const uint32_t D = chunks * limbs * G;
     uint32_t d;
     if ((D & 7) == 0) { const uint32_t r = b >> 3; mt = r % mtiles; d = (r / mtiles) * 8 + (b & 7); }
@@ -30,12 +41,12 @@ template <int MT, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const uint64_t *__restrict__ Wl,
                                                      const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                      uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys) {
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
     uint32_t chunk, limb, mt, g;
-    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
+    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];
@@ -110,12 +121,12 @@ template <int MT, int NL, int LW, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const double *__restrict__ Wd,
                                                          const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys) {
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
     uint32_t chunk, limb, mt, g;
-    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g);
+    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];

@@ -7,15 +7,15 @@ template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &
     const uint32_t mtiles = (g.M + MT - 1) / MT;
     const size_t blocks = (size_t)c->chunks * g.polys * c->hc.k * mtiles * g.G;
     hipLaunchKernelGGL((k_scalar_gemm<MT, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const uint64_t *)g.W, g.oidx, g.bias, g.bidx, g.out, c->dc,
-                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys);
+                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, ((c->chunks * g.polys * c->hc.k) & 7) == 0 ? g.order : 0u);
 }
 template <int MT, bool ABS> static void launch_f64(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
     const size_t blocks = (size_t)c->chunks * g.polys * c->hc.k * mtiles * g.G;
     if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys);
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, ((c->chunks * g.polys * c->hc.k) & 7) == 0 ? g.order : 0u);
     else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys);
+                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, ((c->chunks * g.polys * c->hc.k) & 7) == 0 ? g.order : 0u);
 }
 template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
     if (g.small) {

@@ -154,6 +154,7 @@ struct cn_ctx {
     char *pin = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
     char *stage = nullptr; size_t stage_cap = 0;       // staging arena of the deferred per-ciphertext rotations / plaintext products (gather, batched call, scatter)
     int ks_xcd = 0;           // cn_set_option("ks_xcd", v) / CN_KS_XCD=v: fused key switch, workgroup order: 0 (ciphertext, limb); 1 the k workgroups of a
+    int gemm_order = 1;                          // scalar GEMM (VALU kernels): 1 = slice-major workgroup order (every input slice fetched once per XCD), 0 = group-major
     bool ks_perm_fused = true;                    // rotations through the two-launch key switch apply the automorphism while loading (no k_galois_lds pass)
     int stream_tries = 0;                        // streams created until one had a hardware queue of its own (cn_api.hip: pick_stream)
                               // ciphertext on one XCD (share its source limbs in that L2); 2 limb-major (one key slice per XCD L2 at a time)
@@ -219,6 +220,7 @@ struct GemmLaunch {
     uint32_t G, M, K, lazy, Kp, obase;
     uint32_t P = 0, mtiles = 0, ksteps = 0;          // matrix-core kernel: weight digit planes, 32-row output tiles, 32-term K steps
     uint32_t polys = 2;                              // ciphertext size of inputs and outputs (3: unrelinearized products)
+    uint32_t order = 0;                              // workgroup order of the VALU kernels: 0 group-major, 1 slice-major (gemm_block_coords)
 };
 int cn_l_gemm(cn_ctx *c, const GemmLaunch &g);
 int cn_l_gemm_mfma(cn_ctx *c, const GemmLaunch &g);   // k_scalar_gemm_mfma: W = weight digit fragments, idx rows of ksteps * 32 entries

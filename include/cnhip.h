@@ -76,6 +76,7 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * (cn_sync, downloads, ...) needs the results.  Same words as immediate calls; argument errors (ranges, zero plaintexts, missing Galois keys) are
  * reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle with pending readers is safe
  * (the array returns to the pool after the flush).
+ * "gemm_order" = 1 (default): slice-major workgroup order of the VALU scalar GEMM (every input slice fetched once per XCD), 0 = group-major.
  * "ks_perm_fused" = 1 (default): a rotation of a small batch (two-launch key switch) has no permutation pass - the key-switch kernels apply the
  * automorphism while they load c1 and c0; 0 = k_galois_lds in front of them.  "stream_tries" (read only): streams cn_ctx_create tried until one had a
  * hardware queue of its own (< 0: none had; CN_STREAM_PROBE=0 takes the first).
