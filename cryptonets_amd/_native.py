@@ -139,6 +139,7 @@ SIGNATURES = {
     "cn_mul_relin": (C.c_int, [_CTX, _H, _u32, _u32, _H, _u32, _u32, _H, _u32, _u32]),
     "cn_apply_galois": (C.c_int, [_CTX, _H, _u32, C.c_uint64, _H, _u32, _u32]),
     "cn_rotate_rows": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _u32]),
+    "cn_rotate_rows_many": (C.c_int, [_CTX, _H, C.POINTER(C.c_uint32), C.POINTER(C.c_int), _u32, _H, C.POINTER(C.c_uint32)]),
     "cn_rotate_columns": (C.c_int, [_CTX, _H, _u32, _H, _u32, _u32]),
     "cn_rotate_rows_add": (C.c_int, [_CTX, _H, _u32, C.c_int, _H, _u32, _H, _u32, _u32]),
     "cn_rotate_columns_add": (C.c_int, [_CTX, _H, _u32, _H, _u32, _H, _u32, _u32]),
@@ -448,6 +449,14 @@ class Context:
 
     def rotate_rows(self, src, ii, steps, out, oi, count=1):
         self._chk(self.L.cn_rotate_rows(self._h, src, ii, steps, out, oi, count))
+
+    def rotate_rows_many(self, src, iis, steps, out, ois):
+        """out[ois[i]] = RotateRows(src[iis[i]], steps[i]): n rotations by n different step counts as one launch chain"""
+        a = np.ascontiguousarray(iis, dtype=np.uint32)
+        st = np.ascontiguousarray(steps, dtype=np.int32)
+        o = np.ascontiguousarray(ois, dtype=np.uint32)
+        self._chk(self.L.cn_rotate_rows_many(self._h, src, a.ctypes.data_as(C.POINTER(C.c_uint32)), st.ctypes.data_as(C.POINTER(C.c_int)), len(a), out,
+                                             o.ctypes.data_as(C.POINTER(C.c_uint32))))
 
     def rotate_rows_add(self, src, ii, steps, acc, ai, out, oi, count=1):
         """out = acc + RotateRows(src, steps) (fused rotate-and-add of SumAllSlots)"""

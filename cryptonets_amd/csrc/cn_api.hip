@@ -137,6 +137,23 @@ static int upload_bytes(cn_ctx *c, const void *host, size_t bytes, void *dev) {
     HIPCHK(hipMemcpyAsync(dev, keep.back().get(), bytes, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
+// A SMALL table (a few hundred bytes of operand addresses) does not travel at all: the kernels read it where pin_block put it - pinned host memory is
+// mapped into the device's address space.  A copy would be one more dispatch in front of the kernel that needs the table (the runtime's blit kernel),
+// and dependent dispatches are what the latency of a single-image chain is made of (20 of the 125 dispatches of a LoLa image were
+// such copies).  *dev = where the kernel finds the table: inside the pinned ring, or `fallback` (device memory the caller owns) after a copy when the
+// table is large, a graph is being recorded (a recorded launch must find its table at every replay) or CN_TABLES_ZERO_COPY=0.
+static const size_t SMALL_TABLE_BYTES = 4096;
+static int place_table(cn_ctx *c, const void *host, size_t bytes, void *fallback, const void **dev) {
+    static const bool zero_copy = !(getenv("CN_TABLES_ZERO_COPY") && !atoi(getenv("CN_TABLES_ZERO_COPY")));
+    if (zero_copy && !c->capturing && bytes <= SMALL_TABLE_BYTES) {
+        if (char *p = pin_block(c, bytes)) {
+            if (!c->pin_dev) { void *d = nullptr; if (hipHostGetDevicePointer(&d, c->pin, 0) == hipSuccess) c->pin_dev = (char *)d; else (void)hipGetLastError(); }
+            if (c->pin_dev) { memcpy(p, host, bytes); *dev = c->pin_dev + (p - c->pin); return 0; }
+        }
+    }
+    *dev = fallback;
+    return upload_bytes(c, host, bytes, fallback);
+}
 template <class T> static int upload_tmp(cn_ctx *c, const T *host, size_t count, T **dev) {
     *dev = salloc<T>(c, count);
     if (!*dev) return fail(CN_ERR_HIP, "internal: scratch exhausted");
@@ -1179,7 +1196,7 @@ static int ks_planned_mode(cn_ctx *ctx, uint32_t cnt, int galois) {
 // READS and the kernels apply the automorphism x -> x^perm_elt while loading them
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                         const KsKey &key, uint64_t *out, uint32_t cnt, int galois, const uint64_t *extra = nullptr, size_t xstride = 0,
-                        uint64_t *const *out_tab = nullptr, uint32_t perm_elt = 0) {
+                        uint64_t *const *out_tab = nullptr, uint32_t perm_elt = 0, const KsItem *items = nullptr) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
@@ -1191,8 +1208,8 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     const bool rr = !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14;                // register-radix kernels available
     a.mode = ks_planned_mode(ctx, cnt, galois);
     if (a.mode) CHECK(ensure_ks_part(ctx, (size_t)cnt * (a.mode == 2 ? k : tot_dig) * ctx->ctw2 * 8));
-    a.perm_elt = perm_elt;
-    if (perm_elt && !a.mode) return fail(CN_ERR_ARG, "internal: automorphism inside the fused key switch");
+    a.perm_elt = perm_elt; a.items = items;
+    if ((perm_elt || items) && !a.mode) return fail(CN_ERR_ARG, "internal: automorphism inside the fused key switch");
     if (a.mode == 0 && rr && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14) {   // N = 16384 as two 8192-point halves per limb
         CHECK(ensure_ks_part(ctx, (size_t)cnt * ctx->ctw2 * 8));
         ks_ops[bits <= 44 ? POL_F64L : POL_F64]->split14(ctx, a);
@@ -1364,6 +1381,75 @@ static int rotate_check(cn_ctx *ctx, int steps) {
     for (int s2 : naf) { if ((uint32_t)std::abs(s2) == ctx->hc.n / 2) continue; CHECK(rotate_check(ctx, s2)); }
     return 0;
 }
+// ---- rotations of n ciphertexts by n DIFFERENT step counts as one launch chain (cn_rotate_rows_many; the queued RotateRows calls of one level).
+// A single-image network rotates the 13 masked vectors of an Interleave by 13 different amounts, the 5 maps of a Vectorize by 5: one rotation
+// is 2 dependent dispatches per hop, and dependent dispatches are what the latency of such a chain is made of.  The hops of a
+// rotation (the element of its step count if the key exists, else its NAF terms - the same decomposition rotate_rec walks, so the words are the
+// same) are taken in rounds: round r is ONE two-launch key switch over every ciphertext that has an r-th hop, each with its own key and element
+// from a table (KsItem); round 0 reads the source and writes the destination, later rounds work on the destination in place.
+struct Tab2 { const NTT_GLOBAL uint64_t *src; NTT_GLOBAL uint64_t *dst; };          // one (source, destination) pair of k_copy_tab
+static int ensure_stage(cn_ctx *ctx, size_t bytes);
+static int copy_by_table(cn_ctx *ctx, const std::vector<Tab2> &tab, Tab2 *dtab, uint32_t words_per_item);
+struct RotJob { const uint64_t *src; uint64_t *dst; int steps; std::vector<uint64_t> elts; };
+static int rotation_hops(cn_ctx *ctx, int steps, std::vector<uint64_t> &elts) {
+    if (steps == 0) return 0;
+    const uint64_t elt = cn_galois_elt_from_step(ctx, steps);
+    if (!elt) return fail(CN_ERR_ARG, "step count too large");
+    if (galois_key_present(ctx, elt)) { elts.push_back(elt); return 0; }
+    std::vector<int> naf;
+    bool sign = steps < 0; int v = std::abs(steps);
+    for (int i = 0; v; i++) { int zi = (v & 1) ? 2 - (v & 3) : 0; v = (v - zi) >> 1; if (zi) naf.push_back((sign ? -zi : zi) * (1 << i)); }
+    if (naf.size() == 1) return fail(CN_ERR_NOKEY, "Galois key not present");
+    for (int s2 : naf) { if ((uint32_t)std::abs(s2) == ctx->hc.n / 2) continue; CHECK(rotation_hops(ctx, s2, elts)); }
+    return 0;
+}
+static int rotate_jobs(cn_ctx *ctx, std::vector<RotJob> &jobs) {
+    const uint32_t n = (uint32_t)jobs.size();
+    if (!n) return 0;
+    size_t rounds = 0;
+    for (RotJob &j : jobs) { CHECK(rotation_hops(ctx, j.steps, j.elts)); rounds = std::max(rounds, j.elts.size()); }
+    bool tables_ok = ctx->ks_perm_fused && ks_planned_mode(ctx, n, 1) != 0;
+    for (uint32_t a = 0; a < n && tables_ok; a++) for (uint32_t b = 0; b < n; b++) if (a != b && (jobs[a].dst == jobs[b].src || jobs[a].dst == jobs[b].dst)) { tables_ok = false; break; }
+    if (!tables_ok) {                                      // large batches (fused kernel), aliased operands: one after the other
+        CHECK(ensure_scratch(ctx, al(ctx->ctw2 * 8)));
+        for (RotJob &j : jobs) {
+            ctx->soff = 0;
+            uint64_t *tmp = salloc<uint64_t>(ctx, ctx->ctw2);
+            if (j.elts.size() == 1) { CHECK(do_galois(ctx, j.src, j.elts[0], j.dst, tmp, 1)); continue; }
+            if (j.dst != j.src) HIPCHK(hipMemcpyAsync(j.dst, j.src, ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            for (uint64_t e : j.elts) CHECK(do_galois(ctx, j.dst, e, j.dst, tmp, 1));
+        }
+        return 0;
+    }
+    {   // rotations by 0 steps: copies
+        std::vector<Tab2> cp;
+        for (RotJob &j : jobs) if (j.elts.empty() && j.dst != j.src) cp.push_back({(const NTT_GLOBAL uint64_t *)j.src, (NTT_GLOBAL uint64_t *)j.dst});
+        if (!cp.empty()) { CHECK(ensure_stage(ctx, al(cp.size() * sizeof(Tab2)))); CHECK(copy_by_table(ctx, cp, (Tab2 *)ctx->stage, (uint32_t)ctx->ctw2)); }
+    }
+    for (size_t r = 0; r < rounds; r++) {
+        std::vector<KsItem> items; std::vector<uint64_t *> outs;
+        const KsKey *any = nullptr;
+        for (RotJob &j : jobs) {
+            if (j.elts.size() <= r) continue;
+            const KsKey &key = ctx->gk.find(j.elts[r])->second;
+            any = &key;
+            items.push_back({r == 0 ? j.src : j.dst, key.d, (uint32_t)j.elts[r], 0u});
+            outs.push_back(j.dst);
+        }
+        const uint32_t cnt = (uint32_t)items.size();
+        ctx->soff = 0;
+        CHECK(ensure_scratch(ctx, al(cnt * sizeof(KsItem)) + al(cnt * sizeof(uint64_t *))));
+        KsItem *d_items = salloc<KsItem>(ctx, cnt);
+        uint64_t **d_outs = salloc<uint64_t *>(ctx, cnt);
+        const void *p_items, *p_outs;
+        CHECK(place_table(ctx, items.data(), cnt * sizeof(KsItem), d_items, &p_items));
+        CHECK(place_table(ctx, outs.data(), cnt * sizeof(uint64_t *), d_outs, &p_outs));
+        CHECK(do_keyswitch(ctx, nullptr, 0, nullptr, nullptr, 0, *any, nullptr, cnt, 1, nullptr, 0, (uint64_t *const *)p_outs, 0, (const KsItem *)p_items));
+        ctx->st.Rotation += cnt;
+    }
+    return 0;
+}
+
 extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK_ONLY; GETCT(I, in, 2); GETCT(O, out, 2);
     if (deferring(ctx) && count && count <= DEFER_STAGED_MAX) {
@@ -1373,6 +1459,26 @@ extern "C" int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps,
     }
     CHECK(cn_defer_flush(ctx));
     return rotate_rows_impl(ctx, I, ii, steps, O, oi, count);
+API_END }
+// RotateRows of n ciphertexts by n different step counts, one launch chain (see include/cnhip.h)
+extern "C" int cn_rotate_rows_many(cn_ctx *ctx, cn_handle in, const uint32_t *ii, const int *steps, uint32_t n, cn_handle out, const uint32_t *oi) { API_BODY
+    LOCK_ONLY; GETCT(I, in, 2); GETCT(O, out, 2);
+    if (!n) return 0;
+    if (!ii || !steps || !oi) return fail(CN_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < n; i++) {
+        if (!range_ok(I, ii[i], 1) || !range_ok(O, oi[i], 1)) return fail(CN_ERR_ARG, "index out of range");
+        CHECK(rotate_check(ctx, steps[i]));
+        for (uint32_t j = 0; j < i; j++) if (O == I ? (oi[i] == oi[j] || oi[i] == ii[j] || ii[i] == oi[j]) : oi[i] == oi[j])
+            return fail(CN_ERR_ARG, "rotate_rows_many: a result would overwrite another rotation's operand or result");
+    }
+    if (deferring(ctx)) {                                   // queued like n cn_rotate_rows calls
+        for (uint32_t i = 0; i < n; i++) CHECK(defer_staged(ctx, DOP_ROT, I, ii[i], nullptr, 0, nullptr, 0, O, oi[i], 1, steps[i]));
+        return 0;
+    }
+    CHECK(cn_defer_flush(ctx));
+    std::vector<RotJob> jobs(n);
+    for (uint32_t i = 0; i < n; i++) jobs[i] = {I->d + (size_t)ii[i] * I->item_words, O->d + (size_t)oi[i] * O->item_words, steps[i], {}};
+    return rotate_jobs(ctx, jobs);
 API_END }
 // out = acc + RotateRows(in, steps): the rotate-and-add step of SumAllSlots (AtomicSealBfvVector.cs:862-868) with the addition
 // fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
@@ -1902,7 +2008,7 @@ static int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all
 // copies move 2 x 640 KiB per ciphertext and call - microseconds against the key switches they let merge (13 rows of LoLa's dense
 // layer: 13 x 10 single-ciphertext key switches become 10 key switches of 13 ciphertexts).  Same words: the batched implementations
 // are bit-identical to their count-1 selves (tests/test_deferred.py, tests/test_lola.py).
-struct Tab2 { const NTT_GLOBAL uint64_t *src; NTT_GLOBAL uint64_t *dst; };
+
 __global__ void k_copy_tab(const Tab2 *__restrict__ tab, uint32_t pairs_per_item) {          // grid (chunks, items); 16 B per thread
     const Tab2 t = tab[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1923,9 +2029,10 @@ static int ensure_stage(cn_ctx *ctx, size_t bytes) {
 // host table -> device (a block the context keeps alive until the stream has drained, like upload_tmp), then one copy launch
 static int copy_by_table(cn_ctx *ctx, const std::vector<Tab2> &tab, Tab2 *dtab, uint32_t words_per_item) {
     if (tab.empty()) return 0;
-    CHECK(upload_bytes(ctx, tab.data(), tab.size() * sizeof(Tab2), dtab));
+    const void *ptab;
+    CHECK(place_table(ctx, tab.data(), tab.size() * sizeof(Tab2), dtab, &ptab));
     const uint32_t pairs = words_per_item / 2;
-    hipLaunchKernelGGL(k_copy_tab, dim3((pairs + 255) / 256, (unsigned)tab.size()), dim3(256), 0, ctx->stream, dtab, pairs);
+    hipLaunchKernelGGL(k_copy_tab, dim3((pairs + 255) / 256, (unsigned)tab.size()), dim3(256), 0, ctx->stream, (const Tab2 *)ptab, pairs);
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;
 }
@@ -1935,6 +2042,11 @@ static int flush_staged_group(cn_ctx *ctx, const std::vector<const DOp *> &all, 
         std::vector<Tab2> tab(all.size());
         for (size_t i = 0; i < all.size(); i++) tab[i] = {(const NTT_GLOBAL uint64_t *)all[i]->a, (NTT_GLOBAL uint64_t *)all[i]->out};
         return copy_by_table(ctx, tab, (Tab2 *)ctx->stage, (uint32_t)ctx->ctw2);
+    }
+    if (type == DOP_ROT && all.size() * ctx->hc.k <= KS_WIDE_MAX_BLOCKS) {     // few rotations, any step counts: one launch chain per hop round
+        std::vector<RotJob> jobs(all.size());
+        for (size_t i = 0; i < all.size(); i++) jobs[i] = {all[i]->a, all[i]->out, (int)all[i]->arg, {}};
+        return rotate_jobs(ctx, jobs);
     }
     std::map<int64_t, std::vector<const DOp *>> by_arg;      // one batched call per parameter value (rotation steps, slot count)
     for (const DOp *op : all) by_arg[op->arg].push_back(op);

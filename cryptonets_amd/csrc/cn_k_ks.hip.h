@@ -272,7 +272,8 @@ template <int L> NTT_DEV void ks_gather_automorphism(uint64_t (&raw)[16], const 
 // Same residues as the fused kernel (exact arithmetic in both), HBM traffic 2 * tot * 2kN words per ciphertext more.
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
-                                                                  void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t tot, uint32_t perm_elt) {
+                                                                  void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t tot, uint32_t perm_elt,
+                                                                  const KsItem *__restrict__ items) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -289,6 +290,10 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
     const uint64_t mask = (1ull << dbc) - 1;
     const size_t kn = (size_t)k * n;
     const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    if (items) {                                           // rotations by per-ciphertext step counts in one launch: operand, key and Galois element from a table
+        const KsItem it = items[ct];
+        src = it.in + kn + (size_t)l * n; key_ = it.key; perm_elt = it.elt;
+    }
     T v[16];
     uint64_t raw[16];
     if (perm_elt) ks_gather_automorphism<L>(raw, src, perm_elt, C->q[l].q, s, tid);
@@ -322,7 +327,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
 // instead of k (fused) or digits*k (k_ks_digit_mac), and k_ks_sum_intt adds k partials instead of all digits.
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
-                                                                 void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t accmax, uint32_t perm_elt) {
+                                                                 void *__restrict__ part_, const DevConsts *__restrict__ C, int galois, uint32_t accmax, uint32_t perm_elt,
+                                                                 const KsItem *__restrict__ items) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -340,6 +346,10 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
     for (uint32_t i = 0; i < l; i++) g0 += galois ? C->gk_dig[i] : C->rl_dig[i];
     const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
     const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    if (items) {
+        const KsItem it = items[ct];
+        src = it.in + kn + (size_t)l * n; key_ = it.key; perm_elt = it.elt;
+    }
     uint64_t raw[16];
     if (perm_elt) ks_gather_automorphism<L>(raw, src, perm_elt, C->q[l].q, s, tid);
     else {
@@ -391,7 +401,8 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__restrict__ part_, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
                                                                  size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, uint32_t tot,
-                                                                 uint32_t accmax, const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab, uint32_t perm_elt) {
+                                                                 uint32_t accmax, const uint64_t *extra, size_t ex_stride, uint64_t *const *__restrict__ out_tab, uint32_t perm_elt,
+                                                                 const KsItem *__restrict__ items) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -418,13 +429,15 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__re
     }
     ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
     const uint64_t *ad = p ? add1 : add0;
+    if (ad) ad += (size_t)ct * add_stride + (size_t)j * n;
+    if (items) { const KsItem it = items[ct]; ad = p ? nullptr : it.in + (size_t)j * n; perm_elt = it.elt; }
     uint64_t addv[16];
     if (ad && perm_elt) {                                  // sigma(c0): the whole limb is read (through the image) before a word of the result is written
         __syncthreads();                                   // everybody has taken its coefficients out of the image
-        ks_gather_automorphism<L>(addv, ad + (size_t)ct * add_stride + (size_t)j * n, perm_elt, qm.q, s, tid);
+        ks_gather_automorphism<L>(addv, ad, perm_elt, qm.q, s, tid);
     } else if (ad) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) addv[r] = ad[(size_t)ct * add_stride + (size_t)j * n + pass_index<L, SA, 0>(tid, r)];
+        for (int r = 0; r < 16; r++) addv[r] = ad[pass_index<L, SA, 0>(tid, r)];
     }
     NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
 #pragma unroll

@@ -46,14 +46,14 @@ template <int L> static void launch_two_phase(cn_ctx *c, const KsArgs &a) {
     const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
     if (a.mode == 2) {              // one partial per (ct, source limb): k*k workgroups per ciphertext, k partials to sum
         hipLaunchKernelGGL((k_ks_limb_mac<L, AR>), dim3(a.cnt * k * k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, (const void *)a.key, c->ks_part,
-                           c->dc, a.galois, a.accmax, a.perm_elt);
+                           c->dc, a.galois, a.accmax, a.perm_elt, a.items);
         hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(a.cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, a.add0, a.add1, a.astride,
-                           a.out, c->dc, k, 0xffffffffu, a.extra, a.xstride, a.out_tab, a.perm_elt);
+                           a.out, c->dc, k, 0xffffffffu, a.extra, a.xstride, a.out_tab, a.perm_elt, a.items);
     } else {                        // one partial per (ct, digit)
         hipLaunchKernelGGL((k_ks_digit_mac<L, AR>), dim3(a.cnt * tot * k), dim3(NttPlan<L>::NT), lds, c->stream, a.target, a.tstride, (const void *)a.key, c->ks_part,
-                           c->dc, a.galois, tot, a.perm_elt);
+                           c->dc, a.galois, tot, a.perm_elt, a.items);
         hipLaunchKernelGGL((k_ks_sum_intt<L, AR>), dim3(a.cnt * k * 2), dim3(NttPlan<L>::NT), lds, c->stream, (const void *)c->ks_part, a.add0, a.add1, a.astride,
-                           a.out, c->dc, tot, a.accmax, a.extra, a.xstride, a.out_tab, a.perm_elt);
+                           a.out, c->dc, tot, a.accmax, a.extra, a.xstride, a.out_tab, a.perm_elt, a.items);
     }
     cn_launch_count(c);
 }

@@ -151,7 +151,7 @@ struct cn_ctx {
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
-    char *pin = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
+    char *pin = nullptr, *pin_dev = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
     char *stage = nullptr; size_t stage_cap = 0;       // staging arena of the deferred per-ciphertext rotations / plaintext products (gather, batched call, scatter)
     int ks_xcd = 0;           // cn_set_option("ks_xcd", v) / CN_KS_XCD=v: fused key switch, workgroup order: 0 (ciphertext, limb); 1 the k workgroups of a
     int gemm_order = 1;                          // scalar GEMM (VALU kernels): 1 = slice-major workgroup order (every input slice fetched once per XCD), 0 = group-major
@@ -180,6 +180,9 @@ enum { POL_U64 = 0, POL_F64 = 1, POL_F64L = 2 };       // ArU64 (Shoup, any modu
 // One key switch of `cnt` ciphertexts: out[ct] = (add0[ct], add1[ct]) + KeySwitch(target[ct]) (+ extra[ct] - the fused accumulator of
 // the cn_*_add entry points).  target / add0 / add1 / extra are strided per ciphertext (in words); out is dense size-2, or - out_tab -
 // one address per ciphertext (deferred per-ciphertext calls whose results live in separate arrays).
+// per-ciphertext operands of a two-launch key switch that rotates every ciphertext by its own step count (cn_rotate_rows_many): the ciphertext it reads
+// (c0 at in, c1 behind it), the Galois key of its element, the element
+struct KsItem { const uint64_t *in; const void *key; uint32_t elt, pad; };
 struct KsArgs {
     const uint64_t *target; size_t tstride;
     const uint64_t *add0, *add1; size_t astride;
@@ -189,6 +192,7 @@ struct KsArgs {
     int mode;                 // 0 fused, 1 two launches / workgroup per digit, 2 two launches / workgroup per source limb
     uint64_t *const *out_tab;
     uint32_t xcd_cts = 0;     // fused kernel: ciphertexts (a multiple of 8) placed XCD-aware, see k_keyswitch_rr
+    const KsItem *items = nullptr;   // two-launch variants: per-ciphertext (operand, key, element) table instead of target / add0 / key / perm_elt
     uint32_t perm_elt = 0;    // two-launch variants: Galois element of a rotation whose automorphism the kernels apply while loading (target / add0 = the UNPERMUTED c1 / c0)
 };
 struct RrOps {                // register-radix kernels of one arithmetic policy; every launcher returns false when the size has no kernel

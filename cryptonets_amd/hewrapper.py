@@ -412,31 +412,44 @@ class AtomicSealBfvEncryptedVector:
         def ones_mask(count):
             return env.mask_plain("ones", count)
 
-        for k, src in enumerate(vecs):
+        def geometry(k):
             thisShift = shift * k
             if thisShift < 0:
                 thisShift = half + thisShift
             inBlockShift = thisShift % blockSize
-            startBlock = thisShift // blockSize
-            endBlock = (thisShift + absShift) // blockSize
-            v, v2 = 2 * k, 2 * k + 1
+            return thisShift, inBlockShift, thisShift // blockSize, (thisShift + absShift) // blockSize
 
-            def rotated(steps):
-                """work[v] = RotateRows(src, steps): the reference copies the ciphertext and rotates the copy in place (LITERAL keeps that)"""
-                if LITERAL or steps == 0:
-                    ctx.copy(src.h, src.first, work.h, v, 1)
-                    if steps != 0:
-                        ctx.rotate_rows(work.h, v, steps, work.h, v, 1)
-                else:
-                    ctx.rotate_rows(src.h, src.first, steps, work.h, v, 1)
+        def steps_of(k):
+            """the RotateRows step count of vector k (0: none)"""
+            thisShift, inBlockShift, _, _ = geometry(k)
             if inBlockShift == 0:
-                rotated(0)
+                return 0
+            if inBlockShift + absShift < half:
+                return -thisShift
+            return -(inBlockShift - half) if inBlockShift >= half else -inBlockShift
+
+        # work[2k] = RotateRows(vecs[k], steps_of(k)).  The reference copies every ciphertext and rotates the copy in place, one Evaluator call each
+        # (LITERAL keeps that); otherwise all rotations of the interleave are ONE library call (cn_rotate_rows_many: the hops of the 13
+        # differently rotated vectors run in rounds - same words) when the vectors share an array, else one direct rotation each.
+        if not LITERAL and hasattr(ctx, "rotate_rows_many") and len(vecs) > 1 and all(x.buf is vecs[0].buf for x in vecs):
+            ctx.rotate_rows_many(vecs[0].h, [x.first for x in vecs], [steps_of(k) for k in range(len(vecs))], work.h, [2 * k for k in range(len(vecs))])
+        else:
+            for k, src in enumerate(vecs):
+                st = steps_of(k)
+                if LITERAL or st == 0:
+                    ctx.copy(src.h, src.first, work.h, 2 * k, 1)
+                    if st != 0:
+                        ctx.rotate_rows(work.h, 2 * k, st, work.h, 2 * k, 1)
+                else:
+                    ctx.rotate_rows(src.h, src.first, st, work.h, 2 * k, 1)
+        for k in range(len(vecs)):
+            thisShift, inBlockShift, startBlock, endBlock = geometry(k)
+            v, v2 = 2 * k, 2 * k + 1
+            if inBlockShift == 0:
                 lower[startBlock].append(v)
             elif inBlockShift + absShift < half:
-                rotated(-thisShift)
                 lower[startBlock].append(v)
             elif inBlockShift >= half:
-                rotated(-(inBlockShift - half))
                 if startBlock == endBlock:
                     upper[startBlock].append(v)
                 else:
@@ -448,7 +461,6 @@ class AtomicSealBfvEncryptedVector:
                     upper[startBlock].append(v2)
                     lower[endBlock].append(v)
             else:
-                rotated(-inBlockShift)
                 upperPartSize = inBlockShift + absShift - half
                 if upperPartSize > 0:
                     ctx.copy(work.h, v, work.h, v2, 1)

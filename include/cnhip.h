@@ -201,6 +201,12 @@ int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t galois_elt,
 /* Evaluator.RotateRows(/Inplace): NAF decomposition when no key exists for the step
  * (AtomicSealBfvVector.cs:625,631,637,660,864,1420,1458) */
 int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count);
+/* RotateRows of n ciphertexts by n DIFFERENT step counts: out[oi[i]] = RotateRows(in[ii[i]], steps[i]), same words as n cn_rotate_rows calls.
+ * The reference rotates the vectors of an Interleave / a Vectorize one Evaluator.RotateRows at a time (AtomicSealBfvVector.cs:628-688); here the
+ * hops of all n rotations run in rounds - one two-launch key switch per round over every ciphertext that has a hop left, each with the key
+ * and the element of ITS step count - so a single-image network pays the dispatches of the longest rotation instead of the sum (n <= 32 / k; more
+ * run one after the other).  in == out is allowed when no result overwrites another rotation's operand or result (its own is fine). */
+int cn_rotate_rows_many(cn_ctx *ctx, cn_handle in, const uint32_t *ii, const int *steps, uint32_t n, cn_handle out, const uint32_t *oi);
 /* Evaluator.RotateColumns(/Inplace) (AtomicSealBfvVector.cs:709,914,1391) */
 int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_handle out, uint32_t oi, uint32_t count);
 /* out[i] = acc[i] + RotateRows(in[i], steps) / + RotateColumns(in[i]): the rotate-and-add step of SumAllSlots / RotateRowsAndAdd

@@ -103,7 +103,7 @@ class OracleBackend:
     # ---- emulation of cn_graph_begin / cn_graph_end / cn_graph_launch for the CPU suite: the compute calls made while recording are
     # logged (and executed), a launch re-executes them on the same handles - what the HIP graph does with the same device addresses.
     # Uploads / downloads / synchronisation are refused while recording, like the library does.
-    _REPLAYED = ("copy", "copy_many", "add", "sub", "add_many", "add_plain", "mul_plain", "mul_scalar", "scalar_gemm", "gemm_apply", "mul_relin", "multiply",
+    _REPLAYED = ("copy", "copy_many", "rotate_rows_many", "add", "sub", "add_many", "add_plain", "mul_plain", "mul_scalar", "scalar_gemm", "gemm_apply", "mul_relin", "multiply",
                  "relinearize", "rotate_rows", "rotate_rows_add", "rotate_columns", "rotate_columns_add", "sum_slots", "rowdot_batch")
     _REFUSED = ("sync", "ct_upload", "ct_download", "pt_upload", "pt_download", "encode", "decode", "encode_batch", "decode_batch", "set_relin_key", "set_galois_key")
 
@@ -212,6 +212,11 @@ class OracleBackend:
     def rotate_rows(self, src, ii, steps, out, oi, count=1):
         for i in range(count):
             self.bufs[out][oi + i] = self.o.rotate_rows(self.bufs[src][ii + i], steps)
+
+    def rotate_rows_many(self, src, iis, steps, out, ois):
+        res = [self.o.rotate_rows(self.bufs[src][int(i)], int(s_)) if int(s_) else self.bufs[src][int(i)].copy() for i, s_ in zip(iis, steps)]
+        for r, o_ in zip(res, ois):
+            self.bufs[out][int(o_)] = r
 
     def rotate_rows_add(self, src, ii, steps, acc, ai, out, oi, count=1):
         for c in range(count):

@@ -1005,3 +1005,50 @@ def test_rotation_with_and_without_the_permutation_pass(name, rng):
         g.set_option("ks_perm_fused", 1)
     g.free(h)
     g.free(out)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_rotate_rows_many(name, rng):
+    """cn_rotate_rows_many: n ciphertexts rotated by n different step counts (direct keys, multi-hop NAF steps, 0) as one launch chain per hop
+    round - words of n cn_rotate_rows calls; in place; more rotations than one two-launch key switch takes (run one after the other); queued
+    under deferred submission (rotations of one level share the rounds whatever their step counts); overlapping operands are refused."""
+    from cryptonets_amd._native import CnError
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    half = o.n // 2
+    steps = [1, -3, 0, 169 % half, -(half - 1), 2, -676 % half - half, 7]
+    vals, cts = enc_batch(o, rng, len(steps))
+    exp = np.stack([o.rotate_rows(c, s) if s else c for c, s in zip(cts, steps)])
+    h, out = up(g, cts), g.ct_alloc(len(steps) + 1)
+    l0 = g.stats()["kernel_launches"]
+    g.rotate_rows_many(h, list(range(len(steps))), steps, out, [i + 1 for i in range(len(steps))])
+    many = g.stats()["kernel_launches"] - l0
+    assert np.array_equal(g.ct_download(out, 1, len(steps)), exp)
+    l0 = g.stats()["kernel_launches"]
+    for i, s in enumerate(steps):
+        if s:
+            g.rotate_rows(h, i, s, out, i + 1, 1)
+    assert many < g.stats()["kernel_launches"] - l0                       # fewer dispatches than one call per rotation
+    w = up(g, cts)
+    g.rotate_rows_many(w, list(range(len(steps))), steps, w, list(range(len(steps))))          # in place
+    assert np.array_equal(g.ct_download(w, 0, len(steps)), exp)
+    with pytest.raises(CnError):
+        g.rotate_rows_many(w, [0, 1], [1, 1], w, [1, 2])                   # result 0 overwrites operand 1
+    with pytest.raises(CnError):
+        g.rotate_rows_many(h, [0, 1], [1, 2], out, [3, 3])                 # two results in one place
+    g.ct_upload(w, 0, cts)
+    g.set_option("defer", 1)
+    try:
+        for i, s in enumerate(steps):
+            g.rotate_rows(w, i, s, out, i, 1)                              # per-call rotations by different steps: one level of the queue
+        got = g.ct_download(out, 0, len(steps))
+    finally:
+        g.set_option("defer", 0)
+    assert np.array_equal(got, exp)
+    # more rotations than a two-launch key switch takes at once
+    big = 40
+    idx = [i % len(steps) for i in range(big)]
+    hb = g.ct_alloc(big)
+    g.rotate_rows_many(h, idx, [steps[i] for i in idx], hb, list(range(big)))
+    assert np.array_equal(g.ct_download(hb, 0, big), exp[idx])
+    for x in (h, out, w, hb):
+        g.free(x)

@@ -28,7 +28,7 @@ LIB = os.path.join(ROOT, "cryptonets_amd", "lib", "libcntrace.so")
 
 OPS = ["CT_ALLOC", "PT_ALLOC", "FREE", "COPY", "ADD", "SUB", "NEGATE", "ADD_MANY", "ADD_PLAIN", "MUL_PLAIN", "MUL_SCALAR", "SCALAR_DOT", "MUL_RELIN",
        "ROTATE_ROWS", "ROTATE_COLUMNS", "ROTATE_ROWS_ADD", "ROTATE_COLUMNS_ADD", "SUM_SLOTS", "ENCODE_BATCH", "PT_UPLOAD", "GEMM_APPLY", "MULTIPLY",
-       "RELINEARIZE", "APPLY_GALOIS", "ROWDOT_BATCH", "SCALAR_GEMM", "COPY_MANY"]
+       "RELINEARIZE", "APPLY_GALOIS", "ROWDOT_BATCH", "SCALAR_GEMM", "COPY_MANY", "ROTATE_ROWS_MANY"]
 OP = {name: i for i, name in enumerate(OPS)}
 
 
@@ -102,6 +102,13 @@ class Recorder:
                    np.concatenate([np.array([R._pack(h) for h in hs], dtype=np.uint64), np.asarray(sfirsts, dtype=np.uint64).reshape(-1)]))
             return R._orig["copy_many"](srcs, sfirsts, dst, dfirst)
 
+        def rotate_rows_many(src, iis, steps, out, ois):
+            n = len(iis)
+            R._rec("ROTATE_ROWS_MANY", [R._h(src), R._h(out), n],
+                   np.concatenate([np.asarray(iis, dtype=np.uint64).reshape(-1), np.asarray(steps, dtype=np.int64).astype(np.uint64).reshape(-1),
+                                   np.asarray(ois, dtype=np.uint64).reshape(-1)]))
+            return R._orig["rotate_rows_many"](src, iis, steps, out, ois)
+
         def add_many(src, idx, out, oi):
             R._rec("ADD_MANY", [R._h(src), R._h(out), int(oi)], np.asarray(idx, dtype=np.uint64))
             return R._orig["add_many"](src, idx, out, oi)
@@ -140,7 +147,7 @@ class Recorder:
             bi = np.zeros(O, dtype=np.int64) if bias_idx is None else np.asarray(bias_idx, dtype=np.int64)
             R._rec("SCALAR_GEMM", [R._h(src), O, K, R._h(bias_pt), R._h(out), int(oi)], np.concatenate([idx_.reshape(-1).view(np.uint64), W_.reshape(-1), bi.view(np.uint64)]))
             return R._orig["scalar_gemm"](src, W, out, oi, idx, bias_pt, bias_idx)
-        wrap.update(copy_many=copy_many, add_many=add_many, mul_scalar=mul_scalar, scalar_dot=scalar_dot, encode_batch=encode_batch, encode=encode, pt_upload=pt_upload, scalar_gemm=scalar_gemm)
+        wrap.update(copy_many=copy_many, rotate_rows_many=rotate_rows_many, add_many=add_many, mul_scalar=mul_scalar, scalar_dot=scalar_dot, encode_batch=encode_batch, encode=encode, pt_upload=pt_upload, scalar_gemm=scalar_gemm)
         for name in ("sync", "ct_download", "pt_download", "decode", "decode_batch", "ct_upload", "decrypt", "encrypt", "gemm_plan", "graph_begin", "graph_end", "graph_launch",
                      "set_relin_key", "set_galois_key", "keygen"):
             def refuse(*a, _n=name, **k):

@@ -18,7 +18,7 @@
 
 namespace {
 enum Op { CT_ALLOC, PT_ALLOC, FREE, COPY, ADD, SUB, NEGATE, ADD_MANY, ADD_PLAIN, MUL_PLAIN, MUL_SCALAR, SCALAR_DOT, MUL_RELIN, ROTATE_ROWS, ROTATE_COLUMNS,
-          ROTATE_ROWS_ADD, ROTATE_COLUMNS_ADD, SUM_SLOTS, ENCODE_BATCH, PT_UPLOAD, GEMM_APPLY, MULTIPLY, RELINEARIZE, APPLY_GALOIS, ROWDOT_BATCH, SCALAR_GEMM, COPY_MANY };
+          ROTATE_ROWS_ADD, ROTATE_COLUMNS_ADD, SUM_SLOTS, ENCODE_BATCH, PT_UPLOAD, GEMM_APPLY, MULTIPLY, RELINEARIZE, APPLY_GALOIS, ROWDOT_BATCH, SCALAR_GEMM, COPY_MANY, ROTATE_ROWS_MANY };
 struct Rec { uint64_t op; const uint64_t *ints; uint64_t n_ints; const uint64_t *blob; uint64_t blob_words; };
 struct Trace {
     cn_ctx *ctx; std::vector<Rec> recs; const uint64_t *ext; uint64_t n_ext, n_new;
@@ -63,6 +63,9 @@ int run_one(Trace &t, const Rec &r) {
     case COPY_MANY: { const uint32_t n = U(2); std::vector<cn_handle> hs(n); std::vector<uint32_t> fs(n);
                       for (uint32_t i = 0; i < n; i++) { hs[i] = t.H(r.blob[i]); fs[i] = (uint32_t)r.blob[n + i]; }
                       return cn_copy_many(t.ctx, hs.data(), fs.data(), n, t.H(a[0]), U(1)); }
+    case ROTATE_ROWS_MANY: { const uint32_t n = U(2); std::vector<uint32_t> ii(n), oi(n); std::vector<int> st(n);
+                             for (uint32_t i = 0; i < n; i++) { ii[i] = (uint32_t)r.blob[i]; st[i] = (int)(int64_t)r.blob[n + i]; oi[i] = (uint32_t)r.blob[2 * n + i]; }
+                             return cn_rotate_rows_many(t.ctx, t.H(a[0]), ii.data(), st.data(), n, t.H(a[1]), oi.data()); }
     case SCALAR_GEMM: { const uint32_t O = U(1), K = U(2); const int32_t *idx = nullptr; std::vector<int32_t> ix((size_t)O * K), bi(O);
                         for (size_t i = 0; i < (size_t)O * K; i++) ix[i] = (int32_t)(int64_t)r.blob[i];
                         for (uint32_t o = 0; o < O; o++) bi[o] = (int32_t)(int64_t)r.blob[(size_t)2 * O * K + o];
