@@ -9,7 +9,7 @@ timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/benc
 python -c "import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['verified_against_integer_model'], d['roofline']['frac'], d['key_switch']['ms_per_launch'], d['unchanged_caller']['frac_of_batched'], d['unchanged_caller']['skipped_taps']['frac_of_batched'], d['cpu_baseline']['value'])" || tail -20 $OUT/bench.err
 export TMPDIR=/tmp
 R=$PWD
-(cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d $R/$OUT/prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-unchanged-caller --serialize --stagger 0 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d $R/$OUT/prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-unchanged-caller --no-relinearize-late --serialize --stagger 0 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err)
 KT=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); python tools/summarize_trace.py $KT > $OUT/trace_summary.txt 2>&1
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; ; find $OUT/prof -name "*kernel_trace.csv" -delete
 head -14 $OUT/trace_summary.txt | cut -c1-130
