@@ -1182,7 +1182,12 @@ static int ensure_ks_part(cn_ctx *ctx, size_t need) {
 }
 // auto: the fused kernel runs cnt*k workgroups.  Up to 32 of them (1-6 ciphertexts) every digit gets its own workgroup; up to 160
 // every source limb does; above that the fused kernel fills the chip by itself.
-static const uint32_t KS_DIGIT_MAX_BLOCKS = 32, KS_WIDE_MAX_BLOCKS = 160;
+static const uint32_t KS_DIGIT_MAX_BLOCKS = 32;
+static uint32_t ks_wide_max_blocks() {               // (ciphertext, limb) blocks up to which a key switch runs as two launches; CN_KS_WIDE_MAX overrides (A/B)
+    static const uint32_t v = getenv("CN_KS_WIDE_MAX") ? (uint32_t)atoi(getenv("CN_KS_WIDE_MAX")) : 160u;
+    return v;
+}
+#define KS_WIDE_MAX_BLOCKS ks_wide_max_blocks()
 // the variant do_keyswitch takes for `cnt` ciphertexts: 0 = the fused kernel, 1 / 2 = two launches (KsArgs::mode)
 static int ks_planned_mode(cn_ctx *ctx, uint32_t cnt, int galois) {
     const uint32_t k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;

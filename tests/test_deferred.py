@@ -510,3 +510,79 @@ def test_deferred_rotations_and_plain_products_equal_immediate(name, rng):
         g.free(h), g.free(zp)
     finally:
         g.set_option("defer", 0)
+
+
+def _random_program(g, o, cts, pts, seed, defer, length=120):
+    """a random sequence of deferrable calls over a pool of single-ciphertext handles (every ciphertext its own array, like an unchanged
+    caller) plus one 4-ciphertext array: reads and writes collide at random (RAW, WAR, WAW, in place), handles are freed and re-allocated
+    while calls are pending.  Returns the words of every live ciphertext at the end, in a canonical order."""
+    r = np.random.default_rng(seed)
+    g.set_option("defer", 1 if defer else 0)
+    try:
+        pool = []
+        for c in cts:
+            h = g.ct_alloc(1)
+            g.ct_upload(h, 0, c[None, :])
+            pool.append(h)
+        arr = g.ct_alloc(4)
+        g.ct_upload(arr, 0, np.stack(list(cts[:4])))
+        ph = g.pt_alloc(len(pts))
+        g.pt_upload(ph, 0, pts)
+        steps_pool = [1, -1, 2, -3, 5, -4, 7]
+        maxpend = 0
+        for _ in range(length):
+            kind = int(r.integers(0, 11))
+            a, b, c = (int(x) for x in r.integers(0, len(pool), size=3))
+            if kind == 0:
+                g.add(pool[a], 0, pool[b], 0, pool[c], 0)
+            elif kind == 1:
+                g.sub(pool[a], 0, pool[b], 0, pool[c], 0)
+            elif kind == 2:
+                g.add_plain(pool[a], 0, ph, int(r.integers(0, len(pts))), pool[c], 0)
+            elif kind == 3:
+                g.mul_plain(pool[a], 0, ph, int(r.integers(0, len(pts))), pool[c], 0)
+            elif kind == 4:
+                g.rotate_rows(pool[a], 0, int(r.choice(steps_pool)), pool[c], 0)
+            elif kind == 5:
+                g.rotate_rows_add(pool[a], 0, int(r.choice(steps_pool)), pool[b], 0, pool[c], 0)
+            elif kind == 6 and a != c:
+                g.copy(pool[a], 0, pool[c], 0, 1)
+            elif kind == 7:
+                srcs = [pool[int(x)] for x in r.integers(0, len(pool), size=3)]
+                g.copy_many(srcs, [0, 0, 0], arr, int(r.integers(0, 2)))
+            elif kind == 8:
+                ii = [int(x) for x in r.permutation(4)[:3]]
+                g.rotate_rows_many(arr, ii, [int(r.choice(steps_pool + [0])) for _ in ii], arr, ii)          # in place, different step counts
+            elif kind == 9:
+                g.copy(arr, int(r.integers(0, 4)), pool[c], 0, 1)
+            elif kind == 10 and len(pool) > 3:
+                g.free(pool[a])                                            # released while its readers may be pending
+                h = g.ct_alloc(1)
+                g.copy(pool[b if b != a else (a + 1) % len(pool)], 0, h, 0, 1)
+                pool[a] = h
+            if defer:
+                maxpend = max(maxpend, g.get_option("pending_calls"))
+        out = [g.ct_download(h, 0, 1)[0] for h in pool] + list(g.ct_download(arr, 0, 4))
+        for h in pool + [arr, ph]:
+            g.free(h)
+        return out, maxpend
+    finally:
+        g.set_option("defer", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "c4"])
+def test_random_programs_deferred_equal_immediate(name, rng):
+    """hazard logic of the deferred queue under fire: random programs of every deferrable call kind (element-wise, plaintext products,
+    rotations, rotate-and-add, copies, cn_copy_many, cn_rotate_rows_many, frees of handles with pending readers) give the same ciphertext words
+    queued as launched one by one"""
+    o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
+    cts = _fresh(o, rng, 7)
+    pts = np.stack([o.encode(rng.integers(1, 5, size=o.n, dtype=np.uint64)) for _ in range(3)])
+    for seed in range(16 if name == "tiny" else 4):
+        now, _ = _random_program(g, o, cts, pts, seed, defer=False, length=300)
+        later, pending = _random_program(g, o, cts, pts, seed, defer=True, length=300)
+        assert pending >= 40, pending
+        assert len(now) == len(later)
+        for i, (x, y) in enumerate(zip(now, later)):
+            assert np.array_equal(x, y), (seed, i)
