@@ -2252,7 +2252,11 @@ extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *i
     if (oi >= O->count) return fail(CN_ERR_ARG, "index out of range");
     DeferQueue *q = ctx->dq;
     const size_t t0 = q->addr.size();
-    std::vector<const uint64_t *> ins(K, nullptr);
+    const uint64_t *ins_small[64];                           // (no heap allocation per call for the usual window sizes: 25 taps)
+    std::vector<const uint64_t *> ins_big;
+    const uint64_t **ins_p = ins_small;
+    if (K > 64) { ins_big.assign(K, nullptr); ins_p = ins_big.data(); } else for (uint32_t kk = 0; kk < K; kk++) ins_small[kk] = nullptr;
+    struct InsView { const uint64_t **p; const uint64_t *&operator[](uint32_t i) { return p[i]; } const uint64_t **data() { return p; } } ins{ins_p};
     bool any = false;
     uint64_t *o = O->d + (size_t)oi * O->item_words;
     uint64_t nnz = 0;

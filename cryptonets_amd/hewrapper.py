@@ -428,21 +428,8 @@ class AtomicSealBfvEncryptedVector:
                 return -thisShift
             return -(inBlockShift - half) if inBlockShift >= half else -inBlockShift
 
-        # work[2k] = RotateRows(vecs[k], steps_of(k)).  The reference copies every ciphertext and rotates the copy in place, one Evaluator call each
-        # (LITERAL keeps that); otherwise all rotations of the interleave are ONE library call (cn_rotate_rows_many: the hops of the 13
-        # differently rotated vectors run in rounds - same words) when the vectors share an array, else one direct rotation each.
-        if not LITERAL and hasattr(ctx, "rotate_rows_many") and len(vecs) > 1 and all(x.buf is vecs[0].buf for x in vecs):
-            ctx.rotate_rows_many(vecs[0].h, [x.first for x in vecs], [steps_of(k) for k in range(len(vecs))], work.h, [2 * k for k in range(len(vecs))])
-        else:
-            for k, src in enumerate(vecs):
-                st = steps_of(k)
-                if LITERAL or st == 0:
-                    ctx.copy(src.h, src.first, work.h, 2 * k, 1)
-                    if st != 0:
-                        ctx.rotate_rows(work.h, 2 * k, st, work.h, 2 * k, 1)
-                else:
-                    ctx.rotate_rows(src.h, src.first, st, work.h, 2 * k, 1)
-        for k in range(len(vecs)):
+        def place(k):
+            """the masks / block assignment of vector k behind its rotation (AtomicSealBfvVector.cs:640-688)"""
             thisShift, inBlockShift, startBlock, endBlock = geometry(k)
             v, v2 = 2 * k, 2 * k + 1
             if inBlockShift == 0:
@@ -471,6 +458,30 @@ class AtomicSealBfvEncryptedVector:
                     lower[startBlock].append(v2)
                 else:
                     lower[startBlock].append(v)
+
+        # work[2k] = RotateRows(vecs[k], steps_of(k)).  The reference copies every ciphertext, rotates the copy in place and masks it, vector by
+        # vector - LITERAL keeps exactly that call sequence.  Otherwise all rotations of the interleave are ONE library call
+        # (cn_rotate_rows_many: the hops of the 13 differently rotated vectors run in rounds - same words) when the vectors share an array,
+        # else one direct rotation each; the masks follow.
+        if LITERAL:
+            for k, src in enumerate(vecs):
+                st = steps_of(k)
+                ctx.copy(src.h, src.first, work.h, 2 * k, 1)
+                if st != 0:
+                    ctx.rotate_rows(work.h, 2 * k, st, work.h, 2 * k, 1)
+                place(k)
+        else:
+            if hasattr(ctx, "rotate_rows_many") and len(vecs) > 1 and all(x.buf is vecs[0].buf for x in vecs):
+                ctx.rotate_rows_many(vecs[0].h, [x.first for x in vecs], [steps_of(k) for k in range(len(vecs))], work.h, [2 * k for k in range(len(vecs))])
+            else:
+                for k, src in enumerate(vecs):
+                    st = steps_of(k)
+                    if st == 0:
+                        ctx.copy(src.h, src.first, work.h, 2 * k, 1)
+                    else:
+                        ctx.rotate_rows(src.h, src.first, st, work.h, 2 * k, 1)
+            for k in range(len(vecs)):
+                place(k)
         res = _Buf(ctx, "ct", outputBlockCount).view()
         tmp = _Buf(ctx, "ct", 1).view()
         for i in range(outputBlockCount):
