@@ -244,12 +244,18 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
         __syncthreads();
     }
 }
+// 16 B of a key (two consecutive words) through a GLOBAL pointer (a struct cannot be copied out of address space 1; a vector type can)
+template <class T> NTT_DEV void ks_load2(const NTT_GLOBAL T *p, T &a, T &b) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    const V2 v = *reinterpret_cast<const NTT_GLOBAL V2 *>(p);
+    a = v.x; b = v.y;
+}
 // A rotation's automorphism x -> x^elt applied while a two-launch key switch LOADS its operand, instead of a permutation kernel in front of
 // it (k_galois_lds): one dispatch less per rotation - a single-image LoLa chain is ~230 dependent dispatches, 66 of them were this
 // permutation, and the command processor retires ~5 us per dependent dispatch whatever queue it comes from.  The limb is
 // loaded coalesced (coefficient tid + NT r, the first pass' own pattern), written to the exchange image at its destination
 // (i elt mod 2N, negated when it wraps), and read back in the first pass' layout: raw[r] = sigma(a)[pass_index(tid, r)].
-template <int L> NTT_DEV void ks_gather_automorphism(uint64_t (&raw)[16], const uint64_t *limb, uint32_t elt, uint64_t q, void *image, uint32_t tid) {
+template <int L> NTT_DEV void ks_gather_automorphism(uint64_t (&raw)[16], const NTT_GLOBAL uint64_t *limb, uint32_t elt, uint64_t q, void *image, uint32_t tid) {
     constexpr uint32_t n = 1u << L, NT = NttPlan<L>::NT;
     uint64_t *s = reinterpret_cast<uint64_t *>(image);
 #pragma unroll
@@ -289,10 +295,12 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
     const int dbc = galois ? C->gdbc : C->dbc, sh = dbc * (int)d;
     const uint64_t mask = (1ull << dbc) - 1;
     const size_t kn = (size_t)k * n;
-    const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    // (addresses that come out of a table are GLOBAL addresses: said so, the accesses stay global_load - a generic pointer would make them flat_load)
+    const NTT_GLOBAL uint64_t *src = (const NTT_GLOBAL uint64_t *)target + (size_t)ct * tgt_stride + (size_t)l * n;
+    const NTT_GLOBAL T *keyp = (const NTT_GLOBAL T *)key_;
     if (items) {                                           // rotations by per-ciphertext step counts in one launch: operand, key and Galois element from a table
         const KsItem it = items[ct];
-        src = it.in + kn + (size_t)l * n; key_ = it.key; perm_elt = it.elt;
+        src = (const NTT_GLOBAL uint64_t *)it.in + kn + (size_t)l * n; keyp = (const NTT_GLOBAL T *)it.key; perm_elt = it.elt;
     }
     T v[16];
     uint64_t raw[16];
@@ -309,13 +317,14 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
     }
     if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
     ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
-    const T *k0 = reinterpret_cast<const T *>(key_) + (size_t)g * 2 * kn + (size_t)j * n, *k1 = k0 + kn;
+    const NTT_GLOBAL T *k0 = keyp + (size_t)g * 2 * kn + (size_t)j * n, *k1 = k0 + kn;
     T *o0 = reinterpret_cast<T *>(part_) + (((size_t)ct * tot + g) * 2) * kn + (size_t)j * n, *o1 = o0 + kn;
     struct alignas(16) P2 { T a, b; };
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const uint32_t pos = tail_index<L>(tid, r);
-        const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+        P2 a, b;
+        ks_load2<T>(k0 + pos, a.a, a.b); ks_load2<T>(k1 + pos, b.a, b.b);
         P2 x = {0, 0}, y = {0, 0};
         KsMac<AR>::mac(x.a, v[r], a.a, qm, A); KsMac<AR>::mac(x.b, v[r + 1], a.b, qm, A);
         KsMac<AR>::mac(y.a, v[r], b.a, qm, A); KsMac<AR>::mac(y.b, v[r + 1], b.b, qm, A);
@@ -345,10 +354,11 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
     uint32_t g0 = 0;                                   // index of the first digit of limb l in the key
     for (uint32_t i = 0; i < l; i++) g0 += galois ? C->gk_dig[i] : C->rl_dig[i];
     const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
-    const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+    const NTT_GLOBAL uint64_t *src = (const NTT_GLOBAL uint64_t *)target + (size_t)ct * tgt_stride + (size_t)l * n;
+    const NTT_GLOBAL T *keyp = (const NTT_GLOBAL T *)key_;
     if (items) {
         const KsItem it = items[ct];
-        src = it.in + kn + (size_t)l * n; key_ = it.key; perm_elt = it.elt;
+        src = (const NTT_GLOBAL uint64_t *)it.in + kn + (size_t)l * n; keyp = (const NTT_GLOBAL T *)it.key; perm_elt = it.elt;
     }
     uint64_t raw[16];
     if (perm_elt) ks_gather_automorphism<L>(raw, src, perm_elt, C->q[l].q, s, tid);
@@ -361,7 +371,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
     T acc0[16], acc1[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
-    const T *kp = reinterpret_cast<const T *>(key_) + (size_t)g0 * 2 * kn;
+    const NTT_GLOBAL T *kp = keyp + (size_t)g0 * 2 * kn;
     uint32_t terms = 0;
     for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
         const int sh = dbc * (int)d;
@@ -376,12 +386,13 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
         }
         if constexpr (std::is_same<T, double>::value) { if (mask >= q) AR::renorm(v, A.m); }
         ntt_forward_regs<AR, L, KS_PRE_SYNC != 0>(v, s, A.fw, A.m, tl);
-        const T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
+        const NTT_GLOBAL T *k0 = kp + (size_t)j * n, *k1 = kp + kn + (size_t)j * n;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const uint32_t pos = tail_index<L>(tl, r);
             struct alignas(16) P2 { T a, b; };
-            const P2 a = *reinterpret_cast<const P2 *>(k0 + pos), b = *reinterpret_cast<const P2 *>(k1 + pos);
+            P2 a, b;
+            ks_load2<T>(k0 + pos, a.a, a.b); ks_load2<T>(k1 + pos, b.a, b.b);
             KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
             KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
         }
@@ -428,9 +439,9 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_sum_intt(const void *__re
         if (++terms == accmax) { terms = 0; KsMac<AR>::settle(v, A); }
     }
     ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
-    const uint64_t *ad = p ? add1 : add0;
+    const NTT_GLOBAL uint64_t *ad = (const NTT_GLOBAL uint64_t *)(p ? add1 : add0);
     if (ad) ad += (size_t)ct * add_stride + (size_t)j * n;
-    if (items) { const KsItem it = items[ct]; ad = p ? nullptr : it.in + (size_t)j * n; perm_elt = it.elt; }
+    if (items) { const KsItem it = items[ct]; ad = p ? nullptr : (const NTT_GLOBAL uint64_t *)it.in + (size_t)j * n; perm_elt = it.elt; }
     uint64_t addv[16];
     if (ad && perm_elt) {                                  // sigma(c0): the whole limb is read (through the image) before a word of the result is written
         __syncthreads();                                   // everybody has taken its coefficients out of the image

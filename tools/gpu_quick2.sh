@@ -1,3 +1,2 @@
 #!/bin/bash
-rocm-smi -c -P 2>&1 | head -20
-python tools/clock_probe.py 2>&1 | tail -8
+cd /tmp; rocprofv3 -L 2>/dev/null | grep -iE "^\s*(Name|.*SQ_(WAIT|INST_LEVEL|ACTIVE|BUSY|WAVE|INSTS|LDS|INST_CYCLES|THREAD|IFETCH|BARRIER|LEVEL))" | head -120 > $GRAFT_REPO_ROOT/gpurun_out/counters.txt; wc -l $GRAFT_REPO_ROOT/gpurun_out/counters.txt; head -100 $GRAFT_REPO_ROOT/gpurun_out/counters.txt | cut -c1-160
