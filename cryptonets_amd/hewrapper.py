@@ -34,6 +34,9 @@ class EMatrixFormat(enum.Enum):
 # AtomicSealBfvEncryptedVector method call per row / column / map (EncryptedSealBfvMatrix.cs:79-120, LLPoolLayer.cs, LLInterleaveLayer.cs,
 # LLDenseLayer.cs).  That is the call sequence the C# twin receives; tools/call_trace.py records it at the C ABI and
 # tools/replay_call_trace.cpp replays it from native code (bench.py --workload lola: `unchanged_caller`).  Same ciphertext words.
+# What a vector method does INSIDE is the twin's own business on both sides of the switch: AtomicSealBfvEncryptedVector is the file the twin
+# replaces (integration/GpuAtomicSealBfvEncryptedVector.cs), and like it this class gathers with cn_copy_many and rotates the vectors of an
+# Interleave / the copies of a Duplicate with one cn_rotate_rows_many.
 LITERAL = bool(int(os.environ.get("CN_LITERAL_CALLS", "0")))
 
 
@@ -103,7 +106,7 @@ def _gather(ctx, views):
         return b0.h, [v.first + i for v in views for i in range(v.count)], None
     total = sum(v.count for v in views)
     tmp = _Buf(ctx, "ct", total).view()
-    if not LITERAL and hasattr(ctx, "copy_many"):          # one launch for the whole gather (cn_copy_many) instead of one per vector
+    if hasattr(ctx, "copy_many"):                          # one launch for the whole gather (cn_copy_many) instead of one per vector
         ctx.copy_many([v.h for v in views for _ in range(v.count)], [v.first + i for v in views for i in range(v.count)], tmp.h, 0)
         return tmp.h, list(range(total)), tmp
     pos, idx = 0, []
@@ -404,7 +407,8 @@ class AtomicSealBfvEncryptedVector:
             raise Exception("Shifts of more than half block size with multiple output blocks are not implemented yet")
         if absShift * len(vecs) > blockSize * outputBlockCount:
             raise Exception("not enough room for interleaving")
-        work = _Buf(ctx, "ct", 2 * len(vecs)).view()      # slot 2k: v, slot 2k+1: v2
+        n = len(vecs)
+        work = _Buf(ctx, "ct", 2 * n).view()               # slot k: v, slot n + k: v2 (the split-off part)
         lower = [[] for _ in range(outputBlockCount)]
         upper = [[] for _ in range(outputBlockCount)]
         half = blockSize // 2
@@ -428,10 +432,25 @@ class AtomicSealBfvEncryptedVector:
                 return -thisShift
             return -(inBlockShift - half) if inBlockShift >= half else -inBlockShift
 
-        def place(k):
-            """the masks / block assignment of vector k behind its rotation (AtomicSealBfvVector.cs:640-688)"""
+        # work[k] = RotateRows(vecs[k], steps_of(k)).  The reference copies and rotates vector by vector (:628-660); here - as in the C# twin - all
+        # rotations of the interleave are ONE library call (cn_rotate_rows_many: the hops of the 13 differently rotated vectors run in rounds,
+        # the same hops and words), straight from the source array when the vectors share one, behind one gather launch otherwise
+        steps = [steps_of(k) for k in range(n)]
+        if hasattr(ctx, "rotate_rows_many") and n > 1:
+            if all(x.buf is vecs[0].buf for x in vecs):
+                ctx.rotate_rows_many(vecs[0].h, [x.first for x in vecs], steps, work.h, list(range(n)))
+            else:
+                ctx.copy_many([x.h for x in vecs], [x.first for x in vecs], work.h, 0)
+                ctx.rotate_rows_many(work.h, list(range(n)), steps, work.h, list(range(n)))
+        else:
+            for k, src in enumerate(vecs):
+                if steps[k] == 0:
+                    ctx.copy(src.h, src.first, work.h, k, 1)
+                else:
+                    ctx.rotate_rows(src.h, src.first, steps[k], work.h, k, 1)
+        for k in range(n):
             thisShift, inBlockShift, startBlock, endBlock = geometry(k)
-            v, v2 = 2 * k, 2 * k + 1
+            v, v2 = k, n + k
             if inBlockShift == 0:
                 lower[startBlock].append(v)
             elif inBlockShift + absShift < half:
@@ -458,30 +477,6 @@ class AtomicSealBfvEncryptedVector:
                     lower[startBlock].append(v2)
                 else:
                     lower[startBlock].append(v)
-
-        # work[2k] = RotateRows(vecs[k], steps_of(k)).  The reference copies every ciphertext, rotates the copy in place and masks it, vector by
-        # vector - LITERAL keeps exactly that call sequence.  Otherwise all rotations of the interleave are ONE library call
-        # (cn_rotate_rows_many: the hops of the 13 differently rotated vectors run in rounds - same words) when the vectors share an array,
-        # else one direct rotation each; the masks follow.
-        if LITERAL:
-            for k, src in enumerate(vecs):
-                st = steps_of(k)
-                ctx.copy(src.h, src.first, work.h, 2 * k, 1)
-                if st != 0:
-                    ctx.rotate_rows(work.h, 2 * k, st, work.h, 2 * k, 1)
-                place(k)
-        else:
-            if hasattr(ctx, "rotate_rows_many") and len(vecs) > 1 and all(x.buf is vecs[0].buf for x in vecs):
-                ctx.rotate_rows_many(vecs[0].h, [x.first for x in vecs], [steps_of(k) for k in range(len(vecs))], work.h, [2 * k for k in range(len(vecs))])
-            else:
-                for k, src in enumerate(vecs):
-                    st = steps_of(k)
-                    if st == 0:
-                        ctx.copy(src.h, src.first, work.h, 2 * k, 1)
-                    else:
-                        ctx.rotate_rows(src.h, src.first, st, work.h, 2 * k, 1)
-            for k in range(len(vecs)):
-                place(k)
         res = _Buf(ctx, "ct", outputBlockCount).view()
         tmp = _Buf(ctx, "ct", 1).view()
         for i in range(outputBlockCount):
@@ -796,7 +791,7 @@ class AtomicSealBfvEncryptedVector:
         """AtomicSealBfvVector.cs:1347-1359: first block of every vector becomes one entry of a sparse vector"""
         ctx = env.ctx
         res = _Buf(ctx, "ct", len(encryptedVector)).view()
-        if not LITERAL and hasattr(ctx, "copy_many"):
+        if hasattr(ctx, "copy_many"):
             ctx.copy_many([e.encData.h for e in encryptedVector], [e.encData.first for e in encryptedVector], res.h, 0)
         else:
             for i, e in enumerate(encryptedVector):
@@ -816,6 +811,29 @@ class AtomicSealBfvEncryptedVector:
         slots, ctx = env.SlotCount, env.ctx
         if shift * count > slots:
             raise Exception("Packed vector must fit in a single ciphertext")
+        if hasattr(ctx, "rotate_rows_many") and int(count) > 2:
+            # every copy is a rotation of the SAME ciphertext (or of its column-swapped form) and they are only added up: the count - 1 rotations
+            # are one library call (their hops share rounds), the sum one AddMany - the words of the reference's rotate-and-add chain (modular
+            # addition is exact in any order), 6 dispatches instead of 2 per copy
+            n = int(count) - 1
+            work = _Buf(ctx, "ct", 2 + n).view()    # 0: the vector, 1: its column-swapped form, 2 ..: the rotated copies
+            ctx.copy(self.encData.h, self.encData.first, work.h, 0, 1)
+            srcs, steps = [], []
+            for i in range(1, int(count)):
+                target = i * shift
+                if target * 2 >= slots:
+                    srcs.append(1)
+                    target -= slots // 2
+                else:
+                    srcs.append(0)
+                steps.append(-target)
+            if 1 in srcs:
+                ctx.rotate_columns(self.encData.h, self.encData.first, work.h, 1, 1)
+            ctx.rotate_rows_many(work.h, srcs, steps, work.h, [2 + i for i in range(n)])
+            res = _Buf(ctx, "ct", 1).view()
+            ctx.add_many(work.h, [0] + [2 + i for i in range(n)], res.h, 0)
+            work.release()
+            return AtomicSealBfvEncryptedVector._new(IsSigned=self.IsSigned, Scale=self.Scale, Dim=count * shift, encData=res, Format=EVectorFormat.dense)
         work = _Buf(ctx, "ct", 3).view()            # 0: res, 1: rotator, 2: tmp
         ctx.copy(self.encData.h, self.encData.first, work.h, 0, 1)
         ctx.copy(self.encData.h, self.encData.first, work.h, 1, 1)

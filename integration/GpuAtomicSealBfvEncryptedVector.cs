@@ -516,27 +516,40 @@ namespace HEWrapper
             int half = blockSize / 2;
             var lower = Enumerable.Range(0, outputBlockCount).Select(x => new List<uint>()).ToArray();
             var upper = Enumerable.Range(0, outputBlockCount).Select(x => new List<uint>()).ToArray();
-            using (var work = new CnBuffer(env.device, (uint)(2 * vecs.Length)))          // slot 2k: v, slot 2k+1: v2 (the split-off part)
+            int n = vecs.Length;
+            using (var work = new CnBuffer(env.device, (uint)(2 * n)))          // slot k: v, slot n + k: v2 (the split-off part)
             using (var tmp = new CnBuffer(env.device, 1))
             {
-                for (int k = 0; k < vecs.Length; k++)
+                // work[k] = RotateRows(vecs[k], steps[k]).  The reference copies and rotates vector by vector (:628-660); here the n copies are ONE launch
+                // (cn_copy_many) and the n rotations ONE call whose hops run in rounds (cn_rotate_rows_many: every ciphertext with its own key and
+                // element) - the same hops, the same words, the dispatches of the longest rotation instead of the sum
+                var steps = new int[n]; var slot = new uint[n];
+                for (int k = 0; k < n; k++)
+                {
+                    var thisShift = shift * k;
+                    if (thisShift < 0) thisShift = half + thisShift;
+                    var inBlockShift = thisShift % blockSize;
+                    slot[k] = (uint)k;
+                    if (inBlockShift == 0) steps[k] = 0;
+                    else if (inBlockShift + absShift < half) steps[k] = -thisShift;
+                    else if (inBlockShift >= half) steps[k] = -(inBlockShift - half);
+                    else steps[k] = -inBlockShift;
+                    if (steps[k] != 0) OperationsCount.Add(ref OperationsCount.Rotation, 1);
+                }
+                CnHip.Check(CnHip.cn_copy_many(ctx, vecs.Select(x => x.enc.Handle).ToArray(), new uint[n], (uint)n, work.Handle, 0));
+                CnHip.Check(CnHip.cn_rotate_rows_many(ctx, work.Handle, slot, steps, (uint)n, work.Handle, slot));
+                for (int k = 0; k < n; k++)
                 {
                     var thisShift = shift * k;
                     if (thisShift < 0) thisShift = half + thisShift;
                     var inBlockShift = thisShift % blockSize;
                     var startBlock = thisShift / blockSize;
                     var endBlock = (thisShift + absShift) / blockSize;
-                    uint v = (uint)(2 * k), v2 = v + 1;
-                    CnHip.Check(CnHip.cn_copy(ctx, vecs[k].enc.Handle, 0, work.Handle, v, 1));
+                    uint v = (uint)k, v2 = (uint)(n + k);
                     if (inBlockShift == 0) lower[startBlock].Add(v);
-                    else if (inBlockShift + absShift < half)
-                    {
-                        CnHip.Check(CnHip.cn_rotate_rows(ctx, work.Handle, v, -thisShift, work.Handle, v, 1));
-                        lower[startBlock].Add(v);
-                    }
+                    else if (inBlockShift + absShift < half) lower[startBlock].Add(v);
                     else if (inBlockShift >= half)
                     {
-                        CnHip.Check(CnHip.cn_rotate_rows(ctx, work.Handle, v, -(inBlockShift - half), work.Handle, v, 1));
                         if (startBlock == endBlock) upper[startBlock].Add(v);
                         else
                         {
@@ -546,7 +559,6 @@ namespace HEWrapper
                     }
                     else
                     {
-                        CnHip.Check(CnHip.cn_rotate_rows(ctx, work.Handle, v, -inBlockShift, work.Handle, v, 1));
                         int upperPartSize = inBlockShift + absShift - half;
                         if (upperPartSize > 0)
                         {
@@ -555,7 +567,6 @@ namespace HEWrapper
                         }
                         else lower[startBlock].Add(v);
                     }
-                    OperationsCount.Add(ref OperationsCount.Rotation, 1);
                 }
                 var res = new CnBuffer(env.device, (uint)outputBlockCount);
                 for (int i = 0; i < outputBlockCount; i++)
@@ -973,8 +984,9 @@ namespace HEWrapper
             var eenv = env as AtomicSealBfvEncryptedEnvironment;
             var res = Result(eenv, (uint)encryptedVector.Length);
             res.Scale = encryptedVector[0].Scale; res.Dim = (ulong)encryptedVector.Length; res.Format = EVectorFormat.sparse; res.IsSigned = encryptedVector[0].IsSigned;
-            for (int i = 0; i < encryptedVector.Length; i++)
-                CnHip.Check(CnHip.cn_copy(eenv.device.Ctx, encryptedVector[i].enc.Handle, 0, res.enc.Handle, (uint)i, 1));
+            // the first block of every vector into one sparse vector: one launch (the reference copies element by element, :1352-1357)
+            CnHip.Check(CnHip.cn_copy_many(eenv.device.Ctx, encryptedVector.Select(x => x.enc.Handle).ToArray(), new uint[encryptedVector.Length],
+                                           (uint)encryptedVector.Length, res.enc.Handle, 0));
             return res;
         }
         public void RegisterScale(double scale) { Scale = scale; }
@@ -991,27 +1003,30 @@ namespace HEWrapper
             if (shift * count > (ulong)slots) throw new Exception("Packed vector must fit in a single ciphertext");
             var ctx = eenv.device.Ctx;
             var res = new CnBuffer(eenv.device, 1);
-            CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, res.Handle, 0, 1));
-            bool columnRotated = false;
-            using (var rotator = new CnBuffer(eenv.device, 1))
+            // every copy is a rotation of THIS ciphertext (or of its column-swapped form) and they are only added up (RotateRowsAndAdd into the
+            // result, :862-868, :1385-1404): the count - 1 rotations are one call whose hops share rounds (cn_rotate_rows_many), the sum one
+            // AddMany - modular addition is exact in any order, so these are the words of the reference's rotate-and-add chain
+            int n = (int)count - 1;
+            if (n <= 0) { CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, res.Handle, 0, 1)); }
+            else using (var work = new CnBuffer(eenv.device, (uint)(2 + n)))          // 0: this vector, 1: its column-swapped form, 2 ..: the rotated copies
             {
-                CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, rotator.Handle, 0, 1));
-                for (ulong i = 1; i < count; i++)
+                CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, work.Handle, 0, 1));
+                var src = new uint[n]; var steps = new int[n]; var dst = new uint[n]; var terms = new uint[n + 1];
+                bool columnRotated = false;
+                for (int i = 1; i <= n; i++)
                 {
-                    int targetShiftSize = (int)(i * shift);
-                    if (targetShiftSize * 2 >= slots)
-                    {
-                        if (!columnRotated)
-                        {
-                            columnRotated = true;
-                            CnHip.Check(CnHip.cn_rotate_columns(ctx, enc.Handle, 0, rotator.Handle, 0, 1));
-                            OperationsCount.Add(ref OperationsCount.Rotation, 1);
-                        }
-                        targetShiftSize -= slots / 2;
-                    }
-                    CnHip.Check(CnHip.cn_rotate_rows_add(ctx, rotator.Handle, 0, -targetShiftSize, res.Handle, 0, res.Handle, 0, 1));      // RotateRowsAndAdd (:862-868)
+                    int targetShiftSize = (int)((ulong)i * shift);
+                    if (targetShiftSize * 2 >= slots) { columnRotated = true; src[i - 1] = 1; targetShiftSize -= slots / 2; }
+                    steps[i - 1] = -targetShiftSize; dst[i - 1] = (uint)(1 + i); terms[i] = (uint)(1 + i);
                     OperationsCount.Add(ref OperationsCount.Rotation, 1); OperationsCount.Add(ref OperationsCount.Addition, 1);
                 }
+                if (columnRotated)
+                {
+                    CnHip.Check(CnHip.cn_rotate_columns(ctx, enc.Handle, 0, work.Handle, 1, 1));
+                    OperationsCount.Add(ref OperationsCount.Rotation, 1);
+                }
+                CnHip.Check(CnHip.cn_rotate_rows_many(ctx, work.Handle, src, steps, (uint)n, work.Handle, dst));
+                CnHip.Check(CnHip.cn_add_many(ctx, work.Handle, terms, (uint)(n + 1), res.Handle, 0));
             }
             return new AtomicSealBfvEncryptedVector() { owner = eenv, IsSigned = IsSigned, Scale = Scale, Dim = count * shift, enc = res, plainData = null, Format = EVectorFormat.dense };
         }
