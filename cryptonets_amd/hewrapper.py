@@ -367,7 +367,15 @@ class AtomicSealBfvEncryptedVector:
                 ctx.add_many(terms.h, [k * l + i for k in range(K)], res.h, i)
             terms.release()
         elif denses[0].IsEncrypted:
-            # ct blocks x constant plaintexts: one scalar GEMM with l outputs
+            # ct blocks x constant plaintexts.  The twin's form (integration/GpuAtomicSealBfvEncryptedVector.cs): ONE cn_scalar_dot per output block
+            # over the K ciphertexts where they lie - no gather copies
+            if hasattr(ctx, "scalar_dot"):
+                w = np.array(sparse.plainSparse, dtype=np.uint64)
+                for i in range(l):
+                    ctx.scalar_dot([d.encData.h for d in denses], [d.encData.first + i for d in denses], w, res.h, i)
+                return AtomicSealBfvEncryptedVector._new(Format=EVectorFormat.dense, Scale=denses[0].Scale * sparse.Scale, IsSigned=sparse.IsSigned,
+                                                         encData=res, Dim=denses[0].Dim)
+            # (backends without cn_scalar_dot - the CPU test harness): one scalar GEMM with l outputs over a gathered array
             h, idx, tmp = _gather(ctx, [d.encData for d in denses])
             W = np.tile(np.array(sparse.plainSparse, dtype=np.uint64), (l, 1))
             gidx = np.array([[idx[k * l + i] for k in range(K)] for i in range(l)], dtype=np.int32)
