@@ -635,8 +635,9 @@ class AtomicSealBfvEncryptedVector:
         """AtomicSealBfvVector.cs:862-868: agg += RotateRows(c, -steps)"""
         ctx.rotate_rows_add(c_h, c_i, -steps, agg_h, agg_i, agg_h, agg_i, 1)      # rotation + AddInplace in one launch chain
 
-    def SumAllSlots(self, env, length=None, ForceOutputInColumn=None):
-        """AtomicSealBfvVector.cs:877-955 (length None = Int32.MaxValue = full sum)"""
+    def SumAllSlots(self, env, length=None, ForceOutputInColumn=None, _consume=False):
+        """AtomicSealBfvVector.cs:877-955 (length None = Int32.MaxValue = full sum).  _consume: the caller owns this vector as a temporary (the
+        product inside DotProduct) - the sum is built in its array instead of in a copy, and this object must not be used or disposed afterwards"""
         INT_MAX = 2 ** 31 - 1
         if length is None:
             length = INT_MAX
@@ -651,28 +652,31 @@ class AtomicSealBfvEncryptedVector:
         if length == 1:
             return self
         ctx, slots = env.ctx, env.SlotCount
-        work = _Buf(ctx, "ct", 3).view()           # 0: sum, 1: tmp, 2: sumLong
-        if self.encData.count > 1:
-            ctx.add_many(self.encData.h, [self.encData.first + i for i in range(self.encData.count)], work.h, 2)
+        if _consume and self.encData.count == 1 and self.encData.first == 0 and self.encData.buf.refs == 1:
+            res, self.encData = self.encData, None
         else:
-            ctx.copy(self.encData.h, self.encData.first, work.h, 2, 1)
-        ctx.copy(work.h, 2, work.h, 0, 1)
-        ctx.sum_slots(work.h, 0, 1, 0 if length >= slots else length)      # column swap + log2 rotate-and-add steps in one call
+            res = _Buf(ctx, "ct", 1).view()        # the sum is built where it is returned (as in the twin: one copy, not three)
+            if self.encData.count > 1:
+                ctx.add_many(self.encData.h, [self.encData.first + i for i in range(self.encData.count)], res.h, 0)
+            else:
+                ctx.copy(self.encData.h, self.encData.first, res.h, 0, 1)
+            if _consume:
+                self.Dispose()
+        ctx.sum_slots(res.h, 0, 1, 0 if length >= slots else length)      # column swap + log2 rotate-and-add steps in one call
         if length >= slots // 2:
             length = slots // 2
         if ForceOutputInColumn is not None:
             p = env.mask_plain("slot", ForceOutputInColumn)
-            ctx.mul_plain(work.h, 0, p.h, 0, work.h, 0, 1)
+            ctx.mul_plain(res.h, 0, p.h, 0, res.h, 0, 1)
             length = 1
-        res = _Buf(ctx, "ct", 1).view()
-        ctx.copy(work.h, 0, res.h, 0, 1)
-        work.release()
         return AtomicSealBfvEncryptedVector._new(IsSigned=self.IsSigned, Scale=self.Scale, Dim=1 if length >= slots // 2 else self.Dim, encData=res,
                                                  Format=EVectorFormat.sparse if length >= slots else EVectorFormat.dense)
 
     def DotProduct(self, v, env, length=None, ForceOutputInColumn=None):
         """AtomicSealBfvVector.cs:963-977"""
         mul = self.PointwiseMultiply(v, env)
+        if (length is None or length > 1) and mul.encData is not None and mul.Format == EVectorFormat.dense:
+            return mul.SumAllSlots(env, length, ForceOutputInColumn, _consume=True)       # the product is a temporary: summed in its own array
         res = mul.SumAllSlots(env, length, ForceOutputInColumn)
         if res is not mul:
             mul.Dispose()

@@ -682,7 +682,10 @@ namespace HEWrapper
         public Task<IVector> SumAllSlotsTask(ulong length, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => SumAllSlots(length, env)); }
         public IVector SumAllSlots(ulong length, IComputationEnvironment env) => SumAllSlots(length, env, null);
         /// <summary>AddMany of the blocks, column swap + add when length >= N/2, log2 rotate-and-add steps (cn_sum_slots), optional one-hot mask</summary>
-        public IVector SumAllSlots(ulong length, IComputationEnvironment env, int? ForceOutputInColumn = null)
+        public IVector SumAllSlots(ulong length, IComputationEnvironment env, int? ForceOutputInColumn = null) { return SumAllSlots(length, env, ForceOutputInColumn, false); }
+        /// <summary>consume: the caller owns this vector as a temporary (the product inside DotProduct) - the sum is built in its array instead of
+        /// in a copy; this object is spent afterwards</summary>
+        IVector SumAllSlots(ulong length, IComputationEnvironment env, int? ForceOutputInColumn, bool consume)
         {
             if (Format != EVectorFormat.dense) throw new Exception("Expecting dense vector format");
             if (length != Int32.MaxValue && ForceOutputInColumn != null) throw new Exception("forcing output in a column works only when doing complete sum");
@@ -692,13 +695,19 @@ namespace HEWrapper
             if (length == 1) return this;
             var ctx = eenv.device.Ctx;
             ulong slots = eenv.builder.SlotCount;
-            var sum = new CnBuffer(eenv.device, 1);
-            if (enc.Count > 1)
+            CnBuffer sum;
+            if (consume && enc.Count == 1) { sum = enc; enc = null; }
+            else
             {
-                CnHip.Check(CnHip.cn_add_many(ctx, enc.Handle, Enumerable.Range(0, (int)enc.Count).Select(i => (uint)i).ToArray(), enc.Count, sum.Handle, 0));
-                OperationsCount.Add(ref OperationsCount.AddMany, 1); OperationsCount.Add(ref OperationsCount.AddManyItemCount, (int)enc.Count);
+                sum = new CnBuffer(eenv.device, 1);
+                if (enc.Count > 1)
+                {
+                    CnHip.Check(CnHip.cn_add_many(ctx, enc.Handle, Enumerable.Range(0, (int)enc.Count).Select(i => (uint)i).ToArray(), enc.Count, sum.Handle, 0));
+                    OperationsCount.Add(ref OperationsCount.AddMany, 1); OperationsCount.Add(ref OperationsCount.AddManyItemCount, (int)enc.Count);
+                }
+                else CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, sum.Handle, 0, 1));
+                if (consume) Dispose();
             }
-            else CnHip.Check(CnHip.cn_copy(ctx, enc.Handle, 0, sum.Handle, 0, 1));
             CnHip.Check(CnHip.cn_sum_slots(ctx, sum.Handle, 0, 1, length >= slots ? 0 : (uint)length));      // RotateColumns + Add, then RotateRows(-2^s) + AddInplace (:914-930)
             if (length >= slots / 2) length = slots / 2;
             if (ForceOutputInColumn != null)
@@ -722,12 +731,15 @@ namespace HEWrapper
         public IVector DotProduct(IVector v, IComputationEnvironment env) => DotProduct(v, env, null);
         public IVector DotProduct(IVector v, IComputationEnvironment env, int? ForceOutputInColumn = null)
         {
-            using (var mul = (AtomicSealBfvEncryptedVector)PointwiseMultiply(v, env)) return mul.SumAllSlots(env, ForceOutputInColumn);
+            var mul = (AtomicSealBfvEncryptedVector)PointwiseMultiply(v, env);          // a temporary: summed in its own array
+            return mul.SumAllSlots(Int32.MaxValue, env, ForceOutputInColumn, true);
         }
         public Task<IVector> DotProductTask(IVector v, ulong length, IComputationEnvironment env) { return Task<IVector>.Factory.StartNew(() => DotProduct(v, length, env)); }
         public IVector DotProduct(IVector v, ulong length, IComputationEnvironment env)
         {
-            using (var mul = (AtomicSealBfvEncryptedVector)PointwiseMultiply(v, env)) return mul.SumAllSlots(length, env);
+            var mul = (AtomicSealBfvEncryptedVector)PointwiseMultiply(v, env);
+            if (length == 1) return mul;
+            return mul.SumAllSlots(length, env, null, true);
         }
 
         // ---------------------------------------------------------------------------------------------------- linear (:983-1024, 1238-1271)
