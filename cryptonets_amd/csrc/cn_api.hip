@@ -1182,7 +1182,13 @@ static int ensure_ks_part(cn_ctx *ctx, size_t need) {
 }
 // auto: the fused kernel runs cnt*k workgroups.  Up to 32 of them (1-6 ciphertexts) every digit gets its own workgroup; up to 160
 // every source limb does; above that the fused kernel fills the chip by itself.
-static const uint32_t KS_DIGIT_MAX_BLOCKS = 32;
+static uint32_t ks_digit_max_blocks() {              // (ciphertext, limb) blocks up to which the two-launch key switch runs one workgroup per DIGIT (above: per source limb); CN_KS_DIGIT_MAX overrides (A/B)
+    // 10 since round 3 (1-2 ciphertexts; 32 before): with the four chains of an image on four hardware queues, per-source-limb workgroups cost the
+    // chip less for 3-6 ciphertexts too (four chains 5.13-5.24 vs 5.36 ms per image, one chain alone unchanged; 50 / 65: 6.4 / 7.5 ms)
+    static const uint32_t v = getenv("CN_KS_DIGIT_MAX") ? (uint32_t)atoi(getenv("CN_KS_DIGIT_MAX")) : 10u;
+    return v;
+}
+#define KS_DIGIT_MAX_BLOCKS ks_digit_max_blocks()
 static uint32_t ks_wide_max_blocks() {               // (ciphertext, limb) blocks up to which a key switch runs as two launches; CN_KS_WIDE_MAX overrides (A/B)
     static const uint32_t v = getenv("CN_KS_WIDE_MAX") ? (uint32_t)atoi(getenv("CN_KS_WIDE_MAX")) : 160u;
     return v;

@@ -59,7 +59,7 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
 /* tuning switches (A/B testing): "f64" = 1 (default) runs transforms of moduli < 2^49 and key switching in exact FP64
  * (set BEFORE uploading keys), 0 = integer Shoup path everywhere; "legacy_ntt" = 1 selects the radix-2 LDS kernels;
  * "ks_wide" = -1 (default: automatic by batch size) / 0 fused one-launch kernel / 1 two launches with one workgroup per digit
- * (1-6 ciphertexts: single-image latency) / 2 two launches with one workgroup per source limb (7-32 ciphertexts);
+ * (1-2 ciphertexts; 1-6 until round 3) / 2 two launches with one workgroup per source limb (3-32 ciphertexts);
  * "ks_tight" = 1 the 128-VGPR fused variant; "ks_split14" = 1 (default) runs the N = 16384 key switch as two 8192-point
  * halves per limb (no register spills), 0 = the fused 1024-thread kernel; "sq_fused" = 1 (default) runs the transforms and the tensor
  * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
