@@ -80,6 +80,10 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * "ks_perm_fused" = 1 (default): a rotation of a small batch (two-launch key switch) has no permutation pass - the key-switch kernels apply the
  * automorphism while they load c1 and c0; 0 = k_galois_lds in front of them.  "stream_tries" (read only): streams cn_ctx_create tried until one had a
  * hardware queue of its own (< 0: none had; CN_STREAM_PROBE=0 takes the first).
+ * Environment switches read once per process (A/B measurements, all default to the measured best): CN_STREAM_PROBE=0 (no hardware-queue selection),
+ * CN_TABLES_ZERO_COPY=0 (small operand tables are copied to the device instead of read from the pinned ring), CN_KS_WIDE_MAX / CN_KS_DIGIT_MAX ((ciphertext,
+ * limb) blocks up to which a key switch runs as two launches: 160 / with one workgroup per digit: 10), CN_GEMM_ORDER, CN_DEFER_TRACE=1 (one stderr line
+ * per flushed queue level: calls per kind, launches).
  * "ks_xcd": workgroup order of the fused key switch - 0 (ciphertext, limb), 1 the limbs of a ciphertext on one XCD, 2 limb-major (default up to
  * N = 8192: one key slice per XCD L2 at a time).  Environment: CN_LOCK_GRACE_NS / CN_LOCK_COMBINE switch the two context-lock experiments that
  * are kept but off (cn_host.cpp). */
