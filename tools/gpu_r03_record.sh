@@ -25,5 +25,5 @@ for ln in open("$OUT/unchanged_caller_replay.txt"):
 PY
 timeout 900 python tools/lola_unchanged_caller.py LoLa --reps 20 > $OUT/lola_unchanged_caller.txt 2>&1; cut -c1-300 $OUT/lola_unchanged_caller.txt | tail -12
 timeout 900 python bench.py --workload lola --steps 20 --warmup 2 > $OUT/bench_lola.json 2> $OUT/bench_lola.err; python -c "import json; d=json.load(open('$OUT/bench_lola.json')); u=d.get('unchanged_caller',{}); print(d['value'], d['ms_per_step'], d['verified_against_integer_model'], {k:u.get(k) for k in u if k!='all_rows'})"
-timeout 1200 python bench.py --workload cifar --steps 2 --warmup 1 > $OUT/bench_cifar.json 2> $OUT/bench_cifar.err; cut -c1-330 $OUT/bench_cifar.json
+timeout 1200 python bench.py --workload cifar --steps 2 --warmup 2 > $OUT/bench_cifar.json 2> $OUT/bench_cifar.err; cut -c1-330 $OUT/bench_cifar.json
 timeout 600 python tools/ntt_grid.py > $OUT/ntt_grid.txt 2>&1; tail -14 $OUT/ntt_grid.txt | cut -c1-160
