@@ -1,2 +1,3 @@
 #!/bin/bash
-python bench.py --workload cifar --steps 2 --warmup 2 > gpurun_out/bench_cifar_q.json 2>/dev/null; cut -c1-330 gpurun_out/bench_cifar_q.json
+CN_KS_WIDE_MAX=400 python tools/sumslots_merge_probe.py 2>&1 | tail -2
+python tools/sumslots_merge_probe.py 2>&1 | tail -1
