@@ -49,6 +49,23 @@ def _deps(path, seen=None):
     return seen
 
 
+# Instruction-scheduling strategy of the compiler per translation unit (-mllvm -amdgpu-sched-strategy=...), measured on the MI355X against the default
+# (profiles/r03_sched_strategy.txt, one box, alternating runs): the key-switch unit of the moduli up to 44 bits (CryptoNets / LoLa: N <= 8192) under
+# "max-memory-clause" (fused key switch 3.37-3.41 -> 3.27-3.31 ms, the same 212 VGPRs; batch -0.7 %); under "max-ilp" the key switch is 18 % SLOWER (224
+# VGPRs).  The unit of the 48-49-bit moduli (N = 16384) stays with the default: the split key switch of the LoLa-CIFAR shapes lost 29 % under
+# "max-memory-clause" (1.77 against 1.37 s per image).  The transform units stay with the default: "max-ilp" makes the forward
+# N=8192 kernel of the roofline line 7 % faster (0.46-0.47 -> 0.50 of the HBM peak at 115 VGPRs) but takes the inverse kernel to 162 VGPRs (one workgroup
+# per CU instead of two) and makes the N=16384 kernels spill.  CN_SCHED_STRATEGY=0 builds everything with the default.
+SCHED_STRATEGY = {"cn_l_ks_f64l.hip": "max-memory-clause"}
+
+
+def _unit_flags(src):
+    if os.environ.get("CN_SCHED_STRATEGY", "1") == "0":
+        return []
+    st = SCHED_STRATEGY.get(os.path.basename(src))
+    return ["-mllvm", "-amdgpu-sched-strategy=" + st] if st else []
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU): the translation units are compiled in
     parallel into lib/obj/ (only those whose sources changed), then linked.  `defines` / `out`: A/B builds of tools/ (-D switches,
@@ -69,7 +86,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
         newest = max(os.path.getmtime(d) for d in _deps(src))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
+            jobs.append([hipcc, *flags, *_unit_flags(src), "-c", src, "-o", obj])
     objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
     if not jobs and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for o in objs):
         return lib_path
