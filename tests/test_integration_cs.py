@@ -147,3 +147,23 @@ def test_sealnet_manifest_reference_backing_is_real():
         f, line = m["reference_use"].rsplit(":", 1)
         lines = open(os.path.join("/root/reference", f), encoding="utf-8-sig").read().splitlines()
         assert re.search(m["reference_pattern"], lines[int(line) - 1]), (m["type"], m["member"], lines[int(line) - 1])
+
+
+@pytest.mark.parametrize("path", ["GpuAtomicSealBfvEncryptedVector.cs", "GpuSealBfvFactory.cs", "CnHip.cs"])
+def test_twin_sources_are_bracket_balanced(path):
+    """no .NET toolchain in the image: the least a compiler would check - braces, parentheses and brackets of the twin's sources balance
+    (comments, strings and character literals stripped) and never go negative"""
+    src = open(os.path.join(ROOT, "integration", path)).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r'"(\\.|[^"\\])*"', '""', src)
+    src = re.sub(r"'(\\.|[^'\\])'", "''", src)
+    depth = {"{": 0, "(": 0, "[": 0}
+    close = {"}": "{", ")": "(", "]": "["}
+    for ch in src:
+        if ch in depth:
+            depth[ch] += 1
+        elif ch in close:
+            depth[close[ch]] -= 1
+            assert depth[close[ch]] >= 0, "unbalanced %s in %s" % (ch, path)
+    assert all(v == 0 for v in depth.values()), depth
