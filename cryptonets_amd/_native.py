@@ -121,6 +121,7 @@ SIGNATURES = {
     "cn_set_galois_key": (C.c_int, [_CTX, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
     "cn_ctx_broadcast_keys": (C.c_int, [C.POINTER(_CTX), C.c_int]),
     "cn_has_galois_key": (C.c_int, [_CTX, C.c_uint64]),
+    "cn_load_key": (C.c_int, [_CTX, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "cn_galois_elt_from_step": (C.c_uint64, [_CTX, C.c_int]),
     "cn_ct_alloc": (C.c_int, [_CTX, _u32, _u32, C.POINTER(_H)]),
     "cn_pt_alloc": (C.c_int, [_CTX, _u32, C.POINTER(_H)]),
@@ -285,6 +286,12 @@ class Context:
 
     def has_galois_key(self, elt):
         return bool(self.L.cn_has_galois_key(self._h, elt))
+
+    def load_key(self, which, words, elt=0, coeff_form=False):
+        """cn_load_key: which 0 relin, 1 galois (elt), 2 public, 3 secret; coeff_form: the polynomials are in coefficient form and the
+        device transforms them with its own tables"""
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._chk(self.L.cn_load_key(self._h, which, elt, w.ctypes.data, w.size, 0, int(bool(coeff_form))))
 
     def galois_elt_from_step(self, steps):
         return int(self.L.cn_galois_elt_from_step(self._h, steps))

@@ -386,6 +386,13 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
+    if (!strcmp(name, "ks_xi")) {                // decomposition convention of the key switch (DevConsts::ks_xi); the keys must be of the same convention
+        if (ctx->capturing) return fail(CN_ERR_ARG, "ks_xi cannot change while a graph is recorded");
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->hc.ks_xi = value != 0;
+        HIPCHK(hipMemcpy(ctx->dc, &ctx->hc, sizeof(DevConsts), hipMemcpyHostToDevice));
+        return 0;
+    }
     return fail(CN_ERR_ARG, "unknown option %s", name);
 API_END }
 // read-back of the switches and of choices the library made (tests, diagnostics)
@@ -395,6 +402,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     if (!strcmp(name, "f64")) *value = ctx->use_f64;
     else if (!strcmp(name, "defer")) *value = ctx->defer;
     else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
+    else if (!strcmp(name, "ks_xi")) *value = (int)ctx->hc.ks_xi;
     else if (!strcmp(name, "ks_xcd")) *value = ctx->ks_xcd;
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
@@ -439,7 +447,8 @@ extern "C" size_t cn_key_words(cn_ctx *ctx, int which) { return (size_t)(which ?
 
 // does this context keep its key-switch keys as FP64 images (the FP64 key-switch kernels read doubles)?
 static bool keys_as_f64(const cn_ctx *ctx) { return ctx->use_f64 && ctx->hc.q_f64 && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14; }
-static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count, size_t expect, int is_dev) {
+// coeff_form: the words are coefficient-form polynomials [..][k][N]; the device transforms them with its own tables (cn_load_key, form 1)
+static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count, size_t expect, int is_dev, bool coeff_form = false) {
     if (!words || count != expect) return fail(CN_ERR_ARG, "key has %zu words, expected %zu", count, expect);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (slot.owned && slot.d) HIPCHK(hipFree(slot.d));
@@ -450,6 +459,7 @@ static int set_key(cn_ctx *ctx, KsKey &slot, const uint64_t *words, size_t count
         slot.owned = true;
         HIPCHK(hipMemcpy(slot.d, words, count * 8, hipMemcpyHostToDevice));
     }
+    if (coeff_form) CHECK(cn_run_ntt(ctx, slot.d, (uint32_t)(count / ctx->hc.n), 0, ctx->hc.k, 0));
     if (keys_as_f64(ctx)) {
         // FP64 key-switch kernel reads the key as doubles: convert once, in place (an adopted device buffer is converted too)
         hipLaunchKernelGGL(k_u64_to_f64, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, slot.d, count);
@@ -1590,13 +1600,28 @@ extern "C" int cn_rotate_columns(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_hand
 API_END }
 
 // ---------------------------------------------------------------- client side on the device
-static int set_plain_key(cn_ctx *ctx, uint64_t **slot, const uint64_t *words, size_t count, size_t expect) {
+static int set_plain_key(cn_ctx *ctx, uint64_t **slot, const uint64_t *words, size_t count, size_t expect, bool is_dev = false, bool coeff_form = false) {
     if (!words || count != expect) return fail(CN_ERR_ARG, "key has %zu words, expected %zu", count, expect);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (!*slot) HIPCHK(hipMalloc((void **)slot, expect * 8));
-    HIPCHK(hipMemcpy(*slot, words, expect * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*slot, words, expect * 8, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    if (coeff_form) { CHECK(cn_run_ntt(ctx, *slot, (uint32_t)(expect / ctx->hc.n), 0, ctx->hc.k, 0)); HIPCHK(hipStreamSynchronize(ctx->stream)); }
     return 0;
 }
+// any key in either representation (include/cnhip.h)
+extern "C" int cn_load_key(cn_ctx *ctx, int which, uint64_t elt, const uint64_t *words, size_t count, int is_dev, int form) { API_BODY
+    LOCK; NOT_CAPTURING("cn_load_key");
+    if (form != 0 && form != 1) return fail(CN_ERR_ARG, "key form must be 0 (NTT) or 1 (coefficients)");
+    switch (which) {
+        case 0: return set_key(ctx, ctx->rlk, words, count, cn_key_words(ctx, 0), is_dev, form == 1);
+        case 1:
+            if (!(elt & 1) || elt >= 2ull * ctx->hc.n) return fail(CN_ERR_ARG, "invalid Galois element");
+            return set_key(ctx, ctx->gk[elt], words, count, cn_key_words(ctx, 1), is_dev, form == 1);
+        case 2: return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2, is_dev != 0, form == 1);
+        case 3: return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2, is_dev != 0, form == 1);
+    }
+    return fail(CN_ERR_ARG, "unknown key kind %d", which);
+API_END }
 extern "C" int cn_set_public_key(cn_ctx *ctx, const uint64_t *words, size_t count) { API_BODY LOCK; NOT_CAPTURING("cn_set_public_key"); return set_plain_key(ctx, &ctx->pk, words, count, ctx->ctw2); API_END }
 extern "C" int cn_set_secret_key(cn_ctx *ctx, const uint64_t *words, size_t count) { API_BODY LOCK; NOT_CAPTURING("cn_set_secret_key"); return set_plain_key(ctx, &ctx->sk, words, count, ctx->ctw2 / 2); API_END }
 // which: 0 relin, 1 galois(elt), 2 public, 3 secret.  Exports u64 residues (FP64-form keys are converted back).
@@ -1641,14 +1666,21 @@ static int gen_ksk(cn_ctx *ctx, const uint64_t *snew, int dbc, const uint32_t *d
     const uint32_t n = ctx->hc.n, k = ctx->hc.k; const size_t kn = (size_t)k * n;
     uint64_t *p = key;
     for (uint32_t l = 0; l < k; l++) {
-        const uint64_t ql = ctx->hc.q[l].q; unsigned __int128 f = 1;
         for (uint32_t d = 0; d < dig[l]; d++, p += 2 * kn) {
             CHECK(sample_poly(ctx, p + kn, 1, 2, seed, 3));                 // a: uniform, directly in the NTT domain
             CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
             CHECK(cn_run_ntt(ctx, e, k, 0, k, 0));
-            hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, p + kn, e, ctx->sk, snew, (uint64_t)f, (int)l, p, ctx->dc, ctx->chunks);
+            // message term 2^(dbc d) snew in limb l only; "ks_xi": (q/q_l) 2^(dbc d) snew in every limb (DevConsts::ks_xi)
+            KeyFactors fac{};
+            for (uint32_t j = 0; j < k; j++) {
+                if (!ctx->hc.ks_xi && j != l) continue;
+                const uint64_t qj = ctx->hc.q[j].q; unsigned __int128 f = 1;
+                for (uint32_t i = 0; i < d; i++) f = (f << dbc) % qj;
+                if (ctx->hc.ks_xi) f = f * ctx->hc.qhat_q[l][j] % qj;
+                fac.f[j] = (uint64_t)f;
+            }
+            hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, p + kn, e, ctx->sk, snew, fac, p, ctx->dc, ctx->chunks);
             HIPCHK(hipGetLastError()); launch_count(ctx);
-            f = (f << dbc) % ql;
         }
     }
     (void)tot;
@@ -1706,7 +1738,7 @@ extern "C" int cn_keygen(cn_ctx *ctx, uint64_t seed, int with_galois) { API_BODY
     CHECK(sample_poly(ctx, ctx->pk + kn, 1, 2, seed, 3));
     CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
     CHECK(cn_run_ntt(ctx, e, k, 0, k, 0));
-    hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->pk + kn, e, ctx->sk, ctx->sk, 0ull, -1, ctx->pk, ctx->dc, ctx->chunks);
+    hipLaunchKernelGGL(k_key_b, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->pk + kn, e, ctx->sk, ctx->sk, KeyFactors{}, ctx->pk, ctx->dc, ctx->chunks);
     HIPCHK(hipGetLastError());
     // relinearisation key: target s^2
     hipLaunchKernelGGL(k_mul_limbs, dim3(k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, ctx->sk, ctx->sk, snew, ctx->dc, ctx->chunks);

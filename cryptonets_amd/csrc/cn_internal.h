@@ -60,6 +60,12 @@ struct DevConsts {
     // key switching
     int32_t dbc, gdbc;
     uint32_t rl_dig[CN_MAXK], gk_dig[CN_MAXK], rl_tot, gk_tot;
+    // Decomposition convention of the key switch (cn_set_option("ks_xi")).  0 (default): the digits are those of the RAW residue c_l of source limb l
+    // and key (l, d) carries 2^(dbc d) s' in limb l only - the CRT-basis form (q/q_l) [(q/q_l)^-1]_{q_l} = delta_{jl} of SURVEY 9.5.  1: the digits are
+    // those of xi_l = [c_l (q/q_l)^-1]_{q_l} and key (l, d) carries (q/q_l) 2^(dbc d) s' in EVERY limb (the BEHZ paper's xi_q decomposition).  Both are
+    // exact key switches; the keys of one do not work with the digits of the other.  qhat_q[l][j] = (q/q_l) mod q_j.
+    uint32_t ks_xi;
+    uint64_t qhat_q[CN_MAXK][CN_MAXK];
 };
 
 // host-side precompute (cn_tables.cpp). tw_host must hold (k+kb+1)*4*n words; index_map (n entries) receives the

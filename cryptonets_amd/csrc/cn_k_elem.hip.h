@@ -154,11 +154,15 @@ __global__ void __launch_bounds__(1024) k_keyswitch(const uint64_t *__restrict__
     for (uint32_t l = 0; l < k; l++) {
         const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
         const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+        const bool xi = C->ks_xi != 0;             // digits of [c_l (q/q_l)^-1]_{q_l} instead of c_l (cn_set_option("ks_xi"))
+        const DMod ql = C->q[l]; const uint64_t xf = C->inv_qhat_q[l];
         for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
             const int sh = dbc * (int)d;
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
-                uint64_t v = (src[tid + e * nt] >> sh) & mask;
+                uint64_t v = src[tid + e * nt];
+                if (xi) v = mulmod(v, xf, ql);
+                v = (v >> sh) & mask;
                 if (mask >= q) v = v >= q ? bred128(v, 0, qm) : v;
                 s[tid + e * nt] = v;
             }
@@ -297,12 +301,16 @@ __global__ void k_sample_uniform(uint64_t *__restrict__ out, const DevConsts *__
 #pragma unroll
     for (int c = 0; c < 8; c++) out[(size_t)limb * n + (size_t)b * 8 + c] = v[c];
 }
-__global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, uint64_t factor, int hot, uint64_t *b,
+// b = -(a s + e) + f[limb] snew: the first component of a public key (f all zero) or of key-switch key (l, d) - f = 2^(dbc d) in limb l and zero
+// elsewhere, or (q/q_l) 2^(dbc d) mod q_j in every limb j under cn_set_option("ks_xi", 1)
+struct KeyFactors { uint64_t f[CN_MAXK]; };
+__global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, KeyFactors fac, uint64_t *b,
                         const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);
     const DMod qm = C->q[limb]; size_t o = (size_t)limb * C->n + i;
     uint64_t v = negmod(addmod(mulmod(a[o], s[o], qm), e[o], qm.q), qm.q);
-    if ((int)limb == hot) v = addmod(v, mulmod(snew[o], factor, qm), qm.q);
+    const uint64_t factor = fac.f[limb];
+    if (factor) v = addmod(v, mulmod(snew[o], factor, qm), qm.q);
     b[o] = v;
 }
 __global__ void k_mul_limbs(const uint64_t *a, const uint64_t *b, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {   // NTT-form product, [k][N]

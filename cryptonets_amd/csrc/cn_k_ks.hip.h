@@ -20,6 +20,15 @@ DEV void stage_table(double *dst, const NTT_GLOBAL double *src, uint32_t words, 
         dst[i] = a; dst[i + 1] = b;
     }
 }
+// cn_set_option("ks_xi", 1): the digits of a source limb are those of xi_l = [c_l (q/q_l)^-1]_{q_l} instead of those of c_l (DevConsts::ks_xi) - one
+// exact modular product per source word, once per (workgroup, source limb); wave-uniform branch, off by default
+DEV void ks_premultiply(uint64_t (&raw)[16], const DevConsts *C, uint32_t l) {
+    if (C->ks_xi) {
+        const DMod ql = C->q[l]; const uint64_t f = C->inv_qhat_q[l];
+#pragma unroll
+        for (int r = 0; r < 16; r++) raw[r] = mulmod(raw[r], f, ql);
+    }
+}
 template <class AR> struct KsMac;
 template <> struct KsMac<ArU64> {
     static DEV void mac(uint64_t &acc, uint64_t x, uint64_t key, const DMod &qm, const ArCtx<ArU64> &A) { acc = addmod(acc, mulmod(canon4(x, qm.q), key, qm), qm.q); }
@@ -109,6 +118,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
 #pragma unroll
             for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
         }
+        ks_premultiply(raw, C, l);
         for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
             const int sh = dbc * (int)d;
             uint32_t tl = tid;
@@ -169,7 +179,9 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
 // k_keyswitch_rr<13> (512 threads, 204 VGPRs, no scratch) on its half: stage 0 is folded into the digit load (both inputs of the
 // butterfly are read, one output kept), keys are read at h*N' + position.  The two inverse sub-transforms leave through `half`
 // and k_ks_combine14 applies the last inverse stage (u + v, (u - v) w^-1), the N^-1 scaling and the (c0, c1) addends.
-template <class AR>
+// XI: the "ks_xi" convention as a second instantiation (the premultiplication sits inside the digit loop here - as a run-time branch it cost the default
+// kernel 30-70 VGPRs)
+template <class AR, bool XI = false>
 __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uint64_t *__restrict__ target, size_t tgt_stride, const void *__restrict__ key_,
                                                                         uint64_t *__restrict__ half, const DevConsts *__restrict__ C, int galois, uint32_t accmax) {
     typedef typename AR::T T;
@@ -210,7 +222,9 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const uint32_t e = pass_index<L, SA, 0>(tl, r);
-                T X = A.load((src[e] >> sh) & mask), Y = A.load((src[e + n2] >> sh) & mask);
+                uint64_t sx = src[e], sy = src[e + n2];
+                if constexpr (XI) { const DMod ql = C->q[l]; const uint64_t xf = C->inv_qhat_q[l]; sx = mulmod(sx, xf, ql); sy = mulmod(sy, xf, ql); }   // digits of xi_l
+                T X = A.load((sx >> sh) & mask), Y = A.load((sy >> sh) & mask);
                 AR::fwd(X, Y, A.fw, 1, A.m);        // stage 0 of the 2N'-point transform: (x + w y, x - w y), w = root[1]
                 v[r] = h ? Y : X;
             }
@@ -309,6 +323,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_digit_mac(const uint64_t 
 #pragma unroll
         for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(tid, r)];
     }
+    ks_premultiply(raw, C, l);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         uint64_t t = (raw[r] >> sh) & mask;
@@ -368,6 +383,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_ks_limb_mac(const uint64_t *
 #pragma unroll
         for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
     }
+    ks_premultiply(raw, C, l);
     T acc0[16], acc1[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }

@@ -23,7 +23,7 @@ static int set_attrs(uint32_t logn, size_t bytes) {
     if (logn == 13) { CHECK(set_attrs_l<13>(bytes)); CHECK(big_lds(k_keyswitch_rr<13, AR, 4>, bytes)); }
     if (logn == 14) {
         CHECK(set_attrs_l<14>(bytes));
-        if constexpr (kF64) CHECK(big_lds(k_keyswitch_split14<AR>, (size_t)ntt_lds_words(8192) * 8));
+        if constexpr (kF64) { CHECK(big_lds(k_keyswitch_split14<AR>, (size_t)ntt_lds_words(8192) * 8)); CHECK(big_lds(k_keyswitch_split14<AR, true>, (size_t)ntt_lds_words(8192) * 8)); }
     }
     return 0;
 }
@@ -75,8 +75,12 @@ static bool launch(cn_ctx *c, const KsArgs &a) {
 // N = 16384 as two 8192-point halves per limb: partial halves into c->ks_part (the caller runs k_ks_combine14 behind it)
 static bool split14(cn_ctx *c, const KsArgs &a) {
     if constexpr (kF64) {
-        hipLaunchKernelGGL((k_keyswitch_split14<AR>), dim3(a.cnt * c->hc.k * 2), dim3(NttPlan<13>::NT), (size_t)ntt_lds_words(8192) * 8, c->stream, a.target, a.tstride,
-                           (const void *)a.key, (uint64_t *)c->ks_part, c->dc, a.galois, a.accmax);
+        if (c->hc.ks_xi)
+            hipLaunchKernelGGL((k_keyswitch_split14<AR, true>), dim3(a.cnt * c->hc.k * 2), dim3(NttPlan<13>::NT), (size_t)ntt_lds_words(8192) * 8, c->stream, a.target, a.tstride,
+                               (const void *)a.key, (uint64_t *)c->ks_part, c->dc, a.galois, a.accmax);
+        else
+            hipLaunchKernelGGL((k_keyswitch_split14<AR>), dim3(a.cnt * c->hc.k * 2), dim3(NttPlan<13>::NT), (size_t)ntt_lds_words(8192) * 8, c->stream, a.target, a.tstride,
+                               (const void *)a.key, (uint64_t *)c->ks_part, c->dc, a.galois, a.accmax);
         return true;
     }
     return false;

@@ -253,6 +253,8 @@ int cn_build_consts(DevConsts *c, uint32_t n, const uint64_t *q, uint32_t k, uin
         c->rl_dig[j] = ndigits(q[j], dbc); c->gk_dig[j] = ndigits(q[j], gdbc);
         c->rl_tot += c->rl_dig[j]; c->gk_tot += c->gk_dig[j];
     }
+    c->ks_xi = 0;
+    for (uint32_t l = 0; l < k; l++) for (uint32_t j = 0; j < k; j++) c->qhat_q[l][j] = prod_except(q, k, (int)l, q[j]);
     return 0;
 }
 

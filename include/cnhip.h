@@ -86,7 +86,13 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * per flushed queue level: calls per kind, launches).
  * "ks_xcd": workgroup order of the fused key switch - 0 (ciphertext, limb), 1 the limbs of a ciphertext on one XCD, 2 limb-major (default up to
  * N = 8192: one key slice per XCD L2 at a time).  Environment: CN_LOCK_GRACE_NS / CN_LOCK_COMBINE switch the two context-lock experiments that
- * are kept but off (cn_host.cpp). */
+ * are kept but off (cn_host.cpp).
+ * "ks_xi": DECOMPOSITION CONVENTION of the key switch (relinearisation and rotations).  0 (default): base-2^dbc digits of the raw residue c_l of every
+ * source limb l; key (l, d) = (-(a s + e) + 2^(dbc d) s' [in limb l only], a) - SURVEY 9.5, the form in which the CRT basis element
+ * (q/q_l) [(q/q_l)^-1]_{q_l} is folded into the key.  1: digits of xi_l = [c_l (q/q_l)^-1]_{q_l}; key (l, d) = (-(a s + e) + (q/q_l) 2^(dbc d) s' [in every
+ * limb], a) - the xi_q decomposition as the BEHZ paper writes it.  Both are exact key switches and decrypt identically with their own keys; keys of
+ * one convention give garbage under the other.  Set it BEFORE cn_keygen / the key uploads; the start-up self-test of the host mirrors
+ * (hewrapper.AtomicSealBfvEncryptedEnvironment.SelfTest, the C# twin's SelfTest) picks the one the client's evaluator obeys. */
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* reads a switch back, or a choice the library made: "behz_small_base" (1: auxiliary primes below 2^49 - the FP64 kernels - k+1 of them,
  * or k+2 where k+1 are too few (N = 16384); 0: SEAL's 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not
@@ -101,6 +107,13 @@ size_t cn_key_words(cn_ctx *ctx, int which);
 int cn_set_relin_key(cn_ctx *ctx, const uint64_t *words, size_t count, int is_device_ptr);
 int cn_set_galois_key(cn_ctx *ctx, uint64_t galois_elt, const uint64_t *words, size_t count, int is_device_ptr);
 int cn_has_galois_key(cn_ctx *ctx, uint64_t galois_elt);
+/* Any key in either representation.  which: 0 relin, 1 galois (galois_elt), 2 public, 3 secret - as cn_get_key; a public / secret key is always copied.
+ * form 0: NTT form in this library's transform order (what cn_set_relin_key / cn_set_galois_key / cn_set_public_key take: SEAL's in-memory form IF its
+ * transform uses the minimal primitive 2N-th root and bit-reversed output).  form 1: COEFFICIENT form - the device transforms the polynomials
+ * with its own tables, so the upload does not depend on the root or the output order of the key generator's transform (an adopted device buffer is
+ * transformed in place).  The C# twin's start-up self-test falls back to form 1 (Evaluator.TransformFromNTTInplace on the key ciphertexts) when the
+ * NTT-form words of the SEAL it runs beside do not reproduce SEAL's own results (integration/GpuAtomicSealBfvEncryptedVector.cs: SelfTest). */
+int cn_load_key(cn_ctx *ctx, int which, uint64_t galois_elt, const uint64_t *words, size_t count, int is_device_ptr, int form);
 /* Multi-GPU, single process (the path shards by independent batches / plaintext primes, the only exchange is the one-time
  * key broadcast): copies the relinearisation key and every Galois key of ctxs[0] into ctxs[1..n-1] (same encryption parameters, any
  * devices) - ONE RCCL broadcast per key over xGMI to the contexts on other GPUs (librccl is loaded on demand; peer copies without it),

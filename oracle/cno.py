@@ -60,7 +60,7 @@ COEFF_MODULUS_128 = {
 class Oracle:
     """One SEAL context + keys (AtomicSealBfvEncryptedEnvironment, AtomicSealBfvVector.cs:19-206)."""
 
-    def __init__(self, n, t, q=None, small_modulus_count=-1, dbc=10, gdbc=20):
+    def __init__(self, n, t, q=None, small_modulus_count=-1, dbc=10, gdbc=20, ks_xi=False):
         q = list(COEFF_MODULUS_128[n] if q is None else q)
         if small_modulus_count > 0:
             q = q[:small_modulus_count]
@@ -71,6 +71,25 @@ class Oracle:
         if not self.h:
             raise ValueError("invalid BFV parameters")
         self.ctw = 2 * self.k * n
+        self.ks_xi = bool(ks_xi)
+        if ks_xi:
+            self.L.cno_set_ks_xi(self.h, 1)
+
+    def set_ks_xi(self, on):
+        """decomposition convention of the key switch (seal32_oracle.c: gen_ksk): False = digits of the raw residues, message term in limb l
+        only; True = digits of [c_l (q/q_l)^-1]_{q_l}, message term (q/q_l) 2^(dbc d) s' in every limb.  Affects keys generated
+        and key switches run after the call."""
+        self.ks_xi = bool(on)
+        self.L.cno_set_ks_xi(self.h, int(bool(on)))
+
+    def key_to_coeff_form(self, words):
+        """a key (any [..][k][N] array of NTT-form polynomials) in coefficient form - what a client produces with
+        Evaluator.TransformFromNTTInplace before a coefficient-form upload (cn_load_key, form 1)"""
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, self.k, self.n).copy()
+        for i in range(w.shape[0]):
+            for j in range(self.k):
+                self.L.cno_ntt_inv(self.h, j, _p(w[i, j]))
+        return w.reshape(-1)
 
     def __del__(self):
         try:

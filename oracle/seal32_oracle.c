@@ -194,6 +194,7 @@ typedef struct cno_ctx {
     uint64_t tg_q[MAXK], qhat_t[MAXK], qhat_g[MAXK], neg_inv_q_t, neg_inv_q_g, inv_g_t;
     /* keys */
     int dbc, gdbc; uint32_t rl_dig[MAXK], gk_dig[MAXK], rl_tot, gk_tot;
+    int ks_xi; uint64_t qhat_q[MAXK][MAXK];   /* key-switch decomposition convention (cno_set_ks_xi); (q/q_l) mod q_j */
     uint64_t *sk, *pk, *rlk;
     uint32_t n_gk; uint64_t gk_elt[MAXG]; uint64_t *gk[MAXG];
     rng_t rng;
@@ -287,6 +288,7 @@ cno_ctx *cno_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, i
     for (uint32_t i = 0; i <= k; i++) if (ntt_init(&c->bskntt[i], c->logn, c->bsk[i].q)) { cno_ctx_destroy(c); return NULL; }
     for (uint32_t i = 0; i < k; i++) {
         c->inv_qhat_q[i] = invmod(prod_mod(c->q, k, (int)i, &c->q[i]), &c->q[i]);
+        for (uint32_t j = 0; j < k; j++) c->qhat_q[i][j] = prod_mod(c->q, k, (int)i, &c->q[j]);
         c->mt_inv_qhat_q[i] = mulmod(c->inv_qhat_q[i], c->mtilde % c->q[i].q, &c->q[i]);
         c->qhat_mt[i] = prod_mod_pow2_32(c->q, k, (int)i);
         for (uint32_t j = 0; j <= k; j++) c->qhat_bsk[j][i] = prod_mod(c->q, k, (int)i, &c->bsk[j]);
@@ -325,6 +327,9 @@ void cno_ctx_destroy(cno_ctx *c) {
     for (uint32_t g = 0; g < c->n_gk; g++) free(c->gk[g]);
     free(c);
 }
+/* decomposition convention of the key switch (see gen_ksk): affects keys generated and key switches run AFTER the call */
+void cno_set_ks_xi(cno_ctx *c, int on) { c->ks_xi = on != 0; }
+int cno_get_ks_xi(const cno_ctx *c) { return c->ks_xi; }
 uint32_t cno_n(const cno_ctx *c) { return c->n; }
 uint32_t cno_k(const cno_ctx *c) { return c->k; }
 int cno_batching(const cno_ctx *c) { return c->batching; }
@@ -389,17 +394,28 @@ static void encrypt_zero_sym_ntt(cno_ctx *c, const uint64_t *s, uint64_t *out /*
     free(e);
 }
 /* key-switch key for target poly `snew` (NTT form): for limb l, digit d:
- * (-(a s + e) + 2^(dbc d) * snew [limb l only], a)                           */
+ * (-(a s + e) + 2^(dbc d) * snew [limb l only], a)                           (ks_xi = 0)
+ * Two self-consistent conventions exist for an RNS digit key switch without a special prime and SEAL's
+ * source is not on disk to say which one 3.2 ships:
+ *   ks_xi = 0  digits of the raw residue c_l; the CRT basis element (q/q_l)[(q/q_l)^-1]_{q_l} = delta_jl is
+ *              folded into the key, so the message term lives in limb l only;
+ *   ks_xi = 1  digits of xi_l = [c_l (q/q_l)^-1]_{q_l}; message term (q/q_l) 2^(dbc d) snew in EVERY limb
+ *              (the xi_q decomposition as the BEHZ paper writes it).
+ * Both are restated here so that the product can be tested against a client of either kind.          */
 static uint64_t *gen_ksk(cno_ctx *c, const uint64_t *snew, int dbc, const uint32_t *dig, uint32_t tot) {
     uint32_t n = c->n, k = c->k; size_t kn = (size_t)k * n;
     uint64_t *key = malloc(8 * 2 * kn * tot), *p = key;
     for (uint32_t l = 0; l < k; l++) {
-        uint64_t f = 1, w = (dbc >= 64) ? 0 : ((1ull << dbc) % c->q[l].q);
         for (uint32_t d = 0; d < dig[l]; d++, p += 2 * kn) {
             encrypt_zero_sym_ntt(c, c->sk, p);
-            uint64_t *b = p + (size_t)l * n; const uint64_t *sn = snew + (size_t)l * n;
-            for (uint32_t i = 0; i < n; i++) b[i] = addmod(b[i], mulmod(sn[i], f, &c->q[l]), c->q[l].q);
-            f = mulmod(f, w, &c->q[l]);
+            for (uint32_t j = 0; j < k; j++) {
+                if (!c->ks_xi && j != l) continue;
+                uint64_t f = 1, w = (dbc >= 64) ? 0 : ((1ull << dbc) % c->q[j].q);
+                for (uint32_t e = 0; e < d; e++) f = mulmod(f, w, &c->q[j]);
+                if (c->ks_xi) f = mulmod(f, c->qhat_q[l][j], &c->q[j]);
+                uint64_t *b = p + (size_t)j * n; const uint64_t *sn = snew + (size_t)j * n;
+                for (uint32_t i = 0; i < n; i++) b[i] = addmod(b[i], mulmod(sn[i], f, &c->q[j]), c->q[j].q);
+            }
         }
     }
     return key;
@@ -671,7 +687,11 @@ static void keyswitch_add(const cno_ctx *c, const uint64_t *target /*[k][N]*/, c
     const uint64_t *kp = key;
     for (uint32_t l = 0; l < k; l++) for (uint32_t d = 0; d < dig[l]; d++, kp += 2 * kn) {
         int sh = dbc * (int)d;
-        for (uint32_t i = 0; i < n; i++) dg[i] = (target[(size_t)l * n + i] >> sh) & mask;
+        for (uint32_t i = 0; i < n; i++) {
+            uint64_t x = target[(size_t)l * n + i];
+            if (c->ks_xi) x = mulmod(x, c->inv_qhat_q[l], &c->q[l]);      /* digits of xi_l instead of c_l */
+            dg[i] = (x >> sh) & mask;
+        }
         for (uint32_t j = 0; j < k; j++) {
             memcpy(tmp, dg, 8ull * n);
             if (mask >= c->q[j].q) for (uint32_t i = 0; i < n; i++) tmp[i] %= c->q[j].q;   /* digit can exceed q_j only when 2^dbc > q_j */

@@ -218,16 +218,28 @@ def digits_of(limb, qj, dbc):
     return [[(int(c) >> (dbc * d)) & mask for c in limb] for d in range(nd)]
 
 
-def key_switch_eval(target, key_words, q, dbc, n):
+def xi_residues(limb, l, q):
+    """xi_l = [c_l (q/q_l)^-1]_{q_l}: the source residues of the BEHZ-paper form of the key switch (ks_xi)"""
+    ql = q[l]
+    qhat = 1
+    for j, qj in enumerate(q):
+        if j != l:
+            qhat *= qj
+    inv = pow(qhat % ql, -1, ql)
+    return [(int(c) * inv) % ql for c in limb]
+
+
+def key_switch_eval(target, key_words, q, dbc, n, xi=False):
     """sum over (source limb l, digit d) of digit polynomial x key (l, d), component c in {0, 1}, as VALUES at the evaluation points
-    of every output limb j: acc[c][j][p].  key_words: flat [(l, d)][2][k][N] NTT-form words."""
+    of every output limb j: acc[c][j][p].  key_words: flat [(l, d)][2][k][N] NTT-form words.  xi: the digits are those of
+    [c_l (q/q_l)^-1]_{q_l} instead of c_l (the other self-consistent convention, oracle gen_ksk / libcnhip "ks_xi")."""
     k = len(q)
     kw = [int(x) for x in key_words]
     pts = [eval_points(n, qj) for qj in q]
     acc = [[[0] * n for _ in range(k)] for _ in range(2)]
     pos = 0
     for l in range(k):
-        for dig in digits_of(target[l], q[l], dbc):
+        for dig in digits_of(xi_residues(target[l], l, q) if xi else target[l], q[l], dbc):
             for j, qj in enumerate(q):
                 vals = evaluate(dig, pts[j], qj)                       # the SAME small integers are residues in every limb
                 for c in range(2):
@@ -239,11 +251,11 @@ def key_switch_eval(target, key_words, q, dbc, n):
     return acc, pts
 
 
-def assert_key_switched(out, add0, add1, target, key_words, q, dbc):
+def assert_key_switched(out, add0, add1, target, key_words, q, dbc, xi=False):
     """out == (add0 + KS(target)_0, add1 + KS(target)_1), compared through the values of (out - add) at all N evaluation points of
     every limb (N distinct points determine a polynomial of degree < N: this pins every word).  add1 None = zero."""
     k, n = len(q), len(target[0])
-    acc, pts = key_switch_eval(target, key_words, q, dbc, n)
+    acc, pts = key_switch_eval(target, key_words, q, dbc, n, xi=xi)
     for c, add in ((0, add0), (1, add1)):
         for j, qj in enumerate(q):
             diff = [(int(out[c][j][i]) - (int(add[j][i]) if add is not None else 0)) % qj for i in range(n)]

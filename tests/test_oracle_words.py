@@ -25,10 +25,16 @@ SMALL = [
 ]
 
 
-def _oracle(n, t, q, dbc, gdbc, seed=7, galois=True):
-    o = Oracle(n, t, q=q, dbc=dbc, gdbc=gdbc)
+def _oracle(n, t, q, dbc, gdbc, seed=7, galois=True, xi=False):
+    o = Oracle(n, t, q=q, dbc=dbc, gdbc=gdbc, ks_xi=xi)
     o.keygen(seed, galois=galois)
     return o
+
+
+# the two self-consistent decomposition conventions of the digit key switch (oracle gen_ksk, libcnhip "ks_xi"): SURVEY 9.5's raw-residue
+# digits, and the xi_q form of the BEHZ paper.  SEAL's source is not on disk to say which one 3.2 ships, so both are restated, both are
+# pinned to the big-integer model, and the product carries both behind a start-up self-test.
+XI = pytest.mark.parametrize("xi", [False, True], ids=["raw-digits", "xi-digits"])
 
 
 def _fresh(o, rng, hi=None):
@@ -115,12 +121,13 @@ def test_behz_lift_is_congruent_and_bounded():
 
 
 # ---------------------------------------------------------------------------------------------------- key switching
+@XI
 @pytest.mark.parametrize("n,t,q,dbc,gdbc", SMALL, ids=lambda v: None)
-def test_relinearize_words(n, t, q, dbc, gdbc):
+def test_relinearize_words(n, t, q, dbc, gdbc, xi):
     """Evaluator.Relinearize: digits of every limb of c2, low -> high, times key (limb, digit), added to (c0, c1) - checked at all N
     evaluation points of every output limb.  Inputs: a real product and extreme size-3 words (digits 1023 / 0 patterns)."""
     rng = np.random.default_rng(n + dbc)
-    o = _oracle(n, t, q, dbc, gdbc, galois=False)
+    o = _oracle(n, t, q, dbc, gdbc, galois=False, xi=xi)
     a, b = _fresh(o, rng), _fresh(o, rng)
     rk = o.relin_key()
     c3s = [o.multiply(a, b)]
@@ -132,7 +139,11 @@ def test_relinearize_words(n, t, q, dbc, gdbc):
     for c3 in c3s:
         out = M.ct_limbs(o.relinearize(c3), 2, o.k, n)
         x = M.ct_limbs(c3, 3, o.k, n)
-        M.assert_key_switched(out, x[0], x[1], x[2], rk, q, dbc)
+        M.assert_key_switched(out, x[0], x[1], x[2], rk, q, dbc, xi=xi)
+    # and the product still means what it should: decrypt(relinearize(a b)) == decrypt(a) decrypt(b) slot by slot
+    if o.L.cno_batching(o.h):
+        want = (o.decode(o.decrypt(a)).astype(object) * o.decode(o.decrypt(b)).astype(object)) % t
+        assert [int(v) for v in o.decode(o.decrypt(o.relinearize(c3s[0])))] == [int(v) for v in want]
 
 
 def _check_galois(o, ct, out_words, elt, key):
@@ -140,15 +151,16 @@ def _check_galois(o, ct, out_words, elt, key):
     c = M.ct_limbs(ct, 2, o.k, n)
     s0 = [M.galois_poly(c[0][j], elt, q[j]) for j in range(o.k)]
     s1 = [M.galois_poly(c[1][j], elt, q[j]) for j in range(o.k)]
-    M.assert_key_switched(M.ct_limbs(out_words, 2, o.k, n), s0, None, s1, key, q, o.gdbc)
+    M.assert_key_switched(M.ct_limbs(out_words, 2, o.k, n), s0, None, s1, key, q, o.gdbc, xi=o.ks_xi)
 
 
+@XI
 @pytest.mark.parametrize("n,t,q,dbc,gdbc", SMALL[:4], ids=lambda v: None)
-def test_apply_galois_and_rotation_words(n, t, q, dbc, gdbc):
+def test_apply_galois_and_rotation_words(n, t, q, dbc, gdbc, xi):
     """Evaluator.ApplyGalois = (sigma(c0) + KS(sigma(c1))_0, KS(sigma(c1))_1) with the element's key; RotateRows with a direct key, with a
     NAF-decomposed step count (successive +-2^i rotations, low-order first), RotateColumns (element 2N - 1)"""
     rng = np.random.default_rng(n + gdbc)
-    o = _oracle(n, t, q, dbc, gdbc)
+    o = _oracle(n, t, q, dbc, gdbc, xi=xi)
     elts = o.galois_elts()
     ct = _fresh(o, rng)
     for gi in (0, 1, len(elts) // 2, len(elts) - 1):
@@ -172,13 +184,20 @@ def test_apply_galois_and_rotation_words(n, t, q, dbc, gdbc):
     _check_galois(o, ct, o.rotate_columns(ct), 2 * n - 1, o.galois_key(elts.index(2 * n - 1)))
     ext = _extreme_ct(o, "max")
     _check_galois(o, ext, o.apply_galois(ext, 3), 3, o.galois_key(elts.index(3)))
+    if o.L.cno_batching(o.h):                                                 # the rotation rotates: slots move left by one inside both rows
+        v = o.decode(o.decrypt(ct))
+        r = o.decode(o.decrypt(o.rotate_rows(ct, 1)))
+        assert np.array_equal(r[:n // 2], np.roll(v[:n // 2], -1)) and np.array_equal(r[n // 2:], np.roll(v[n // 2:], -1))
 
 
-def test_key_material_has_the_documented_structure():
+@XI
+def test_key_material_has_the_documented_structure(xi):
     """the key layout the models read: key (l, d) = (-(a s + e) + 2^(dbc d) s' [only in limb l], a) at the evaluation points
-    psi^(2 bitrev(p) + 1), psi the minimal primitive 2N-th root - K0 + K1 s - [j == l] 2^(dbc d) s^2 must be a SMALL polynomial (-e)"""
+    psi^(2 bitrev(p) + 1), psi the minimal primitive 2N-th root - K0 + K1 s - [j == l] 2^(dbc d) s^2 must be a SMALL polynomial (-e).
+    xi-digits: the message term is (q/q_l) 2^(dbc d) s^2 in EVERY limb."""
     n, t, q, dbc = 64, 257, [0xffffee001, 0xffffc4001, 0x1ffffe0001], 10
-    o = _oracle(n, t, q, dbc, 20, galois=False)
+    o = _oracle(n, t, q, dbc, 20, galois=False, xi=xi)
+    Q = M.product(q)
     for j, qj in enumerate(q):
         assert o.psi(j) == M.minimal_primitive_root(n, qj)
     sk = [int(x) for x in o.secret_key()]
@@ -191,7 +210,8 @@ def test_key_material_has_the_documented_structure():
                 s = sk[j * n:(j + 1) * n]
                 k0 = rk[((pos * 2 + 0) * o.k + j) * n:][:n]
                 k1 = rk[((pos * 2 + 1) * o.k + j) * n:][:n]
-                vals = [(k0[p] + k1[p] * s[p] - ((pow(2, dbc * d, qj) * s[p] * s[p]) if j == l else 0)) % qj for p in range(n)]
+                msg = (Q // q[l]) * pow(2, dbc * d) % qj if xi else (pow(2, dbc * d, qj) if j == l else 0)
+                vals = [(k0[p] + k1[p] * s[p] - msg * s[p] * s[p]) % qj for p in range(n)]
                 # interpolate: the unique polynomial of degree < n with these values must have coefficients in [-19, 19] (clipped normal)
                 # - checked by evaluating every candidate is impossible; instead invert the evaluation with the Vandermonde relation
                 # e_i = n^-1 sum_p vals[p] x_p^-i  (x_p^n = -1: the points are the roots of x^n + 1)
@@ -210,6 +230,25 @@ def test_key_material_has_the_documented_structure():
 
 
 # ---------------------------------------------------------------------------------------------------- the tests above can fail
+def test_the_two_key_switch_conventions_are_not_key_compatible():
+    """what the start-up self-test of the drop-in exists for: keys of one convention under the digits of the other relinearize to words
+    that differ from the client's AND no longer decrypt - rc 0 and garbage, unless somebody compares"""
+    n, t, q, dbc = 64, 257, [0xffffee001, 0xffffc4001, 0x1ffffe0001], 10
+    rng = np.random.default_rng(11)
+    o = _oracle(n, t, q, dbc, 20, galois=False, xi=False)
+    a, b = _fresh(o, rng), _fresh(o, rng)
+    c3 = o.multiply(a, b)
+    good = o.relinearize(c3)
+    want = (o.decode(o.decrypt(a)).astype(object) * o.decode(o.decrypt(b)).astype(object)) % t
+    assert [int(v) for v in o.decode(o.decrypt(good))] == [int(v) for v in want]
+    o.set_ks_xi(True)                                       # same (raw-convention) keys, xi digits
+    bad = o.relinearize(c3)
+    assert not np.array_equal(good, bad)
+    assert [int(v) for v in o.decode(o.decrypt(bad))] != [int(v) for v in want]
+    o.set_ks_xi(False)
+    assert np.array_equal(o.relinearize(c3), good)
+
+
 @pytest.mark.parametrize("what", ["digit order high->low", "no plain lift", "beta dropped", "r not centred", "NAF high-order first", "upper-half increment dropped"])
 def test_a_deviating_variant_is_caught(what, monkeypatch):
     """Mutation check: each free choice of SEAL 3.2 that still DECRYPTS correctly when made differently (digit order, plain lift, the
@@ -219,7 +258,7 @@ def test_a_deviating_variant_is_caught(what, monkeypatch):
     if what == "digit order high->low":
         orig = M.digits_of
         monkeypatch.setattr(M, "digits_of", lambda limb, qj, dbc: orig(limb, qj, dbc)[::-1])
-        run = lambda: test_relinearize_words(*case)
+        run = lambda: test_relinearize_words(*case, False)
     elif what == "no plain lift":
         monkeypatch.setattr(M, "plain_lift", lambda m, qj, t: int(m))
         run = lambda: test_multiply_plain_words_full_size(Q8192[:2], 549764251649)
@@ -237,7 +276,7 @@ def test_a_deviating_variant_is_caught(what, monkeypatch):
     elif what == "NAF high-order first":
         orig = M.naf
         monkeypatch.setattr(M, "naf", lambda v: orig(v)[::-1])
-        run = lambda: test_apply_galois_and_rotation_words(*case)
+        run = lambda: test_apply_galois_and_rotation_words(*case, False)
     else:
         orig = M.add_plain
         def no_increment(ct, plain, q, t, subtract=False):
