@@ -59,7 +59,9 @@ template <class FW0> struct KsPassA<FW0, true> { typedef ArPassA<FW0> P; };
 #endif
 // (Measured, not kept - round 2: the first key component of a digit requested BEFORE the digit's transform into registers nobody else
 // uses, read back behind it.  Bit-exact; 3.37 vs 3.33 ms: the key stream costs bandwidth on the vector memory path, not exposed latency.)
-template <int L, class AR, int MINW = 1, bool TWL = false>
+// XI: the "ks_xi" decomposition (digits of [c_l (q/q_l)^-1]_{q_l}) as a separate instantiation - the default kernel is instruction for instruction the one
+// that is profiled and priced (tools/ks_isa_counts.py)
+template <int L, class AR, int MINW = 1, bool TWL = false, bool XI = false>
 __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                                  const uint64_t *__restrict__ add1, size_t add_stride, const void *__restrict__ key_,
                                                                  uint64_t *out, const DevConsts *__restrict__ C, int galois, uint32_t accmax,
@@ -118,7 +120,11 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
 #pragma unroll
             for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
         }
-        ks_premultiply(raw, C, l);
+        if constexpr (XI) {
+            const DMod ql = C->q[l]; const uint64_t xf = C->inv_qhat_q[l];
+#pragma unroll
+            for (int r = 0; r < 16; r++) raw[r] = mulmod(raw[r], xf, ql);
+        }
         for (uint32_t d = 0; d < nd; d++, kp += 2 * kn) {
             const int sh = dbc * (int)d;
             uint32_t tl = tid;

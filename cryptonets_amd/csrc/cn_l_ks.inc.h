@@ -13,13 +13,13 @@ template <class K> static int big_lds(K kern, size_t bytes) {
 // dynamic LDS of the fused key switch with LDS-resident forward twiddles: exchange image + table
 template <int L> static size_t ks_twl_lds() { return ((size_t)ntt_lds_words(1u << L) + (1u << L)) * 8; }
 template <int L> static int set_attrs_l(size_t bytes) {
-    CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes));
-    if constexpr (KsFwd<AR, L>::lds) CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>()));
+    CHECK(big_lds(k_keyswitch_rr<L, AR>, bytes)); CHECK(big_lds(k_keyswitch_rr<L, AR, 1, false, true>, bytes));
+    if constexpr (KsFwd<AR, L>::lds) { CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true>, ks_twl_lds<L>())); CHECK(big_lds(k_keyswitch_rr<L, AR, 1, true, true>, ks_twl_lds<L>())); }
     CHECK(big_lds(k_ks_digit_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_limb_mac<L, AR>, bytes)); CHECK(big_lds(k_ks_sum_intt<L, AR>, bytes));
     return 0;
 }
 static int set_attrs(uint32_t logn, size_t bytes) {
-    if constexpr (kF64) { if (logn == 12) CHECK(big_lds(k_keyswitch_rr<12, AR, 1, true>, ks_twl_lds<12>())); }   // N = 4096: image + LDS twiddle table = 66.5 KiB
+    if constexpr (kF64) { if (logn == 12) { CHECK(big_lds(k_keyswitch_rr<12, AR, 1, true>, ks_twl_lds<12>())); CHECK(big_lds(k_keyswitch_rr<12, AR, 1, true, true>, ks_twl_lds<12>())); } }   // N = 4096: image + LDS twiddle table = 66.5 KiB
     if (logn == 13) { CHECK(set_attrs_l<13>(bytes)); CHECK(big_lds(k_keyswitch_rr<13, AR, 4>, bytes)); }
     if (logn == 14) {
         CHECK(set_attrs_l<14>(bytes));
@@ -29,17 +29,21 @@ static int set_attrs(uint32_t logn, size_t bytes) {
 }
 // the LDS copy of the twiddle table pays once a workgroup runs enough digit transforms of its modulus
 static const uint32_t KS_TWL_MIN_DIGITS = 12;
-template <int L, int MINW = 1> static void launch_fused(cn_ctx *c, const KsArgs &a) {
+template <int L, int MINW, bool XI> static void launch_fused_x(cn_ctx *c, const KsArgs &a) {
     const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot;
     if constexpr (KsFwd<AR, L>::lds && MINW == 1) {
         if (tot >= KS_TWL_MIN_DIGITS) {
-            hipLaunchKernelGGL((k_keyswitch_rr<L, AR, 1, true>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), ks_twl_lds<L>(), c->stream, a.target, a.tstride, a.add0, a.add1,
+            hipLaunchKernelGGL((k_keyswitch_rr<L, AR, 1, true, XI>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), ks_twl_lds<L>(), c->stream, a.target, a.tstride, a.add0, a.add1,
                                a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.xcd_cts);
             return;
         }
     }
-    hipLaunchKernelGGL((k_keyswitch_rr<L, AR, MINW>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, a.target, a.tstride,
+    hipLaunchKernelGGL((k_keyswitch_rr<L, AR, MINW, false, XI>), dim3(a.cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, a.target, a.tstride,
                        a.add0, a.add1, a.astride, (const void *)a.key, a.out, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.xcd_cts);
+}
+template <int L, int MINW = 1> static void launch_fused(cn_ctx *c, const KsArgs &a) {
+    if constexpr (MINW == 1) { if (c->hc.ks_xi) { launch_fused_x<L, 1, true>(c, a); return; } }      // (the 128-VGPR A/B variant exists for the default convention only)
+    launch_fused_x<L, MINW, false>(c, a);
 }
 template <int L> static void launch_two_phase(cn_ctx *c, const KsArgs &a) {
     const uint32_t tot = a.galois ? c->hc.gk_tot : c->hc.rl_tot, k = c->hc.k;
@@ -59,7 +63,7 @@ template <int L> static void launch_two_phase(cn_ctx *c, const KsArgs &a) {
 }
 template <int L> static void launch_rr(cn_ctx *c, const KsArgs &a) {
     if (a.mode) { launch_two_phase<L>(c, a); return; }
-    if constexpr (L == 13) { if (c->ks_tight) { launch_fused<L, 4>(c, a); return; } }      // 128-VGPR variant (A/B only)
+    if constexpr (L == 13) { if (c->ks_tight && !c->hc.ks_xi) { launch_fused<L, 4>(c, a); return; } }      // 128-VGPR variant (A/B only)
     launch_fused<L>(c, a);
 }
 static bool launch(cn_ctx *c, const KsArgs &a) {

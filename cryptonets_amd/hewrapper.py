@@ -63,6 +63,20 @@ class ClientCrypto:
     def decrypt(self, ct):          # ciphertext words -> N plaintext coefficients
         raise NotImplementedError
 
+    def reference_evaluator(self):
+        """The client's OWN evaluator on host words, or None.  AtomicSealBfvEncryptedEnvironment keeps a live SEAL `Evaluator` next to
+        the keys (AtomicSealBfvVector.cs:22,66); the start-up self-test (AtomicSealBfvEncryptedEnvironment.SelfTest) runs a handful of
+        operations through it and through the device and compares ciphertext WORDS.  Methods, all on flat u64 word arrays:
+        multiply_plain(ct, plain_coeffs) (a length-1 plain = constant plaintext), add_plain(ct, plain_coeffs), multiply(a, b) -> size 3,
+        relinearize(c3), rotate_rows(ct, steps), rotate_columns(ct)."""
+        return None
+
+    def relin_key_coeff_form(self):   # the relinearisation key with every polynomial in COEFFICIENT form (Evaluator.TransformFromNTTInplace), or None
+        return None
+
+    def galois_keys_coeff_form(self):
+        return None
+
 
 # ------------------------------------------------------------------------------------------------ device buffers
 class _Buf:
@@ -178,6 +192,99 @@ class AtomicSealBfvEncryptedEnvironment:
         if with_galois:
             for elt, words in self.client.galois_keys().items():
                 self.ctx.set_galois_key(elt, words)
+        self.SelfTest(with_galois)
+
+    # what the last SelfTest found: None (not run: the client has no evaluator of its own), or a dict
+    #   {"ks_xi": 0 | 1, "key_form": "ntt" | "coeff", "ops": [names compared], "tried": [(ks_xi, key_form, first failing op or None), ...]}
+    self_test_report = None
+
+    def SelfTest(self, with_galois=True):
+        """Start-up agreement check of the drop-in with the evaluator it replaces (the C# twin does the same at the end of
+        CreateDevice, integration/GpuAtomicSealBfvEncryptedVector.cs).  Two fresh ciphertexts go through the client's own evaluator and
+        through the device: MultiplyPlain (dense and constant), AddPlain, Multiply - then the key-switching operations Relinearize,
+        RotateRows(+1), RotateRows(-1), RotateColumns.  WORDS are compared.  Two things about real SEAL 3.2 keys cannot be read off
+        the reference (SEAL is an un-vendored dependency): which decomposition convention the key switch uses (cn_set_option "ks_xi")
+        and whether the NTT-form key words are in this library's transform order.  So when a key-switching operation disagrees the test
+        retries with the other convention, then with coefficient-form keys (cn_load_key form 1: the device transforms them itself),
+        and keeps the first combination that reproduces the client's words.  Nothing matches: an exception that names the operation -
+        never rc 0 and garbage."""
+        ev = self.client.reference_evaluator() if hasattr(self.client, "reference_evaluator") else None
+        if ev is None:
+            return None
+        ctx, n, t = self.ctx, self.ctx.n, self.ctx.t
+        # deterministic operands (the encryption randomness is the client's): slot-like values over the whole range of t
+        v0 = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(t)
+        v1 = (np.arange(n, dtype=np.uint64) * np.uint64(40503) + np.uint64(7)) % np.uint64(t)
+        ca, cb = self.client.encrypt(v0), self.client.encrypt(v1)
+        h2, h3, o2, pt = ctx.ct_alloc(2), ctx.ct_alloc(1, 3), ctx.ct_alloc(1), ctx.pt_alloc(1)
+        try:
+            ctx.ct_upload(h2, 0, np.stack([ca, cb]))
+            ctx.pt_upload(pt, 0, v1)
+            const = int(v1[1]) or 1
+
+            def dev(op):
+                if op == "MultiplyPlain":
+                    ctx.mul_plain(h2, 0, pt, 0, o2, 0)
+                elif op == "MultiplyPlain(constant)":
+                    ctx.mul_scalar(h2, 0, [const], o2, 0)
+                elif op == "AddPlain":
+                    ctx.add_plain(h2, 0, pt, 0, o2, 0)
+                elif op == "Multiply":
+                    ctx.multiply(h2, 0, h2, 1, h3, 0)
+                    return ctx.ct_download(h3, 0, 1, size=3)[0]
+                elif op == "Relinearize":
+                    ctx.multiply(h2, 0, h2, 1, h3, 0)
+                    ctx.relinearize(h3, 0, o2, 0)
+                elif op == "RotateRows(1)":
+                    ctx.rotate_rows(h2, 0, 1, o2, 0)
+                elif op == "RotateRows(-1)":
+                    ctx.rotate_rows(h2, 0, -1, o2, 0)
+                elif op == "RotateColumns":
+                    ctx.rotate_columns(h2, 0, o2, 0)
+                return ctx.ct_download(o2, 0, 1)[0]
+
+            c3 = ev.multiply(ca, cb)
+            want = {"MultiplyPlain": lambda: ev.multiply_plain(ca, v1), "MultiplyPlain(constant)": lambda: ev.multiply_plain(ca, np.array([const], dtype=np.uint64)),
+                    "AddPlain": lambda: ev.add_plain(ca, v1), "Multiply": lambda: c3, "Relinearize": lambda: ev.relinearize(c3),
+                    "RotateRows(1)": lambda: ev.rotate_rows(ca, 1), "RotateRows(-1)": lambda: ev.rotate_rows(ca, -1),
+                    "RotateColumns": lambda: ev.rotate_columns(ca)}
+            want = {k: np.asarray(f(), dtype=np.uint64).reshape(-1) for k, f in want.items()
+                    if with_galois or not k.startswith("Rotate")}
+            for op in ("MultiplyPlain", "MultiplyPlain(constant)", "AddPlain", "Multiply"):
+                if not np.array_equal(dev(op), want[op]):
+                    raise Exception("libcnhip self-test: %s differs from the client's evaluator (plaintext modulus %d) - the device does not implement "
+                                    "this evaluator's arithmetic; no key convention can repair that" % (op, t))
+            ks_ops = [op for op in ("Relinearize", "RotateRows(1)", "RotateRows(-1)", "RotateColumns") if op in want]
+
+            def first_failure():
+                for op in ks_ops:
+                    if not np.array_equal(dev(op), want[op]):
+                        return op
+                return None
+
+            xi0 = ctx.get_option("ks_xi")
+            tried = []
+            for form in ("ntt", "coeff"):
+                if form == "coeff":
+                    rk = self.client.relin_key_coeff_form() if hasattr(self.client, "relin_key_coeff_form") else None
+                    if rk is None:
+                        break
+                    ctx.load_key(0, rk, coeff_form=True)
+                    for elt, words in (self.client.galois_keys_coeff_form() or {}).items() if with_galois else ():
+                        ctx.load_key(1, words, elt=elt, coeff_form=True)
+                for xi in (xi0, 1 - xi0):
+                    ctx.set_option("ks_xi", xi)
+                    bad = first_failure()
+                    tried.append((xi, form, bad))
+                    if bad is None:
+                        self.self_test_report = {"ks_xi": xi, "key_form": form, "ops": list(want), "tried": tried}
+                        return self.self_test_report
+            ctx.set_option("ks_xi", xi0)
+            raise Exception("libcnhip self-test: no key-switch convention reproduces the client's evaluator (plaintext modulus %d); tried (ks_xi, key form, "
+                            "first differing operation): %s" % (t, tried))
+        finally:
+            for h in (h2, h3, o2, pt):
+                ctx.free(h)
 
     def encode(self, values):
         """BatchEncoder.Encode into a fresh device plaintext; returns a pt view."""

@@ -108,6 +108,17 @@ class Oracle:
         sk = np.ascontiguousarray(sk, dtype=np.uint64); pk = np.ascontiguousarray(pk, dtype=np.uint64)
         self.L.cno_import_keys(self.h, _p(sk), _p(pk))
 
+    def import_relin_key(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        assert w.size == self.L.cno_relin_digits(self.h) * self.ctw
+        self.L.cno_import_relin_key(self.h, _p(w))
+
+    def import_galois_key(self, elt, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        assert w.size == self.L.cno_galois_digits(self.h) * self.ctw
+        if self.L.cno_import_galois_key(self.h, C.c_uint64(int(elt)), _p(w)):
+            raise ValueError("too many Galois keys")
+
     def public_key(self):
         return self._arr(self.L.cno_public_key(self.h), 2 * self.k * self.n)
 

@@ -465,6 +465,21 @@ void cno_import_keys(cno_ctx *c, const uint64_t *sk, const uint64_t *pk) {
     c->sk = malloc(8 * kn); c->pk = malloc(8 * 2 * kn);
     memcpy(c->sk, sk, 8 * kn); memcpy(c->pk, pk, 8 * 2 * kn);
 }
+/* evaluation keys made elsewhere (a second oracle instance standing in for "the device" in the CPU tests of the drop-in's start-up self-test) */
+void cno_import_relin_key(cno_ctx *c, const uint64_t *words) {
+    size_t w = (size_t)c->rl_tot * 2 * c->k * c->n;
+    uint64_t *p = malloc(8 * w); memcpy(p, words, 8 * w);
+    free(c->rlk); c->rlk = p;
+}
+int cno_import_galois_key(cno_ctx *c, uint64_t elt, const uint64_t *words) {
+    size_t w = (size_t)c->gk_tot * 2 * c->k * c->n;
+    uint32_t g = 0;
+    while (g < c->n_gk && c->gk_elt[g] != elt) g++;
+    if (g == c->n_gk) { if (g == MAXG) return -1; c->gk_elt[g] = elt; c->gk[g] = NULL; c->n_gk++; }
+    uint64_t *p = malloc(8 * w); memcpy(p, words, 8 * w);
+    free(c->gk[g]); c->gk[g] = p;
+    return 0;
+}
 const uint64_t *cno_secret_key(const cno_ctx *c) { return c->sk; }
 const uint64_t *cno_public_key(const cno_ctx *c) { return c->pk; }
 const uint64_t *cno_relin_key(const cno_ctx *c) { return c->rlk; }

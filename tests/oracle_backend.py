@@ -31,6 +31,16 @@ class OracleClient:
     def decrypt(self, ct):
         return self.o.decrypt(np.ascontiguousarray(ct, dtype=np.uint64))
 
+    # the client's own evaluator and its keys in coefficient form: what AtomicSealBfvEncryptedEnvironment.SelfTest compares the device with
+    def reference_evaluator(self):
+        return self.o
+
+    def relin_key_coeff_form(self):
+        return self.o.key_to_coeff_form(self.o.relin_key())
+
+    def galois_keys_coeff_form(self):
+        return {e: self.o.key_to_coeff_form(self.o.galois_key(i)) for i, e in enumerate(self.o.galois_elts())}
+
     def noise_poly(self, ct):
         """t * (c0 + c1 s + c2 s^2) mod q_j, [k, n]: the polynomial whose centred norm Decryptor.InvariantNoiseBudget measures"""
         o = self.o
@@ -167,6 +177,27 @@ class OracleBackend:
     def set_galois_key(self, elt, words):
         pass
 
+    def load_key(self, which, words, elt=0, coeff_form=False):
+        pass
+
+    def get_option(self, name):
+        if name == "ks_xi":
+            return int(self.o.ks_xi)
+        raise KeyError(name)
+
+    def set_option(self, name, value):
+        if name != "ks_xi":
+            raise KeyError(name)
+        self.o.set_ks_xi(bool(value))
+
+    def multiply(self, a, ai, b, bi, out3, oi, count=1):
+        for i in range(count):
+            self.bufs[out3][oi + i] = self.o.multiply(self.bufs[a][ai + i], self.bufs[b][bi + i])
+
+    def relinearize(self, in3, ii, out, oi, count=1):
+        for i in range(count):
+            self.bufs[out][oi + i] = self.o.relinearize(self.bufs[in3][ii + i])
+
     def sync(self):
         pass
 
@@ -246,6 +277,33 @@ class OracleBackend:
     def rotate_columns(self, src, ii, out, oi, count=1):
         for i in range(count):
             self.bufs[out][oi + i] = self.o.rotate_columns(self.bufs[src][ii + i])
+
+
+class OracleDeviceBackend(OracleBackend):
+    """An OracleBackend with an oracle instance of its OWN that receives the evaluation keys the way a device does (set_relin_key /
+    set_galois_key / load_key) and has its own "ks_xi" switch - the device side of the CPU tests of the start-up self-test, where the
+    client may follow the other key-switch convention or hand over NTT-form keys in another transform order."""
+
+    def set_relin_key(self, words):
+        self.o.import_relin_key(words)
+
+    def set_galois_key(self, elt, words):
+        self.o.import_galois_key(elt, words)
+
+    def load_key(self, which, words, elt=0, coeff_form=False):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        if coeff_form:                                  # the device transforms with ITS tables
+            w = w.reshape(-1, self.k, self.n).copy()
+            for i in range(w.shape[0]):
+                for j in range(self.k):
+                    w[i, j] = self.o.ntt_fwd(j, w[i, j])
+            w = w.reshape(-1)
+        if which == 0:
+            self.o.import_relin_key(w)
+        elif which == 1:
+            self.o.import_galois_key(elt, w)
+        else:
+            raise NotImplementedError
 
 
 class _RecordingBackend(OracleBackend):

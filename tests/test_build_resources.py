@@ -18,8 +18,8 @@ BUDGETS = [
     ("cn_l_rr_f64l.o", "void k_square_fused<13, ArF64T<0>, true>", 256, "one workgroup per CU: image + parked operand in LDS"),
     ("cn_l_rr_f64.o", "void k_square_fused<13, ArF64T<1>, true>", 256, "one workgroup per CU"),
     ("cn_l_rr_f64l.o", "void k_mul_plain_fused<13, ArF64T<0> >", 128, "two workgroups per CU"),
-    ("cn_l_ks_f64l.o", "void k_keyswitch_rr<13, ArF64T<0>, 1, true>", 256, "one workgroup per CU (image + LDS twiddles), two waves per SIMD"),
-    ("cn_l_ks_f64.o", "void k_keyswitch_rr<13, ArF64T<1>, 1, true>", 256, "one workgroup per CU"),
+    ("cn_l_ks_f64l.o", "void k_keyswitch_rr<13, ArF64T<0>, 1, true, false>", 256, "one workgroup per CU (image + LDS twiddles), two waves per SIMD"),
+    ("cn_l_ks_f64.o", "void k_keyswitch_rr<13, ArF64T<1>, 1, true, false>", 256, "one workgroup per CU"),
     ("cn_l_ks_f64.o", "void k_keyswitch_split14<ArF64T<1>, false>", 256, "N = 16384 as two 8192-point halves: 512 threads"),
     ("cn_l_gemm.o", "void k_scalar_gemm_mfma<2, false>", 256, "two 256-thread workgroups per CU (two waves per SIMD); 3 or 4 per CU spill"),
 ]

@@ -66,6 +66,56 @@ def test_encrypt_decrypt_cross_implementation(name, rng):
         g.free(h)
 
 
+@pytest.mark.parametrize("name", ["tiny", "c4", "c5"])
+def test_device_keygen_under_the_xi_convention(name, rng):
+    """cn_set_option("ks_xi", 1) before cn_keygen: key (l, d) carries (q/q_l) 2^(dbc d) s' in EVERY limb.  The device-made keys, imported
+    into an oracle of the same convention, give the device's words there too (cross-implementation, both directions of trust) and the
+    results decrypt to the product / the rotated slots."""
+    from cryptonets_amd._native import Context
+    from oracle.cno import Oracle
+    p = PARAMS[name]
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    g.set_option("ks_xi", 1)
+    g.keygen(31, galois=True)
+    o = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], ks_xi=True)
+    o.import_keys(g.get_key(3), g.get_key(2))
+    o.import_relin_key(g.get_key(0))
+    e1, em1 = g.galois_elt_from_step(1), g.galois_elt_from_step(-2)
+    for e in (e1, em1, 2 * o.n - 1):
+        o.import_galois_key(e, g.get_key(1, e))
+    vals = rng.integers(0, o.t, size=(2, o.n), dtype=np.uint64)
+    cts = np.stack([o.encrypt(o.encode(v)) for v in vals])
+    h, out, dh = g.ct_alloc(2), g.ct_alloc(3), g.pt_alloc(3)
+    g.ct_upload(h, 0, cts)
+    g.mul_relin(h, 0, h, 1, out, 0, 1)
+    g.rotate_rows(h, 0, 1, out, 1, 1)
+    g.rotate_columns(h, 1, out, 2, 1)
+    got = g.ct_download(out, 0, 3)
+    assert np.array_equal(got[0], o.relinearize(o.multiply(cts[0], cts[1])))
+    assert np.array_equal(got[1], o.apply_galois(cts[0], e1))
+    assert np.array_equal(got[2], o.rotate_columns(cts[1]))
+    g.decrypt(out, 0, 3, dh, 0)
+    dec = g.decode_batch(dh, 0, 3)
+    half = o.n // 2
+    assert np.array_equal(dec[0], np.array([int(a) * int(b) % o.t for a, b in zip(vals[0], vals[1])], dtype=np.uint64))
+    assert np.array_equal(dec[1], np.concatenate([np.roll(vals[0][:half], -1), np.roll(vals[0][half:], -1)]))
+    assert np.array_equal(dec[2], np.concatenate([vals[1][half:], vals[1][:half]]))
+    # structure: the message term sits in a limb OTHER than l too
+    n, k = o.n, o.k
+    sk = g.get_key(3).reshape(k, n)
+    rl = g.get_key(0).reshape(-1, 2, k, n)
+    Q = 1
+    for qj in o.q:
+        Q *= int(qj)
+    l, d, j = 0, 0, 1                                    # key component 0 = (limb 0, digit 0), looked at in limb 1
+    msg = (Q // int(o.q[l])) * pow(2, o.dbc * d) % int(o.q[j])
+    v = (rl[d, 0, j].astype(object) + rl[d, 1, j].astype(object) * sk[j].astype(object) - sk[j].astype(object) ** 2 * msg) % int(o.q[j])
+    assert np.abs(centered(o.ntt_inv(j, np.array(v, dtype=np.uint64)), o.q[j])).max() <= 19
+    for x in (h, out, dh):
+        g.free(x)
+    g.close()
+
+
 def test_decrypt_size3(rng):
     g, o = make("c3", galois=False)
     vals = rng.integers(0, o.t, size=(2, o.n), dtype=np.uint64)

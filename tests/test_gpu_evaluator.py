@@ -523,6 +523,62 @@ def test_key_switch_variants_agree(name, f64, rng):
         g.free(x)
 
 
+@pytest.mark.parametrize("name,f64,legacy", [("tiny", True, False), ("tiny", True, True), ("c3", True, False), ("c3", False, False), ("c4", True, False),
+                                             ("c5", True, False), ("default4096", False, False)])
+def test_key_switch_xi_convention_variants_agree(name, f64, legacy, rng):
+    """cn_set_option("ks_xi", 1): digits of [c_l (q/q_l)^-1]_{q_l} with keys that carry (q/q_l) 2^(dbc d) s' in every limb - the other
+    self-consistent convention of a digit key switch (include/cnhip.h).  Every kernel variant (fused, per-digit, per-source-limb, the
+    N = 16384 halves and the fused 1024-thread kernel, the radix-2 LDS kernel; FP64 and integer arithmetic) against the oracle built with
+    that convention; keys uploaded in NTT form and - second pass - in coefficient form (cn_load_key form 1)."""
+    from cryptonets_amd._native import Context
+    from oracle.cno import Oracle
+    p = PARAMS[name]
+    o = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], ks_xi=True)
+    o.keygen(23, galois=True)
+    g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+    if not f64:
+        g.set_option("f64", 0)
+    if legacy:
+        g.set_option("legacy_ntt", 1)
+    g.set_option("ks_xi", 1)
+    assert g.get_option("ks_xi") == 1
+    elts = o.galois_elts()
+    vals, cts = enc_batch(o, rng, 3)
+    h, out = up(g, cts), g.ct_alloc(3)
+    exp_mul = [o.relinearize(o.multiply(cts[i], cts[(i + 1) % 3])) for i in range(3)]
+    exp_rot = [o.rotate_rows(c, -3) for c in cts]
+    exp_col = [o.rotate_columns(c) for c in cts]
+    for coeff_form in (False, True):
+        if coeff_form:
+            g.load_key(0, o.key_to_coeff_form(o.relin_key()), coeff_form=True)
+            for i, e in enumerate(elts):
+                g.load_key(1, o.key_to_coeff_form(o.galois_key(i)), elt=e, coeff_form=True)
+        else:
+            g.set_relin_key(o.relin_key())
+            for i, e in enumerate(elts):
+                g.set_galois_key(e, o.galois_key(i))
+        for wide, split in ((0, 1), (1, 1), (2, 1)) + (((0, 0),) if o.n == 16384 else ()):
+            g.set_option("ks_wide", wide)
+            g.set_option("ks_split14", split)
+            for i in range(3):
+                g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_mul)), (wide, split, coeff_form)
+            g.rotate_rows(h, 0, -3, out, 0, 3)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_rot)), (wide, split, coeff_form)
+            g.rotate_columns(h, 0, out, 0, 3)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_col)), (wide, split, coeff_form)
+            g.rotate_rows_add(h, 0, 1, h, 0, out, 0, 3)                    # the fused "+ accumulator" forms
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack([o.add(c, o.rotate_rows(c, 1)) for c in cts])), (wide, split, coeff_form)
+    # the raw convention on these keys is NOT the client's evaluator (what the start-up self-test notices)
+    g.set_option("ks_xi", 0)
+    g.set_option("ks_wide", -1)
+    g.mul_relin(h, 0, h, 1, out, 0, 1)
+    assert not np.array_equal(g.ct_download(out, 0, 1)[0], exp_mul[0])
+    for x in (h, out):
+        g.free(x)
+    g.close()
+
+
 def _extreme_ciphertexts(o):
     """ciphertext WORDS (not valid encryptions: the multiplication is a function of words) at the corners of the BEHZ argument: every
     coefficient 0, q-1 (= -1), floor(q/2) and ceil(q/2) (the largest centred magnitudes: the tensor product then reaches N (q/2)^2, the

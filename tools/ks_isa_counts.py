@@ -7,7 +7,7 @@ transforms) and every `v_*_f64` instruction is weighted with the trip counts of 
 per limb)` is what bench.py prices against the FP64 issue rate (one wave-instruction per ~4.4 cycles per SIMD,
 profiles/r01_ubench_mulmod.txt) to get the key switch's arithmetic floor.
 
-    python tools/ks_isa_counts.py            # prints the structure found in k_keyswitch_rr<13, ArF64T<0>, 1, true>
+    python tools/ks_isa_counts.py            # prints the structure found in k_keyswitch_rr<13, ArF64T<0>, 1, true, false>
 """
 import glob
 import json
@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-KERNEL = "_Z14k_keyswitch_rrILi13E6ArF64TILi0EELi1ELb1EE"          # k_keyswitch_rr<13, ArF64T<0>, 1, true>
+KERNEL = "_Z14k_keyswitch_rrILi13E6ArF64TILi0EELi1ELb1ELb0EE"          # k_keyswitch_rr<13, ArF64T<0>, 1, true, false>
 
 
 def disassemble(obj, kernel=KERNEL):
@@ -80,7 +80,7 @@ def structure(obj=None, kernel=KERNEL):
         raise RuntimeError("unrecognised loop structure in the key-switch kernel: %s" % [(hex(h), [hex(x) for x in e]) for h, e in big])
     (h1, (digit_end, limb_end)), (h2, e2) = big
     tail_end = max(e2)
-    return dict(kernel="k_keyswitch_rr<13, ArF64T<0>, 1, true>", instructions=len(ins), fp64_total=len(f64),
+    return dict(kernel="k_keyswitch_rr<13, ArF64T<0>, 1, true, false>", instructions=len(ins), fp64_total=len(f64),
                 fp64_digit_loop=within(h1, digit_end), fp64_limb_loop_only=within(digit_end + 1, limb_end),
                 fp64_tail_loop=within(h2, tail_end), fp64_once=len(f64) - within(h1, limb_end) - within(h2, tail_end),
                 valu_digit_loop=owithin(h1, digit_end), valu_limb_loop_only=owithin(digit_end + 1, limb_end),

@@ -35,7 +35,7 @@ for n, t, logn, cnt in ((8192, 549764251649, 13, 845), (4096, 40961, 12, 1690)):
     bits = max(int(q).bit_length() for q in g.q)
     pol = "0" if bits <= 44 else "1"
     obj = os.path.join(ROOT, "cryptonets_amd", "lib", "obj", "cn_l_ks_f64l.o" if pol == "0" else "cn_l_ks_f64.o")
-    kern = "_Z14k_keyswitch_rrILi%dE6ArF64TILi%sEELi1ELb1EE" % (logn, pol)
+    kern = "_Z14k_keyswitch_rrILi%dE6ArF64TILi%sEELi1ELb1ELb0EE" % (logn, pol)
     fp, isa = ks_isa_counts.fp64_per_thread(g.k, per_limb, obj, kern)
     vo = ks_isa_counts.valu_per_thread(per_limb, isa)
     waves = (n // 16) // 64
