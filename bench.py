@@ -154,6 +154,15 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
     if args.shard == "primes":
         parms["primes"] = shard_primes(all_primes, rank, world)
     active = len(parms["primes"]) > 0
+    exchanges = []
+    if args.client_seed is not None:
+        parms["client_seed"] = args.client_seed
+    if args.shared_keys:
+        if args.shard != "images":
+            raise SystemExit("--shared-keys goes with --shard images (with --shard primes every rank owns different plaintext primes: nothing to share)")
+        from cryptonets_amd.client import SharedKeyDeviceClient
+        parms["device_client_factory"] = lambda ctx, t: SharedKeyDeviceClient(ctx, dist, dev, 0, seed=None if args.client_seed is None else args.client_seed ^ t,
+                                                                                exchanges=exchanges)
     rng = np.random.default_rng(5)
     if cifar:
         qz = lambda a, sc: np.rint(a * sc) / sc
@@ -259,6 +268,11 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
             flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             verified = bool(flag.item())
+    import hashlib
+    digest = hashlib.sha256()                                  # the result ciphertext WORDS of this rank's timed images (reproducible under --client-seed)
+    for m in results:
+        for a, e in zip(m.GetColumn(0).eVectors, env.Environments):
+            digest.update(e.ctx.ct_download(a.encData.h, a.encData.first, a.encData.count).tobytes())
     for m in results:
         m.Dispose()
     if rank == 0:
@@ -267,7 +281,14 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                "value": round(images_done / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak" if args.shard == "images" else "strong",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic images" + (", synthetic weights of the reference's shapes" if cifar else ", the reference's trained weights"),
-               "verified_against_integer_model": verified,
+               "verified_against_integer_model": verified, "result_words_sha256": digest.hexdigest(),
+               "launcher": os.environ.get("BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"), "process_group": "nccl" if dist is not None else None,
+               "keys": ("one client: rank 0 ran KeyGenerator, every key broadcast with RCCL and adopted in place" if args.shared_keys else "every rank is its own client (own KeyGenerator)"),
+               "key_broadcast": ({"bytes": sum(b for b, _ in exchanges), "ms": round(1e3 * sum(t for _, t in exchanges), 2), "contexts": len(exchanges),
+                                  "GB_per_s": round(sum(b for b, _ in exchanges) / max(1e-9, sum(t for _, t in exchanges)) / 1e9, 2),
+                                  "keys_per_context": 1 + 2 * (parms["n"].bit_length() - 2) + 1 + 2,
+                                  "note": "outside the timed window; relinearisation key + the default Galois key set + public and secret key per plaintext prime; "
+                                          "host staging of the root's words included (cn_get_key converts the FP64 key image back to u64 words)"} if args.shared_keys else None),
                "verified_what": ("all 5488 outputs of the 5488 x 16268 dense layer of the last timed image, every plaintext prime (the 8-limb network has no "
                                  "noise budget left behind its second squaring - a property of the reference's operation sequence)") if cifar
                                 else "the 10 logits of every timed image, CRT-joined over the plaintext primes",
@@ -301,6 +322,45 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def single_image_lines(gpu_index):
+    """BASELINE configs 4 and 5 on the driver's line: `python bench.py --workload lola|cifar` run as child processes of the default
+    workload (a process of their own: every plaintext-prime channel then gets a hardware queue of its own, cn_api.hip pick_stream) on the same GPU,
+    bounded - LoLa-MNIST 20 timed images + the unchanged-caller replay, LoLa-CIFAR 1 warm-up + 1 timed image - each verified against the exact integer
+    model inside its run.  A child that fails or exceeds its time limit is reported with the reason instead of a number."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_LAUNCHER",
+                                                            "BENCH_FORCE_DIST", "BENCH_SELF_LAUNCH", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "").split(",")[gpu_index] if os.environ.get("HIP_VISIBLE_DEVICES") else str(gpu_index)
+
+    def child(workload, steps, warmup, limit):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup)]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
+        except subprocess.TimeoutExpired:
+            return None, {"skipped": "child exceeded its %d s limit" % limit, "command": " ".join(cmd[1:])}
+        wall = time.perf_counter() - t0
+        lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if p.returncode or not lines:
+            return None, {"error": "rc %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-300:]), "command": " ".join(cmd[1:])}
+        d = json.loads(lines[-1])
+        return d, {"command": "python bench.py " + " ".join(cmd[2:]), "child_wall_s": round(wall, 1)}
+
+    d, lola = child("lola", 20, 3, 240)
+    if d is not None:
+        u = d.get("unchanged_caller") or {}
+        lola.update({"metric": d["metric"], "ms_per_image": d["ms_per_step"], "images_per_s": d["value"], "steps": d["steps"],
+                     "verified": d["verified_against_integer_model"], "verified_what": d["verified_what"], "plaintext_primes": d["config"]["plaintext_primes"],
+                     "unchanged_caller_ms": u.get("ms_per_image"), "unchanged_caller_logits_exact": u.get("logits_exact"), "launches_per_prime": u.get("launches_per_prime"),
+                     "calls_per_prime": u.get("calls_per_prime"), "batched_from_the_same_host_ms": u.get("batched_from_the_same_host_ms"),
+                     "unchanged_frac_of_batched": u.get("frac_of_batched"), "unchanged_caller_error": u.get("error")})
+    d, cifar = child("cifar", 1, 1, 300)
+    if d is not None:
+        cifar.update({"metric": d["metric"], "s_per_image": round(d["ms_per_step"] / 1e3, 3), "steps": d["steps"], "verified": d["verified_against_integer_model"],
+                      "verified_what": d["verified_what"], "plaintext_primes": d["config"]["plaintext_primes"], "data": d["data"]})
+    return lola, cifar
 
 
 def _conv_tile():
@@ -391,6 +451,10 @@ def main():
     ap.add_argument("--workload", choices=("cryptonets", "lola", "cifar"), default="cryptonets",
                     help="cryptonets: BASELINE config 3, the headline metric (default); lola / cifar: the single-image networks of configs 4 / 5")
     ap.add_argument("--shard", choices=("images", "primes"), default="images", help="lola / cifar on N GPUs: independent images per rank, or the plaintext primes of one image")
+    ap.add_argument("--shared-keys", action="store_true", help="lola / cifar, --shard images: ONE client's keys on every rank - rank 0 runs KeyGenerator, the relinearisation key, "
+                    "every Galois key and the client keys are broadcast with RCCL and adopted in place (default: every rank is its own client)")
+    ap.add_argument("--client-seed", type=int, default=None, help="lola / cifar: reproducible keys and encryption randomness (tests: two runs must give the same ciphertext words)")
+    ap.add_argument("--no-single-image", action="store_true", help="default workload: skip the LoLa-MNIST / LoLa-CIFAR sub-benchmarks (BASELINE configs 4 and 5) of the line")
     args = ap.parse_args()
 
     # N > 1 without a launcher around us: start the ranks ourselves (the driver's own torchrun line sets WORLD_SIZE and is honoured as is)
@@ -582,6 +646,45 @@ def main():
         except Exception as ex:                                            # no disassembler / unrecognised code shape: no floor rather than a stale one
             key_switch.update({"fp64_issue_floor_ms": None, "frac": None, "isa_error": str(ex)[:200]})
 
+    # ---- the second-largest family: the BEHZ product of the first squaring layer - k_behz_extend (Bsk limbs of the operand),
+    # k_square_fused on the q base and on the Bsk base (2 forward + 3 inverse transforms + the tensor per (ciphertext, limb), operand parked in LDS),
+    # k_behz_floor - timed as ONE chain with HIP events on the ctx stream (Evaluator.Multiply(a, a) of 845 ciphertexts) and priced against both
+    # bounds: FP64 issue (ISA count of the BUILT k_square_fused from tools/ks_isa_counts.py x the issue rate measured in this run; the two
+    # element-wise kernels are not counted: a lower bound) and HBM (algorithmic: 2k limbs read + 3k written per ciphertext; designed: what the four
+    # kernels move by construction - extend R 2k W 2kb, squares R 2(k + kb) W 3(k + kb), floor R 3(k + kb) W 3k).  The per-kernel split of the same
+    # launches is in profiles/r04_bench_kernel_trace_summary.txt.
+    square = None
+    if rank == 0:
+        try:
+            cts = 845
+            t3 = g.ct_alloc(cts, 3)
+            g.multiply(chans[0].h1, 0, chans[0].h1, 0, t3, 0, cts); g.sync()
+            g.time_begin()
+            for _ in range(5):
+                g.multiply(chans[0].h1, 0, chans[0].h1, 0, t3, 0, cts)
+            sq_ms = g.time_end() / 5
+            g.free(t3)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ks_isa_counts
+            ss = ks_isa_counts.square_structure()
+            kq, kb = g.k, g.get_option("aux_primes")
+            waves = cts * (kq + kb) * 8                                      # 512-thread workgroups
+            f_fp64 = waves * ss["fp64"]["per_thread"] / 1024 * fp64_ns * 1e-6
+            f_valu = waves * (ss["fp64"]["per_thread"] * fp64_ns + ss["valu"]["per_thread"] * valu_ns) / 1024 * 1e-6
+            limb = g.n * 8
+            alg = cts * (2 * kq + 3 * kq) * limb
+            designed = cts * (2 * kq + 2 * kb + 5 * (kq + kb) + 3 * (kq + kb) + 3 * kq) * limb
+            square = {"chain": "Evaluator.Multiply(a, a) of 845 ciphertexts: k_behz_extend, k_square_fused (q: %d limbs, Bsk: %d limbs), k_behz_floor" % (kq, kb),
+                      "ms_per_chain": round(sq_ms, 3), "share_of_batch": round(2 * sq_ms / (1e3 * dt / args.steps), 3),
+                      "fp64_per_thread_square_fused": ss["fp64"]["per_thread"], "valu_other_per_thread_square_fused": ss["valu"]["per_thread"],
+                      "fp64_ns_per_instr_in_situ": round(fp64_ns, 3), "fp64_issue_floor_in_situ_ms": round(f_fp64, 3), "frac_fp64_in_situ": round(f_fp64 / sq_ms, 3),
+                      "valu_issue_floor_in_situ_ms": round(f_valu, 3), "frac_valu_in_situ": round(f_valu / sq_ms, 3),
+                      "algorithmic_bytes": alg, "hbm_frac_algorithmic": round(alg / (sq_ms * 1e-3) / 8e12, 3),
+                      "designed_bytes": designed, "hbm_frac_designed": round(designed / (sq_ms * 1e-3) / 8e12, 3),
+                      "bound": "neither saturated: FP64 issue of the two transform kernels and the HBM traffic of the two element-wise kernels add up (the chain is four dependent launches)"}
+        except Exception as ex:
+            square = {"error": str(ex)[:300]}
+
     # ---- the reference's UNCHANGED caller: one evaluator call per ciphertext from the caller's threads (tools/replay_reference_calls.cpp), merged
     # by libcnhip's deferred submission; same inputs.  Main figure: the LITERAL pattern - a padded convolution tap is a fresh encryption of
     # the zero vector (PoolLayer.ElementAt, PoolLayer.cs:67-80: 645 per plaintext prime and batch, made on the device and queued like the
@@ -593,12 +696,24 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import replay_reference_calls as rp
             ref_words = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
-            batched_ms = 1e3 * dt / args.steps
             nthreads = args.caller_threads or effective_cores()[0]
             reps = max(2, min(args.steps, 5))
+            # the SAME statistic on both sides of the ratio: best of five windows of `reps` steps for the batched path too (the headline
+            # `value` stays the mean over all timed steps)
+            bwin = []
+            for _ in range(5):
+                sync_all()
+                tb = time.perf_counter()
+                for _ in range(reps):
+                    step()
+                sync_all()
+                bwin.append(1e3 * (time.perf_counter() - tb) / reps)
+            batched_ms = min(bwin)
             # best of five (three for the secondary rows) short measurements each (a 100 ms window on a shared host: one scheduling hiccup is a third of it - the run-to-run
             # spread of single measurements is in profiles/r03_unchanged_caller_*.txt)
-            lms, lwords = min((rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True) for _ in range(5)), key=lambda r: r[0])
+            lruns = [rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True) for _ in range(5)]
+            lwin = [r[0] for r in lruns]
+            lms, lwords = min(lruns, key=lambda r: r[0])
             dec = rp.decrypt_outputs(chans, lwords)
             lok = all(bool(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t))) for d, ch in zip(dec, chans))
             ums, uwords = min((rp.measure(chans, layers, 4, reps, warmup=2) for _ in range(3)), key=lambda r: r[0])
@@ -608,7 +723,9 @@ def main():
                 visible = {"threads": effective_cores()[1], "ms_per_step": round(vms, 2), "frac_of_batched": round(batched_ms / vms, 3)}
             unchanged = {"value": round(8192e3 / lms, 1), "unit": "images/s", "ms_per_step": round(lms, 2), "threads": nthreads,
                          "frac_of_batched": round(batched_ms / lms, 3), "verified_against_integer_model": lok, "verified_slots": 8192 * 10 * len(chans),
-                         "timing": "best of 5 measurements of %d steps (skipped_taps, at_visible_cpu_count: best of 3)" % reps, "at_visible_cpu_count": visible,
+                         "timing": "best of 5 windows of %d steps on BOTH sides of frac_of_batched (skipped_taps, at_visible_cpu_count: best of 3)" % reps,
+                         "windows_ms": {"unchanged": [round(x, 2) for x in lwin], "batched": [round(x, 2) for x in bwin]},
+                         "frac_of_batched_mean_over_mean": round((sum(bwin) / len(bwin)) / (sum(lwin) / len(lwin)), 3), "at_visible_cpu_count": visible,
                          "pattern": "PoolLayer.Apply: per (map, corner) [cn_ct_alloc + cn_encrypt(zero) per padded tap] + cn_scalar_dot (K = 25 real handles) + "
                                     "cn_add_plain + cn_free, ReleaseTemp: cn_free per zero encryption; SquareActivation: per column cn_mul_relin(count 1); every "
                                     "ciphertext its own handle; 2 x (2855 + 3 x 645) calls per batch; cn_set_option(defer, 1); threads = Defaults.ThreadCount = processor count "
@@ -662,7 +779,7 @@ def main():
                           "arithmetic": "exact modular integers over 43-49-bit RNS primes (results are u64 words, bit-identical to the integer "
                                         "oracle); products evaluated with error-free FP64 instruction sequences where the modulus is below 2^49, "
                                         "64-bit integer instructions otherwise"},
-               "roofline": roofline, "key_switch": key_switch, "unchanged_caller": unchanged, "relinearize_late": late,
+               "roofline": roofline, "key_switch": key_switch, "square": square, "unchanged_caller": unchanged, "relinearize_late": late,
                # the WHOLE batch against HBM (inputs read once + outputs written once per layer, 640 KiB per ciphertext, per prime:
                # conv (784+845), square 845 x 2, dense (845+100), square 100 x 2, dense (100+10)): the path is FP64-issue bound, not HBM bound
                "batch_hbm": (lambda nbytes: {"algorithmic_bytes_per_step": nbytes, "achieved": round(nbytes / (dt / args.steps) / 1e9, 1), "peak": 8000.0,
@@ -670,6 +787,8 @@ def main():
                    2 * (784 + 845 + 2 * 845 + 845 + 100 + 2 * 100 + 100 + 10) * 2 * g.k * g.n * 8)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(effective_cores()[0], layers)
+        if world == 1 and not args.no_single_image:
+            out["lola"], out["cifar"] = single_image_lines(local)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -81,12 +81,17 @@ def build(force=False, verbose=False, defines=(), out=None):
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", *["-D" + d for d in defines]]
-    jobs = []
+    jobs, stamps = [], {}
     for src in SOURCES:
         obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
         newest = max(os.path.getmtime(d) for d in _deps(src))
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            jobs.append([hipcc, *flags, *_unit_flags(src), "-c", src, "-o", obj])
+        cmd = [hipcc, *flags, *_unit_flags(src), "-c", src, "-o", obj]
+        # the command line is part of the staleness key (toggling CN_SCHED_STRATEGY used to reuse objects built with the other setting)
+        stamp = obj + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest or not same_cmd:
+            jobs.append(cmd)
+            stamps[obj] = (stamp, " ".join(cmd))
     objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
     if not jobs and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for o in objs):
         return lib_path
@@ -97,6 +102,9 @@ def build(force=False, verbose=False, defines=(), out=None):
         subprocess.check_call(cmd)
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(run, jobs))
+    for stamp, text in stamps.values():
+        with open(stamp, "w") as f:
+            f.write(text)
     run([hipcc, "-shared", "--offload-arch=gfx950", *objs, "-o", lib_path])
     return lib_path
 

@@ -230,35 +230,52 @@ __global__ void k_spin(uint64_t ticks) {
 }
 static std::mutex g_ctx_reg_mu;
 static std::vector<cn_ctx *> g_ctx_reg;
+// (both streams idle and nobody else submitting to them: the caller holds the lock of the context that owns `b`)
 static bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
     double best = 1e9;
     for (int rep = 0; rep < 3 && best > 150e-6; rep++) {
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }   // (sticky error cleared)
         const auto t0 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, (uint64_t)10000);
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, (uint64_t)10000);
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
         best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     return best > 150e-6;
 }
+// Caller holds g_ctx_reg_mu (no context is created or destroyed meanwhile).  The stream of another live context is only touched UNDER THAT
+// CONTEXT'S LOCK, with `capturing` re-read under it: no API call of another thread can submit to it, start recording on it or free it while the two
+// spin kernels run, and a recording stream never sees a foreign launch (the probe used to read o->capturing and launch on o->stream
+// unsynchronised).  Lock order: registry, then ONE context lock at a time; nothing takes them the other way round (cn_ctx_destroy leaves the
+// registry lock before it takes the context's).  A probe waits for the work the other context has queued (at most a few batches); CN_STREAM_PROBE=0
+// switches the whole selection off.  No early return between the creation of a candidate and the clean-up below: rejected candidates are destroyed on
+// every path.
 static int pick_stream(cn_ctx *c) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->stream_tries = 1;
     const char *env = getenv("CN_STREAM_PROBE");
     if (env && !atoi(env)) return 0;
-    std::vector<hipStream_t> others;
-    for (cn_ctx *o : g_ctx_reg) if (o->device == c->device && !o->capturing) others.push_back(o->stream);      // (a recording stream must not see foreign launches)
+    std::vector<cn_ctx *> others;
+    for (cn_ctx *o : g_ctx_reg) if (o->device == c->device) others.push_back(o);
     if (others.empty()) return 0;
     hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, (uint64_t)1);          // code object loaded, queue created
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }          // (no selection; the context itself will report a broken device)
+    auto collides = [&](hipStream_t s) {
+        for (cn_ctx *o : others) {
+            CnGuard lk(o->mu);
+            if (o->capturing) continue;                       // a recording stream must not see foreign launches: not probed
+            if (streams_share_a_queue(s, o->stream)) return true;
+        }
+        return false;
+    };
     std::vector<hipStream_t> rejected;
-    auto collides = [&](hipStream_t s) { for (hipStream_t o : others) if (streams_share_a_queue(s, o)) return true; return false; };
-    hipStream_t first = c->stream;
+    const hipStream_t first = c->stream;
     bool found = !collides(c->stream);
     while (!found && c->stream_tries < 6) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
         rejected.push_back(c->stream);
-        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->stream = s;
         c->stream_tries++;
         found = !collides(c->stream);
     }
@@ -267,6 +284,8 @@ static int pick_stream(cn_ctx *c) {
     return 0;
 }
 
+static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<uint64_t> &tw);
+static void ctx_teardown(cn_ctx *ctx);
 extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t t, int dbc, int gdbc, int device, cn_ctx **out) {
     if (!out || !q) return fail(CN_ERR_ARG, "null argument");
     int ndev = cn_device_count();
@@ -279,6 +298,19 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     char err[256];
     c->index_map.assign(n, 0);
     if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), c->index_map.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
+    c->dq = cn_defer_new();
+    c->slabs = new std::vector<Slab>();
+    const int rc = ctx_init(c, n, k, device, tw);
+    if (rc) {                                   // whatever was created so far is released (streams, events, tables); the message of the failing call stays
+        (void)hipGetLastError();
+        ctx_teardown(c);
+        return rc;
+    }
+    { std::lock_guard<std::mutex> reg(g_ctx_reg_mu); g_ctx_reg.push_back(c); }
+    *out = c;
+    return 0;
+}
+static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<uint64_t> &tw) {
     c->device = device;
     HIPCHK(hipSetDevice(device));
     {
@@ -332,10 +364,6 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
     }
     for (int pol = 0; pol < 3; pol++) { CHECK(rr_ops[pol]->set_attrs(c->hc.logn, lds)); CHECK(ks_ops[pol]->set_attrs(c->hc.logn, lds)); }
-    c->dq = cn_defer_new();
-    c->slabs = new std::vector<Slab>();
-    { std::lock_guard<std::mutex> reg(g_ctx_reg_mu); g_ctx_reg.push_back(c); }
-    *out = c;
     return 0;
 }
 extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
@@ -344,14 +372,19 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
         std::lock_guard<std::mutex> reg(g_ctx_reg_mu);
         g_ctx_reg.erase(std::remove(g_ctx_reg.begin(), g_ctx_reg.end(), ctx), g_ctx_reg.end());
     }
+    ctx_teardown(ctx);
+    return 0;
+}
+// releases everything a context owns; also the clean-up of a cn_ctx_create that failed half way (every member is null / empty until it is created)
+static void ctx_teardown(cn_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
-    {   // queued per-ciphertext calls are launched (their results die with the context, but the arrays parked behind them - cn_free while
+    if (ctx->stream) {   // queued per-ciphertext calls are launched (their results die with the context, but the arrays parked behind them - cn_free while
         // calls were pending - go back to the pool and are released with it)
         CnGuard lk(ctx->mu);
         if (ctx->capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(ctx->stream, &g); if (g) (void)hipGraphDestroy(g); ctx->capturing = false; }
         (void)cn_defer_flush(ctx);
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->bufs.for_each([&](Buffer &b) {
         if (b.kind == 2) (void)free_gemm_plan(ctx, b);
         else if (b.kind == 3) (void)free_graph(ctx, b);
@@ -364,11 +397,12 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
     for (auto &kv : ctx->gk) if (kv.second.owned) (void)hipFree(kv.second.d);
     (void)hipFree(ctx->sk); (void)hipFree(ctx->pk); (void)hipFree(ctx->ks_part); (void)hipFree(ctx->d_index_map); (void)hipFree(ctx->stage); if (ctx->pin) (void)hipHostFree(ctx->pin);
     (void)hipFree(ctx->scratch); (void)hipFree(ctx->tw); (void)hipFree(ctx->twd); (void)hipFree(ctx->twdh); (void)hipFree(ctx->dc);
-    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     cn_defer_delete(ctx->dq);
     delete ctx;
-    return 0;
 }
 extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BODY
     LOCK;

@@ -46,7 +46,14 @@ static long futex(std::atomic<int> *addr, int op, int val, const struct timespec
 // MI355X box (profiles/r03_unchanged_caller_lock.txt) the bias does not pay - with the literal padded taps the unchanged caller ran at
 // 0.85 / 0.85 / 0.84 / 0.82 of the batched rate at 1 / 4 / 16 / 256 threads without it and at 0.84 / 0.84 / 0.78 / 0.72 (400 ns),
 // 0.86 / 0.77 / 0.51 / 0.80 (1 us) with it: the threads that lose the grace period queue up behind a holder that is not coming back.
+#if defined(__x86_64__) || defined(__i386__)
 #include <x86intrin.h>
+static inline uint64_t cycle_counter() { return __rdtsc(); }
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+#else
+static inline uint64_t cycle_counter() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
+static inline void cpu_relax() { sched_yield(); }
+#endif
 static const uint32_t MAX_BURST = 256;
 static std::atomic<uint32_t> g_next_tid{1};
 static thread_local uint32_t t_tid = 0;
@@ -57,9 +64,9 @@ static uint64_t grace_cycles() {
         const double ns = e ? atof(e) : 0.0;
         if (ns <= 0) return (uint64_t)0;
         struct timespec a, b;                                          // TSC cycles per nanosecond, measured over ~2 ms
-        clock_gettime(CLOCK_MONOTONIC, &a); const uint64_t c0 = __rdtsc();
+        clock_gettime(CLOCK_MONOTONIC, &a); const uint64_t c0 = cycle_counter();
         do clock_gettime(CLOCK_MONOTONIC, &b); while ((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec) < 2000000);
-        const uint64_t c1 = __rdtsc();
+        const uint64_t c1 = cycle_counter();
         const double per_ns = (double)(c1 - c0) / (double)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec));
         return (uint64_t)(ns * per_ns);
     }();
@@ -69,7 +76,7 @@ bool CnMutex::try_take(uint32_t me) {
     if (held.load(std::memory_order_relaxed)) return false;
     const uint64_t g = grace_cycles();
     if (g && last_owner.load(std::memory_order_relaxed) != me && burst.load(std::memory_order_relaxed) < MAX_BURST &&
-        __rdtsc() - released_at.load(std::memory_order_relaxed) < g) return false;                 // the releasing thread may still come back
+        cycle_counter() - released_at.load(std::memory_order_relaxed) < g) return false;                 // the releasing thread may still come back
     if (held.exchange(1, std::memory_order_acquire)) return false;
     if (last_owner.load(std::memory_order_relaxed) == me) burst.fetch_add(1, std::memory_order_relaxed);
     else { last_owner.store(me, std::memory_order_relaxed); burst.store(0, std::memory_order_relaxed); }
@@ -82,27 +89,38 @@ void CnMutex::lock(Node &) {
         if (spinners.fetch_add(1, std::memory_order_acq_rel) < MAX_SPINNERS) {
             for (int spins = 0;; spins++) {
                 if (try_take(me)) { spinners.fetch_sub(1, std::memory_order_acq_rel); return; }
-                if (spins < 64) __builtin_ia32_pause(); else sched_yield();
+                if (spins < 64) cpu_relax(); else sched_yield();
             }
         }
         spinners.fetch_sub(1, std::memory_order_acq_rel);
         const int seq = wake_seq.load(std::memory_order_acquire);
-        sleepers.fetch_add(1, std::memory_order_acq_rel);
-        if (!held.load(std::memory_order_acquire)) {                        // freed meanwhile: do not sleep on a free lock
+        sleepers.fetch_add(1, std::memory_order_seq_cst);
+        if (!held.load(std::memory_order_seq_cst)) {                        // freed meanwhile: do not sleep on a free lock
             sleepers.fetch_sub(1, std::memory_order_acq_rel);
             if (try_take(me)) return;
             continue;
         }
         const struct timespec to = {0, 2000000};                            // 2 ms backstop (a wake-up skipped because a spinner existed that then left)
-        futex(&wake_seq, FUTEX_WAIT_PRIVATE, seq, &to);
+        const long wrc = futex(&wake_seq, FUTEX_WAIT_PRIVATE, seq, &to);
         sleepers.fetch_sub(1, std::memory_order_acq_rel);
         if (try_take(me)) return;
+        if (wrc != 0) {                                                      // timed out (not woken): join the spinners for one bounded round so that a sleeper makes
+            spinners.fetch_add(1, std::memory_order_acq_rel);               // progress even while three hot threads keep the spinner slots busy
+            for (int spins = 0; spins < 256; spins++) {
+                if (try_take(me)) { spinners.fetch_sub(1, std::memory_order_acq_rel); return; }
+                if (spins < 64) cpu_relax(); else sched_yield();
+            }
+            spinners.fetch_sub(1, std::memory_order_acq_rel);
+        }
     }
 }
 void CnMutex::unlock(Node &) {
-    if (grace_cycles()) released_at.store(__rdtsc(), std::memory_order_relaxed);
-    held.store(0, std::memory_order_release);
-    if (sleepers.load(std::memory_order_acquire) > 0 && spinners.load(std::memory_order_acquire) == 0) {
+    if (grace_cycles()) released_at.store(cycle_counter(), std::memory_order_relaxed);
+    // seq_cst exchange, not a release store: the store of `held` must not pass the load of `sleepers` (store-load reordering is what x86 does) -
+    // a waiter does sleepers++ then reads held, this thread writes held then reads sleepers; without the full barrier both could see the old value and
+    // the wake-up would be lost until the futex timeout
+    held.exchange(0, std::memory_order_seq_cst);
+    if (sleepers.load(std::memory_order_seq_cst) > 0 && spinners.load(std::memory_order_acquire) == 0) {
         wake_seq.fetch_add(1, std::memory_order_acq_rel);
         futex(&wake_seq, FUTEX_WAKE_PRIVATE, 1, nullptr);
     }
@@ -147,7 +165,7 @@ int CnMutex::submit(CnReq &r) {
     for (int spins = 0;; spins++) {
         if (r.done.load(std::memory_order_acquire)) break;
         if (try_take(me)) { serve(); release(); continue; }     // every request taken by an earlier holder was completed before it released: mine is done now
-        if (spins < 256) __builtin_ia32_pause();
+        if (spins < 256) cpu_relax();
         else {                                                   // sleep on the request itself; woken by the thread that serves it (50 us backstop)
             r.asleep.store(1, std::memory_order_release);
             if (!r.done.load(std::memory_order_acquire)) { const struct timespec to = {0, 50000}; futex(&r.done, FUTEX_WAIT_PRIVATE, 0, &to); }

@@ -118,11 +118,11 @@ struct CnGuard {
 
 struct DeferQueue;            // cn_api.hip, second half
 struct cn_ctx {
-    int device;
-    hipStream_t stream;
+    int device = 0;
+    hipStream_t stream = nullptr;
     DevConsts hc;             // host copy
-    DevConsts *dc;            // device copy
-    uint64_t *tw;
+    DevConsts *dc = nullptr;  // device copy
+    uint64_t *tw = nullptr;
     CnMutex mu;
     HandleTable bufs;
     KsKey rlk{nullptr, false, false};
@@ -135,7 +135,7 @@ struct cn_ctx {
     char *scratch = nullptr; size_t scap = 0, soff = 0, smax;
     std::vector<std::unique_ptr<char[]>> staged;   // host blocks of in-flight upload_tmp copies
     cn_stats st{};
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_order = nullptr;     // cn_ctx_wait_for: marks a point of this context's stream another context waits for
     uint32_t bs, chunks;      // element-wise geometry
     std::vector<uint32_t> index_map;   // BatchEncoder slot -> coefficient position

@@ -67,3 +67,58 @@ def crt_join_over_ranks(residues, primes, dist, signed=True):
         v = sum(c * int(merged[int(p)][i]) for c, p in zip(coef, primes)) % M
         out.append(v - M if signed and 2 * v > M else v)
     return out
+
+
+def default_galois_elements(n):
+    """the element set of KeyGenerator.GaloisKeys(dbc) / cn_keygen(with_galois): 2N - 1, then 3^(2^i) and 3^(-2^i) for i < log2(N) - 1"""
+    m = 2 * n
+    elts, p3, ip3 = [m - 1], 3, pow(3, -1, m)
+    for _ in range(n.bit_length() - 2):
+        elts += [p3, ip3]
+        p3, ip3 = p3 * p3 % m, ip3 * ip3 % m
+    return elts
+
+
+class BroadcastKeys:
+    """ONE client's keys on every rank (north_star: "RCCL broadcast of evaluation/Galois keys over xGMI and no cross-GPU reduction"): rank
+    `src` has generated them (KeyGenerator on its GPU or uploaded there); every key is broadcast as a device tensor - backend "nccl" = RCCL - and ADOPTED
+    in place by the receiving context (cn_set_relin_key / cn_set_galois_key with is_device_ptr = 1: no host copy; the library converts the buffer to its
+    FP64 key image in place).  The tensors must stay alive as long as the context uses them: this object owns them.  `with_client_keys`: the public and
+    secret key travel too (a benchmark rank also plays the data owner that encrypts the inputs and decrypts the logits; a real server receives the
+    evaluation keys only).  bytes / seconds of the whole exchange are recorded."""
+
+    def __init__(self, ctx, src, device, dist, with_galois=True, with_client_keys=True, adopt_on_src=None):
+        import time
+        import torch
+        self.tensors, self.bytes = [], 0
+        rank = dist.get_rank() if dist is not None else 0
+        adopt = (rank != src) or (dist is not None if adopt_on_src is None else adopt_on_src)   # world 1 with a forced process group: the adoption path runs too
+        if device is not None and str(device) != "cpu":
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        jobs = [(0, 0, ctx.key_words(False))]
+        if with_galois:
+            jobs += [(1, e, ctx.key_words(True)) for e in default_galois_elements(ctx.n)]
+        for which, elt, words in jobs:
+            t = broadcast_words(ctx.get_key(which, elt) if rank == src else None, words, src, device, dist)
+            self.bytes += words * 8
+            if adopt:
+                if which == 0:
+                    ctx.set_relin_key_device(t.data_ptr(), t.numel())
+                else:
+                    ctx.set_galois_key_device(elt, t.data_ptr(), t.numel())
+                self.tensors.append(t)
+        if with_client_keys:
+            for which, words in ((2, ctx.ctw), (3, ctx.ctw // 2)):
+                t = broadcast_words(ctx.get_key(which) if rank == src else None, words, src, device, dist)
+                self.bytes += words * 8
+                if rank != src:
+                    w = t.cpu().numpy().view(np.uint64)
+                    (ctx.set_public_key if which == 2 else ctx.set_secret_key)(w)
+        if device is not None and str(device) != "cpu":
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        self.seconds = time.perf_counter() - t0

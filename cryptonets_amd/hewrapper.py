@@ -1614,9 +1614,10 @@ class EncryptedSealBfvFactory:
     DefaultGaloisDecompositionBitCount = 20
 
     def __init__(self, primes=None, n=4096, DecompositionBitCount=10, GaloisDecompositionBitCount=20, SmallModulusCount=-1,
-                 client_factory=None, context_factory=None, device=0, galois=True, client_seed=None):
+                 client_factory=None, context_factory=None, device=0, galois=True, client_seed=None, device_client_factory=None):
         """client_seed: None (default) = keys and encryption randomness from the OS entropy source; an integer makes the default
-        DeviceClient reproducible (tests only - whoever knows it can regenerate the secret key)."""
+        DeviceClient reproducible (tests only - whoever knows it can regenerate the secret key).  device_client_factory(ctx, t): a client
+        that lives on the context (e.g. client.SharedKeyDeviceClient: one rank generates, the others receive the keys by RCCL broadcast)."""
         if primes is None:
             primes = [40961, 65537, 114689, 147457, 188417]
             n = 4096
@@ -1635,6 +1636,8 @@ class EncryptedSealBfvFactory:
             ctx = context_factory(n, t, q, DecompositionBitCount, GaloisDecompositionBitCount)
             if client_factory is not None:
                 client = client_factory(t, n, q, DecompositionBitCount, GaloisDecompositionBitCount)
+            elif device_client_factory is not None:
+                client = device_client_factory(ctx, t)
             else:
                 from .client import DeviceClient                   # keygen / encrypt / decrypt on the device, seeded from os.urandom
                 client = DeviceClient(ctx, seed=None if client_seed is None else client_seed ^ t)

@@ -6,10 +6,12 @@
 //   * which device(s) the plaintext-prime channels live on (one context per prime; round-robin over `devices`),
 //   * deferred submission (on by default: the layers' per-ciphertext calls are merged into batched launches by libcnhip),
 //   * optionally a cap on the caller thread count.  The reference uses Environment.ProcessorCount threads per ParallelProcessInEnv
-//     (Defaults.cs) to keep CPU cores busy with SEAL arithmetic; here the threads only enqueue work.  libcnhip no longer needs the cap -
-//     its context lock keeps at most four threads awake and biased to the thread that holds it (round 3: flat from 1 to 256 caller
-//     threads) - so a program that keeps `new EncryptedSealBfvFactory(...)` and the default thread count behaves the same; the cap
-//     (callerThreads > 0) only saves the program its own thread start-up,
+//     (Defaults.cs) to keep CPU cores busy with SEAL arithmetic; here the threads only enqueue work.  libcnhip does not need the cap -
+//     its context lock lets at most three waiters spin and puts the others to sleep on a futex (cn_host.cpp; the owner bias and the
+//     combining experiments of round 3 ship OFF: CN_LOCK_GRACE_NS = 0, CN_LOCK_COMBINE = 0).  Measured: the unchanged caller runs at
+//     0.82-0.92 of the batched rate from 1 to 256 caller threads (profiles/r03_unchanged_caller_lock.txt) - not flat, but without a cliff -
+//     so a program that keeps `new EncryptedSealBfvFactory(...)` and the default thread count works; the cap (callerThreads > 0) saves the
+//     program its own thread start-up and the last ~10 %,
 //   * replicas on other GPUs for independent batches: same SEAL keys, evaluation keys copied with ONE RCCL broadcast per key over xGMI
 //     (cn_ctx_broadcast_keys) - no ciphertext ever crosses GPUs (SURVEY.md section 8e).
 // Not compiled in this repository (no .NET toolchain in the build image); see INTEGRATION.md.

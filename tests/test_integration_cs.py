@@ -80,6 +80,22 @@ def test_twin_covers_the_hot_path_entry_points():
     assert "cn_ctx_broadcast_keys" in {n for n, _ in _calls(open(FACTORY).read())}
 
 
+def test_twin_runs_the_start_up_self_test():
+    """CreateDevice ends with SelfTest(): SEAL's own Evaluator against the device, both key-switch conventions, coefficient-form fallback,
+    an exception when nothing matches (the Python mirror of the same procedure is executed by tests/test_self_test.py)"""
+    src = open(TWIN).read()
+    body = src[src.index("void CreateDevice("):src.index("public string SelfTestReport")]
+    assert body.rstrip().endswith("SelfTest();\n        }".replace("\n", "\n")) or "SelfTest();" in body
+    st = src[src.index("public void SelfTest()"):src.index("void UploadKeysInCoefficientForm()")]
+    for op in ("MultiplyPlain", "MultiplyPlain(constant)", "AddPlain", "Multiply", "Relinearize", "RotateRows(1)", "RotateRows(-1)", "RotateColumns"):
+        assert st.count('"%s"' % op) >= 3, op                      # device side, SEAL side, the list that is walked
+    assert 'cn_set_option(device.Ctx, "ks_xi"' in st and "UploadKeysInCoefficientForm()" in st and st.count("throw new Exception") == 2
+    up = src[src.index("void UploadKeysInCoefficientForm()"):]
+    assert up.count("cn_load_key(") >= 3 and "TransformFromNTTInplace" in up
+    # the first device nonce is not derived from the sampler key (ADVICE r03)
+    assert "BitConverter.ToInt64(rngKey" not in src
+
+
 def test_twin_defines_every_member_the_unchanged_files_use():
     src = open(TWIN).read()
     for name in USED_MEMBERS + IVECTOR:
@@ -111,7 +127,7 @@ SEAL_TYPES = ["EncryptionParameters", "SchemeType", "SmallModulus", "DefaultPara
               "CKKSEncoder", "KSwitchKeys", "Serialization"]
 RECOLLECTED = {("SEALContext", "FirstParmsId"), ("Ciphertext", "UInt64Count"), ("Ciphertext", "this[ulong] get/set"), ("Ciphertext", "Resize(context, parmsId, size)"),
                ("Ciphertext", "IsNTTForm"), ("Plaintext", "this[ulong]"), ("PublicKey", "Data"), ("RelinKeys", "Data"), ("RelinKeys", "DecompositionBitCount"),
-               ("GaloisKeys", "Data"), ("GaloisKeys", "DecompositionBitCount")}
+               ("GaloisKeys", "Data"), ("GaloisKeys", "DecompositionBitCount"), ("Evaluator", "TransformFromNTTInplace(encryptedNTT)")}
 
 
 def _manifest():

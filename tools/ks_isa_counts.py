@@ -98,6 +98,75 @@ def valu_per_thread(digits_per_limb, s):
     return sum(d * s["valu_digit_loop"] + s["valu_limb_loop_only"] for d in digits_per_limb) + 2 * s["valu_tail_loop"] + s["valu_once"]
 
 
+SQUARE_KERNEL = "_Z14k_square_fusedILi13E6ArF64TILi0EELb1EE"          # k_square_fused<13, ArF64T<0>, true>: fused squaring, operand parked in LDS
+
+
+def _branches(ins):
+    """[(index, address, mnemonic, target address)] of every branch of the kernel"""
+    out = []
+    for k, (addr, op, args) in enumerate(ins):
+        if op.startswith("s_cbranch") or op == "s_branch":
+            m = re.search(r"(-?\d+)", args)
+            if not m:
+                continue
+            off = int(m.group(1))
+            off = off - 65536 if off >= 32768 else off
+            nxt = ins[k + 1][0] if k + 1 < len(ins) else addr + 4
+            out.append((k, addr, op, nxt + 4 * off))
+    return out
+
+
+def square_structure(obj=None, kernel=SQUARE_KERNEL):
+    """FP64 / other VALU instructions ONE THREAD of k_square_fused executes for one (ciphertext, limb) block, from the built code object.
+    The kernel is one rolled loop over the three steps (cn_k_rr.hip.h); the compiler rotates it so that the body starts with the inverse
+    transform + store (all three steps), followed by the exit test, then EITHER the forward transform with the step-0 / step-1 tensor
+    variants (each variant skipped by one forward branch in the other step) OR the step-2 block (A1^2 out of LDS).  Weights: inverse part
+    x 3, forward part x 2, each skippable variant block x 1, step-2 block x 1."""
+    obj = obj or os.path.join(ROOT, "cryptonets_amd", "lib", "obj", "cn_l_rr_f64l.o")
+    ins = disassemble(obj, kernel)
+    addrs = [a for a, _, _ in ins]
+    is64 = lambda op: op.startswith("v_") and "_f64" in op
+    isv = lambda op: op.startswith("v_") and "_f64" not in op and not op.startswith("v_readfirstlane")
+    br = _branches(ins)
+    back = [(a, t) for _, a, _, t in br if t <= a and a - t > 4096]
+    if not back:
+        raise RuntimeError("no step loop found in %s" % kernel)
+    head = min(t for _, t in back)
+    last = max(a for a, _ in back)
+    end = addrs[-1]
+    body = [(k, a, op, t) for k, a, op, t in br if head <= a <= last]
+    exit_br = [(a, t) for _, a, op, t in body if op.startswith("s_cbranch") and t > last]
+    if len(exit_br) != 1:
+        raise RuntimeError("unrecognised exit structure in %s: %s" % (kernel, [(hex(a), hex(t)) for a, t in exit_br]))
+    exit_at = exit_br[0][0]
+    # the first forward conditional branch behind the exit test selects the step-2 block
+    sel = [(a, t) for _, a, op, t in body if op.startswith("s_cbranch") and a > exit_at and exit_at < t <= last]
+    if not sel:
+        raise RuntimeError("no step selector found in %s" % kernel)
+    sel_at, step2_at = sel[0]
+    variants = [(a, t) for a, t in sel[1:] if a < step2_at and t <= step2_at + 8]
+    if len(variants) != 2:
+        raise RuntimeError("expected the step-0 / step-1 tensor variants in %s, found %s" % (kernel, [(hex(a), hex(t)) for a, t in variants]))
+
+    def count(pred, lo, hi):                 # instructions with lo <= address < hi
+        return sum(1 for a, op, _ in ins if lo <= a < hi and pred(op))
+    res = {}
+    for name, pred in (("fp64", is64), ("valu", isv)):
+        inv = count(pred, head, exit_at)
+        var = [count(pred, a + 4, t) for a, t in variants]
+        fwd = count(pred, sel_at, step2_at) - sum(var)
+        st2 = count(pred, step2_at, last + 4)
+        once = count(pred, addrs[0], head) + count(pred, last + 4, end + 4)
+        res[name] = dict(inverse_part=inv, forward_part=fwd, tensor_variants=var, step2_block=st2, once=once,
+                         per_thread=3 * inv + 2 * fwd + sum(var) + st2 + once)
+    if not 4500 <= res["fp64"]["per_thread"] <= 7500:
+        raise RuntimeError("implausible FP64 count %d for k_square_fused (2 forward + 3 inverse 8192-point transforms are ~5600)" % res["fp64"]["per_thread"])
+    res["kernel"] = "k_square_fused<13, ArF64T<0>, true>"
+    res["instructions"] = len(ins)
+    return res
+
+
 if __name__ == "__main__":
     s = structure(sys.argv[1] if len(sys.argv) > 1 else None)
     print(json.dumps(s, indent=1))
+    print(json.dumps(square_structure(), indent=1))
