@@ -286,7 +286,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                "keys": ("one client: rank 0 ran KeyGenerator, every key broadcast with RCCL and adopted in place" if args.shared_keys else "every rank is its own client (own KeyGenerator)"),
                "key_broadcast": ({"bytes": sum(b for b, _ in exchanges), "ms": round(1e3 * sum(t for _, t in exchanges), 2), "contexts": len(exchanges),
                                   "GB_per_s": round(sum(b for b, _ in exchanges) / max(1e-9, sum(t for _, t in exchanges)) / 1e9, 2),
-                                  "keys_per_context": 1 + 2 * (parms["n"].bit_length() - 2) + 1 + 2,
+                                  "keys_per_context": 1 + 2 * (parms["n"].bit_length() - 2) + 2,
                                   "note": "outside the timed window; relinearisation key + the default Galois key set + public and secret key per plaintext prime; "
                                           "host staging of the root's words included (cn_get_key converts the FP64 key image back to u64 words)"} if args.shared_keys else None),
                "verified_what": ("all 5488 outputs of the 5488 x 16268 dense layer of the last timed image, every plaintext prime (the 8-limb network has no "
@@ -330,25 +330,36 @@ def single_image_lines(gpu_index):
     bounded - LoLa-MNIST 20 timed images + the unchanged-caller replay, LoLa-CIFAR 1 warm-up + 1 timed image - each verified against the exact integer
     model inside its run.  A child that fails or exceeds its time limit is reported with the reason instead of a number."""
     import subprocess
+    # (OMP_*: cpu_baseline sets OMP_PROC_BIND=spread for the oracle's OpenMP team in THIS process; inherited, it binds the child's initial thread to one core
+    # and every std::thread of the unchanged-caller replay with it - the LoLa child then crawls: 240 s instead of 20, profiles/r04_notes)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_LAUNCHER",
-                                                            "BENCH_FORCE_DIST", "BENCH_SELF_LAUNCH", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+                                                            "BENCH_FORCE_DIST", "BENCH_SELF_LAUNCH", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")
+           and not k.startswith("OMP_")}
     env["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "").split(",")[gpu_index] if os.environ.get("HIP_VISIBLE_DEVICES") else str(gpu_index)
 
     def child(workload, steps, warmup, limit):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup)]
         t0 = time.perf_counter()
+        proc = subprocess.Popen(cmd, env=dict(env, PYTHONFAULTHANDLER="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
+            so, se = proc.communicate(timeout=limit)
         except subprocess.TimeoutExpired:
-            return None, {"skipped": "child exceeded its %d s limit" % limit, "command": " ".join(cmd[1:])}
+            import signal
+            proc.send_signal(signal.SIGABRT)                   # faulthandler: the Python stacks of all threads go to stderr - the reason travels with the line
+            try:
+                so, se = proc.communicate(timeout=10)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                so, se = proc.communicate()
+            return None, {"skipped": "child exceeded its %d s limit" % limit, "command": " ".join(cmd[1:]), "where": se.decode(errors="replace")[-1500:]}
         wall = time.perf_counter() - t0
-        lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-        if p.returncode or not lines:
-            return None, {"error": "rc %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-300:]), "command": " ".join(cmd[1:])}
+        lines = [l for l in so.decode(errors="replace").splitlines() if l.startswith("{")]
+        if proc.returncode or not lines:
+            return None, {"error": "rc %d: %s" % (proc.returncode, se.decode(errors="replace")[-300:]), "command": " ".join(cmd[1:])}
         d = json.loads(lines[-1])
         return d, {"command": "python bench.py " + " ".join(cmd[2:]), "child_wall_s": round(wall, 1)}
 
-    d, lola = child("lola", 20, 3, 240)
+    d, lola = child("lola", 20, 3, int(os.environ.get("BENCH_CHILD_LIMIT", "240")))
     if d is not None:
         u = d.get("unchanged_caller") or {}
         lola.update({"metric": d["metric"], "ms_per_image": d["ms_per_step"], "images_per_s": d["value"], "steps": d["steps"],

@@ -70,11 +70,14 @@ def crt_join_over_ranks(residues, primes, dist, signed=True):
 
 
 def default_galois_elements(n):
-    """the element set of KeyGenerator.GaloisKeys(dbc) / cn_keygen(with_galois): 2N - 1, then 3^(2^i) and 3^(-2^i) for i < log2(N) - 1"""
+    """the element set of KeyGenerator.GaloisKeys(dbc) / cn_keygen(with_galois): 2N - 1, then 3^(2^i) and 3^(-2^i) for i < log2(N) - 1.
+    The last pair coincides (3^(N/4) has order 2 modulo 2N): 2 (log2 N - 1) distinct elements - 24 at N = 8192, 26 at N = 16384."""
     m = 2 * n
     elts, p3, ip3 = [m - 1], 3, pow(3, -1, m)
     for _ in range(n.bit_length() - 2):
-        elts += [p3, ip3]
+        for e in (p3, ip3):
+            if e not in elts:
+                elts.append(e)
         p3, ip3 = p3 * p3 % m, ip3 * ip3 % m
     return elts
 

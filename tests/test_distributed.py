@@ -76,3 +76,74 @@ def test_gloo_world2_one_inference_split_by_plaintext_prime():
     v, w = np.array([1000, -2000, 3000, 4000]), np.array([900, 800, -700, 600])
     exp = int(np.sum(v * v * w))
     assert int(r0["joined"][3]) == exp and int(r1["joined"][3]) == exp
+
+
+class _FakeCtx:
+    """the slice of the libcnhip Context protocol BroadcastKeys uses, on host memory: keys are word arrays, an adopted "device" buffer is read
+    back through its address (what cn_set_*_key(..., is_device_ptr = 1) does with a real device pointer)"""
+
+    def __init__(self, n, k, digits, root):
+        self.n, self.k, self.ctw, self.digits = n, k, 2 * k * n, digits
+        self.keys, self.adopted = {}, {}
+        if root:
+            from cryptonets_amd.distributed import default_galois_elements
+            rng = np.random.default_rng(4)
+            self.keys[(0, 0)] = rng.integers(0, 2 ** 62, size=self.key_words(False), dtype=np.uint64)
+            for e in default_galois_elements(n):
+                self.keys[(1, e)] = rng.integers(0, 2 ** 62, size=self.key_words(True), dtype=np.uint64)
+            self.keys[(2, 0)] = rng.integers(0, 2 ** 62, size=self.ctw, dtype=np.uint64)
+            self.keys[(3, 0)] = rng.integers(0, 2 ** 62, size=self.ctw // 2, dtype=np.uint64)
+
+    def key_words(self, galois=False):
+        return self.digits * self.ctw
+
+    def get_key(self, which, elt=0):
+        return self.keys[(which, elt)]
+
+    def _read(self, ptr, words):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint64 * words).from_address(ptr)).copy()
+
+    def set_relin_key_device(self, ptr, words):
+        self.adopted[(0, 0)] = self._read(ptr, words)
+
+    def set_galois_key_device(self, elt, ptr, words):
+        self.adopted[(1, elt)] = self._read(ptr, words)
+
+    def set_public_key(self, w):
+        self.adopted[(2, 0)] = np.array(w, copy=True)
+
+    def set_secret_key(self, w):
+        self.adopted[(3, 0)] = np.array(w, copy=True)
+
+
+def _key_worker(rank, world, path, out):
+    import torch.distributed as dist
+    from cryptonets_amd.distributed import BroadcastKeys
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
+    ctx = _FakeCtx(64, 3, 9, root=(rank == 0))
+    bk = BroadcastKeys(ctx, 0, "cpu", dist, with_galois=True)
+    np.savez(out % rank, bytes=bk.bytes, n_adopted=len(ctx.adopted), **{"k_%d_%d" % key: v for key, v in ctx.adopted.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_one_clients_keys_reach_every_rank():
+    """bench.py --shared-keys / client.SharedKeyDeviceClient: rank 0's relinearisation key, every default Galois key (2 (log2 N - 1) distinct elements) and
+    the client keys arrive bit-identical on rank 1, the evaluation keys through the adopt-a-device-buffer calls; rank 0 (world > 1 means a process
+    group exists) adopts its own broadcast buffers too"""
+    import torch.multiprocessing as mp
+    from cryptonets_amd.distributed import default_galois_elements
+    d = tempfile.mkdtemp()
+    path, out = os.path.join(d, "store"), os.path.join(d, "rank%d.npz")
+    mp.spawn(_key_worker, args=(2, path, out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    elts = default_galois_elements(64)
+    assert len(elts) == 2 * 5 and elts[0] == 127 and elts[1] == 3 and (elts[1] * elts[2]) % 128 == 1 and len(set(elts)) == len(elts)
+    want = _FakeCtx(64, 3, 9, root=True).keys
+    assert int(r1["n_adopted"]) == len(elts) + 3 and int(r0["n_adopted"]) == len(elts) + 1       # rank 0 keeps its own client keys
+    for (which, elt), words in want.items():
+        assert np.array_equal(r1["k_%d_%d" % (which, elt)], words)
+        if which < 2:
+            assert np.array_equal(r0["k_%d_%d" % (which, elt)], words)
+    assert int(r0["bytes"]) == int(r1["bytes"]) == sum(w.size for w in want.values()) * 8

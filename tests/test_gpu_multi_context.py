@@ -89,7 +89,7 @@ def _bench(extra_env, *args):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST"):
         env.pop(k, None)
     env.update(extra_env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-unchanged-caller", *args],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-unchanged-caller", "--no-single-image", *args],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
@@ -107,6 +107,27 @@ def test_bench_with_the_process_group_forced_equals_the_plain_run():
         assert line["n_gpus"] == 1 and line["verified_against_integer_model"] is True and line["verified_slots"] == 2 * 8192 * 10
         assert line["roofline"]["frac"] > 0.2 and line["metric"].startswith("encrypted images/sec")
     assert plain["logit_words_sha256"] == forced["logit_words_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["lola", "cifar"])
+def test_single_image_bench_with_one_clients_keys_broadcast(workload):
+    """BASELINE configs 4 / 5 as north_star words them: ONE client's keys on every rank.  --shared-keys: rank 0 runs KeyGenerator, the relinearisation
+    key, all 24 / 26 distinct Galois keys and the client keys of every plaintext prime travel through dist.broadcast (RCCL; world 1 with the process group
+    forced) and are adopted in place from the broadcast buffers - the full-size key set (C5: ~0.9 GB) moves through the only collective of the
+    project.  Same seeds -> the result ciphertext words must be those of the run where the rank generated its own keys."""
+    own = _bench({}, "--workload", workload, "--client-seed", "1234")
+    shared = _bench({"BENCH_FORCE_DIST": "1", "MASTER_PORT": "29549"}, "--workload", workload, "--client-seed", "1234", "--shared-keys")
+    for line in (own, shared):
+        assert line["n_gpus"] == 1 and line["verified_against_integer_model"] is True
+    assert shared["process_group"] == "nccl" and own["process_group"] is None
+    kb = shared["key_broadcast"]
+    n, k, primes = (16384, 8, 2) if workload == "cifar" else (8192, 5, 4)
+    digits = k * (1 if workload == "cifar" else 3)                      # Galois dbc 60 -> one digit per 48-49-bit limb; 20 -> three per 43-44-bit limb
+    galois_key_bytes = digits * 2 * k * n * 8
+    assert kb["contexts"] == primes and kb["bytes"] >= primes * 2 * (n.bit_length() - 2) * galois_key_bytes
+    assert own["key_broadcast"] is None
+    assert own["result_words_sha256"] == shared["result_words_sha256"]
 
 
 @pytest.mark.gpu
