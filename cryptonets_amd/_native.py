@@ -134,6 +134,8 @@ SIGNATURES = {
     "cn_ct_alloc": (C.c_int, [_CTX, _u32, _u32, C.POINTER(_H)]),
     "cn_pt_alloc": (C.c_int, [_CTX, _u32, C.POINTER(_H)]),
     "cn_free": (C.c_int, [_CTX, _H]),
+    "cn_free_many": (C.c_int, [_CTX, C.POINTER(_H), _u32]),
+    "cn_encrypt_zero_new": (C.c_int, [_CTX, C.c_uint64, C.POINTER(_H)]),
     "cn_ct_upload": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_ct_download": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
     "cn_pt_upload": (C.c_int, [_CTX, _H, _u32, _u32, U64P]),
@@ -321,6 +323,21 @@ class Context:
             return
         self._chk(self.L.cn_free(self._h, h))
         self._ct_size.pop(h, None)
+
+    def free_many(self, handles):
+        if self._h is None or not len(handles):
+            return
+        a = (_H * len(handles))(*[int(h) for h in handles])
+        self._chk(self.L.cn_free_many(self._h, a, len(handles)))
+        for h in handles:
+            self._ct_size.pop(int(h), None)
+
+    def encrypt_zero_new(self, seed=1):
+        """a new one-ciphertext array holding a fresh encryption of zero (cn_ct_alloc + cn_encrypt(pt = 0) in one call)"""
+        h = _H()
+        self._chk(self.L.cn_encrypt_zero_new(self._h, seed, C.byref(h)))
+        self._ct_size[h.value] = 2
+        return h.value
 
     def ct_upload(self, h, first, data):
         d = np.ascontiguousarray(data, dtype=np.uint64)

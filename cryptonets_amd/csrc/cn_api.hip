@@ -596,6 +596,30 @@ extern "C" int cn_free(cn_ctx *ctx, cn_handle h) { API_BODY
     ctx->bufs.erase(h);
     return 0;
 API_END }
+// n handles in one call (ReleaseTemp of the unchanged PoolLayer: one Dispose per zero encryption, PoolLayer.cs:83-90; BaseLayer.GetNext: one per column of a
+// layer's input, BaseLayer.cs:23-49): the handles are checked first - nothing is released when one of them is invalid - then released like n cn_free calls
+extern "C" int cn_free_many(cn_ctx *ctx, const cn_handle *h, uint32_t n) { API_BODY
+    LOCK_ONLY;
+    if (!h && n) return fail(CN_ERR_ARG, "null argument");
+    bool heavy = false;
+    for (uint32_t i = 0; i < n; i++) {
+        Buffer *it = ctx->bufs.find(h[i]);
+        if (!it) return fail(CN_ERR_ARG, "invalid handle at position %u", i);
+        for (uint32_t j = 0; j < i; j++) if (h[j] == h[i]) return fail(CN_ERR_ARG, "handle at position %u is listed twice", i);
+        heavy = heavy || it->kind >= 2;
+    }
+    if (heavy) { NOT_CAPTURING("releasing a GEMM plan / a graph"); CHECK(cn_defer_flush(ctx)); }
+    const bool pending = cn_defer_pending(ctx);
+    for (uint32_t i = 0; i < n; i++) {
+        Buffer *it = ctx->bufs.find(h[i]);
+        if (it->kind == 2) CHECK(free_gemm_plan(ctx, *it));
+        else if (it->kind == 3) CHECK(free_graph(ctx, *it));
+        else if (pending) ctx->dq->frees.emplace_back(it->d, it->item_words * 8 * it->count);
+        else CHECK(dev_release(ctx, it->d, it->item_words * 8 * it->count));
+        ctx->bufs.erase(h[i]);
+    }
+    return 0;
+API_END }
 // ---- captured sequences: the launch-bound chains of small kernels of a single-image inference (LoLa: ~235 launches per plaintext
 // prime) are recorded once on the context stream and replayed with one hipGraphLaunch - no per-launch host work, dependent kernels
 // back to back on the device.  Recording rules: the same sequence must have run once before (so that every temporary comes out of
@@ -1837,6 +1861,23 @@ extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_st
     if (deferring(ctx) && count <= 4) return defer_encrypt(ctx, ptd, pt_stride ? ctx->hc.n : 0, O, oi, count, seed);
     CHECK(cn_defer_flush(ctx));
     return encrypt_chain(ctx, count, ptd, pt_stride ? ctx->hc.n : 0, O->d + oi * O->item_words, seed, nullptr);
+API_END }
+// AllocateCiphertext + Encryptor.Encrypt(PlainZero) in ONE call (the unchanged PoolLayer does both per padded convolution tap, PoolLayer.cs:67-80,
+// AtomicSealBfvVector.cs:566): one lock acquisition instead of two, same queue entry / same words as cn_ct_alloc followed by cn_encrypt(pt = 0)
+extern "C" int cn_encrypt_zero_new(cn_ctx *ctx, uint64_t seed, cn_handle *out) { API_BODY
+    LOCK_ONLY; NOT_CAPTURING("cn_encrypt_zero_new (a replayed graph would reuse its randomness)");
+    if (!out) return fail(CN_ERR_ARG, "null argument");
+    if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
+    if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
+    cn_handle h = 0;
+    CHECK(alloc_buf(ctx, 0, 1, 2, &h));
+    Buffer *O = ctx->bufs.find(h);
+    int rc;
+    if (deferring(ctx)) rc = defer_encrypt(ctx, nullptr, 0, O, 0, 1, seed);
+    else { rc = cn_defer_flush(ctx); if (!rc) rc = encrypt_chain(ctx, 1, nullptr, 0, O->d, seed, nullptr); }
+    if (rc) { (void)dev_release(ctx, O->d, O->item_words * 8); ctx->bufs.erase(h); return rc; }
+    *out = h;
+    return 0;
 API_END }
 #define DISPATCH_K2(fn, ...) switch (ctx->hc.k) { \
     case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; \

@@ -128,6 +128,9 @@ uint64_t cn_galois_elt_from_step(cn_ctx *ctx, int steps);
 int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out);   /* size = polys per ct (2 or 3) */
 int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out);                  /* dense plaintexts, N coeffs each */
 int cn_free(cn_ctx *ctx, cn_handle h);
+/* n handles with one call (one lock acquisition): ReleaseTemp of the unchanged PoolLayer disposes one zero encryption per padded tap (PoolLayer.cs:83-90),
+ * BaseLayer.GetNext one column at a time (BaseLayer.cs:23-49).  All handles are validated first; an invalid or repeated one releases nothing. */
+int cn_free_many(cn_ctx *ctx, const cn_handle *h, uint32_t n);
 int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host);
 int cn_ct_download(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, uint64_t *host);
 int cn_pt_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host);
@@ -259,6 +262,10 @@ int cn_get_key(cn_ctx *ctx, int which /*0 relin,1 galois,2 public,3 secret*/, ui
  * cn_set_option("defer", 1) a call for up to 4 ciphertexts is queued like the evaluator calls (the unchanged PoolLayer encrypts a zero
  * vector per padded convolution tap, PoolLayer.cs:67-80: 645 calls per layer and plaintext prime become one launch chain). */
 int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed);
+/* AllocateCiphertext + Encryptor.Encrypt(PlainZero) as ONE call: a new one-ciphertext array holding a fresh encryption of zero (PoolLayer.ElementAt per
+ * padded tap, PoolLayer.cs:67-80; the IsZero branches of AtomicSealBfvVector.cs:566,587).  Same words and - under "defer" - the same queue entry as
+ * cn_ct_alloc followed by cn_encrypt(pt = 0, count = 1, seed). */
+int cn_encrypt_zero_new(cn_ctx *ctx, uint64_t seed, cn_handle *out);
 /* Decryptor.Decrypt of size-2 or size-3 ciphertexts into dense plaintexts */
 int cn_decrypt(cn_ctx *ctx, cn_handle ct, uint32_t ci, uint32_t count, cn_handle pt_out, uint32_t pi);
 /* Decryptor.InvariantNoiseBudget as CryptoTracker.TestBudget probes it (HE Wrapper/CryptoTracker.cs:41-52, BaseLayer.cs:37): writes the

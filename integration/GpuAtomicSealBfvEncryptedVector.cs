@@ -46,6 +46,41 @@ namespace HEWrapper
         }
         ~CnDevice() { if (Ctx != IntPtr.Zero) { CnHip.cn_ctx_destroy(Ctx); Ctx = IntPtr.Zero; } }
         public int CtWords(int size = 2) { return (int)(size * K * N); }
+
+        // Disposal in batches.  The unchanged layers dispose one vector at a time from many threads (PoolLayer.ReleaseTemp: one Dispose per zero
+        // encryption, PoolLayer.cs:83-90; BaseLayer.GetNext: the columns of a layer's input, BaseLayer.cs:23-49): a released handle is parked in a list of
+        // the calling thread and the list goes to the library 32 handles at a time (cn_free_many: one lock acquisition instead of 32).  What is
+        // left in the lists only holds device memory; it is released when results leave the device (Download / Decrypt call FlushFrees) and by the finalizer.
+        [ThreadStatic] static Dictionary<CnDevice, List<ulong>> parked;
+        static readonly ConcurrentBag<Dictionary<CnDevice, List<ulong>>> allParked = new ConcurrentBag<Dictionary<CnDevice, List<ulong>>>();
+        const int FreeBatch = 32;
+        public void DeferFree(ulong handle)
+        {
+            if (parked == null) { parked = new Dictionary<CnDevice, List<ulong>>(); allParked.Add(parked); }
+            List<ulong> list;
+            lock (parked)
+            {
+                if (!parked.TryGetValue(this, out list)) { list = new List<ulong>(FreeBatch); parked[this] = list; }
+                list.Add(handle);
+                if (list.Count < FreeBatch) return;
+                var batch = list.ToArray();
+                list.Clear();
+                if (Ctx != IntPtr.Zero) CnHip.cn_free_many(Ctx, batch, (uint)batch.Length);
+            }
+        }
+        /// <summary>releases the parked handles of every thread for this device</summary>
+        public void FlushFrees()
+        {
+            foreach (var dict in allParked)
+                lock (dict)
+                {
+                    List<ulong> list;
+                    if (!dict.TryGetValue(this, out list) || list.Count == 0) continue;
+                    var batch = list.ToArray();
+                    list.Clear();
+                    if (Ctx != IntPtr.Zero) CnHip.cn_free_many(Ctx, batch, (uint)batch.Length);
+                }
+        }
     }
 
     /// <summary>A device array of ciphertexts (libcnhip handle).  Released by Dispose or by the finalizer (AtomicSealBfvVector.cs:379-404).</summary>
@@ -58,7 +93,9 @@ namespace HEWrapper
             if (plain) CnHip.Check(CnHip.cn_pt_alloc(dev.Ctx, count, out Handle)); else CnHip.Check(CnHip.cn_ct_alloc(dev.Ctx, count, 2, out Handle));
         }
         ~CnBuffer() { Free(); }
-        void Free() { if (Handle != 0 && Dev.Ctx != IntPtr.Zero) { CnHip.cn_free(Dev.Ctx, Handle); Handle = 0; } }
+        /// <summary>adopts an array the library allocated itself (cn_encrypt_zero_new)</summary>
+        public CnBuffer(CnDevice dev, ulong handle, uint count) { Dev = dev; Handle = handle; Count = count; }
+        void Free() { if (Handle != 0 && Dev.Ctx != IntPtr.Zero) { Dev.DeferFree(Handle); Handle = 0; } }
         public void Dispose() { Free(); GC.SuppressFinalize(this); }
     }
 
@@ -524,6 +561,7 @@ namespace HEWrapper
             var dev = enc.Dev;
             var words = new ulong[enc.Count * dev.CtWords()];
             CnHip.Check(CnHip.cn_ct_download(dev.Ctx, enc.Handle, 0, enc.Count, words));       // drains the deferred queue, synchronises
+            dev.FlushFrees();                                                                  // results leave the device: the parked disposals of every thread go too
             var res = new Ciphertext[enc.Count];
             for (int i = 0; i < res.Length; i++)
                 res[i] = SealInterop.ToCiphertext(words.Skip(i * dev.CtWords()).Take(dev.CtWords()).ToArray(), owner);
@@ -1038,11 +1076,23 @@ namespace HEWrapper
         void EncryptPlaintexts(Plaintext[] plain, AtomicSealBfvEncryptedEnvironment eenv)
         {
             owner = eenv;
+            if (plain.Length == 1 && plain[0].IsZero)
+            {
+                // the zero vector of a padded convolution tap (PoolLayer.ElementAt: Factory.GetEncryptedVector(zeros), PoolLayer.cs:67-80) - 645 per layer and
+                // plaintext prime in CryptoNets: AllocateCiphertext + Encrypt(PlainZero) as ONE library call (cn_encrypt_zero_new), queued like the evaluator calls
+                ulong zh;
+                CnHip.Check(CnHip.cn_encrypt_zero_new(eenv.device.Ctx, eenv.DeviceNonce(), out zh));
+                enc = new CnBuffer(eenv.device, zh, 1);
+                plain[0].Dispose();
+                plainData = null;
+                OperationsCount.Add(ref OperationsCount.Encryption, 1);
+                return;
+            }
             enc = new CnBuffer(eenv.device, (uint)plain.Length);
             if (plain.All(p => p.IsZero))
             {
-                // an all-zero vector (PoolLayer.ElementAt for a padded tap: Factory.GetEncryptedVector(zeros), PoolLayer.cs:67-80): nothing secret
-                // goes in, the public key is on the device - one queued cn_encrypt instead of SEAL Encrypt + upload per block
+                // an all-zero vector of several blocks: nothing secret goes in, the public key is on the device - one queued cn_encrypt instead of SEAL
+                // Encrypt + upload per block
                 CnHip.Check(CnHip.cn_encrypt(eenv.device.Ctx, 0, 0, 0, enc.Handle, 0, enc.Count, eenv.DeviceNonce()));
                 foreach (var p in plain) p.Dispose();
                 plainData = null;

@@ -390,8 +390,14 @@ def test_literal_padded_taps_in_the_unchanged_caller(rng):
     g.set_option("defer", 1)
     try:
         out = r.run(ins, 8, literal_taps=True, nonce0=77)
+        # the twin's merged calls (cn_encrypt_zero_new = alloc + encrypt(0) in one call, cn_free_many for disposed arrays): same calls above the twin
+        # (word equality of the two forms of a zero vector: tests/test_gpu_client.py::test_encrypt_zero_new_and_free_many)
+        b = r.run(ins, 8, literal_taps=True, nonce0=500, merged=True)
     finally:
         g.set_option("defer", 0)
+    wb = np.stack([g.ct_download(int(h), 0, 1)[0] for h in b[0]])
+    for h in b[0]:
+        g.free(int(h))
     got = np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[0]])
     padded = (layers[0]["idx"] < 0).any(axis=1)
     assert padded.sum() == 125 and (layers[0]["idx"] < 0).sum() == 645
@@ -400,6 +406,7 @@ def test_literal_padded_taps_in_the_unchanged_caller(rng):
     dec = rp.decrypt_outputs([ch], [got])[0]
     want = rp.decrypt_outputs([ch], [ref])[0]
     assert np.array_equal(dec, want)
+    assert np.array_equal(wb[~padded], ref[~padded]) and np.array_equal(rp.decrypt_outputs([ch], [wb])[0], want)
     for h in list(out[0]) + list(ins[0]):
         g.free(int(h))
     assert g.live_handles() == live

@@ -421,3 +421,43 @@ def test_encryptions_depend_on_key_nonce_and_item(rng):
     assert not np.array_equal(base, enc(bytes(32), 6, 0))
     assert not np.array_equal(base, enc(bytes([1] + [0] * 31), 5, 0))
     assert not np.array_equal(base, enc(bytes(32), 5, 1))
+
+
+def test_encrypt_zero_new_and_free_many(rng):
+    """cn_encrypt_zero_new = cn_ct_alloc + cn_encrypt(pt = 0) in one call (PoolLayer.ElementAt per padded tap, PoolLayer.cs:67-80): same words -
+    immediately and under deferred submission - on two contexts with the same keys and the same history; cn_free_many releases n handles with one call,
+    all or nothing."""
+    from cryptonets_amd._native import CnError
+    words = []
+    for merged in (False, True):
+        for defer in (0, 1):
+            g, o = make("tiny", seed=5, galois=False)
+            g.set_option("defer", defer)
+            hs = []
+            for i in range(6):
+                if merged:
+                    hs.append(g.encrypt_zero_new(seed=100 + i))
+                else:
+                    h = g.ct_alloc(1)
+                    g.encrypt(0, 0, h, 0, 1, seed=100 + i)
+                    hs.append(h)
+            w = np.stack([g.ct_download(h, 0, 1)[0] for h in hs])
+            assert all(not o.decrypt(c).any() for c in w) and len({c.tobytes() for c in w}) == 6
+            words.append(w)
+            live = g.live_handles()
+            with pytest.raises(CnError):
+                g.free_many(hs[:3] + [hs[1]])                 # repeated handle: nothing is released
+            with pytest.raises(CnError):
+                g.free_many(hs[:3] + [0xdeadbeef])            # invalid handle: nothing is released
+            assert g.live_handles() == live
+            t = g.ct_alloc(1)
+            g.add(hs[0], 0, hs[1], 0, t, 0)                   # (deferred: a pending reader of the arrays that are released next)
+            g.free_many(hs)
+            assert g.live_handles() == live - 6 + 1
+            assert np.array_equal(g.ct_download(t, 0, 1)[0], o.add(w[0], w[1]))
+            g.free_many([])
+            g.free_many([t])
+            assert g.live_handles() == live - 6
+            g.close()
+    for w in words[1:]:
+        assert np.array_equal(w, words[0])

@@ -30,6 +30,7 @@
 #include <unistd.h>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -84,6 +85,35 @@ public:
         while (!done_flag.load(std::memory_order_acquire)) fut(&done_flag, FUTEX_WAIT_PRIVATE, 0);
     }
 };
+// What the twin does INSIDE the classes it owns (integration/GpuAtomicSealBfvEncryptedVector.cs), mode bit 1 of `literal_taps`:
+//   * a zero vector is made with ONE library call (cn_encrypt_zero_new = AllocateCiphertext + Encrypt(PlainZero)),
+//   * Dispose() of a device array parks the handle in a per-thread list that is released with one cn_free_many per 32 handles
+//     (CnBuffer.Free -> CnDevice.DeferFree); what is left is released at the end of the inference (Download / Decrypt flush every list).
+// The unchanged layers above the twin make exactly the same calls as before.
+struct FreeBin { cn_ctx *ctx; std::vector<cn_handle> h; };
+struct FreeBins {
+    std::mutex mu; std::vector<std::vector<FreeBin> *> all;
+    void add(std::vector<FreeBin> *b) { std::lock_guard<std::mutex> g(mu); all.push_back(b); }
+    int flush_all() {
+        std::lock_guard<std::mutex> g(mu);
+        int rc = 0;
+        for (auto *bins : all) for (FreeBin &b : *bins) if (!b.h.empty()) { const int r = cn_free_many(b.ctx, b.h.data(), (uint32_t)b.h.size()); if (r && !rc) rc = r; b.h.clear(); }
+        return rc;
+    }
+};
+FreeBins &free_bins() { static FreeBins f; return f; }
+int defer_free(cn_ctx *ctx, cn_handle h) {
+    thread_local std::vector<FreeBin> *bins = nullptr;
+    if (!bins) { bins = new std::vector<FreeBin>(); free_bins().add(bins); }
+    FreeBin *b = nullptr;
+    for (FreeBin &x : *bins) if (x.ctx == ctx) b = &x;
+    if (!b) { bins->push_back(FreeBin{ctx, {}}); b = &bins->back(); }
+    b->h.push_back(h);
+    if (b->h.size() < 32) return 0;
+    const int rc = cn_free_many(ctx, b->h.data(), (uint32_t)b->h.size());
+    b->h.clear();
+    return rc;
+}
 Pool &pool() { static Pool p; return p; }
 void parallel_process(int count, int threads, const std::function<void(int)> &body) { pool().run(count, threads, body); }
 }  // namespace
@@ -94,12 +124,15 @@ void parallel_process(int count, int threads, const std::function<void(int)> &bo
 extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nlayers, const cn_handle *in, uint32_t n_in, cn_handle *out, int threads,
                        int literal_taps, uint64_t nonce0, char *errmsg, size_t errlen) {
     Err err;
+    const bool merged = (literal_taps & 2) != 0;                                     // the twin's one-call zero vectors and batched disposal (see FreeBins)
+    literal_taps &= 1;
+    auto release = [&](cn_ctx *c, cn_handle h) { return merged ? defer_free(c, h) : cn_free(c, h); };
     std::atomic<uint64_t> nonce{nonce0};
     std::vector<std::vector<cn_handle>> cur(nprimes);
     for (int p = 0; p < nprimes; p++) cur[p].assign(in + (size_t)p * n_in, in + (size_t)(p + 1) * n_in);
     bool cur_owned = false;
     auto dispose = [&](std::vector<std::vector<cn_handle>> &m) {                  // IMatrix.Dispose: every column, every prime
-        for (int p = 0; p < nprimes; p++) for (cn_handle h : m[p]) note(err, cn_free(ctx[p], h));
+        for (int p = 0; p < nprimes; p++) for (cn_handle h : m[p]) note(err, release(ctx[p], h));
     };
     for (int li = 0; li < nlayers && !err.rc; li++) {
         const rp_layer &L = layers[li];
@@ -117,8 +150,11 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
                     patch[t] = 0;
                     if (!literal_taps) continue;
                     cn_handle z = 0;                                                 // ElementAt: Factory.GetEncryptedVector(zeros, dense, m.Scale)
-                    rc = cn_ct_alloc(ctx[p], 1, 2, &z);
-                    if (!rc) rc = cn_encrypt(ctx[p], 0, 0, 0, z, 0, 1, nonce.fetch_add(1));
+                    if (merged) rc = cn_encrypt_zero_new(ctx[p], nonce.fetch_add(1), &z);
+                    else {
+                        rc = cn_ct_alloc(ctx[p], 1, 2, &z);
+                        if (!rc) rc = cn_encrypt(ctx[p], 0, 0, 0, z, 0, 1, nonce.fetch_add(1));
+                    }
                     if (!rc) { patch[t] = z; temps[k].emplace_back(p, z); }
                 }
                 if (rc) { note(err, rc); return; }
@@ -128,7 +164,7 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
                 if (!rc && L.bias_pt) {
                     rc = cn_ct_alloc(ctx[p], 1, 2, &r);
                     if (!rc) rc = cn_add_plain(ctx[p], conv, 0, L.bias_pt[p], (uint32_t)L.bias_idx[k], 0, r, 0, 1);
-                    if (!rc) rc = cn_free(ctx[p], conv);                           // using (conv) { ... }
+                    if (!rc) rc = release(ctx[p], conv);                           // using (conv) { ... }
                 } else r = conv;
                 res[p][k] = r;
                 if (rc) { note(err, rc); return; }
@@ -137,7 +173,7 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
         if (literal_taps) {                                                         // ReleaseTemp(): Parallel.ForEach(TempVectors, v => v.Dispose())
             std::vector<std::pair<int, cn_handle>> all;
             for (auto &v : temps) all.insert(all.end(), v.begin(), v.end());
-            parallel_process((int)all.size(), threads, [&](int i) { note(err, cn_free(ctx[all[i].first], all[i].second)); });
+            parallel_process((int)all.size(), threads, [&](int i) { note(err, release(ctx[all[i].first], all[i].second)); });
         }
         if (cur_owned) dispose(cur);                                                // BaseLayer.GetNext: m.Dispose()
         cur.swap(res); cur_owned = true;
@@ -159,9 +195,11 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
     }
     if (err.rc) {
         if (cur_owned) dispose(cur);
+        (void)free_bins().flush_all();
         if (errmsg && errlen) snprintf(errmsg, errlen, "%s", err.msg);
         return err.rc;
     }
+    if (merged) note(err, free_bins().flush_all());                                  // end of the inference: the parked handles of every thread
     const uint32_t O = layers[nlayers - 1].O;
     for (int p = 0; p < nprimes; p++) memcpy(out + (size_t)p * O, cur[p].data(), (size_t)O * sizeof(cn_handle));
     return 0;
