@@ -354,6 +354,7 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD"));
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
+    if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
     if (getenv("CN_GEMM_ORDER")) c->gemm_order = atoi(getenv("CN_GEMM_ORDER"));
@@ -415,6 +416,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "ks_xcd")) { ctx->ks_xcd = value; return 0; }              // 0 (ct, limb) order, 1 the limbs of a ciphertext on one XCD, 2 limb-major
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
+    if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
@@ -442,6 +444,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
     else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
+    else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
     else if (!strcmp(name, "behz_small_base")) *value = ctx->hc.bsk[ctx->hc.kb - 1].q < (1ull << 49);     // auxiliary primes below 2^49 (FP64 kernels) instead of SEAL's 61-bit ones
     else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;

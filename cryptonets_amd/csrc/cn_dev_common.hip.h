@@ -49,6 +49,13 @@ DEV double bz_canon(double x, const BzF::Mod &m) { double r = BzF::center(x, m);
 // ------------------------------------------------------------------ register-radix NTT kernels (N = 2^L, L = 10..14)
 DEV uint64_t modulus_of(const DevConsts *C, uint32_t mod) { return mod < C->k ? C->q[mod].q : (mod < C->k + C->kb ? C->bsk[mod - C->k].q : C->t.q); }
 
+// copy `words` doubles of a global table behind the exchange image (all threads; caller synchronises)
+DEV void stage_table(double *dst, const NTT_GLOBAL double *src, uint32_t words, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid * 2; i < words; i += nthreads * 2) {
+        const double a = src[i], b = src[i + 1];               // adjacent lanes, adjacent pairs: 16 B per lane either way
+        dst[i] = a; dst[i + 1] = b;
+    }
+}
 // per-policy views of the context constants
 template <class AR> struct ArCtx;
 template <> struct ArCtx<ArU64> {

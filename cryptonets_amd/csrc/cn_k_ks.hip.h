@@ -13,13 +13,6 @@
 // (N <= 8192: image + table = 132 KiB of the 160 KiB; the N = 16384 image alone is 136 KiB)
 template <class AR, int L> struct KsFwd { typedef AR P; static constexpr bool lds = false; };
 template <int RN, int L> struct KsFwd<ArF64T<RN>, L> { typedef typename std::conditional<(L <= 13), ArF64LdsT<RN>, ArF64T<RN>>::type P; static constexpr bool lds = L <= 13; };
-// copy `words` doubles of a global table behind the exchange image (all threads; caller synchronises)
-DEV void stage_table(double *dst, const NTT_GLOBAL double *src, uint32_t words, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t i = tid * 2; i < words; i += nthreads * 2) {
-        const double a = src[i], b = src[i + 1];               // adjacent lanes, adjacent pairs: 16 B per lane either way
-        dst[i] = a; dst[i + 1] = b;
-    }
-}
 // cn_set_option("ks_xi", 1): the digits of a source limb are those of xi_l = [c_l (q/q_l)^-1]_{q_l} instead of those of c_l (DevConsts::ks_xi) - one
 // exact modular product per source word, once per (workgroup, source limb); wave-uniform branch, off by default
 DEV void ks_premultiply(uint64_t (&raw)[16], const DevConsts *C, uint32_t l) {

@@ -249,6 +249,102 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, PLDS ? 2 : 4) k_square_fused(c
         for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(to, r)] = A.scaled(v[r]);
     }
 }
+// The same squaring as a PIPELINED, RESIDENT kernel (round 4; N <= 8192, FP64 policies).  k_square_fused<.., PLDS> runs at 0.5 of its FP64 issue
+// floor with one workgroup per CU: every step loads its operand and waits, every pass of every transform fetches its roots from L2 and waits, with two
+// waves per SIMD to hide either (profiles/r03_bench_kernel_trace_summary.txt: 736 / 900 us for the q / Bsk side of the 845-ciphertext layer against an
+// issue floor of 349 / 419 us).  Here:
+//   * the grid is RESIDENT: gridDim.x = Lm * G workgroups (one per CU), workgroup (l, w) squares limb l of ciphertexts w, w + G, ... - one modulus per
+//     workgroup for its whole life, so
+//   * the INVERSE root table of that modulus is copied into LDS once (8 N bytes behind the exchange image - the room the parked operand took) and the
+//     three inverse transforms of every block read their roots with ds_read instead of global loads; the first-pass roots of the forward transforms
+//     live in SGPRs (ArPassA) - the two devices of the fused key switch (cn_k_ks.hip.h);
+//   * the NTT-form operand is parked in REGISTERS (16 doubles: one workgroup per CU leaves 256 VGPRs per thread);
+//   * the NEXT operand (a1 of this block, a0 of the workgroup's next block) is requested right behind the forward transform - after its last root load,
+//     so that no later wait on a vector-memory counter has to drain it early (the counter is in-order) - and arrives under the tensor, the inverse
+//     transform (no vector-memory loads any more) and the stores.
+// Same words as the separate launches (tests/test_gpu_evaluator.py::test_squaring_fused_kernel_is_the_separate_launches).
+template <class AR> struct LdsTwiddles;
+template <int RN> struct LdsTwiddles<ArF64T<RN>> { typedef ArF64LdsT<RN> type; };
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT, 2) k_square_pipe(const uint64_t *__restrict__ A_, size_t a_stride, const uint64_t *const *__restrict__ a_tab,
+                                                                    uint64_t *__restrict__ D, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t Lm, uint32_t cnt) {
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value && L <= 13, "FP64 policies, N <= 8192");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t G = gridDim.x / Lm, l = blockIdx.x % Lm, w0 = blockIdx.x / Lm, mod = base_off + l;
+    const ArCtx<AR> A(C, mod);
+    const size_t Ln = (size_t)Lm * n;
+    typedef ArPassA<AR> FW;
+    typename FW::Tw fwt;
+    static_cast<typename AR::Tw &>(fwt) = A.fw;
+    ntt_load_pass_a<SA>(fwt, A.fw.w);
+    typedef typename LdsTwiddles<AR>::type IV;
+    typename IV::Tw ivt;
+    {
+        double *tws = reinterpret_cast<double *>(smem) + ntt_lds_words(n);
+        stage_table(tws, A.iv.w, n, tid, NttPlan<L>::NT);
+        ivt.w = (const __attribute__((address_space(3))) double *)tws;
+        __syncthreads();
+    }
+    auto operand = [&](uint32_t ct) { return (const NTT_GLOBAL uint64_t *)(a_tab ? a_tab[ct] : A_ + (size_t)ct * a_stride) + (size_t)l * n; };
+    uint64_t nxt[16];
+    {                                                            // (the launcher guarantees G <= cnt: every workgroup has a first block)
+        const NTT_GLOBAL uint64_t *x = operand(w0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) nxt[r] = x[pass_index<L, SA, 0>(tid, r)];
+    }
+    for (uint32_t ct = w0; ct < cnt; ct += G) {
+        uint64_t *d0 = D + (size_t)ct * 3 * Ln + (size_t)l * n;
+        T P[16];                                                 // the parked NTT-form operand: A0 after step 0, A1 after step 1
+#pragma unroll 1
+        for (int step = 0; step < 3; step++) {
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));                         // one transform's address math / twiddles live at a time
+            T v[16];
+            if (step < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = A.load(nxt[r]);
+                ntt_forward_regs<FW, L, true>(v, s, fwt, A.m, tl);   // PRE: the image of the previous inverse transform is free
+                AR::renorm(v, A.m);
+                // the next operand: a1 of this ciphertext, or a0 of the workgroup's next one.  UNCONDITIONAL (the last block of a workgroup re-reads its
+                // own a0 and drops it): behind a branch the wait-count pass has to assume the path without these loads and makes every later wait
+                // drain them - and the stores behind them - early
+                {
+                    const uint32_t nct = step ? (ct + G < cnt ? ct + G : ct) : ct;
+                    const NTT_GLOBAL uint64_t *x = operand(nct) + (step ? 0 : Ln);
+                    uint32_t tp = tid;
+                    asm volatile("" : "+v"(tp));
+#pragma unroll
+                    for (int r = 0; r < 16; r++) nxt[r] = x[pass_index<L, SA, 0>(tp, r)];
+                }
+                if (step == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { P[r] = v[r]; v[r] = AR::mulmod(v[r], v[r], A.m); }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { const T a0 = P[r]; P[r] = v[r]; v[r] = AR::mulmod(__dadd_rn(a0, a0), v[r], A.m); }
+                }
+                if (!ntt_tail_local<L>()) __syncthreads();
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = AR::mulmod(P[r], P[r], A.m);
+                __syncthreads();                                 // no forward transform in this step: the previous inverse's image is free
+            }
+            uint32_t ti = tid;
+            asm volatile("" : "+v"(ti));
+            ntt_inverse_regs<IV, L>(v, s, ivt, A.m, ti);
+            uint64_t *o = d0 + (size_t)step * Ln;
+            uint32_t to = tid;
+            asm volatile("" : "+v"(to));
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(to, r)] = A.scaled(v[r]);
+        }
+    }
+}
 // encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form, e = the int8 noise polynomials
 // [ct][2][N] of k_sample_small.  tab: per-ciphertext output address and plaintext (deferred per-ciphertext calls), else out + ct*2kN and
 // pt + ct*pt_stride_words (pt null: encryptions of zero)

@@ -2,6 +2,7 @@
 // cn_l_rr_f64.hip and cn_l_rr_f64l.hip, so that the three policies compile in parallel.
 #include "cn_runtime.h"
 #include "cn_k_rr.hip.h"
+#include <algorithm>
 
 typedef RR_POLICY AR;
 static constexpr bool kF64 = std::is_same<typename AR::T, double>::value;
@@ -12,7 +13,10 @@ template <class K> static int big_lds(K kern, size_t bytes) {
 }
 template <int L> static int set_attrs_l(size_t bytes) {
     CHECK(big_lds(k_ntt_rr<L, AR, false>, bytes)); CHECK(big_lds(k_ntt_rr<L, AR, true>, bytes)); CHECK(big_lds(k_intt_tensor<L, AR>, bytes));
-    if constexpr (kF64) { CHECK(big_lds(k_square_fused<L, AR>, bytes)); if constexpr (L <= 13) CHECK(big_lds(k_square_fused<L, AR, true>, bytes + ((size_t)8 << L))); }
+    if constexpr (kF64) {
+        CHECK(big_lds(k_square_fused<L, AR>, bytes));
+        if constexpr (L <= 13) { CHECK(big_lds(k_square_fused<L, AR, true>, bytes + ((size_t)8 << L))); CHECK(big_lds(k_square_pipe<L, AR>, bytes + ((size_t)8 << L))); }
+    }
     CHECK(big_lds(k_lift_ntt<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_fused<L, AR>, bytes));
 #ifdef RR_ENC_TAIL
     CHECK(big_lds(k_encrypt_tail<L, AR>, bytes));
@@ -20,7 +24,7 @@ template <int L> static int set_attrs_l(size_t bytes) {
     return 0;
 }
 static int set_attrs(uint32_t logn, size_t bytes) {      // transforms whose padded LDS image exceeds the default dynamic-LDS limit (N >= 8192)
-    if constexpr (kF64) { if (logn == 12) CHECK(big_lds(k_square_fused<12, AR, true>, bytes + ((size_t)8 << 12))); }   // image + parked operand = 66.5 KiB
+    if constexpr (kF64) { if (logn == 12) { CHECK(big_lds(k_square_fused<12, AR, true>, bytes + ((size_t)8 << 12))); CHECK(big_lds(k_square_pipe<12, AR>, bytes + ((size_t)8 << 12))); } }   // image + parked operand / root table = 66.5 KiB
     if (logn == 13) return set_attrs_l<13>(bytes);
     if (logn == 14) return set_attrs_l<14>(bytes);
     return 0;
@@ -47,6 +51,12 @@ template <int L> static void l_square_fused(cn_ctx *c, const uint64_t *A, size_t
     if constexpr (kF64) {
         const size_t lds = (size_t)ntt_lds_words(1u << L) * 8;
         if constexpr (L <= 13) {
+            // pipelined resident kernel (k_square_pipe): one workgroup per CU and modulus for the whole launch; pays once a workgroup squares several blocks
+            const uint32_t per_limb = std::min<uint32_t>((uint32_t)std::max(1, c->cus) / Lm, cnt);
+            if (per_limb >= 1 && (c->sq_pipe == 2 || (c->sq_pipe && cnt >= 4 * per_limb))) {
+                hipLaunchKernelGGL((k_square_pipe<L, AR>), dim3(per_limb * Lm), dim3(NttPlan<L>::NT), lds + ((size_t)8 << L), c->stream, A, astride, atab, D, c->dc, base_off, Lm, cnt);
+                return;
+            }
             if (c->sq_lds) {             // NTT-form operand parked in LDS (one workgroup per CU) instead of in the outputs' place (two)
                 hipLaunchKernelGGL((k_square_fused<L, AR, true>), dim3(cnt * Lm), dim3(NttPlan<L>::NT), lds + ((size_t)8 << L), c->stream, A, astride, atab, D, c->dc, base_off, Lm);
                 return;

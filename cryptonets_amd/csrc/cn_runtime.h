@@ -168,6 +168,7 @@ struct cn_ctx {
     int cus = 0;              // compute units of the device
     bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per
                               // block (profiles/r02_pmc_square_gemm.txt); cn_set_option("sq_lds", 0): parked in the outputs' place (two workgroups per CU)
+    int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
     // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
     bool defer = false;

@@ -64,7 +64,8 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * halves per limb (no register spills), 0 = the fused 1024-thread kernel; "sq_fused" = 1 (default) runs the transforms and the tensor
  * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
  * MultiplyPlain as two launches (lift + transform of the plaintexts; transform, product, inverse transform of the ciphertext limbs),
- * 0 = six; "sq_lds" = 1 (default) parks the NTT-form operand of a fused squaring in LDS (N <= 8192), 0 = in the outputs' place;
+ * 0 = six; "sq_lds" = 1 (default) parks the NTT-form operand of a fused squaring in LDS (N <= 8192), 0 = in the outputs' place; "sq_pipe" = 1 (default) runs the fused squaring of a batch on the
+ * pipelined resident kernel (k_square_pipe: one workgroup per CU and modulus, inverse root table in LDS, next operand prefetched), 0 = k_square_fused;
  * "gemm_mfma" = 1 (default) runs wide scalar GEMMs (cn_scalar_gemm / cn_scalar_dot batches with >= 16 outputs) on the int8 matrix
  * cores.  All variants produce identical words. */
 /* "defer" = 1: DEFERRED SUBMISSION for callers that issue one evaluator call per ciphertext from many threads - the unchanged

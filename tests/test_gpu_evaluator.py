@@ -205,9 +205,10 @@ def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
     out3, out2 = g.ct_alloc(cnt, 3), g.ct_alloc(cnt)
     exp3 = [o.multiply(c, c) for c in cts]
     got = {}
-    for fused in (1, 2, 0):                                      # 2: fused with the NTT-form operand parked in LDS (cn_set_option("sq_lds", 1))
-        g.set_option("sq_fused", int(fused > 0))
+    for fused in (1, 2, 3, 0):                                   # 2: fused with the NTT-form operand parked in LDS (cn_set_option("sq_lds", 1)); 3: the pipelined
+        g.set_option("sq_fused", int(fused > 0))                 # resident kernel (k_square_pipe, N <= 8192) forced for this small count
         g.set_option("sq_lds", int(fused == 2))
+        g.set_option("sq_pipe", 2 if fused == 3 else 0)
         g.multiply(h, 1, h, 1, out3, 1, cnt - 1)                 # squares of ciphertexts 1.. (offset into the array)
         got[fused] = g.ct_download(out3, 1, cnt - 1, size=3)
         for i in range(cnt - 1):
@@ -215,11 +216,60 @@ def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
         g.mul_relin(h, 0, h, 0, out2, 0, cnt)
         assert np.array_equal(g.ct_download(out2, 0, cnt), o.mul_relin_batch(cts, cts)), (name, fused)
     g.set_option("sq_fused", 1)
-    g.set_option("sq_lds", 0)
-    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    g.set_option("sq_lds", 1)
+    g.set_option("sq_pipe", 1)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]) and np.array_equal(got[0], got[3])
     assert np.array_equal(g.ct_download(h, 0, cnt), cts)         # operands intact (the q side is read in place)
     for x in (h, out3, out2):
         g.free(x)
+
+
+@pytest.mark.parametrize("name,cnt", [("tiny", 700), ("default4096", 300), ("c3", 230)])
+def test_pipelined_squaring_of_a_batch(name, cnt, rng):
+    """k_square_pipe as the library picks it by itself (a batch of at least four blocks per resident workgroup): every workgroup squares several
+    ciphertexts of one limb in turn with the next operand prefetched - uneven shares (cnt is not a multiple of the workgroups per limb), an offset
+    into the array, operands at the edges of the residue range, the deferred per-ciphertext form (operand address table) - all against the
+    separate launches, a sample against the oracle."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    from bench import uniform_ct_words
+    cts = uniform_ct_words(rng, o.q, o.n, cnt)
+    for j, qj in enumerate(o.q):                                     # extreme residues in the first ciphertexts
+        w = cts[:3].reshape(3, 2, o.k, o.n)
+        w[0, :, j, :] = qj - 1
+        w[1, :, j, :] = 0
+        w[2, 0, j, :] = qj // 2
+    h, out3, ref3, out2 = up(g, cts), g.ct_alloc(cnt, 3), g.ct_alloc(cnt, 3), g.ct_alloc(cnt)
+    try:
+        g.set_option("sq_pipe", 0)
+        g.multiply(h, 0, h, 0, ref3, 0, cnt)
+        want = g.ct_download(ref3, 0, cnt, size=3)
+        g.set_option("sq_pipe", 1)
+        g.multiply(h, 0, h, 0, out3, 0, cnt)
+        assert np.array_equal(g.ct_download(out3, 0, cnt, size=3), want)
+        g.multiply(h, 7, h, 7, out3, 0, cnt - 7)                     # offset: another share per workgroup
+        assert np.array_equal(g.ct_download(out3, 0, cnt - 7, size=3), want[7:])
+        for i in (0, 1, 2, 3, cnt // 2, cnt - 1):
+            assert np.array_equal(want[i], o.multiply(cts[i], cts[i])), i
+        assert np.array_equal(g.ct_download(h, 0, cnt), cts)
+        # deferred per-ciphertext calls: every operand its own array, merged into one launch chain with an operand address table
+        g.mul_relin(h, 0, h, 0, out2, 0, cnt)
+        want2 = g.ct_download(out2, 0, cnt)
+        hs = [g.ct_alloc(1) for _ in range(cnt)]
+        for i, x in enumerate(hs):
+            g.copy(h, i, x, 0, 1)
+        g.set_option("defer", 1)
+        rs = [g.ct_alloc(1) for _ in range(cnt)]
+        for x, r in zip(hs, rs):
+            g.mul_relin(x, 0, x, 0, r, 0, 1)
+        g.set_option("defer", 0)
+        got2 = np.stack([g.ct_download(r, 0, 1)[0] for r in rs])
+        assert np.array_equal(got2, want2)
+        g.free_many(hs + rs)
+    finally:
+        g.set_option("defer", 0)
+        g.set_option("sq_pipe", 1)
+        for x in (h, out3, ref3, out2):
+            g.free(x)
 
 
 @pytest.mark.parametrize("name", ["tiny", "c4", "n16k7"])
