@@ -964,8 +964,8 @@ template <class ROW> static void pack_gemm_weights(cn_ctx *ctx, uint32_t G, uint
     const uint32_t k = ctx->hc.k; const uint64_t t = ctx->hc.t.q;
     if (small) {
         const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
-        std::vector<double> hWd((size_t)G * mtf * K * MTf + 8 * MTf, 0.0);   // [g][mtile][kk][m], zero padded; + 8 rows: the kernel's software
-                                                                               // pipeline reads (and multiplies by 0) up to 7 terms past a block
+        std::vector<double> hWd((size_t)G * mtf * K * MTf + 16 * MTf, 0.0);  // [g][mtile][kk][m], zero padded; + 16 rows: the kernel's software
+                                                                               // pipeline reads (and multiplies by 0) up to 15 terms past a block
         for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
             const uint64_t *wr = row(g, m);
             if (!wr) continue;
@@ -1087,7 +1087,7 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
     const GemmArith ar = gemm_arith(ctx, gemm_weights_small(ctx, W, (size_t)O * K));
     const bool small = ar.small, mfma = gemm_mfma_ok(ctx, ar, M, K);
     // gather rows padded with -1 to 16 B multiples (+ 8 spare): the kernels read 4 at a time; matrix-core form: 32 entries per K step
-    const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 7) & ~7u) + 8;
+    const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 15) & ~15u) + 16;       // gather rows: 16 spare entries (the VALU kernels request up to 2 x 8 terms ahead)
     std::vector<int32_t> hidx((size_t)G * Kp, -1), hoidx((size_t)G * M, -1), hbidx((size_t)G * M, 0);
     std::vector<uint32_t> member((size_t)G * M, NONE);           // output index of (group, m)
     {
@@ -2044,7 +2044,7 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
     for (const DOp *op : ops) wsmall = wsmall && gemm_weights_small(ctx, &q->wt[op->terms], K);
     const GemmArith ar = gemm_arith(ctx, wsmall);
     const bool mfma = gemm_mfma_ok(ctx, ar, M, K);
-    const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 7) & ~7u) + 8;
+    const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 15) & ~15u) + 16;       // gather rows: 16 spare entries (the VALU kernels request up to 2 x 8 terms ahead)
     std::vector<uint64_t> hidx((size_t)G * Kp, 0), hoidx((size_t)G * M, 0), hbidx((size_t)G * M, 0);
     std::vector<const DOp *> member((size_t)G * M, nullptr);
     bool any_bias = false;

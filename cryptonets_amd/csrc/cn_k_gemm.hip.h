@@ -160,27 +160,40 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     // 2*MT*NL FMAs.  Two register sets ping-pong: the input elements of the NEXT PF terms are requested before the FMAs of the
     // current PF terms are issued.  Fetch and compute are branch-free (padded taps and terms past the block read as x = 0 and
     // multiply whatever weight row follows - the table carries 8 spare rows), so the waits stay exact.
-    constexpr int PF = 4;
+#ifndef GEMM_PF_SMALL
+#define GEMM_PF_SMALL 4       // terms requested ahead per register set for MT <= 5 (convolution windows: 25 taps, 5 maps).  8 - two gather lists of four in flight per
+                              // thread, VERDICT r03 next #7 - was measured in round 4 and is NOT the default: 91 instead of 66 VGPRs (5 instead of 7 waves per SIMD),
+                              // 476 against 462 us for the CryptoNets convolution (profiles/HISTORY.md, round 4): the layer is not waiting for its loads
+#endif
+    constexpr int PF = (MT <= 5) ? GEMM_PF_SMALL : 4;
+    static_assert(PF % 4 == 0, "gather indices travel in 16 B scalar loads of four");
     auto fetch = [&](uint64_t (&x)[PF], uint32_t kk, uint32_t k1) {
-        // ONE 16 B scalar load for the PF gather indices (four dependent s_load_dword + wait chains cost more than the FMAs)
-        if constexpr (ABS) {               // PF addresses: two 16 B scalar loads; a padded tap reads (and discards) the fallback ciphertext `in`
-            const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4), 16));
-            const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4) + 2, 16));
-            const uint64_t ad[PF] = {a01.x, a01.y, a23.x, a23.y};
+        // ONE 16 B scalar load per four gather indices (four dependent s_load_dword + wait chains cost more than the FMAs)
+        const uint32_t kc = min(kk, Kp - PF);
+        if constexpr (ABS) {               // addresses: two 16 B scalar loads per four; a padded tap reads (and discards) the fallback ciphertext `in`
 #pragma unroll
-            for (int p = 0; p < PF; p++) {
-                const bool ok = kk + p < k1 && ad[p] != 0;
-                const uint64_t v = gmem(ad[p] ? ad[p] : (uint64_t)in)[e];
-                x[p] = ok ? v : 0;
+            for (int c = 0; c < PF; c += 4) {
+                const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + kc + c, 16));
+                const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + kc + c + 2, 16));
+                const uint64_t ad[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const bool ok = kk + c + p < k1 && ad[p] != 0;
+                    const uint64_t v = gmem(ad[p] ? ad[p] : (uint64_t)in)[e];
+                    x[c + p] = ok ? v : 0;
+                }
             }
         } else {
-            const int4 ids = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + min(kk, Kp - 4), 16));
-            const int32_t id[PF] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-            for (int p = 0; p < PF; p++) {
-                const bool ok = kk + p < k1 && id[p] >= 0;
-                const uint64_t v = in[(size_t)max(id[p], 0) * ctw + e];
-                x[p] = ok ? v : 0;
+            for (int c = 0; c < PF; c += 4) {
+                const int4 ids = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + kc + c, 16));
+                const int32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const bool ok = kk + c + p < k1 && id[p] >= 0;
+                    const uint64_t v = in[(size_t)max(id[p], 0) * ctw + e];
+                    x[c + p] = ok ? v : 0;
+                }
             }
         }
     };
