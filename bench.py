@@ -5,8 +5,11 @@ One step = one 8192-image ciphertext batch through the five evaluated layers (th
 window, CryptoNets/CryptoNets.cs:31,74) for BOTH plaintext-prime channels, inputs resident in HBM.
 N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL), every rank evaluates its own
 independent batch (weak scaling, no data-path collective); evaluation keys are broadcast once from rank 0.
-Prints ONE JSON line on rank 0 with `roofline` (the N=8192 NTT kernel, HIP-event timed) and, at N=1,
-`cpu_baseline` (the CPU oracle = port of the reference's SEAL path, timed on a bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` (the N=8192 NTT kernel, HIP-event timed), `key_switch` and `square` (the two kernel
+families that are 90 % of the batch, priced against FP64 issue with instruction counts read from the built code object) and, at N=1,
+`unchanged_caller` (the reference's per-ciphertext call pattern replayed on the C ABI), `lola` / `cifar` (BASELINE configs 4 and 5 as
+child processes: `--workload lola|cifar`, each verified inside its run; `--no-single-image` skips them) and `cpu_baseline` (the CPU
+oracle = port of the reference's SEAL path, timed on a bounded sample).  The whole default line takes about a minute.
 """
 import argparse
 import json
