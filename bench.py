@@ -450,8 +450,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--stub", action="store_true", help="launcher plumbing only (gloo, no device work): what the CPU test of `--gpus N` runs")
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weights", choices=("trained", "synthetic"), default="trained",
                     help="trained: the reference's CryptoNets/Weights.cs (shipped as package data); synthetic: random-init weights of the same shapes")
