@@ -355,6 +355,7 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
+    if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
     if (getenv("CN_GEMM_ORDER")) c->gemm_order = atoi(getenv("CN_GEMM_ORDER"));
@@ -417,6 +418,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
+    if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value != 0; return 0; }
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
@@ -445,6 +447,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
+    else if (!strcmp(name, "enc_fused")) *value = ctx->enc_fused;
     else if (!strcmp(name, "behz_small_base")) *value = ctx->hc.bsk[ctx->hc.kb - 1].q < (1ull << 49);     // auxiliary primes below 2^49 (FP64 kernels) instead of SEAL's 61-bit ones
     else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
@@ -1842,11 +1845,20 @@ static int encrypt_chain(cn_ctx *ctx, uint32_t cnt, const uint64_t *ptd, uint32_
     const uint64_t item0 = ctx->rng_item;
     hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, seed, 0u, item0, (const EncTab *)dtab);
     hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, seed, 1u, item0, (const EncTab *)dtab);
+    if (!htab) ctx->rng_item += cnt;
+    const bool f64 = ctx->use_f64 && ctx->hc.q_f64;
+    if (ctx->enc_fused && !ctx->legacy_ntt) {                 // one kernel behind the samplers: u stays in registers between its transform and the two components
+        uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+        const int pol = f64 ? ((qmax >> 44) ? POL_F64 : POL_F64L) : POL_U64;
+        if (rr_ops[pol]->enc_fused(ctx, us, ptd, pt_stride_words, out, cnt, es, dtab)) {
+            HIPCHK(hipGetLastError()); launch_count(ctx, 3);
+            ctx->st.ntt_forward_limbs += (uint64_t)cnt * k;          // (counted like the three-launch chain)
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(k_expand_small, dim3(cnt * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, us, u, ctx->dc, ctx->chunks);
     HIPCHK(hipGetLastError()); launch_count(ctx, 3);
-    if (!htab) ctx->rng_item += cnt;
     CHECK(cn_run_ntt(ctx, u, cnt * k, 0, k, 0));
-    const bool f64 = ctx->use_f64 && ctx->hc.q_f64;
     if (!rr_ops[f64 ? POL_F64 : POL_U64]->enc_tail(ctx, u, ptd, pt_stride_words, out, cnt, es, dtab)) return fail(CN_ERR_ARG, "unsupported size");
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;

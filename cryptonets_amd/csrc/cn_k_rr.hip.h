@@ -383,3 +383,63 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t 
         o[e] = val;
     }
 }
+
+// Encryptor.Encrypt in ONE kernel behind the samplers (round 4): block = (ciphertext, limb j).  The ternary u arrives as the sampler's int8 polynomial, becomes
+// residues mod q_j in registers, is transformed ONCE and stays in registers (16 values) for both components: out[ct][p][j] = INTT(NTT(u) * pk[p][j]) + e_p
+// (+ Delta m for p = 0).  Replaces k_expand_small (u as k limbs of u64 in HBM), the batched forward transform over those limbs and k_encrypt_tail (which read
+// them back twice): 1 forward + 2 inverse transforms per block like before, none of the 3 x k limb round trips of u, 3 launches fewer.  The unchanged PoolLayer
+// encrypts a zero vector per padded convolution tap (PoolLayer.cs:67-80: 1 290 per CryptoNets batch) - this chain was ~1 ms per plaintext prime and batch of
+// its extra time (profiles/r04_unchanged_caller_replay.txt).  Same words as the three-launch chain (exact arithmetic; tests/test_gpu_client.py).
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fused(const int8_t *__restrict__ us, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pt,
+                                                                  uint32_t pt_stride_words, uint64_t *__restrict__ out, const DevConsts *__restrict__ C,
+                                                                  const int8_t *__restrict__ noise, const EncTab *__restrict__ tab) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, ct = blockIdx.x / k;
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t q = C->q[j].q;
+    T U[16];
+    {
+        const int8_t *uu = us + (size_t)ct * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const int32_t v = uu[pass_index<L, SA, 0>(tid, r)]; U[r] = A.load(v >= 0 ? (uint64_t)v : q - (uint64_t)(-v)); }
+        ntt_forward_regs<AR, L>(U, s, A.fw, A.m, tid);
+        if constexpr (std::is_same<T, double>::value) AR::renorm(U, A.m);      // lazy transform output -> |x| <= q/2: multiplied twice below
+        else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) U[r] = A.canon(U[r]);
+        }
+    }
+    NTT_GLOBAL uint64_t *obase = tab ? tab[ct].out : (NTT_GLOBAL uint64_t *)out + (size_t)ct * 2 * k * n;
+    const NTT_GLOBAL uint64_t *m = tab ? tab[ct].pt : (pt ? (const NTT_GLOBAL uint64_t *)pt + (size_t)ct * pt_stride_words : nullptr);
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));                                           // one transform's address math live at a time
+        const uint64_t *pp = pk + ((size_t)p * k + j) * n;
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(pp + tail_index<L>(tl, r));
+            v[r] = ops.mul(U[r], A.load(y.x), A); v[r + 1] = ops.mul(U[r + 1], A.load(y.y), A);
+        }
+        if (p || !ntt_tail_local<L>()) __syncthreads();                        // the image of the previous transform is free (block-local tail: the first inverse starts inside the wave's own blocks)
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
+        NTT_GLOBAL uint64_t *o = obase + ((size_t)p * k + j) * n;
+        const int8_t *ee = noise + ((size_t)ct * 2 + p) * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t e = pass_index<L, SA, 0>(tl, r);
+            uint64_t val = A.scaled(v[r]);
+            const int32_t ns = ee[e];
+            val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
+            if (p == 0 && m) val = addmod(val, scale_plain(C, m[e], j), q);
+            o[e] = val;
+        }
+    }
+}

@@ -21,6 +21,7 @@ template <int L> static int set_attrs_l(size_t bytes) {
 #ifdef RR_ENC_TAIL
     CHECK(big_lds(k_encrypt_tail<L, AR>, bytes));
 #endif
+    if constexpr (L <= 13) CHECK(big_lds(k_encrypt_fused<L, AR>, bytes));
     return 0;
 }
 static int set_attrs(uint32_t logn, size_t bytes) {      // transforms whose padded LDS image exceeds the default dynamic-LDS limit (N >= 8192)
@@ -92,6 +93,16 @@ static bool enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t 
 static bool enc_tail(cn_ctx *, const uint64_t *, const uint64_t *, uint32_t, uint64_t *, uint32_t, const int8_t *, const void *) { return false; }
 #endif
 
+// Encryptor.Encrypt behind the samplers as ONE kernel (N <= 8192; N = 16384 keeps the three-launch chain: 1024-thread workgroups have 128 VGPRs per thread)
+template <int L> static void l_enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
+    if constexpr (L <= 13)
+        hipLaunchKernelGGL((k_encrypt_fused<L, AR>), dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, pt, pts, out, c->dc,
+                           noise, (const EncTab *)tab);
+}
+static bool enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
+    if (c->hc.logn > 13) return false;
+    BY_SIZE(l_enc_fused, c, us, pt, pts, out, cnt, noise, tab)
+}
 #ifndef __HIP_DEVICE_COMPILE__      // host-side table (in the device pass a const global would be emitted as device data)
-extern const RrOps RR_NAME = {set_attrs, ntt, intt_tensor, square_fused, mul_plain_fused, enc_tail};
+extern const RrOps RR_NAME = {set_attrs, ntt, intt_tensor, square_fused, mul_plain_fused, enc_tail, enc_fused};
 #endif

@@ -168,6 +168,7 @@ struct cn_ctx {
     int cus = 0;              // compute units of the device
     bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per
                               // block (profiles/r02_pmc_square_gemm.txt); cn_set_option("sq_lds", 0): parked in the outputs' place (two workgroups per CU)
+    bool enc_fused = true;    // Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
     int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
     // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
@@ -204,6 +205,7 @@ struct RrOps {                // register-radix kernels of one arithmetic policy
     bool (*mul_plain_fused)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride, uint32_t pstride,
                             uint64_t *out, uint32_t count, uint32_t polys);
     bool (*enc_tail)(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);   // U64, F64; tab: EncTab[cnt] or null
+    bool (*enc_fused)(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);  // all policies, N <= 8192: u (int8) -> transform -> both components in one kernel
 };
 struct KsOps {
     int (*set_attrs)(uint32_t logn, size_t lds);

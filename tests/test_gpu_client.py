@@ -461,3 +461,44 @@ def test_encrypt_zero_new_and_free_many(rng):
             g.close()
     for w in words[1:]:
         assert np.array_equal(w, words[0])
+
+
+@pytest.mark.parametrize("name,f64", [("tiny", True), ("default4096", True), ("c3", True), ("c3", False), ("n16k7", True)])
+def test_fused_encryption_kernel_is_the_three_launch_chain(name, f64, rng):
+    """k_encrypt_fused (u from the sampler's int8 polynomial -> one transform -> both components, N <= 8192) against expand + batched transform +
+    k_encrypt_tail: the SAME words for the same key, nonce and sampler items - dense plaintexts, encryptions of zero, a broadcast plaintext, and the
+    deferred per-ciphertext form (one-call zero vectors); at N = 16384 the switch changes nothing (the chain stays)."""
+    from cryptonets_amd._native import Context
+    p = PARAMS[name]
+    words = {}
+    for fused in (1, 0):
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        if not f64:
+            g.set_option("f64", 0)
+        g.set_option("enc_fused", fused)
+        assert g.get_option("enc_fused") == fused
+        g.keygen(41, galois=False)
+        r = np.random.default_rng(8)
+        plains = r.integers(0, g.t, size=(5, g.n), dtype=np.uint64)
+        ph, ch = g.pt_alloc(5), g.ct_alloc(12)
+        g.pt_upload(ph, 0, plains)
+        g.encrypt(ph, 0, ch, 0, 5, seed=3)                       # five dense plaintexts
+        g.encrypt(0, 0, ch, 5, 3, seed=4)                        # three encryptions of zero
+        g.encrypt(ph, 2, ch, 8, 2, seed=5, pt_stride=0)          # one plaintext twice (fresh randomness each)
+        g.set_option("defer", 1)
+        z = [g.encrypt_zero_new(seed=60 + i) for i in range(3)]
+        g.encrypt(ph, 1, ch, 10, 2, seed=7)                      # queued beside them
+        g.set_option("defer", 0)
+        w = [g.ct_download(ch, 0, 12)] + [g.ct_download(h, 0, 1) for h in z]
+        words[fused] = np.concatenate(w)
+        if fused:
+            o = get_oracle(name, galois=False)
+            from oracle.cno import Oracle
+            oo = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"])
+            oo.import_keys(g.get_key(3), g.get_key(2))
+            dec = [oo.decrypt(c) for c in words[1]]
+            want = [plains[i] for i in range(5)] + [np.zeros(g.n, dtype=np.uint64)] * 3 + [plains[2]] * 2 + [plains[1], plains[2]] + [np.zeros(g.n, dtype=np.uint64)] * 3
+            assert all(np.array_equal(a, b) for a, b in zip(dec, want))
+            assert not np.array_equal(words[1][8], words[1][9])
+        g.close()
+    assert np.array_equal(words[0], words[1])
