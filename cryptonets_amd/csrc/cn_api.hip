@@ -2307,6 +2307,13 @@ static int cn_defer_flush(cn_ctx *ctx) {
     DeferQueue *q = ctx->dq;
     if (!q) return 0;
     int rc = 0;
+    // CN_DEFER_TRACE=2: host time of every flush (the flush runs on the thread of the call that triggered it, under the context lock: every other caller of the
+    // context waits for it, and so does the device if it has run dry)
+    static const bool timing = getenv("CN_DEFER_TRACE") && atoi(getenv("CN_DEFER_TRACE")) >= 2;
+    struct FlushTimer { bool on; size_t nops; cn_ctx *c; std::chrono::steady_clock::time_point t0; ~FlushTimer() {
+        if (on && nops) fprintf(stderr, "defer %p flush of %zu calls: %.0f us of host time\n", (void *)c, nops,
+                                1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } }
+        ft{timing, q->ops.size(), ctx, std::chrono::steady_clock::now()};
     if (!q->ops.empty()) {
         std::vector<DOp> &ops = q->ops;
         // ---- an AddPlain that only adds the bias to a DenseMatrixBySparseVectorMultiply result the caller has already released

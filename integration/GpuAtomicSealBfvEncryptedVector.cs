@@ -95,7 +95,15 @@ namespace HEWrapper
         ~CnBuffer() { Free(); }
         /// <summary>adopts an array the library allocated itself (cn_encrypt_zero_new)</summary>
         public CnBuffer(CnDevice dev, ulong handle, uint count) { Dev = dev; Handle = handle; Count = count; }
-        void Free() { if (Handle != 0 && Dev.Ctx != IntPtr.Zero) { Dev.DeferFree(Handle); Handle = 0; } }
+        /// <summary>release at once instead of parking the handle: set on the result of DenseMatrixBySparseVectorMultiply - the deferred queue folds the
+        /// `conv.Add(bias)` that follows (PoolLayer.cs:184-186) into the scalar product only for an intermediate it KNOWS to be dead</summary>
+        public bool FreeNow;
+        void Free()
+        {
+            if (Handle == 0 || Dev.Ctx == IntPtr.Zero) return;
+            if (FreeNow) CnHip.cn_free(Dev.Ctx, Handle); else Dev.DeferFree(Handle);
+            Handle = 0;
+        }
         public void Dispose() { Free(); GC.SuppressFinalize(this); }
     }
 
@@ -620,6 +628,7 @@ namespace HEWrapper
                     for (int k = 0; k < K; k++) index[k] = (uint)i;
                     CnHip.Check(CnHip.cn_scalar_dot(ctx, handles, index, w, (uint)K, res.enc.Handle, (uint)i));
                 }
+                res.enc.FreeNow = true;          // `using (conv = ConvolveOnce(..)) res[k] = conv.Add(bias)`: released at once, so that the queue can fold the bias addition
                 OperationsCount.Add(ref OperationsCount.PlainMultiplication, w.Count(x => x != 0) * l);
             }
             else

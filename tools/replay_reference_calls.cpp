@@ -89,6 +89,9 @@ public:
 //   * a zero vector is made with ONE library call (cn_encrypt_zero_new = AllocateCiphertext + Encrypt(PlainZero)),
 //   * Dispose() of a device array parks the handle in a per-thread list that is released with one cn_free_many per 32 handles
 //     (CnBuffer.Free -> CnDevice.DeferFree); what is left is released at the end of the inference (Download / Decrypt flush every list).
+//     Exception: the result of DenseMatrixBySparseVectorMultiply (CnBuffer.FreeNow) is released at once - the queue folds `conv.Add(bias)` into the
+//     scalar product only for an intermediate it knows to be dead (parked, 5-25 of the 100 outputs of the dense layer missed the fold and the layer
+//     was cut into two GEMM launches, profiles/HISTORY.md round 4).
 // The unchanged layers above the twin make exactly the same calls as before.
 struct FreeBin { cn_ctx *ctx; std::vector<cn_handle> h; };
 struct FreeBins {
@@ -164,7 +167,8 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
                 if (!rc && L.bias_pt) {
                     rc = cn_ct_alloc(ctx[p], 1, 2, &r);
                     if (!rc) rc = cn_add_plain(ctx[p], conv, 0, L.bias_pt[p], (uint32_t)L.bias_idx[k], 0, r, 0, 1);
-                    if (!rc) rc = release(ctx[p], conv);                           // using (conv) { ... }
+                    if (!rc) rc = cn_free(ctx[p], conv);                           // using (conv) { ... }: released AT ONCE, never parked - the library folds the bias
+                                                                                       // addition into the scalar product only when it knows the intermediate is dead
                 } else r = conv;
                 res[p][k] = r;
                 if (rc) { note(err, rc); return; }
