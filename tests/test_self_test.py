@@ -88,6 +88,25 @@ def test_self_test_finds_the_clients_convention(device, n, t, q, dbc, gdbc, xi, 
     _after_words_agree(env, client)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c3", "c5"])
+@pytest.mark.parametrize("xi", [False, True], ids=["raw-digits", "xi-digits"])
+def test_self_test_at_the_reference_parameter_sets(name, xi):
+    """the same at BASELINE sizes: CryptoNets (N = 8192, 5 limbs, dbc 10 / 20: fused and two-launch key switches) and LoLa-CIFAR (N = 16384, 8 limbs, dbc 60:
+    the two-halves key switch), clients of either convention with keys in the other transform order - the self-test ends on coefficient-form keys and the
+    client's convention, and the drop-in is word-exact afterwards"""
+    from conftest import PARAMS as P
+    p = P[name]
+    q = p["q"] if p["q"] is not None else __import__("oracle.cno", fromlist=["COEFF_MODULUS_128"]).COEFF_MODULUS_128[p["n"]]
+    client = _client(OtherOrderClient, p["n"], p["t"], q, p["dbc"], p["gdbc"], xi)
+    env = AtomicSealBfvEncryptedEnvironment(_gpu_device(p["n"], p["t"], q, p["dbc"], p["gdbc"]), client)
+    env.GenerateEncryptionKeys(with_galois=True)
+    rep = env.self_test_report
+    assert rep["ks_xi"] == int(xi) and rep["key_form"] == "coeff" and len(rep["tried"]) == 3 + int(xi)
+    _after_words_agree(env, client)
+    env.ctx.close()
+
+
 @pytest.mark.parametrize("device", DEVICES)
 def test_self_test_without_galois_keys(device):
     n, t, q, dbc, gdbc = PARAMS[0]
