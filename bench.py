@@ -691,6 +691,8 @@ def main():
             square = {"chain": "Evaluator.Multiply(a, a) of 845 ciphertexts: k_behz_extend, k_square_fused (q: %d limbs, Bsk: %d limbs), k_behz_floor" % (kq, kb),
                       "ms_per_chain": round(sq_ms, 3), "share_of_batch": round(2 * sq_ms / (1e3 * dt / args.steps), 3),
                       "fp64_per_thread_square_fused": ss["fp64"]["per_thread"], "valu_other_per_thread_square_fused": ss["valu"]["per_thread"],
+                      "counted_on": ss["kernel"] + " (the launch runs k_square_pipe for this batch size: the same two forward + three inverse transforms and tensor per "
+                                    "block - 2 368 static FP64 instructions in both code objects - around a resident loop with the inverse roots in LDS)",
                       "fp64_ns_per_instr_in_situ": round(fp64_ns, 3), "fp64_issue_floor_in_situ_ms": round(f_fp64, 3), "frac_fp64_in_situ": round(f_fp64 / sq_ms, 3),
                       "valu_issue_floor_in_situ_ms": round(f_valu, 3), "frac_valu_in_situ": round(f_valu / sq_ms, 3),
                       "algorithmic_bytes": alg, "hbm_frac_algorithmic": round(alg / (sq_ms * 1e-3) / 8e12, 3),
