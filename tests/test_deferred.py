@@ -538,7 +538,7 @@ def _random_program(g, o, cts, pts, seed, defer, length=120):
         steps_pool = [1, -1, 2, -3, 5, -4, 7]
         maxpend = 0
         for _ in range(length):
-            kind = int(r.integers(0, 11))
+            kind = int(r.integers(0, 13))
             a, b, c = (int(x) for x in r.integers(0, len(pool), size=3))
             if kind == 0:
                 g.add(pool[a], 0, pool[b], 0, pool[c], 0)
@@ -567,6 +567,21 @@ def _random_program(g, o, cts, pts, seed, defer, length=120):
                 h = g.ct_alloc(1)
                 g.copy(pool[b if b != a else (a + 1) % len(pool)], 0, h, 0, 1)
                 pool[a] = h
+            elif kind == 11 and len(pool) > 4 and a != b:                  # two handles released with ONE call (cn_free_many) while their readers may be pending
+                g.free_many([pool[a], pool[b]])
+                for x in (a, b):
+                    h = g.ct_alloc(1)
+                    g.copy(pool[c if c not in (a, b) else next(i for i in range(len(pool)) if i not in (a, b))], 0, h, 0, 1)
+                    pool[x] = h
+            elif kind == 12:                                               # the PoolLayer item: scalar product into a temporary, bias addition, the temporary released
+                K = int(r.integers(2, 5))                                  # at once (the queue folds the addition into the product) - under random hazards
+                src = [pool[int(x)] for x in r.integers(0, len(pool), size=K)]
+                w = r.integers(1, 30, size=K, dtype=np.uint64)
+                w[0] = g.t - 2
+                tmp = g.ct_alloc(1)
+                g.scalar_dot(src, np.zeros(K, dtype=np.uint32), w, tmp, 0)
+                g.add_plain(tmp, 0, ph, int(r.integers(0, len(pts))), pool[c], 0)
+                g.free(tmp)
             if defer:
                 maxpend = max(maxpend, g.get_option("pending_calls"))
         out = [g.ct_download(h, 0, 1)[0] for h in pool] + list(g.ct_download(arr, 0, 4))
@@ -581,8 +596,8 @@ def _random_program(g, o, cts, pts, seed, defer, length=120):
 @pytest.mark.parametrize("name", ["tiny", "c4"])
 def test_random_programs_deferred_equal_immediate(name, rng):
     """hazard logic of the deferred queue under fire: random programs of every deferrable call kind (element-wise, plaintext products,
-    rotations, rotate-and-add, copies, cn_copy_many, cn_rotate_rows_many, frees of handles with pending readers) give the same ciphertext words
-    queued as launched one by one"""
+    rotations, rotate-and-add, copies, cn_copy_many, cn_rotate_rows_many, frees of handles with pending readers - one at a time and with
+    cn_free_many - and the scalar product / bias addition / release item of PoolLayer) give the same ciphertext words queued as launched one by one"""
     o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
     cts = _fresh(o, rng, 7)
     pts = np.stack([o.encode(rng.integers(1, 5, size=o.n, dtype=np.uint64)) for _ in range(3)])
