@@ -611,8 +611,13 @@ extern "C" int cn_free_many(cn_ctx *ctx, const cn_handle *h, uint32_t n) { API_B
     for (uint32_t i = 0; i < n; i++) {
         Buffer *it = ctx->bufs.find(h[i]);
         if (!it) return fail(CN_ERR_ARG, "invalid handle at position %u", i);
-        for (uint32_t j = 0; j < i; j++) if (h[j] == h[i]) return fail(CN_ERR_ARG, "handle at position %u is listed twice", i);
         heavy = heavy || it->kind >= 2;
+    }
+    {   // a handle listed twice would be released twice: refused (sorted copy: the list of a layer's temporaries can be thousands long)
+        std::vector<cn_handle> sorted(h, h + n);
+        std::sort(sorted.begin(), sorted.end());
+        const auto dup = std::adjacent_find(sorted.begin(), sorted.end());
+        if (dup != sorted.end()) return fail(CN_ERR_ARG, "handle 0x%llx is listed twice", (unsigned long long)*dup);
     }
     if (heavy) { NOT_CAPTURING("releasing a GEMM plan / a graph"); CHECK(cn_defer_flush(ctx)); }
     const bool pending = cn_defer_pending(ctx);
