@@ -65,7 +65,8 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
  * MultiplyPlain as two launches (lift + transform of the plaintexts; transform, product, inverse transform of the ciphertext limbs),
  * 0 = six; "sq_lds" = 1 (default) parks the NTT-form operand of a fused squaring in LDS (N <= 8192), 0 = in the outputs' place; "sq_pipe" = 1 (default) runs the fused squaring of a batch on the
- * pipelined resident kernel (k_square_pipe: one workgroup per CU and modulus, inverse root table in LDS, next operand prefetched), 0 = k_square_fused;
+ * pipelined resident kernel (k_square_pipe: one workgroup per CU and modulus, inverse root table in LDS, next operand prefetched), 0 = k_square_fused; "enc_fused" = 1 (default) runs Encryptor.Encrypt behind the samplers as ONE kernel (N <= 8192: the ternary u goes from the sampler's int8
+ * polynomial through one transform and stays in registers for both components), 0 = expansion + batched transform + tail kernel;
  * "gemm_mfma" = 1 (default) runs wide scalar GEMMs (cn_scalar_gemm / cn_scalar_dot batches with >= 16 outputs) on the int8 matrix
  * cores.  All variants produce identical words. */
 /* "defer" = 1: DEFERRED SUBMISSION for callers that issue one evaluator call per ciphertext from many threads - the unchanged
@@ -97,7 +98,7 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* reads a switch back, or a choice the library made: "behz_small_base" (1: auxiliary primes below 2^49 - the FP64 kernels - k+1 of them,
  * or k+2 where k+1 are too few (N = 16384); 0: SEAL's 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not
- * hold for the small primes or a data prime has 49 bits or more), "behz_f64", "aux_primes" (primes of B plus m_sk), "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "sq_fused", "mp_fused" */
+ * hold for the small primes or a data prime has 49 bits or more), "behz_f64", "aux_primes" (primes of B plus m_sk), "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "ks_xi", "sq_fused", "sq_pipe", "enc_fused", "mp_fused" */
 int cn_get_option(cn_ctx *ctx, const char *name, int *value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
