@@ -340,8 +340,9 @@ class OracleHarness:
     """Factories for EncryptedSealBfvFactory(client_factory=..., context_factory=...): backend 'gpu' = libcnhip contexts with
     oracle-made keys; backend 'cpu' = everything on the oracle."""
 
-    def __init__(self, backend):
+    def __init__(self, backend, ks_xi=False):
         self.backend = backend
+        self.ks_xi = ks_xi             # the CLIENT's key-switch convention (the device finds it out in its start-up self-test)
         self.oracles = {}
 
     def default_coeff_modulus(self, n):
@@ -350,7 +351,7 @@ class OracleHarness:
     def _oracle(self, n, t, q, dbc, gdbc):
         key = (n, t, tuple(q), dbc, gdbc)
         if key not in self.oracles:
-            self.oracles[key] = Oracle(n, t, q=q, dbc=dbc, gdbc=gdbc)
+            self.oracles[key] = Oracle(n, t, q=q, dbc=dbc, gdbc=gdbc, ks_xi=self.ks_xi)
         return self.oracles[key]
 
     def client_factory(self, t, n, q, dbc, gdbc):
@@ -363,7 +364,7 @@ class OracleHarness:
         return Context(n, t, q=q, dbc=dbc, gdbc=gdbc, device=0)
 
 
-def make_factory(backend, primes=None, n=4096, dbc=10, gdbc=20, small_modulus_count=-1, galois=True):
+def make_factory(backend, primes=None, n=4096, dbc=10, gdbc=20, small_modulus_count=-1, galois=True, ks_xi=False):
     from cryptonets_amd.hewrapper import EncryptedSealBfvFactory
-    h = OracleHarness(backend)
+    h = OracleHarness(backend, ks_xi=ks_xi)
     return EncryptedSealBfvFactory(primes, n, dbc, gdbc, small_modulus_count, client_factory=h.client_factory, context_factory=h, galois=galois)

@@ -11,7 +11,10 @@ import pytest
 from oracle_backend import make_factory
 from cryptonets_amd.hewrapper import EMatrixFormat, EVectorFormat
 
-BACKENDS = [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu)]
+# "-xi": the CLIENT (keys, its own evaluator) follows the other key-switch decomposition convention (oracle ks_xi): on the cpu backend the reference's KATs then pin
+# THAT restatement at the slot level too; on the gpu backend the drop-in has to find the convention out in its start-up self-test (hewrapper SelfTest) before a
+# single KAT can pass
+BACKENDS = [pytest.param("cpu"), pytest.param("gpu", marks=pytest.mark.gpu), pytest.param("cpu-xi"), pytest.param("gpu-xi", marks=pytest.mark.gpu)]
 _factories = {}
 
 values1 = np.array([-1, 9, 3, 20, 1000, -6945], dtype=float)
@@ -22,7 +25,9 @@ values_m = np.array([[1, -2, 3, -44, 5, 7], [99, 12, -88, 22, 16, 13]], dtype=fl
 
 class Fix:
     def __init__(self, backend):
-        self.Factory = make_factory(backend)
+        self.Factory = make_factory(backend.split("-")[0], ks_xi=backend.endswith("-xi"))
+        if backend == "gpu-xi":
+            assert all(e.self_test_report["ks_xi"] == 1 for e in self.Factory.referenceEnvironment.Environments)
         f = self.Factory
         self.env = f.AllocateComputationEnv()
         self.enc1 = f.GetEncryptedVector(values1, EVectorFormat.dense, scale)
