@@ -27,8 +27,11 @@ def digest(a):
 
 
 def digests(name):
-    p = SETS[name]
-    o = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"])
+    """name or name + "-xi": the same parameter set with the other key-switch decomposition convention (oracle ks_xi, round 4) - keys and every
+    key-switching operation then have other words, everything else must keep the digests of the plain name"""
+    xi = name.endswith("-xi")
+    p = SETS[name[:-3] if xi else name]
+    o = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], ks_xi=xi)
     o.keygen(20250926, galois=True)
     o.seed(7)
     r = np.random.default_rng(5)
@@ -49,7 +52,7 @@ def digests(name):
 
 
 if __name__ == "__main__":
-    res = {name: digests(name) for name in SETS}
+    res = {name: digests(name) for base in SETS for name in (base, base + "-xi")}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_digests.json")
     json.dump(res, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)

@@ -119,7 +119,7 @@ def test_oracle_against_bigint_models(n, t, q, dbc, gdbc):
         assert ((X * t * 2 + Q) // (2 * Q)) % t == int(d[i])
 
 
-@pytest.mark.parametrize("name", ["tiny", "default4096", "c3"])
+@pytest.mark.parametrize("name", ["tiny", "default4096", "c3", "tiny-xi", "default4096-xi", "c3-xi"])
 def test_oracle_words_match_the_committed_digests(name):
     """Regression pin: SHA-256 of the oracle's words (keys, fresh encryption under a seeded stream, every evaluator op) for seeded inputs
     equal tests/golden/oracle_digests.json (written by tests/golden/make_oracle_digests.py).  A drift of the oracle - and with it of the
@@ -134,3 +134,7 @@ def test_oracle_words_match_the_committed_digests(name):
     want = json.load(open(os.path.join(here, "oracle_digests.json")))[name]
     got = mod.digests(name)
     assert got == want, sorted(k for k in want if got.get(k) != want[k])
+    if name.endswith("-xi"):                 # the other key-switch convention changes the keys and what is computed WITH them - nothing else
+        plain = json.load(open(os.path.join(here, "oracle_digests.json")))[name[:-3]]
+        differ = {k for k in want if want[k] != plain[k]}
+        assert differ == {"relin_key", "galois_key_0", "relinearize", "rotate_rows_3", "rotate_rows_-5", "rotate_columns"}, differ
