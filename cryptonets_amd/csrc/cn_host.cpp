@@ -104,7 +104,8 @@ void CnMutex::lock(Node &) {
         const long wrc = futex(&wake_seq, FUTEX_WAIT_PRIVATE, seq, &to);
         sleepers.fetch_sub(1, std::memory_order_acq_rel);
         if (try_take(me)) return;
-        if (wrc != 0) {                                                      // timed out (not woken): join the spinners for one bounded round so that a sleeper makes
+        static const bool timeout_spin = !(getenv("CN_LOCK_TIMEOUT_SPIN") && !atoi(getenv("CN_LOCK_TIMEOUT_SPIN")));       // A/B switch (default on)
+        if (wrc != 0 && timeout_spin) {                                      // timed out (not woken): join the spinners for one bounded round so that a sleeper makes
             spinners.fetch_add(1, std::memory_order_acq_rel);               // progress even while three hot threads keep the spinner slots busy
             for (int spins = 0; spins < 256; spins++) {
                 if (try_take(me)) { spinners.fetch_sub(1, std::memory_order_acq_rel); return; }

@@ -127,7 +127,7 @@ def replay_layers(chans, layers):
 LAST_LAUNCHES = None
 
 
-def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True):
+def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True, per_step=False):
     """images/s of the unchanged caller on the inputs resident in chans[p].h_in; returns (ms per batch, output words [primes][O][...]).
     literal_taps: padded taps are fresh encryptions of zero (PoolLayer.cs:67-80) - the words then differ from the batched path's (fresh
     randomness), the DECRYPTED outputs must not (decrypt_outputs)"""
@@ -147,7 +147,12 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                     g.sync()
                 launches0 = sum(g.stats()["kernel_launches"] for g in ctxs)
                 t0 = time.perf_counter()
+            ts = time.perf_counter()
             out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged)
+            if per_step:
+                for g in ctxs:
+                    g.sync()
+                print("    step %d: %.1f ms" % (it, 1e3 * (time.perf_counter() - ts)), file=sys.stderr)
             if it == warmup + steps - 1:
                 for g in ctxs:
                     g.sync()
@@ -186,6 +191,10 @@ def main():
     ap.add_argument("--immediate", action="store_true", help="also time the unchanged caller with every call launched on its own")
     ap.add_argument("--trained", action="store_true", help="the reference's trained weights (tests/golden/cryptonets_weights.npz)")
     ap.add_argument("--literal-threads", default="", help="thread counts for the LITERAL caller: padded taps as fresh encryptions of zero (PoolLayer.cs:67-80)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed batches in front of every measurement (the first one or two batches behind a new set of input handles carry a "
+                    "one-time ~55 ms - arenas and slabs settling - profiles/HISTORY.md round 4; bench.py warms up with 2 as well)")
+    ap.add_argument("--per-step", action="store_true", help="print the wall time of every timed batch of the literal measurements (a sync after each)")
+    ap.add_argument("--no-merged", action="store_true", help="the twin's round-3 calls: cn_ct_alloc + cn_encrypt per zero vector, one cn_free per disposed array")
     args = ap.parse_args()
     from cryptonets_amd._native import Context
     from cryptonets_amd import cryptonets_mnist as cm
@@ -221,12 +230,12 @@ def main():
     ref = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
     rows = [dict(caller="batched (bench.py)", threads=1, ms_per_batch=round(batched_ms, 2), images_per_s=round(8192e3 / batched_ms, 1), words_identical=True)]
     for t in [int(x) for x in args.threads.split(",")]:
-        ms, words = measure(chans, layers, t, args.steps)
+        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, merged=not args.no_merged)
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
         rows.append(dict(caller="unchanged (per-ciphertext calls), deferred submission", threads=t, ms_per_batch=round(ms, 2),
                          images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES))
     for t in [int(x) for x in args.literal_threads.split(",") if x]:
-        ms, words = measure(chans, layers, t, args.steps, literal_taps=True)
+        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, literal_taps=True, merged=not args.no_merged, per_step=args.per_step)
         dec = decrypt_outputs(chans, words)
         same = all(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t)) for d, ch in zip(dec, chans))
         rows.append(dict(caller="unchanged, padded taps as fresh encryptions of zero (PoolLayer.ElementAt), deferred submission", threads=t, ms_per_batch=round(ms, 2),
