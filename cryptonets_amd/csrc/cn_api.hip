@@ -352,6 +352,9 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     // profiles/r03_pmc_keyswitch_orders.txt); (ciphertext, limb) order at N = 16384, where limb-major measured 30 % slower in round 1
     c->ks_xcd = c->hc.logn <= 13 ? 2 : 0;
     if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD"));
+    if (getenv("CN_KS_PAIR14")) c->ks_pair14 = atoi(getenv("CN_KS_PAIR14")) != 0;             // A/B switches of the N = 16384 key switch (round 5)
+    if (getenv("CN_KS_PAIR_TWL")) c->ks_pair_twl = atoi(getenv("CN_KS_PAIR_TWL")) != 0;
+    if (getenv("CN_KS_CHAIN")) c->ks_chain = atoi(getenv("CN_KS_CHAIN")) != 0;
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
@@ -423,6 +426,9 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
+    if (!strcmp(name, "ks_pair14")) { ctx->ks_pair14 = value != 0; return 0; }
+    if (!strcmp(name, "ks_pair_twl")) { ctx->ks_pair_twl = value != 0; return 0; }
+    if (!strcmp(name, "ks_chain")) { ctx->ks_chain = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     if (!strcmp(name, "ks_xi")) {                // decomposition convention of the key switch (DevConsts::ks_xi); the keys must be of the same convention
         if (ctx->capturing) return fail(CN_ERR_ARG, "ks_xi cannot change while a graph is recorded");
@@ -442,6 +448,9 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
     else if (!strcmp(name, "ks_xi")) *value = (int)ctx->hc.ks_xi;
     else if (!strcmp(name, "ks_xcd")) *value = ctx->ks_xcd;
+    else if (!strcmp(name, "ks_pair14")) *value = ctx->ks_pair14;
+    else if (!strcmp(name, "ks_pair_twl")) *value = ctx->ks_pair_twl;
+    else if (!strcmp(name, "ks_chain")) *value = ctx->ks_chain;
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
     else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
@@ -1284,9 +1293,12 @@ static int ks_planned_mode(cn_ctx *ctx, uint32_t cnt, int galois) {
 }
 // perm_elt != 0 (two-launch variants only - the caller asks ks_planned_mode first): target / add0 are the c1 / c0 of the ciphertext a rotation
 // READS and the kernels apply the automorphism x -> x^perm_elt while loading them
+// N = 16384, fused path: one launch per key switch (k_keyswitch_pair14).  A rotation then hands in target = sigma(c1) (permuted ahead of time: k_galois_limbs, or the
+// previous link of a rotate-and-add chain), add0 = the unpermuted c0 and perm_elt; next_elt / next_out ask for sigma_next of the new c1 on the side.
+static bool ks_pair14_ok(cn_ctx *ctx, uint32_t cnt, int galois, const KsKey &key);
 static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, const uint64_t *add0, const uint64_t *add1, size_t astride,
                         const KsKey &key, uint64_t *out, uint32_t cnt, int galois, const uint64_t *extra = nullptr, size_t xstride = 0,
-                        uint64_t *const *out_tab = nullptr, uint32_t perm_elt = 0, const KsItem *items = nullptr) {
+                        uint64_t *const *out_tab = nullptr, uint32_t perm_elt = 0, const KsItem *items = nullptr, uint32_t next_elt = 0, uint64_t *next_out = nullptr) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, tot_dig = galois ? ctx->hc.gk_tot : ctx->hc.rl_tot;
     uint64_t qmax = 0; for (uint32_t j = 0; j < k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     const int bits = 64 - __builtin_clzll(qmax);
@@ -1299,8 +1311,14 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     a.mode = ks_planned_mode(ctx, cnt, galois);
     if (a.mode) CHECK(ensure_ks_part(ctx, (size_t)cnt * (a.mode == 2 ? k : tot_dig) * ctx->ctw2 * 8));
     a.perm_elt = perm_elt; a.items = items;
-    if ((perm_elt || items) && !a.mode) return fail(CN_ERR_ARG, "internal: automorphism inside the fused key switch");
-    if (a.mode == 0 && rr && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14) {   // N = 16384 as two 8192-point halves per limb
+    a.next_elt = next_elt; a.next_out = next_out;
+    const bool pair = ks_pair14_ok(ctx, cnt, galois, key);
+    if ((perm_elt || items || next_elt) && !a.mode && !(pair && !items)) return fail(CN_ERR_ARG, "internal: automorphism inside the fused key switch");
+    if (pair) {                                                                                      // N = 16384: both 8192-point halves of a limb in one workgroup, one launch
+        CHECK(ensure_ks_part(ctx, (size_t)cnt * ctx->ctw2 * 8));
+        a.xcd_cts = ctx->ks_xcd == 1 ? (cnt & ~7u) : 0u;
+        ks_ops[bits <= 44 ? POL_F64L : POL_F64]->pair14(ctx, a);
+    } else if (a.mode == 0 && rr && key.f64 && ctx->hc.logn == 14 && ctx->hc.twdh && ctx->ks_split14) {   // ... as two workgroups per limb + a combining pass (rounds 1-4; A/B)
         CHECK(ensure_ks_part(ctx, (size_t)cnt * ctx->ctw2 * 8));
         ks_ops[bits <= 44 ? POL_F64L : POL_F64]->split14(ctx, a);
         hipLaunchKernelGGL(k_ks_combine14, dim3(cnt * 2 * k * (n / 512)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ks_part, add0, add1, astride, out, ctx->dc,
@@ -1332,6 +1350,9 @@ static int do_keyswitch(cn_ctx *ctx, const uint64_t *target, size_t tstride, con
     HIPCHK(hipGetLastError()); launch_count(ctx);
     ctx->st.ntt_forward_limbs += (uint64_t)cnt * tot_dig * k; ctx->st.ntt_inverse_limbs += (uint64_t)cnt * 2 * k;
     return 0;
+}
+static bool ks_pair14_ok(cn_ctx *ctx, uint32_t cnt, int galois, const KsKey &key) {
+    return ctx->ks_pair14 && ctx->ks_split14 && !ctx->legacy_ntt && ctx->hc.logn == 14 && ctx->hc.twdh && key.f64 && ks_planned_mode(ctx, cnt, galois) == 0;
 }
 static uint32_t chunk_for(cn_ctx *ctx, size_t per_ct, uint32_t count) {
     size_t c = std::max<size_t>(1, ctx->smax / per_ct);
@@ -1392,12 +1413,26 @@ API_END }
 // ---------------------------------------------------------------- rotations
 // in/out device pointers to size-2 ciphertext arrays; tmp holds count size-2 ciphertexts
 // acc != nullptr: out = acc + galois(in) in the same launches (acc may alias out and/or in)
-static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *out, uint64_t *tmp, uint32_t count, const uint64_t *acc = nullptr) {
+// pre: sigma_elt(c1) of `in` if somebody has produced it already ([ct][k][N]); next_elt / next_out: see do_keyswitch (both only on the one-launch N = 16384 path)
+static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *out, uint64_t *tmp, uint32_t count, const uint64_t *acc = nullptr,
+                     const uint64_t *pre = nullptr, uint64_t next_elt = 0, uint64_t *next_out = nullptr) {
     auto it = ctx->gk.find(elt);
     if (it == ctx->gk.end() || !it->second.d) return fail(CN_ERR_NOKEY, "Galois key not present");
 
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     uint32_t limbs = count * 2 * ctx->hc.k;
+    if (ks_pair14_ok(ctx, count, 1, it->second)) {           // N = 16384, batch: c1 is permuted once (here unless the caller brings it), c0 inside the key switch
+        if (!pre) {
+            hipLaunchKernelGGL(k_galois_limbs, dim3(count * ctx->hc.k), dim3(1024), (size_t)ctx->hc.n * 8, ctx->stream, in + kn, 2 * kn, tmp, kn, ctx->dc, elt);
+            HIPCHK(hipGetLastError()); launch_count(ctx);
+            pre = tmp;
+        }
+        CHECK(do_keyswitch(ctx, pre, kn, in, nullptr, 2 * kn, it->second, out, count, 1, acc, ctx->ctw2, nullptr, (uint32_t)elt, nullptr, (uint32_t)next_elt, next_out));
+        ctx->st.Rotation += count;
+        if (acc) ctx->st.Addition += count;
+        return 0;
+    }
+    if (pre || next_elt) return fail(CN_ERR_ARG, "internal: rotation chain outside the one-launch key switch");
     // small batches (two-launch key switch): no permutation pass - the key-switch kernels apply the automorphism while they load c1 and c0
     if (ctx->ks_perm_fused && ks_planned_mode(ctx, count, 1) != 0) {
         CHECK(do_keyswitch(ctx, in + kn, 2 * kn, in, nullptr, 2 * kn, it->second, out, count, 1, acc, ctx->ctw2, nullptr, (uint32_t)elt));
@@ -1629,6 +1664,24 @@ API_END }
 static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count, uint32_t length) {
     const uint32_t n = ctx->hc.n, half = n / 2;
     uint32_t len = length ? length : n;
+    {   // N = 16384, batch: the links of the chain as ONE launch each - link s leaves sigma_(s+1) of its new c1 beside its result (k_keyswitch_pair14), so only the
+        // first link needs a permutation pass.  Same words as the loop below (the same key switches on the same operands).
+        std::vector<uint64_t> elts;
+        bool ok = ctx->ks_chain && count > 0;
+        uint32_t l2 = len;
+        if (l2 >= half) { elts.push_back(2ull * n - 1); l2 = half; }
+        for (uint32_t steps = 1; steps < l2 && ok; steps *= 2) { if (has_direct_key(ctx, -(int)steps)) elts.push_back(cn_galois_elt_from_step(ctx, -(int)steps)); else ok = false; }
+        for (uint64_t e : elts) { auto it = ctx->gk.find(e); if (it == ctx->gk.end() || !it->second.d || !ks_pair14_ok(ctx, count, 1, it->second)) { ok = false; break; } }
+        if (ok && elts.size() > 1) {
+            const size_t kn = (size_t)ctx->hc.k * n;
+            CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+            uint64_t *pp[2]; pp[0] = salloc<uint64_t>(ctx, count * ctx->ctw2); pp[1] = pp[0] + (size_t)count * kn;
+            uint64_t *h = H->d + first * H->item_words;
+            for (size_t s = 0; s < elts.size(); s++)
+                CHECK(do_galois(ctx, h, elts[s], h, pp[s & 1], count, h, s ? pp[s & 1] : nullptr, s + 1 < elts.size() ? elts[s + 1] : 0, pp[(s + 1) & 1]));
+            return 0;
+        }
+    }
     if (len >= half) { CHECK(rotate_columns_add_impl(ctx, H, first, H, first, H, first, count)); len = half; }
     for (uint32_t steps = 1; steps < len; steps *= 2) CHECK(rotate_rows_add_impl(ctx, H, first, -(int)steps, H, first, H, first, count));
     return 0;

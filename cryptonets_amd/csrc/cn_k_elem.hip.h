@@ -223,6 +223,22 @@ __global__ void __launch_bounds__(1024) k_galois_lds(const uint64_t *__restrict_
     uint64_t *o = dst + (size_t)limb * n;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = gs[i];
 }
+// The permutation of a rotation on SELECTED limbs (k_galois_lds, which permutes whole ciphertexts, with a stride): limb (ct, j) of
+// src + ct*sstride -> dst + ct*dstride.  In front of k_keyswitch_pair14 only c1 is permuted ahead of time.
+__global__ void __launch_bounds__(1024) k_galois_limbs(const uint64_t *__restrict__ src, size_t sstride, uint64_t *__restrict__ dst, size_t dstride,
+                                                       const DevConsts *__restrict__ C, uint64_t elt) {
+    extern __shared__ uint64_t gsl[];
+    const uint32_t n = C->n, k = C->k, ct = blockIdx.x / k, j = blockIdx.x % k, logn = C->logn;
+    const uint64_t q = C->q[j].q;
+    const uint64_t *x = src + (size_t)ct * sstride + (size_t)j * n;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t raw = (uint64_t)i * elt, v = x[i];
+        gsl[(uint32_t)(raw & (n - 1))] = ((raw >> logn) & 1) ? negmod(v, q) : v;
+    }
+    __syncthreads();
+    uint64_t *o = dst + (size_t)ct * dstride + (size_t)j * n;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = gsl[i];
+}
 __global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict__ half, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
                                                        size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, const uint64_t *extra,
                                                        size_t ex_stride, uint64_t *const *__restrict__ out_tab) {

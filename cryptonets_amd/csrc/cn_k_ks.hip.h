@@ -257,6 +257,217 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
         __syncthreads();
     }
 }
+// N = 16384 key switch as ONE launch (round 5).  block = (ct, output limb j) runs BOTH 8192-point halves one after the other on the
+// machinery of k_keyswitch_split14 (512 threads, one accumulator pair live at a time, no scratch): half 0's two inverse sub-transforms
+// are parked (recentred doubles, `stash`, written and read back by the same thread), half 1's meet them in registers, and the last
+// inverse stage (u + v, (u - v) w^-1), the N^-1 scaling and the addends are applied on the way out - what k_ks_combine14 did in a
+// second pass over 2 x 2 MiB per ciphertext.  Rotations: `target` is sigma(c1) (permuted ONCE per ciphertext - by k_galois_limbs in front
+// of a single rotation, or by the previous link of a rotate-and-add chain, see next_elt), add0 is the UNPERMUTED c0 and perm_elt the
+// element: the workgroup that owns output limb j stages c0's limb j through LDS at its permuted positions (coalesced reads, odd-stride
+// conflict-free LDS writes) - the only part of k_galois_lds that is not redundant across the k output limbs.  next_elt != 0: the new
+// c1 limb leaves a second time, permuted by the NEXT rotation's element, into next_out[ct][j] - so a SumAllSlots chain of 14
+// rotate-and-add steps over 5488 ciphertexts is 14 launches + one permutation of c1 instead of 14 x 3 launches.
+// Memory latency (one workgroup per CU - nobody else's arithmetic to hide behind; profiles/r05_ks14_pieces.txt: with every load switched
+// off the kernel takes 23 ms per 5488-ciphertext link, with the plain loads 39.5): the source words of digit g + 1 are requested in four
+// pieces while digit g is transformed - each piece at one pass boundary, taken out of the memory pipeline at the next, stage 0 applied and
+// the result parked in the thread's own LDS slots (Ks14Next) - and the closing step issues every load of a component before its first store
+// (out may alias the addends, so the compiler keeps loads behind earlier stores).
+// Aliasing: a workgroup reads limb j of add0 / add1 / extra in full before (element-wise: at) the stores of limb j of out, and nothing
+// else of those arrays - out may alias add0 / extra (in-place rotate-and-add); target and next_out must be separate arrays.
+// LDS: the exchange image, then 64 KiB: the parked next digit during the digit loops; image + 64 KiB is the staging window afterwards.
+#ifndef KS14_DBG
+#define KS14_DBG 0          // timing experiments (tools/build_ks14_dbg.py; results are wrong with any bit set): 1 no c0 staging, 2 no accumulator, 4 no stash,
+#endif                      // 8 no closing arithmetic, 16 synthetic digit sources (no loads), 32 synthetic keys (no loads)
+#ifndef KS14_PREFETCH
+#define KS14_PREFETCH 1     // 0: every digit loads its source words at its start (A/B)
+#endif
+// stage 0 of the 2N'-point transform on one (x, y) = (c[e], c[e + N']) pair of source words, the output half `sg` keeps, recentred
+template <class AR, bool XI> struct Ks14Stage0 {
+    typedef typename AR::T T;
+    const DevConsts *C; typename AR::Mod m; double sg, w1; uint64_t mask;
+    NTT_DEV T operator()(uint64_t sx, uint64_t sy, uint32_t l, int sh) const {
+        if constexpr (XI) { const DMod ql = C->q[l]; const uint64_t xf = C->inv_qhat_q[l]; sx = mulmod(sx, xf, ql); sy = mulmod(sy, xf, ql); }   // digits of xi_l
+        const T X = AR::from_u64((sx >> sh) & mask), Y = AR::from_u64((sy >> sh) & mask);
+        return AR::center(__fma_rn(sg, AR::mulmod(Y, w1, m), X), m);         // x +- w y
+    }
+};
+// the hook of ntt_forward_regs_hooked: piece c of the next digit's 16 pairs = registers 4c .. 4c+3
+template <class AR, bool XI> struct Ks14Next {
+    typedef typename AR::T T;
+    static constexpr uint32_t n2 = 8192, NT = 512;
+    const Ks14Stage0<AR, XI> &st0;
+    const uint64_t *src; uint32_t l; int sh;          // the next digit: limb, source limb index, shift (src == nullptr: there is none)
+    T *park; uint32_t tid;
+    uint64_t raw[8];
+    template <int CH> NTT_DEV void issue() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t e = (uint32_t)(CH * 4 + q) * NT + tid; raw[2 * q] = src[e]; raw[2 * q + 1] = src[e + n2]; }
+    }
+    template <int CH> NTT_DEV void take() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) park[(uint32_t)(CH * 4 + q) * NT + tid] = st0(raw[2 * q], raw[2 * q + 1], l, sh);
+    }
+    template <int PH> NTT_DEV void at() {
+        if (!src) return;
+        if constexpr (PH > 0) take<PH - 1>();
+        if constexpr (PH < 4) issue<PH>();
+    }
+};
+template <class AR, bool XI = false>
+__global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *add0, const uint64_t *add1,
+                                                                       size_t add_stride, const void *__restrict__ key_, uint64_t *out, double *__restrict__ stash,
+                                                                       const DevConsts *__restrict__ C, int galois, uint32_t accmax, const uint64_t *extra, size_t ex_stride,
+                                                                       uint64_t *const *__restrict__ out_tab, uint32_t perm_elt, uint32_t next_elt, uint64_t *__restrict__ next_out,
+                                                                       uint32_t xcd_cts) {
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value, "FP64 policies only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr int L = 13;
+    constexpr uint32_t n2 = 1u << L, n = 2 * n2, NT = NttPlan<L>::NT;
+    constexpr int SA = NttPlan<L>::SA;
+    static_assert(SA == 4 && NT == 512, "pass A pattern: register r of thread t holds coefficient r * 512 + t");
+    constexpr uint32_t IMG = ntt_lds_words(n2) * 8;                   // bytes of the exchange image
+    T *park = reinterpret_cast<T *>(smem + IMG);                       // [16][512]: the next digit, stage 0 applied, every thread its own slots
+    // staging window of N words: the last 8 N bytes of (image + 64 KiB) - overlaps the image, used only between transforms
+    uint64_t *win = reinterpret_cast<uint64_t *>(smem + (IMG + 65536 - (size_t)n * 8));
+    const uint32_t k = C->k, tid = threadIdx.x;
+    uint32_t ct = blockIdx.x / k, j = blockIdx.x % k;
+    if (blockIdx.x < xcd_cts * k) { const uint32_t x = blockIdx.x & 7, sl = blockIdx.x >> 3; ct = 8 * (sl / k) + x; j = sl % k; }   // as in k_keyswitch_rr
+    const DMod qm = C->q[j];
+    const ArCtx<AR> A(C, j);
+    typedef const NTT_GLOBAL double *GP;
+    typedef typename KsPassA<AR, KS_SGPR_A != 0>::P FW;
+    const int dbc = galois ? C->gdbc : C->dbc;
+    const size_t kn = (size_t)k * n;
+    const uint32_t tot = galois ? C->gk_tot : C->rl_tot;
+    double *stp = stash + ((size_t)ct * k + j) * 2 * n2;
+    const uint64_t *tgt = target + (size_t)ct * tgt_stride;
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; h++) {
+        const GP fwg = (GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2);
+        typename FW::Tw fwh;
+        fwh.w = fwg;
+        if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwh, fwg);
+        const typename AR::Tw ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
+        const Ks14Stage0<AR, XI> st0{C, A.m, h ? -1.0 : 1.0, ntt_uniform(A.fw.w[1]), (1ull << dbc) - 1};
+        T acc0[16], acc1[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+        const T *kp = reinterpret_cast<const T *>(key_);
+        uint32_t terms = 0, l = 0, d = 0;
+        for (uint32_t g = 0; g < tot; g++, kp += 2 * kn) {
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));               // as in k_keyswitch_rr: keep address math and twiddle loads inside the loop
+            // the digit behind this one
+            uint32_t ln = l, dn = d + 1;
+            if (dn == (galois ? C->gk_dig[l] : C->rl_dig[l])) { ln = l + 1; dn = 0; }
+            Ks14Next<AR, XI> nx{st0, (KS14_PREFETCH && !(KS14_DBG & 16) && g + 1 < tot) ? tgt + (size_t)ln * n : nullptr, ln, dbc * (int)dn, park, tl};
+            T v[16];
+            if (KS14_PREFETCH && !(KS14_DBG & 16) && g) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = park[(uint32_t)r * NT + tl];
+            } else {
+                const uint64_t *src = tgt + (size_t)l * n;
+                const int sh = dbc * (int)d;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t e = pass_index<L, SA, 0>(tl, r);
+                    const uint64_t sx = (KS14_DBG & 16) ? (uint64_t)(e * 2654435761u + l) : src[e], sy = (KS14_DBG & 16) ? (uint64_t)(e * 40503u + l) : src[e + n2];
+                    v[r] = st0(sx, sy, l, sh);
+                }
+            }
+            ntt_forward_regs_hooked<FW, L, KS_PRE_SYNC != 0>(v, s, fwh, A.m, tl, nx);
+            const T *k0 = kp + (size_t)j * n + (size_t)h * n2, *k1 = k0 + kn;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t pos = tail_index<L>(tl, r);
+                struct alignas(16) P2 { T a, b; };
+                const P2 a = (KS14_DBG & 32) ? P2{v[r + 1], v[r]} : *reinterpret_cast<const P2 *>(k0 + pos), b = (KS14_DBG & 32) ? P2{v[r], v[r + 1]} : *reinterpret_cast<const P2 *>(k1 + pos);
+                KsMac<AR>::mac(acc0[r], v[r], a.a, qm, A); KsMac<AR>::mac(acc0[r + 1], v[r + 1], a.b, qm, A);
+                KsMac<AR>::mac(acc1[r], v[r], b.a, qm, A); KsMac<AR>::mac(acc1[r + 1], v[r + 1], b.b, qm, A);
+            }
+            nx.template at<4>();
+            if (++terms == accmax) { terms = 0; KsMac<AR>::settle(acc0, A); KsMac<AR>::settle(acc1, A); }
+            if (!KS_PRE_SYNC) __syncthreads();
+            l = ln; d = dn;
+        }
+        if (KS_PRE_SYNC && !ntt_tail_local<L>()) __syncthreads();
+#pragma unroll 1
+        for (int p = 0; p < 2; p++) {
+            T v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = p ? acc1[r] : acc0[r];
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));
+            ntt_inverse_regs<AR, L>(v, s, ivh, A.m, tl);
+            double *st = stp + (size_t)p * n2;
+            if (h == 0) {                                              // parked: |u| <= q/2, this thread reads it back
+#pragma unroll
+                for (int r = 0; r < 16; r++) if (!(KS14_DBG & 4)) st[pass_index<L, SA, 0>(tl, r)] = AR::center(v[r], A.m);
+                __syncthreads();
+                continue;
+            }
+            const uint64_t *ad = p ? add1 : add0;
+            if (KS14_DBG & 1) ad = nullptr;
+            if (ad) ad += (size_t)ct * add_stride + (size_t)j * n;
+            const bool staged = ad && perm_elt && p == 0;
+            const uint64_t *ex = extra && !(KS14_DBG & 2) ? extra + (size_t)ct * ex_stride + (size_t)p * kn + (size_t)j * n : nullptr;
+            if (staged) {                                              // sigma(c0), limb j: N words through the window
+                __syncthreads();                                       // everybody has taken its coefficients out of the image
+#pragma unroll 8
+                for (int r = 0; r < 32; r++) {
+                    const uint32_t i = tl + NT * (uint32_t)r, pos = (i * perm_elt) & (2 * n - 1);
+                    const uint64_t x = ad[i];
+                    win[pos & (n - 1)] = (pos >> (L + 1)) ? negmod(x, qm.q) : x;
+                }
+                __syncthreads();
+            }
+            const double ni = C->ninvd[j], niw = AR::from_u64(C->ninv_w[j]);
+            NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)(out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)p * kn + (size_t)j * n;
+            const bool chain = next_elt && p == 1;
+            if (chain) __syncthreads();                                // the window overlaps the image: everybody has taken its coefficients out
+            // in two pieces of 8 registers; every load of a piece in front of its first store (out may alias the addends, so the compiler keeps a load behind
+            // every earlier store - one exposed round trip per piece instead of one per register); addends summed as exact doubles (each below 2^50)
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                double u[8], alo[8], ahi[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { u[r] = (KS14_DBG & 4) ? v[(r0 + r) ^ 1] : st[pass_index<L, SA, 0>(tl, r0 + r)]; alo[r] = 0; ahi[r] = 0; }
+                if (ex) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = AR::from_u64(ex[e]); ahi[r] = AR::from_u64(ex[e + n2]); }
+                }
+                if (staged) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = __dadd_rn(alo[r], AR::from_u64(win[e])); ahi[r] = __dadd_rn(ahi[r], AR::from_u64(win[e + n2])); }
+                } else if (ad) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = __dadd_rn(alo[r], AR::from_u64(ad[e])); ahi[r] = __dadd_rn(ahi[r], AR::from_u64(ad[e + n2])); }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r);
+                    const double w = AR::center(v[r0 + r], A.m);
+                    uint64_t lo = AR::to_u64(__dadd_rn(AR::mulmod(__dadd_rn(u[r], w), ni, A.m), alo[r]), A.m), hi = AR::to_u64(__dadd_rn(AR::mulmod(__dadd_rn(u[r], -w), niw, A.m), ahi[r]), A.m);
+                    if (KS14_DBG & 8) { lo = (uint64_t)__double_as_longlong(u[r]); hi = (uint64_t)__double_as_longlong(v[r0 + r]); }
+                    o[e] = lo; o[e + n2] = hi;
+                    if (chain) {                                       // the new c1 limb once more, permuted for the next link of the chain
+                        const uint32_t pl = (e * next_elt) & (2 * n - 1), ph = ((e + n2) * next_elt) & (2 * n - 1);
+                        win[pl & (n - 1)] = (pl >> (L + 1)) ? negmod(lo, qm.q) : lo;
+                        win[ph & (n - 1)] = (ph >> (L + 1)) ? negmod(hi, qm.q) : hi;
+                    }
+                }
+            }
+            __syncthreads();
+            if (chain) {
+                NTT_GLOBAL uint64_t *no = (NTT_GLOBAL uint64_t *)next_out + (size_t)ct * kn + (size_t)j * n;
+#pragma unroll 8
+                for (int r = 0; r < 32; r++) no[tl + NT * (uint32_t)r] = win[tl + NT * (uint32_t)r];
+            }
+        }
+    }
+}
 // 16 B of a key (two consecutive words) through a GLOBAL pointer (a struct cannot be copied out of address space 1; a vector type can)
 template <class T> NTT_DEV void ks_load2(const NTT_GLOBAL T *p, T &a, T &b) {
     typedef T V2 __attribute__((ext_vector_type(2)));

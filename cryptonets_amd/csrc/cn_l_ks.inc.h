@@ -6,6 +6,7 @@
 typedef KS_POLICY AR;
 static constexpr bool kF64 = std::is_same<typename AR::T, double>::value;
 
+static constexpr size_t PAIR14_LDS = (size_t)ntt_lds_words(8192) * 8 + 65536;      // k_keyswitch_pair14: exchange image + 64 KiB (the parked next digit / staging window)
 template <class K> static int big_lds(K kern, size_t bytes) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
@@ -23,7 +24,10 @@ static int set_attrs(uint32_t logn, size_t bytes) {
     if (logn == 13) { CHECK(set_attrs_l<13>(bytes)); CHECK(big_lds(k_keyswitch_rr<13, AR, 4>, bytes)); }
     if (logn == 14) {
         CHECK(set_attrs_l<14>(bytes));
-        if constexpr (kF64) { CHECK(big_lds(k_keyswitch_split14<AR>, (size_t)ntt_lds_words(8192) * 8)); CHECK(big_lds(k_keyswitch_split14<AR, true>, (size_t)ntt_lds_words(8192) * 8)); }
+        if constexpr (kF64) {
+            CHECK(big_lds(k_keyswitch_split14<AR>, (size_t)ntt_lds_words(8192) * 8)); CHECK(big_lds(k_keyswitch_split14<AR, true>, (size_t)ntt_lds_words(8192) * 8));
+            CHECK(big_lds(k_keyswitch_pair14<AR, false>, PAIR14_LDS)); CHECK(big_lds(k_keyswitch_pair14<AR, true>, PAIR14_LDS));
+        }
     }
     return 0;
 }
@@ -89,6 +93,19 @@ static bool split14(cn_ctx *c, const KsArgs &a) {
     }
     return false;
 }
+// N = 16384 in one launch: both halves per (ciphertext, output limb) workgroup (k_keyswitch_pair14); a.target = sigma(c1) for rotations
+template <bool XI> static void launch_pair14(cn_ctx *c, const KsArgs &a) {
+    if constexpr (kF64)
+        hipLaunchKernelGGL((k_keyswitch_pair14<AR, XI>), dim3(a.cnt * c->hc.k), dim3(NttPlan<13>::NT), PAIR14_LDS, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride,
+                           (const void *)a.key, a.out, (double *)c->ks_part, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.perm_elt, a.next_elt, a.next_out, a.xcd_cts);
+}
+static bool pair14(cn_ctx *c, const KsArgs &a) {
+    if constexpr (kF64) {
+        if (c->hc.ks_xi) launch_pair14<true>(c, a); else launch_pair14<false>(c, a);
+        return true;
+    }
+    return false;
+}
 #ifndef __HIP_DEVICE_COMPILE__      // host-side table (in the device pass a const global would be emitted as device data)
-extern const KsOps KS_NAME = {set_attrs, launch, split14};
+extern const KsOps KS_NAME = {set_attrs, launch, split14, pair14};
 #endif

@@ -28,7 +28,7 @@
 #endif
 
 NTT_DEV uint32_t lds_pos(uint32_t e) { return e + 2u * (e >> 5); }
-__host__ __device__ inline uint32_t ntt_lds_words(uint32_t n) { return n + 2u * (n >> 5); }
+__host__ __device__ constexpr inline uint32_t ntt_lds_words(uint32_t n) { return n + 2u * (n >> 5); }
 
 NTT_DEV uint64_t ntt_mulshoup(uint64_t y, uint64_t w, uint64_t ws, uint64_t q) { return y * w - __umul64hi(ws, y) * q; }
 
@@ -322,6 +322,35 @@ template <class AR, int L, bool PRE = false> NTT_DEV void ntt_forward_regs(typen
     fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     lds_put<T, L, 4, SA + 4>(x, s, tid);
     if (ntt_tail_local<L>()) ntt_wave_sync(); else __syncthreads();       // pass C -> tail: block-local as well (tail_index)
+    lds_get_tail<T, L>(x, s, tid);
+    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    fwd_tail<AR, L>(x, tw, m, tid);
+}
+// The same transform with a caller's hook between its passes (k_keyswitch_pair14: the NEXT digit's source words are requested at one hook
+// and taken out of the memory pipeline at the next, so their latency is spent under a pass' arithmetic): hk.at<0>() in front of pass A,
+// at<1..3>() behind the arithmetic of passes A, B, C.
+template <class AR, int L, bool PRE, class HK> NTT_DEV void ntt_forward_regs_hooked(typename AR::T (&x)[16], typename AR::T *s, const typename AR::Tw &tw, const typename AR::Mod &m,
+                                                                                     uint32_t tid, HK &hk) {
+    typedef typename AR::T T;
+    constexpr int SA = NttPlan<L>::SA;
+    hk.template at<0>();
+    fwd_stages<AR, L, SA, 0>(x, tw, m, tid);
+    hk.template at<1>();
+    if (PRE) __syncthreads();
+    lds_put<T, L, SA, 0>(x, s, tid);
+    __syncthreads();
+    lds_get<T, L, 4, SA>(x, s, tid);
+    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    fwd_stages<AR, L, 4, SA>(x, tw, m, tid);
+    hk.template at<2>();
+    lds_put<T, L, 4, SA>(x, s, tid);
+    ntt_wave_sync();
+    lds_get<T, L, 4, SA + 4>(x, s, tid);
+    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
+    hk.template at<3>();
+    lds_put<T, L, 4, SA + 4>(x, s, tid);
+    if (ntt_tail_local<L>()) ntt_wave_sync(); else __syncthreads();
     lds_get_tail<T, L>(x, s, tid);
     AR::template renorm_at<RS_FWD_PASS>(x, m);
     fwd_tail<AR, L>(x, tw, m, tid);

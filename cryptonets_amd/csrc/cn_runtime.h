@@ -149,6 +149,9 @@ struct cn_ctx {
     size_t pool_bytes = 0, pool_max;
     void *slabs = nullptr;                // std::vector<Slab>*: small arrays are carved out of slabs (one hipMalloc per <= 64 arrays), cn_api.hip
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
+    bool ks_pair14 = true;    // ... both halves in ONE launch per rotation (k_keyswitch_pair14, round 5); 0 = k_keyswitch_split14 + k_ks_combine14 (+ k_galois_lds)
+    bool ks_pair_twl = false; // k_keyswitch_pair14 with the half's forward roots staged in LDS
+    bool ks_chain = true;     // SumAllSlots at N = 16384: every link of the rotate-and-add chain hands sigma_next(c1) to the next one (no permutation pass between links)
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
     char *pin = nullptr, *pin_dev = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
@@ -196,6 +199,8 @@ struct KsArgs {
     uint32_t xcd_cts = 0;     // fused kernel: ciphertexts (a multiple of 8) placed XCD-aware, see k_keyswitch_rr
     const KsItem *items = nullptr;   // two-launch variants: per-ciphertext (operand, key, element) table instead of target / add0 / key / perm_elt
     uint32_t perm_elt = 0;    // two-launch variants: Galois element of a rotation whose automorphism the kernels apply while loading (target / add0 = the UNPERMUTED c1 / c0)
+                              // k_keyswitch_pair14: target = sigma(c1) already, add0 = the UNPERMUTED c0 (permuted through LDS by the workgroup that owns the limb)
+    uint32_t next_elt = 0; uint64_t *next_out = nullptr;   // k_keyswitch_pair14: the new c1 leaves a second time as sigma_next(c1) -> next_out[ct][k][N] (rotate-and-add chains)
 };
 struct RrOps {                // register-radix kernels of one arithmetic policy; every launcher returns false when the size has no kernel
     int (*set_attrs)(uint32_t logn, size_t lds);
@@ -210,7 +215,8 @@ struct RrOps {                // register-radix kernels of one arithmetic policy
 struct KsOps {
     int (*set_attrs)(uint32_t logn, size_t lds);
     bool (*launch)(cn_ctx *c, const KsArgs &a);                        // fused / two-phase by a.mode
-    bool (*split14)(cn_ctx *c, const KsArgs &a);                       // N = 16384 as two 8192-point halves (FP64 policies)
+    bool (*split14)(cn_ctx *c, const KsArgs &a);                       // N = 16384 as two 8192-point halves (FP64 policies), k_ks_combine14 behind it
+    bool (*pair14)(cn_ctx *c, const KsArgs &a);                        // N = 16384 in one launch: both halves per (ciphertext, limb) workgroup (FP64 policies)
 };
 extern const RrOps cn_rr_u64, cn_rr_f64, cn_rr_f64l;
 extern const KsOps cn_ks_u64, cn_ks_f64, cn_ks_f64l;
