@@ -206,6 +206,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
             encrypted.append(layers[1].Apply(layers[0].GetNext()))
     if active:
         sync()
+    samples = []                                               # wall time of every timed image of this rank (the contexts are synchronised after each)
     for it in range(args.warmup + args.steps):
         if it == args.warmup:
             torch.cuda.synchronize()
@@ -214,6 +215,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
             t0 = time.perf_counter()
         if not active:
             continue
+        t_img = time.perf_counter()
         m = encrypted[it]
         for li, L in enumerate(layers[2:]):
             m2 = L.Apply(m)
@@ -228,6 +230,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
         sync()
         if it >= args.warmup:
             results.append(m)
+            samples.append(time.perf_counter() - t_img)
         else:
             m.Dispose()
     torch.cuda.synchronize()
@@ -284,6 +287,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                "value": round(images_done / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak" if args.shard == "images" else "strong",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic images" + (", synthetic weights of the reference's shapes" if cifar else ", the reference's trained weights"),
+               "ms_per_image": {"min": round(1e3 * min(samples), 2), "median": round(1e3 * float(np.median(samples)), 2), "all": [round(1e3 * x, 2) for x in samples]} if samples else None,
                "verified_against_integer_model": verified, "result_words_sha256": digest.hexdigest(),
                "launcher": os.environ.get("BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"), "process_group": "nccl" if dist is not None else None,
                "keys": ("one client: rank 0 ran KeyGenerator, every key broadcast with RCCL and adopted in place" if args.shared_keys else "every rank is its own client (own KeyGenerator)"),
@@ -299,6 +303,8 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                           "plaintext_primes": all_primes, "sharding": args.shard,
                           "parallelism": ("images round-robin over %d ranks, full replica per rank" % world) if args.shard == "images"
                                          else ("plaintext primes dealt to %d ranks, CRT join of decrypted residues on the client" % world)}}
+        if cifar and active and world == 1:
+            out["key_switch"] = cifar_key_switch_block(env.Environments[0].ctx, 1e3 * dt / args.steps, len(parms["primes"]))
         if not cifar and world == 1 and not args.no_unchanged_caller:
             # the UNCHANGED per-call sequence of the reference's LL layers (one vector method per row / column / map), recorded at the C ABI and
             # replayed from C++ (tools/lola_unchanged_caller.py): ms per image next to the batched conveniences measured the same way
@@ -327,10 +333,57 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
         dist.destroy_process_group()
 
 
+def cifar_key_switch_block(g, ms_per_image, primes):
+    """The kernel that IS a LoLa-CIFAR image: the N = 16384, k = 8 batch key switch - one launch of k_keyswitch_pair14 per
+    rotate-and-add link of the 5488-row SumAllSlots chain (14 links per plaintext prime).  Timed here with HIP events on the context's stream over a
+    5488-ciphertext array of random residues, and priced against the FP64 issue rate measured in this process right behind it (cn_valu_issue_time).
+    Instructions per thread: DYNAMIC counts of the built kernel from the committed counter passes (profiles/r05_ks14_counters.json: SQ_INSTS_VALU* per
+    launch / waves per launch) - rocprofv3 wraps a command, so this process cannot collect them itself; the file and the launch geometry it was collected on
+    are named.  Bound: VALU issue (FP64 and the other vector instructions share one issue port per SIMD); HBM-level bytes from the same passes."""
+    rows = 5488
+    n, k = g.n, g.k
+    rng = np.random.default_rng(7)
+    one = np.concatenate([rng.integers(0, int(q), size=n, dtype=np.uint64) for _ in range(2) for q in g.q])
+    blk = np.repeat(one[None, :], 64, axis=0)
+    h = g.ct_alloc(rows)
+    for i in range(0, rows, 64):
+        g.ct_upload(h, i, blk[:min(64, rows - i)])
+    g.sum_slots(h, 0, rows, 0); g.sync()
+    g.time_begin()
+    g.sum_slots(h, 0, rows, 0)
+    chain_ms = g.time_end()
+    fp64_ns = g.fp64_issue_ns(iters=4096, launches=6)
+    valu_ns = g.valu32_issue_ns(iters=16384, launches=6)
+    g.free(h)
+    links = 1 + (n // 2).bit_length() - 1                       # the column swap + log2(N/2) row rotations
+    link_ms = chain_ms / links
+    blk_ = {"kernel": "k_keyswitch_pair14 (%d ciphertexts x %d output limbs: 2 x %d digit transforms + 4 inverse half-transforms per workgroup, one launch per rotate-and-add link)" % (rows, k, k),
+            "bound": "valu issue (fp64)", "ms_per_link": round(link_ms, 3), "links_per_prime": links, "ms_per_chain": round(chain_ms, 2),
+            "share_of_image": round(primes * chain_ms / ms_per_image, 3)}
+    try:
+        import glob
+        src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ks14_counters.json")))[-1]
+        c = json.load(open(src))
+        waves = rows * k * 8
+        fp64 = c["fp64_per_wave"]; other = c["valu_per_wave"] - fp64
+        floor_fp64 = waves * fp64 / 1024 * fp64_ns * 1e-6
+        floor_valu = waves * (fp64 * fp64_ns + other * valu_ns) / 1024 * 1e-6
+        blk_.update({"fp64_per_thread": round(fp64), "valu_other_per_thread": round(other), "counts_source": os.path.relpath(src, ROOT) + " (committed rocprofv3 --pmc passes of the same launch geometry; not measured by this run)",
+                     "fp64_ns_per_instr_in_situ": round(fp64_ns, 3), "valu32_ns_per_instr_in_situ": round(valu_ns, 3),
+                     "fp64_issue_floor_in_situ_ms": round(floor_fp64, 2), "frac": round(floor_fp64 / link_ms, 3),
+                     "valu_issue_floor_in_situ_ms": round(floor_valu, 2), "frac_valu_in_situ": round(floor_valu / link_ms, 3),
+                     "hbm_level_bytes_per_link": c.get("hbm_bytes_per_launch"), "hbm_frac": round(c["hbm_bytes_per_launch"] / (link_ms * 1e-3) / 8e12, 3) if c.get("hbm_bytes_per_launch") else None,
+                     "algorithmic_bytes_per_link": rows * 2 * k * n * 8 * 2,          # x + rot(x) in place: every ciphertext read once and written once (the Galois key, 16 MiB, is shared by all)
+                     "rounds_1_to_4_ms_per_link": c.get("rounds_1_to_4_ms_per_link")})
+    except Exception as ex:
+        blk_.update({"frac": None, "counts_error": str(ex)[:200]})
+    return blk_
+
+
 def single_image_lines(gpu_index):
     """BASELINE configs 4 and 5 on the driver's line: `python bench.py --workload lola|cifar` run as child processes of the default
     workload (a process of their own: every plaintext-prime channel then gets a hardware queue of its own, cn_api.hip pick_stream) on the same GPU,
-    bounded - LoLa-MNIST 20 timed images + the unchanged-caller replay, LoLa-CIFAR 1 warm-up + 1 timed image - each verified against the exact integer
+    bounded - LoLa-MNIST 20 timed images + the unchanged-caller replay, LoLa-CIFAR 2 warm-up + 3 timed images (min / median / all samples travel with the line) - each verified against the exact integer
     model inside its run.  A child that fails or exceeds its time limit is reported with the reason instead of a number."""
     import subprocess
     # (OMP_*: cpu_baseline sets OMP_PROC_BIND=spread for the oracle's OpenMP team in THIS process; inherited, it binds the child's initial thread to one core
@@ -366,14 +419,16 @@ def single_image_lines(gpu_index):
     if d is not None:
         u = d.get("unchanged_caller") or {}
         lola.update({"metric": d["metric"], "ms_per_image": d["ms_per_step"], "images_per_s": d["value"], "steps": d["steps"],
+                     "ms_per_image_samples": d.get("ms_per_image"),
                      "verified": d["verified_against_integer_model"], "verified_what": d["verified_what"], "plaintext_primes": d["config"]["plaintext_primes"],
                      "unchanged_caller_ms": u.get("ms_per_image"), "unchanged_caller_logits_exact": u.get("logits_exact"), "launches_per_prime": u.get("launches_per_prime"),
                      "calls_per_prime": u.get("calls_per_prime"), "batched_from_the_same_host_ms": u.get("batched_from_the_same_host_ms"),
                      "unchanged_frac_of_batched": u.get("frac_of_batched"), "unchanged_caller_error": u.get("error")})
-    d, cifar = child("cifar", 1, 1, 300)
+    d, cifar = child("cifar", 3, 2, 300)                       # steady state: two untimed images (work arrays at their final size), three timed
     if d is not None:
-        cifar.update({"metric": d["metric"], "s_per_image": round(d["ms_per_step"] / 1e3, 3), "steps": d["steps"], "verified": d["verified_against_integer_model"],
-                      "verified_what": d["verified_what"], "plaintext_primes": d["config"]["plaintext_primes"], "data": d["data"]})
+        cifar.update({"metric": d["metric"], "s_per_image": round(d["ms_per_step"] / 1e3, 3), "ms_per_image": d.get("ms_per_image"), "steps": d["steps"], "warmup": d["warmup"],
+                      "verified": d["verified_against_integer_model"], "verified_what": d["verified_what"], "plaintext_primes": d["config"]["plaintext_primes"], "data": d["data"],
+                      "key_switch": d.get("key_switch")})
     return lola, cifar
 
 

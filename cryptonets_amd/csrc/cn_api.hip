@@ -350,10 +350,9 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     // fused key switch, workgroup order: limb-major up to N = 8192 (one key slice per XCD L2 at a time: 2.34 GiB fetched per 845-ciphertext launch
     // against 3.99 GiB in (ciphertext, limb) order and 3.0 GiB with the limbs of a ciphertext on one XCD, same kernel time -
     // profiles/r03_pmc_keyswitch_orders.txt); (ciphertext, limb) order at N = 16384, where limb-major measured 30 % slower in round 1
-    c->ks_xcd = c->hc.logn <= 13 ? 2 : 0;
+    c->ks_xcd = c->hc.logn <= 13 ? 2 : 1;            // N = 16384 (k_keyswitch_pair14): the k workgroups of a ciphertext on one XCD - they share its source limbs in that L2 (34.3 vs 35.1 ms per 5488-ciphertext link)
     if (getenv("CN_KS_XCD")) c->ks_xcd = atoi(getenv("CN_KS_XCD"));
     if (getenv("CN_KS_PAIR14")) c->ks_pair14 = atoi(getenv("CN_KS_PAIR14")) != 0;             // A/B switches of the N = 16384 key switch (round 5)
-    if (getenv("CN_KS_PAIR_TWL")) c->ks_pair_twl = atoi(getenv("CN_KS_PAIR_TWL")) != 0;
     if (getenv("CN_KS_CHAIN")) c->ks_chain = atoi(getenv("CN_KS_CHAIN")) != 0;
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
@@ -427,7 +426,6 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     if (!strcmp(name, "ks_pair14")) { ctx->ks_pair14 = value != 0; return 0; }
-    if (!strcmp(name, "ks_pair_twl")) { ctx->ks_pair_twl = value != 0; return 0; }
     if (!strcmp(name, "ks_chain")) { ctx->ks_chain = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     if (!strcmp(name, "ks_xi")) {                // decomposition convention of the key switch (DevConsts::ks_xi); the keys must be of the same convention
@@ -449,7 +447,6 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "ks_xi")) *value = (int)ctx->hc.ks_xi;
     else if (!strcmp(name, "ks_xcd")) *value = ctx->ks_xcd;
     else if (!strcmp(name, "ks_pair14")) *value = ctx->ks_pair14;
-    else if (!strcmp(name, "ks_pair_twl")) *value = ctx->ks_pair_twl;
     else if (!strcmp(name, "ks_chain")) *value = ctx->ks_chain;
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;

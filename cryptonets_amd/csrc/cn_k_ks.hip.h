@@ -278,6 +278,9 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
 #ifndef KS14_DBG
 #define KS14_DBG 0          // timing experiments (tools/build_ks14_dbg.py; results are wrong with any bit set): 1 no c0 staging, 2 no accumulator, 4 no stash,
 #endif                      // 8 no closing arithmetic, 16 synthetic digit sources (no loads), 32 synthetic keys (no loads)
+#ifndef KS14_WARM
+#define KS14_WARM 0
+#endif
 #ifndef KS14_PREFETCH
 #define KS14_PREFETCH 1     // 0: every digit loads its source words at its start (A/B)
 #endif
@@ -291,7 +294,9 @@ template <class AR, bool XI> struct Ks14Stage0 {
         return AR::center(__fma_rn(sg, AR::mulmod(Y, w1, m), X), m);         // x +- w y
     }
 };
-// the hook of ntt_forward_regs_hooked: piece c of the next digit's 16 pairs = registers 4c .. 4c+3
+// the hook of ntt_forward_regs_hooked: piece c of the next digit's 16 pairs = registers 4c .. 4c+3, requested at boundary c, parked at boundary c + 1
+// (Measured, not kept: the multiply-accumulate of a digit moved behind the NEXT digit's first pass - its 32 key words requested when that digit starts, the
+// transformed values waiting in the thread's LDS slots meanwhile - to spend the key round trip (3.6 ms of 35 per link) under arithmetic: 37.8 vs 35.9 ms.)
 template <class AR, bool XI> struct Ks14Next {
     typedef typename AR::T T;
     static constexpr uint32_t n2 = 8192, NT = 512;
@@ -343,6 +348,19 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
     const uint32_t tot = galois ? C->gk_tot : C->rl_tot;
     double *stp = stash + ((size_t)ct * k + j) * 2 * n2;
     const uint64_t *tgt = target + (size_t)ct * tgt_stride;
+#if KS14_WARM
+    // (experiment) the closing step touches ~8 arrays this workgroup has not seen before: one word of each now, so that the address translations are in
+    // place when the closing loads arrive
+    uint64_t warm = 0;
+    if (tid < 16) {
+        const uint32_t w = tid & 7;
+        const uint64_t *ob = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)j * n;
+        const uint64_t *a = w == 0 ? (add0 ? add0 + (size_t)ct * add_stride + (size_t)j * n : ob) : w == 1 ? (add1 ? add1 + (size_t)ct * add_stride + (size_t)j * n : ob)
+                          : w == 2 ? (extra ? extra + (size_t)ct * ex_stride + (size_t)j * n : ob) : w == 3 ? (extra ? extra + (size_t)ct * ex_stride + kn + (size_t)j * n : ob)
+                          : w == 4 ? ob : w == 5 ? ob + kn : w == 6 ? (const uint64_t *)stp : (next_out ? next_out + (size_t)ct * kn + (size_t)j * n : ob);
+        warm = a[(tid >> 3) * (n - 1)];
+    }
+#endif
 #pragma unroll 1
     for (uint32_t h = 0; h < 2; h++) {
         const GP fwg = (GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2);
@@ -354,7 +372,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
         T acc0[16], acc1[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
-        const T *kp = reinterpret_cast<const T *>(key_);
+        const T *kp = reinterpret_cast<const T *>(key_) + (size_t)j * n + (size_t)h * n2;      // digit g: component 0 at kp + g 2kN, component 1 kN behind
         uint32_t terms = 0, l = 0, d = 0;
         for (uint32_t g = 0; g < tot; g++, kp += 2 * kn) {
             uint32_t tl = tid;
@@ -362,9 +380,10 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
             // the digit behind this one
             uint32_t ln = l, dn = d + 1;
             if (dn == (galois ? C->gk_dig[l] : C->rl_dig[l])) { ln = l + 1; dn = 0; }
-            Ks14Next<AR, XI> nx{st0, (KS14_PREFETCH && !(KS14_DBG & 16) && g + 1 < tot) ? tgt + (size_t)ln * n : nullptr, ln, dbc * (int)dn, park, tl};
+            const bool pf = KS14_PREFETCH && !(KS14_DBG & 16);
+            Ks14Next<AR, XI> nx{st0, (pf && g + 1 < tot) ? tgt + (size_t)ln * n : nullptr, ln, dbc * (int)dn, park, tl};
             T v[16];
-            if (KS14_PREFETCH && !(KS14_DBG & 16) && g) {
+            if (pf && g) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = park[(uint32_t)r * NT + tl];
             } else {
@@ -378,7 +397,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
                 }
             }
             ntt_forward_regs_hooked<FW, L, KS_PRE_SYNC != 0>(v, s, fwh, A.m, tl, nx);
-            const T *k0 = kp + (size_t)j * n + (size_t)h * n2, *k1 = k0 + kn;
+            const T *k0 = kp, *k1 = kp + kn;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const uint32_t pos = tail_index<L>(tl, r);
@@ -460,6 +479,9 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
                 }
             }
             __syncthreads();
+#if KS14_WARM
+            asm volatile("" :: "v"(warm));
+#endif
             if (chain) {
                 NTT_GLOBAL uint64_t *no = (NTT_GLOBAL uint64_t *)next_out + (size_t)ct * kn + (size_t)j * n;
 #pragma unroll 8

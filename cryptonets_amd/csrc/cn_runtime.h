@@ -150,7 +150,6 @@ struct cn_ctx {
     void *slabs = nullptr;                // std::vector<Slab>*: small arrays are carved out of slabs (one hipMalloc per <= 64 arrays), cn_api.hip
     bool ks_split14 = true;   // N = 16384: key switch as two 8192-point halves per limb (no register spills); 0 = fused 1024-thread kernel
     bool ks_pair14 = true;    // ... both halves in ONE launch per rotation (k_keyswitch_pair14, round 5); 0 = k_keyswitch_split14 + k_ks_combine14 (+ k_galois_lds)
-    bool ks_pair_twl = false; // k_keyswitch_pair14 with the half's forward roots staged in LDS
     bool ks_chain = true;     // SumAllSlots at N = 16384: every link of the rotate-and-add chain hands sigma_next(c1) to the next one (no permutation pass between links)
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]

@@ -555,13 +555,12 @@ def test_key_switch_variants_agree(name, f64, rng):
     exp_rot = [o.rotate_rows(c, -3) for c in cts]
     exp_col = [o.rotate_columns(c) for c in cts]
     try:
-        # (ks_wide, ks_split14, ks_pair14, ks_pair_twl): fused, two-launch, and - N = 16384 only - the one-launch both-halves kernel (round 5; with and
-        # without its LDS root table), the two-workgroups-per-limb kernel + combining pass of rounds 1-4, the fused 1024-thread kernel
-        for wide, split, pair, twl in ((0, 1, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0)) + (((0, 1, 1, 1), (0, 1, 0, 0), (0, 0, 1, 0)) if o.n == 16384 else ()):
+        # (ks_wide, ks_split14, ks_pair14): fused, two-launch, and - N = 16384 only - the one-launch both-halves kernel (round 5), the
+        # two-workgroups-per-limb kernel + combining pass of rounds 1-4, the fused 1024-thread kernel
+        for wide, split, pair in ((0, 1, 1), (1, 1, 1), (2, 1, 1)) + (((0, 1, 0), (0, 0, 1)) if o.n == 16384 else ()):
             g.set_option("ks_wide", wide)
             g.set_option("ks_split14", split)
             g.set_option("ks_pair14", pair)
-            g.set_option("ks_pair_twl", twl)
             for i in range(3):
                 g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
             assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_mul)), wide
@@ -573,7 +572,6 @@ def test_key_switch_variants_agree(name, f64, rng):
         g.set_option("ks_wide", -1)
         g.set_option("ks_split14", 1)
         g.set_option("ks_pair14", 1)
-        g.set_option("ks_pair_twl", 0)
     for x in (h, out):
         g.free(x)
 
@@ -603,15 +601,15 @@ def test_sum_slots_chain_at_n16384(name, rng):
         g.set_option("ks_wide", 0)
         for length in (0, 8, 4):
             exp2 = [reference(c, length) for c in cts[:2]]
-            for pair, chain, twl, xcd in ((1, 1, 0, 0), (1, 0, 0, 0), (1, 1, 1, 0), (0, 1, 0, 0)) + (((1, 1, 0, 1),) if length == 8 else ()):
-                g.set_option("ks_pair14", pair); g.set_option("ks_chain", chain); g.set_option("ks_pair_twl", twl); g.set_option("ks_xcd", xcd)
+            for pair, chain, xcd in ((1, 1, 0), (1, 0, 0), (0, 1, 0)) + (((1, 1, 1),) if length == 8 else ()):
+                g.set_option("ks_pair14", pair); g.set_option("ks_chain", chain); g.set_option("ks_xcd", xcd)
                 g.ct_upload(h, 0, cts)
                 g.sum_slots(h, 0, 9 if xcd else 2, length)
                 exp = np.stack(exp2 + [reference(cts[2], length) if xcd else cts[2]])      # (the third one is outside the range unless all 9 are summed)
-                assert np.array_equal(g.ct_download(h, 0, 3), exp), (length, pair, chain, twl, xcd)
+                assert np.array_equal(g.ct_download(h, 0, 3), exp), (length, pair, chain, xcd)
                 if xcd:                                                        # 8 ciphertexts in the XCD-aware order + 1 in the plain one
                     assert np.array_equal(g.ct_download(h, 8, 1)[0], reference(cts[8], length))
-        g.set_option("ks_pair14", 1); g.set_option("ks_chain", 1); g.set_option("ks_pair_twl", 0); g.set_option("ks_xcd", 0)
+        g.set_option("ks_pair14", 1); g.set_option("ks_chain", 1); g.set_option("ks_xcd", 0)
         g.ct_upload(h, 0, cts)
         g.rotate_rows_add(h, 0, -2, h, 1, h, 2, 1)                            # three different arrays
         assert np.array_equal(g.ct_download(h, 2, 1)[0], o.add(cts[1], o.rotate_rows(cts[0], -2)))
@@ -619,7 +617,7 @@ def test_sum_slots_chain_at_n16384(name, rng):
         assert np.array_equal(g.ct_download(h, 1, 1)[0], o.add(cts[1], o.rotate_columns(cts[0])))
         assert np.array_equal(g.ct_download(h, 0, 1)[0], cts[0])
     finally:
-        for name_, v in (("ks_wide", -1), ("ks_pair14", 1), ("ks_chain", 1), ("ks_pair_twl", 0), ("ks_xcd", 0)):
+        for name_, v in (("ks_wide", -1), ("ks_pair14", 1), ("ks_chain", 1), ("ks_xcd", 1)):
             g.set_option(name_, v)
         g.free(h)
 
@@ -627,7 +625,7 @@ def test_sum_slots_chain_at_n16384(name, rng):
 def test_multi_digit_key_switch_at_n16384(rng):
     """The N = 16384 batch kernels with SEVERAL digits per source limb (the reference's N = 16384 networks use one 60-bit digit): three of the CIFAR
     primes with dbc 20 / gdbc 25 (3 and 2 digits per limb) - relinearisation, a rotation and a short SumAllSlots chain on the one-launch kernel
-    (plain and with the LDS root table) and on the kernels of rounds 1-4, both key-switch conventions' default, against the oracle."""
+    and on the kernels of rounds 1-4 against the oracle."""
     from cryptonets_amd._native import Context
     from oracle.cno import Oracle
     p = PARAMS["c5"]
@@ -643,16 +641,16 @@ def test_multi_digit_key_switch_at_n16384(rng):
     exp_rot = np.stack([o.rotate_rows(c, 5) for c in cts])
     exp_sum = np.stack([o.add(x, o.rotate_rows(x, -2)) for x in [o.add(c, o.rotate_rows(c, -1)) for c in cts]])
     g.set_option("ks_wide", 0)
-    for pair, twl in ((1, 0), (1, 1), (0, 0)):
-        g.set_option("ks_pair14", pair); g.set_option("ks_pair_twl", twl)
+    for pair in (1, 0):
+        g.set_option("ks_pair14", pair)
         for i in range(3):
             g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
-        assert np.array_equal(g.ct_download(out, 0, 3), exp_mul), (pair, twl)
+        assert np.array_equal(g.ct_download(out, 0, 3), exp_mul), pair
         g.rotate_rows(h, 0, 5, out, 0, 3)
-        assert np.array_equal(g.ct_download(out, 0, 3), exp_rot), (pair, twl)
+        assert np.array_equal(g.ct_download(out, 0, 3), exp_rot), pair
         g.copy(h, 0, out, 0, 3)
         g.sum_slots(out, 0, 3, 4)
-        assert np.array_equal(g.ct_download(out, 0, 3), exp_sum), (pair, twl)
+        assert np.array_equal(g.ct_download(out, 0, 3), exp_sum), pair
     g.close()
 
 
@@ -690,14 +688,13 @@ def test_key_switch_xi_convention_variants_agree(name, f64, legacy, rng):
             g.set_relin_key(o.relin_key())
             for i, e in enumerate(elts):
                 g.set_galois_key(e, o.galois_key(i))
-        for wide, split, pair, twl in ((0, 1, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0)) + (((0, 1, 1, 1), (0, 1, 0, 0), (0, 0, 1, 0)) if o.n == 16384 else ()):
+        for wide, split, pair in ((0, 1, 1), (1, 1, 1), (2, 1, 1)) + (((0, 1, 0), (0, 0, 1)) if o.n == 16384 else ()):
             g.set_option("ks_wide", wide)
             g.set_option("ks_split14", split)
             g.set_option("ks_pair14", pair)
-            g.set_option("ks_pair_twl", twl)
             for i in range(3):
                 g.mul_relin(h, i, h, (i + 1) % 3, out, i, 1)
-            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_mul)), (wide, split, pair, twl, coeff_form)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_mul)), (wide, split, pair, coeff_form)
             g.rotate_rows(h, 0, -3, out, 0, 3)
             assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_rot)), (wide, split, coeff_form)
             g.rotate_columns(h, 0, out, 0, 3)

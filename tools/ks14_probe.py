@@ -11,8 +11,7 @@ from cryptonets_amd._native import Context
 
 args = sys.argv[1:]
 cnt = int(args[0]) if args and args[0].isdigit() else 5488
-variants = [a for a in args if "=" in a] or ["ks_pair14=0", "ks_pair14=1,ks_chain=0", "ks_pair14=1,ks_chain=1", "ks_pair14=1,ks_chain=1,ks_pair_twl=1",
-                                             "ks_pair14=1,ks_chain=1,ks_xcd=1", "ks_pair14=1,ks_chain=1,ks_pair_twl=1,ks_xcd=1"]
+variants = [a for a in args if "=" in a] or ["ks_pair14=0", "ks_pair14=1,ks_chain=0,ks_xcd=0", "ks_pair14=1,ks_chain=1,ks_xcd=0", "ks_pair14=1,ks_chain=1,ks_xcd=1"]
 Q = [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001, 0x1ffffffea0001, 0x1ffffffe88001]
 g = Context(16384, 957181001729, q=Q, dbc=60, gdbc=60)
 rng = np.random.default_rng(1)
@@ -27,7 +26,7 @@ blk = np.repeat(one[None, :], 64, axis=0)
 def fill():
     for i in range(0, cnt, 64):
         g.ct_upload(h, i, blk[:min(64, cnt - i)])
-defaults = dict(ks_pair14=1, ks_chain=1, ks_pair_twl=0, ks_xcd=0)
+defaults = dict(ks_pair14=1, ks_chain=1, ks_xcd=1)
 print("N = 16384, k = 8, %d ciphertexts (%.1f GiB)" % (cnt, cnt * 2 * k * n * 8 / 2**30))
 for var in variants * 2:
     opts = dict(defaults); opts.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in var.split(",")})
