@@ -23,6 +23,9 @@
 #ifndef NTT_STAGE_FENCE
 #define NTT_STAGE_FENCE 0
 #endif
+#ifndef NTT_FWD_RECENTRE_ALL
+#define NTT_FWD_RECENTRE_ALL 0      // 1: the forward FP64 transform of moduli above 44 bits recentres before every pass (rounds 1-4; A/B)
+#endif
 #ifndef NTT_TAIL_LOCAL
 #define NTT_TAIL_LOCAL 1      // D = 1: the last pass stays inside the half-wave that owns a 512-coefficient block (see tail_index)
 #endif
@@ -61,10 +64,17 @@ struct ArU64 {
 // r = fma(-h, q, p) + e is EXACT (|r| <= 2q).  v_fma_f64 is half rate like v_mad_u64_u32 but yields a 53-bit product, so a
 // butterfly is 8 FP64 instructions instead of ~60 integer ones; results are bit-identical after canonicalisation.
 // recentring sites of a transform
-enum { RS_FWD_PASS = 0, RS_INV_START = 1, RS_INV_C = 2, RS_INV_B = 3, RS_INV_A = 4 };
+enum { RS_FWD_B = 0, RS_INV_START = 1, RS_INV_C = 2, RS_INV_B = 3, RS_INV_A = 4, RS_FWD_C = 5, RS_FWD_TAIL = 6 };
 
-// RN = 1: recentre before every pass (valid for q < 2^49.4).  RN = 0: moduli <= 44 bits have 2^9 of head-room - the forward
-// transform never recentres (|x| <= q + 13*2.1q = 28.3q < 2^49), the inverse only where the doubling sum path needs it.
+// RN = 0: moduli <= 44 bits have 2^9 of head-room - the forward transform never recentres (|x| <= q + 13*2.1q = 28.3q < 2^49), the
+// inverse only where the doubling sum path needs it.
+// RN = 1: moduli below 2^49 (cn_build_f64_tables admits nothing larger).  A forward butterfly is X +- r with r = mulmod(Y, w):
+// |h - Yw/q| <= 1/2 + |Yw/q| 3 2^-53 (three roundings: the product, 1/q, their product), so for |Y| <= B q and w < q < 2^49
+// |r| <= (1/2 + 0.1875 B) q and a stage takes the bound b (in units of q) to 1.1875 b + 1/2: from canonical input (b = 1) the eight stages
+// of the first two passes reach 11.83 q < 2^53 / q = 16 q, from a recentred image (b = 1/2) the six stages of the last two 6.22 q.  So the
+// forward transform recentres ONCE, in front of the third pass (round 5; before every pass until then: 2 x 48 FP64 instructions of ~1400
+// per transform more); its output is |x| <= 6.3 q (consumers multiply by a canonical word or recentre).  The inverse doubles its sum path
+// every stage and keeps recentring before every pass.
 template <int RN> struct ArF64T {
     typedef double T;
     struct Mod { double q, qinv; };
@@ -94,7 +104,8 @@ template <int RN> struct ArF64T {
         for (int r = 0; r < 16; r++) x[r] = center(x[r], m);
     }
     template <int SITE> static NTT_DEV void renorm_at(T (&x)[16], const Mod &m) {
-        if (RN == 1 || SITE == RS_INV_START || SITE == RS_INV_B || SITE == RS_INV_A) renorm(x, m);
+        if (SITE == RS_FWD_B || SITE == RS_FWD_TAIL) { if (NTT_FWD_RECENTRE_ALL && RN == 1) renorm(x, m); }
+        else if (RN == 1 || SITE == RS_INV_START || SITE == RS_INV_B || SITE == RS_INV_A) renorm(x, m);
     }
     static NTT_DEV uint64_t to_u64(double x, const Mod &m) {        // canonical residue of any |x| < 2^53
         double r = center(x, m);
@@ -301,7 +312,7 @@ NTT_DEV void ntt_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // Forward transform.  In: x[r] = coefficient pass_index<L,SA,0>(tid,r) (canonical).  Out: x[r] = value at bit-reversed
-// position tail_index<L>(tid,r), lazy (U64: [0,4q); F64: |x| <= 4.5q).  `s` = LDS scratch of ntt_lds_words(N) elements.
+// position tail_index<L>(tid,r), lazy (U64: [0,4q); F64: |x| <= 6.3q, see ArF64T).  `s` = LDS scratch of ntt_lds_words(N) elements.
 // PRE: a kernel that pushes one transform after another through the same image (key switch) passes PRE = true instead of ending
 // every iteration with a barrier: the barrier "everybody has finished reading the previous image" then sits AFTER the first pass'
 // arithmetic, where stragglers have 256 FP64 instructions of slack, and the barrier behind the put finds the waves already aligned.
@@ -313,17 +324,17 @@ template <class AR, int L, bool PRE = false> NTT_DEV void ntt_forward_regs(typen
     lds_put<T, L, SA, 0>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA>(x, s, tid);
-    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    AR::template renorm_at<RS_FWD_B>(x, m);
     fwd_stages<AR, L, 4, SA>(x, tw, m, tid);
     lds_put<T, L, 4, SA>(x, s, tid);
     ntt_wave_sync();                      // pass B -> C stays inside the 2^(4+D) threads that own one 2^(8+D)-coefficient block
     lds_get<T, L, 4, SA + 4>(x, s, tid);
-    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    AR::template renorm_at<RS_FWD_C>(x, m);
     fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     lds_put<T, L, 4, SA + 4>(x, s, tid);
     if (ntt_tail_local<L>()) ntt_wave_sync(); else __syncthreads();       // pass C -> tail: block-local as well (tail_index)
     lds_get_tail<T, L>(x, s, tid);
-    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    AR::template renorm_at<RS_FWD_TAIL>(x, m);
     fwd_tail<AR, L>(x, tw, m, tid);
 }
 // The same transform with a caller's hook between its passes (k_keyswitch_pair14: the NEXT digit's source words are requested at one hook
@@ -340,19 +351,19 @@ template <class AR, int L, bool PRE, class HK> NTT_DEV void ntt_forward_regs_hoo
     lds_put<T, L, SA, 0>(x, s, tid);
     __syncthreads();
     lds_get<T, L, 4, SA>(x, s, tid);
-    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    AR::template renorm_at<RS_FWD_B>(x, m);
     fwd_stages<AR, L, 4, SA>(x, tw, m, tid);
     hk.template at<2>();
     lds_put<T, L, 4, SA>(x, s, tid);
     ntt_wave_sync();
     lds_get<T, L, 4, SA + 4>(x, s, tid);
-    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    AR::template renorm_at<RS_FWD_C>(x, m);
     fwd_stages<AR, L, 4, SA + 4>(x, tw, m, tid);
     hk.template at<3>();
     lds_put<T, L, 4, SA + 4>(x, s, tid);
     if (ntt_tail_local<L>()) ntt_wave_sync(); else __syncthreads();
     lds_get_tail<T, L>(x, s, tid);
-    AR::template renorm_at<RS_FWD_PASS>(x, m);
+    AR::template renorm_at<RS_FWD_TAIL>(x, m);
     fwd_tail<AR, L>(x, tw, m, tid);
 }
 // Inverse transform (without the 1/N factor).  In: x[r] = value at position tail_index<L>(tid,r) (U64: [0,2q); F64: any
