@@ -164,8 +164,10 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
         if args.shard != "images":
             raise SystemExit("--shared-keys goes with --shard images (with --shard primes every rank owns different plaintext primes: nothing to share)")
         from cryptonets_amd.client import SharedKeyDeviceClient
+        # with_client_keys: every benchmark rank also plays the data owner (it encrypts its own images and decrypts its logits to verify them), so the client's
+        # public and secret key travel too - the library's default is evaluation keys only (distributed.BroadcastKeys)
         parms["device_client_factory"] = lambda ctx, t: SharedKeyDeviceClient(ctx, dist, dev, 0, seed=None if args.client_seed is None else args.client_seed ^ t,
-                                                                                exchanges=exchanges)
+                                                                                exchanges=exchanges, with_client_keys=True)
     rng = np.random.default_rng(5)
     if cifar:
         qz = lambda a, sc: np.rint(a * sc) / sc
@@ -290,7 +292,7 @@ def single_image_workload(args, rank, world, local, dist, torch, result_fd):
                "ms_per_image": {"min": round(1e3 * min(samples), 2), "median": round(1e3 * float(np.median(samples)), 2), "all": [round(1e3 * x, 2) for x in samples]} if samples else None,
                "verified_against_integer_model": verified, "result_words_sha256": digest.hexdigest(),
                "launcher": os.environ.get("BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"), "process_group": "nccl" if dist is not None else None,
-               "keys": ("one client: rank 0 ran KeyGenerator, every key broadcast with RCCL and adopted in place" if args.shared_keys else "every rank is its own client (own KeyGenerator)"),
+               "keys": ("one client: rank 0 ran KeyGenerator, every evaluation key broadcast with RCCL and adopted in place; the client keys travel too (explicit opt-in: every benchmark rank decrypts its own logits)" if args.shared_keys else "every rank is its own client (own KeyGenerator)"),
                "key_broadcast": ({"bytes": sum(b for b, _ in exchanges), "ms": round(1e3 * sum(t for _, t in exchanges), 2), "contexts": len(exchanges),
                                   "GB_per_s": round(sum(b for b, _ in exchanges) / max(1e-9, sum(t for _, t in exchanges)) / 1e9, 2),
                                   "keys_per_context": 1 + 2 * (parms["n"].bit_length() - 2) + 2,

@@ -429,7 +429,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "ks_chain")) { ctx->ks_chain = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     if (!strcmp(name, "ks_xi")) {                // decomposition convention of the key switch (DevConsts::ks_xi); the keys must be of the same convention
-        if (ctx->capturing) return fail(CN_ERR_ARG, "ks_xi cannot change while a graph is recorded");
+        if (ctx->capturing || ctx->graphs_alive) return fail(CN_ERR_ARG, "ks_xi cannot change while a graph is recorded or alive (its kernels were chosen for the other convention)");
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->hc.ks_xi = value != 0;
         HIPCHK(hipMemcpy(ctx->dc, &ctx->hc, sizeof(DevConsts), hipMemcpyHostToDevice));
@@ -1789,7 +1789,7 @@ static int gen_ksk(cn_ctx *ctx, const uint64_t *snew, int dbc, const uint32_t *d
             CHECK(sample_poly(ctx, p + kn, 1, 2, seed, 3));                 // a: uniform, directly in the NTT domain
             CHECK(sample_poly(ctx, e, 1, 1, seed, 1));
             CHECK(cn_run_ntt(ctx, e, k, 0, k, 0));
-            // message term 2^(dbc d) snew in limb l only; "ks_xi": (q/q_l) 2^(dbc d) snew in every limb (DevConsts::ks_xi)
+            // message term 2^(dbc d) snew in limb l only; "ks_xi": the RNS image of (q/q_l) 2^(dbc d) snew = (q/q_l mod q_l) 2^(dbc d) snew in limb l, zero elsewhere (DevConsts::ks_xi)
             KeyFactors fac{};
             for (uint32_t j = 0; j < k; j++) {
                 if (!ctx->hc.ks_xi && j != l) continue;
@@ -2612,6 +2612,16 @@ done:
     for (void *cm : comms) if (cm) (void)R.CommDestroy(cm);
     for (int i = 1; i < n; i++) {
         CnGuard lk(ctxs[i]->mu);
+        // the keys are of ONE decomposition convention (cn_set_option("ks_xi"), settled per context by the client's start-up self-test): a replica that adopts the
+        // root's keys adopts its convention with them - with the other one every Relinearize / Rotate would return rc 0 and garbage
+        if (!rc && ctxs[i]->hc.ks_xi != root->hc.ks_xi) {
+            if (ctxs[i]->capturing || ctxs[i]->graphs_alive) rc = fail(CN_ERR_ARG, "context %d holds recorded graphs of the other key-switch convention", i);
+            else {
+                (void)hipSetDevice(ctxs[i]->device);
+                ctxs[i]->hc.ks_xi = root->hc.ks_xi;
+                if (hipMemcpy(ctxs[i]->dc, &ctxs[i]->hc, sizeof(DevConsts), hipMemcpyHostToDevice) != hipSuccess) rc = fail(CN_ERR_HIP, "constant upload failed on context %d", i);
+            }
+        }
         for (size_t x = 0; x < items.size(); x++) {
             if (!dst[i][x]) continue;
             if (rc) { (void)hipSetDevice(ctxs[i]->device); (void)hipFree(dst[i][x]); continue; }

@@ -62,8 +62,9 @@ struct DevConsts {
     uint32_t rl_dig[CN_MAXK], gk_dig[CN_MAXK], rl_tot, gk_tot;
     // Decomposition convention of the key switch (cn_set_option("ks_xi")).  0 (default): the digits are those of the RAW residue c_l of source limb l
     // and key (l, d) carries 2^(dbc d) s' in limb l only - the CRT-basis form (q/q_l) [(q/q_l)^-1]_{q_l} = delta_{jl} of SURVEY 9.5.  1: the digits are
-    // those of xi_l = [c_l (q/q_l)^-1]_{q_l} and key (l, d) carries (q/q_l) 2^(dbc d) s' in EVERY limb (the BEHZ paper's xi_q decomposition).  Both are
-    // exact key switches; the keys of one do not work with the digits of the other.  qhat_q[l][j] = (q/q_l) mod q_j.
+    // those of xi_l = [c_l (q/q_l)^-1]_{q_l} and key (l, d) carries the RNS image of (q/q_l) 2^(dbc d) s' (the BEHZ paper's xi_q decomposition) - which is zero in
+    // every limb but l, where it is (q/q_l mod q_l) 2^(dbc d) s': the same key shape with the scalar (q/q_l mod q_l) moved from the digits into the key.  Both are
+    // exact key switches; the keys of one do not work with the digits of the other.  qhat_q[l][j] = (q/q_l) mod q_j (0 unless j == l: only the diagonal is used).
     uint32_t ks_xi;
     uint64_t qhat_q[CN_MAXK][CN_MAXK];
 };

@@ -318,7 +318,7 @@ __global__ void k_sample_uniform(uint64_t *__restrict__ out, const DevConsts *__
     for (int c = 0; c < 8; c++) out[(size_t)limb * n + (size_t)b * 8 + c] = v[c];
 }
 // b = -(a s + e) + f[limb] snew: the first component of a public key (f all zero) or of key-switch key (l, d) - f = 2^(dbc d) in limb l and zero
-// elsewhere, or (q/q_l) 2^(dbc d) mod q_j in every limb j under cn_set_option("ks_xi", 1)
+// elsewhere, or (q/q_l) 2^(dbc d) mod q_j under cn_set_option("ks_xi", 1) (again zero unless j == l: q_j divides q/q_l)
 struct KeyFactors { uint64_t f[CN_MAXK]; };
 __global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, KeyFactors fac, uint64_t *b,
                         const DevConsts *__restrict__ C, uint32_t chunks) {

@@ -86,11 +86,12 @@ class BroadcastKeys:
     """ONE client's keys on every rank (north_star: "RCCL broadcast of evaluation/Galois keys over xGMI and no cross-GPU reduction"): rank
     `src` has generated them (KeyGenerator on its GPU or uploaded there); every key is broadcast as a device tensor - backend "nccl" = RCCL - and ADOPTED
     in place by the receiving context (cn_set_relin_key / cn_set_galois_key with is_device_ptr = 1: no host copy; the library converts the buffer to its
-    FP64 key image in place).  The tensors must stay alive as long as the context uses them: this object owns them.  `with_client_keys`: the public and
-    secret key travel too (a benchmark rank also plays the data owner that encrypts the inputs and decrypts the logits; a real server receives the
-    evaluation keys only).  bytes / seconds of the whole exchange are recorded."""
+    FP64 key image in place).  The tensors must stay alive as long as the context uses them: this object owns them.  The key-switch convention the
+    source settled on (cn_set_option("ks_xi"): the keys are of ONE convention) travels with the keys.  `with_client_keys` (default False: an evaluation
+    server only ever receives public evaluation keys): the public and the SECRET key travel too - a benchmark rank that also plays the data owner
+    (encrypts the inputs, decrypts the logits to verify them) asks for it explicitly.  bytes / seconds of the whole exchange are recorded."""
 
-    def __init__(self, ctx, src, device, dist, with_galois=True, with_client_keys=True, adopt_on_src=None):
+    def __init__(self, ctx, src, device, dist, with_galois=True, with_client_keys=False, adopt_on_src=None):
         import time
         import torch
         self.tensors, self.bytes = [], 0
@@ -101,6 +102,10 @@ class BroadcastKeys:
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
+        xi = broadcast_words(np.array([ctx.get_option("ks_xi")], dtype=np.uint64) if rank == src else None, 1, src, device, dist)
+        xi = int(xi.cpu().numpy().view(np.uint64)[0])
+        if xi != ctx.get_option("ks_xi"):
+            ctx.set_option("ks_xi", xi)
         jobs = [(0, 0, ctx.key_words(False))]
         if with_galois:
             jobs += [(1, e, ctx.key_words(True)) for e in default_galois_elements(ctx.n)]

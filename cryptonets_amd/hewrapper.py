@@ -195,7 +195,8 @@ class AtomicSealBfvEncryptedEnvironment:
         self.SelfTest(with_galois)
 
     # what the last SelfTest found: None (not run: the client has no evaluator of its own), or a dict
-    #   {"ks_xi": 0 | 1, "key_form": "ntt" | "coeff", "ops": [names compared], "tried": [(ks_xi, key_form, first failing op or None), ...]}
+    #   {"ks_xi": 0 | 1, "key_form": "ntt" | "coeff", "ops": [names compared], "tried": [(ks_xi, key_form, first failing op or None), ...],
+    #    "warnings": [key-less operations whose words differ from the client's evaluator while their decrypted slots agree]}
     self_test_report = None
 
     def SelfTest(self, with_galois=True):
@@ -250,15 +251,37 @@ class AtomicSealBfvEncryptedEnvironment:
                     "RotateColumns": lambda: ev.rotate_columns(ca)}
             want = {k: np.asarray(f(), dtype=np.uint64).reshape(-1) for k, f in want.items()
                     if with_galois or not k.startswith("Rotate")}
+            # Operations without keys.  Equal WORDS is what the restatement of SEAL 3.2 predicts; a product whose words differ from the client's but which
+            # DECRYPTS to the same slots is still a valid drop-in for these operations (an evaluator may pick another valid BEHZ auxiliary base, another
+            # representative in a lift: nothing downstream depends on it - only the key-switch convention is an interoperability property): recorded as a
+            # warning in self_test_report, the start-up goes on.  Different slots: fatal, as before.
+            warnings = []
             for op in ("MultiplyPlain", "MultiplyPlain(constant)", "AddPlain", "Multiply"):
-                if not np.array_equal(dev(op), want[op]):
-                    raise Exception("libcnhip self-test: %s differs from the client's evaluator (plaintext modulus %d) - the device does not implement "
-                                    "this evaluator's arithmetic; no key convention can repair that" % (op, t))
+                got = dev(op)
+                if np.array_equal(got, want[op]):
+                    continue
+                try:
+                    same = np.array_equal(np.asarray(self.client.decrypt(got)), np.asarray(self.client.decrypt(want[op])))
+                except Exception:
+                    same = False
+                if not same:
+                    raise Exception("libcnhip self-test: %s differs from the client's evaluator (plaintext modulus %d), words AND decrypted slots - the device "
+                                    "does not implement this evaluator's arithmetic; no key convention can repair that" % (op, t))
+                warnings.append("%s: ciphertext words differ from the client's evaluator, decrypted slots are equal (another valid representative; "
+                                "not an interoperability property)" % op)
             ks_ops = [op for op in ("Relinearize", "RotateRows(1)", "RotateRows(-1)", "RotateColumns") if op in want]
+
+            # Key-switching operations: WORDS again - unless the product itself already differs in words (then Relinearize inherits the difference and only
+            # its decrypted slots can be compared; the rotations still compare words)
+            by_slots = {"Relinearize"} if any(w.startswith("Multiply:") for w in warnings) else set()
 
             def first_failure():
                 for op in ks_ops:
-                    if not np.array_equal(dev(op), want[op]):
+                    got = dev(op)
+                    if op in by_slots:
+                        if not np.array_equal(np.asarray(self.client.decrypt(got)), np.asarray(self.client.decrypt(want[op]))):
+                            return op
+                    elif not np.array_equal(got, want[op]):
                         return op
                 return None
 
@@ -277,7 +300,7 @@ class AtomicSealBfvEncryptedEnvironment:
                     bad = first_failure()
                     tried.append((xi, form, bad))
                     if bad is None:
-                        self.self_test_report = {"ks_xi": xi, "key_form": form, "ops": list(want), "tried": tried}
+                        self.self_test_report = {"ks_xi": xi, "key_form": form, "ops": list(want), "tried": tried, "warnings": warnings}
                         return self.self_test_report
             ctx.set_option("ks_xi", xi0)
             raise Exception("libcnhip self-test: no key-switch convention reproduces the client's evaluator (plaintext modulus %d); tried (ks_xi, key form, "

@@ -77,7 +77,7 @@ class Oracle:
 
     def set_ks_xi(self, on):
         """decomposition convention of the key switch (seal32_oracle.c: gen_ksk): False = digits of the raw residues, message term in limb l
-        only; True = digits of [c_l (q/q_l)^-1]_{q_l}, message term (q/q_l) 2^(dbc d) s' in every limb.  Affects keys generated
+        only; True = digits of [c_l (q/q_l)^-1]_{q_l}, message term the RNS image of (q/q_l) 2^(dbc d) s' (non-zero in limb l only).  Affects keys generated
         and key switches run after the call."""
         self.ks_xi = bool(on)
         self.L.cno_set_ks_xi(self.h, int(bool(on)))

@@ -399,7 +399,8 @@ static void encrypt_zero_sym_ntt(cno_ctx *c, const uint64_t *s, uint64_t *out /*
  * source is not on disk to say which one 3.2 ships:
  *   ks_xi = 0  digits of the raw residue c_l; the CRT basis element (q/q_l)[(q/q_l)^-1]_{q_l} = delta_jl is
  *              folded into the key, so the message term lives in limb l only;
- *   ks_xi = 1  digits of xi_l = [c_l (q/q_l)^-1]_{q_l}; message term (q/q_l) 2^(dbc d) snew in EVERY limb
+ *   ks_xi = 1  digits of xi_l = [c_l (q/q_l)^-1]_{q_l}; message term = the RNS image of (q/q_l) 2^(dbc d) snew (non-zero in limb l only:
+ *              the scalar q/q_l mod q_l has moved from the digits into the key)
  *              (the xi_q decomposition as the BEHZ paper writes it).
  * Both are restated here so that the product can be tested against a client of either kind.          */
 static uint64_t *gen_ksk(cno_ctx *c, const uint64_t *snew, int dbc, const uint32_t *dig, uint32_t tot) {

@@ -85,6 +85,7 @@ class _FakeCtx:
     def __init__(self, n, k, digits, root):
         self.n, self.k, self.ctw, self.digits = n, k, 2 * k * n, digits
         self.keys, self.adopted = {}, {}
+        self.options = {"ks_xi": 1 if root else 0}          # the root's client settled on the other key-switch convention: it must travel with the keys
         if root:
             from cryptonets_amd.distributed import default_galois_elements
             rng = np.random.default_rng(4)
@@ -96,6 +97,12 @@ class _FakeCtx:
 
     def key_words(self, galois=False):
         return self.digits * self.ctw
+
+    def get_option(self, name):
+        return self.options[name]
+
+    def set_option(self, name, value):
+        self.options[name] = value
 
     def get_key(self, which, elt=0):
         return self.keys[(which, elt)]
@@ -122,8 +129,12 @@ def _key_worker(rank, world, path, out):
     from cryptonets_amd.distributed import BroadcastKeys
     dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
     ctx = _FakeCtx(64, 3, 9, root=(rank == 0))
-    bk = BroadcastKeys(ctx, 0, "cpu", dist, with_galois=True)
-    np.savez(out % rank, bytes=bk.bytes, n_adopted=len(ctx.adopted), **{"k_%d_%d" % key: v for key, v in ctx.adopted.items()})
+    bk = BroadcastKeys(ctx, 0, "cpu", dist, with_galois=True, with_client_keys=True)
+    server = _FakeCtx(64, 3, 9, root=(rank == 0))          # the library default: an evaluation server - evaluation keys only
+    bs = BroadcastKeys(server, 0, "cpu", dist, with_galois=True)
+    np.savez(out % rank, bytes=bk.bytes, n_adopted=len(ctx.adopted), ks_xi=ctx.options["ks_xi"], server_bytes=bs.bytes, server_ks_xi=server.options["ks_xi"],
+             server_has_client_keys=int((2, 0) in server.adopted or (3, 0) in server.adopted), server_adopted=len(server.adopted),
+             **{"k_%d_%d" % key: v for key, v in ctx.adopted.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,3 +158,8 @@ def test_gloo_world2_one_clients_keys_reach_every_rank():
         if which < 2:
             assert np.array_equal(r0["k_%d_%d" % (which, elt)], words)
     assert int(r0["bytes"]) == int(r1["bytes"]) == sum(w.size for w in want.values()) * 8
+    # the key-switch convention of the root's client arrives with its keys (a replica with the other one returns rc 0 and garbage)
+    assert int(r0["ks_xi"]) == 1 and int(r1["ks_xi"]) == 1 and int(r1["server_ks_xi"]) == 1
+    # the default exchange carries NO client keys: rank 1 holds neither the public nor the secret key unless the caller asked for them
+    assert int(r1["server_has_client_keys"]) == 0 and int(r1["server_adopted"]) == len(elts) + 1
+    assert int(r1["server_bytes"]) == sum(w.size for (which, _), w in want.items() if which < 2) * 8

@@ -72,6 +72,29 @@ def test_broadcast_keys_to_contexts_on_one_device(name, force_rccl, rng):
 
 
 @pytest.mark.gpu
+def test_broadcast_keys_carry_the_key_switch_convention(rng):
+    """the keys of a context are of ONE decomposition convention (cn_set_option("ks_xi"), settled by the client's start-up self-test).  A replica
+    that adopts the root's keys through cn_ctx_broadcast_keys adopts the convention with them - before, it kept its own default and every Relinearize /
+    Rotate on it returned rc 0 and garbage."""
+    from cryptonets_amd import _native
+    from oracle.cno import Oracle
+    p = PARAMS["tiny"]
+    o = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], ks_xi=True)
+    o.keygen(41, galois=True)
+    root, replica = _ctx("tiny"), _ctx("tiny")
+    root.set_option("ks_xi", 1)
+    root.set_relin_key(o.relin_key())
+    for i, e in enumerate(o.galois_elts()):
+        root.set_galois_key(e, o.galois_key(i))
+    assert replica.get_option("ks_xi") == 0
+    _native.broadcast_keys([root, replica])
+    assert replica.get_option("ks_xi") == 1
+    _check_replica(replica, o, rng)
+    _check_replica(root, o, rng)
+    root.close(), replica.close()
+
+
+@pytest.mark.gpu
 def test_broadcast_keys_argument_errors():
     from cryptonets_amd import _native
     a, b = _ctx("tiny"), _ctx("default4096")

@@ -159,8 +159,41 @@ def test_self_test_names_an_arithmetic_disagreement(device):
             return out
     client.reference_evaluator = lambda: OtherLift(client.o)
     env = AtomicSealBfvEncryptedEnvironment(device(n, t, q, dbc, gdbc), client)
-    with pytest.raises(Exception, match="self-test: MultiplyPlain differs"):
+    with pytest.raises(Exception, match="self-test: MultiplyPlain differs.*words AND decrypted slots"):
         env.GenerateEncryptionKeys(with_galois=True)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_self_test_tolerates_other_words_with_the_same_slots(device):
+    """a client evaluator whose key-less operations return ANOTHER valid representative (here: Multiply / MultiplyPlain with an
+    encryption of zero added - different words, identical decrypted slots, noise a little larger) is still served: the self-test records a warning per
+    operation and continues; Relinearize is then compared by slots (it inherits the product's words), the rotations by words."""
+    n, t, q, dbc, gdbc = PARAMS[0]
+    client = _client(OracleClient, n, t, q, dbc, gdbc, True)
+
+    class OtherRepresentative:
+        def __init__(self, o):
+            self.o = o
+            self.zero = o.encrypt(o.encode(np.zeros(o.n, dtype=np.uint64)))
+
+        def __getattr__(self, name):
+            return getattr(self.o, name)
+
+        def multiply_plain(self, ct, plain):
+            return self.o.add(self.o.multiply_plain(ct, plain), self.zero)
+
+        def multiply(self, a, b):
+            out = self.o.multiply(a, b)                      # size 3: the zero encryption goes onto (c0, c1)
+            two = 2 * self.o.k * self.o.n
+            out[:two] = self.o.add(out[:two].copy(), self.zero)
+            return out
+    client.reference_evaluator = lambda: OtherRepresentative(client.o)
+    env = AtomicSealBfvEncryptedEnvironment(device(n, t, q, dbc, gdbc), client)
+    env.GenerateEncryptionKeys(with_galois=True)
+    rep = env.self_test_report
+    assert rep["ks_xi"] == 1 and rep["key_form"] == "ntt"
+    assert sorted(w.split(":")[0] for w in rep["warnings"]) == ["Multiply", "MultiplyPlain", "MultiplyPlain(constant)"]
+    _after_words_agree(env, client)
 
 
 def test_a_client_without_an_evaluator_is_not_tested():
