@@ -427,6 +427,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
     if (!strcmp(name, "ks_pair14")) { ctx->ks_pair14 = value != 0; return 0; }
     if (!strcmp(name, "ks_chain")) { ctx->ks_chain = value != 0; return 0; }
+    if (!strcmp(name, "mp_bcast")) { ctx->mp_bcast = value != 0; return 0; }
     if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
     if (!strcmp(name, "ks_xi")) {                // decomposition convention of the key switch (DevConsts::ks_xi); the keys must be of the same convention
         if (ctx->capturing || ctx->graphs_alive) return fail(CN_ERR_ARG, "ks_xi cannot change while a graph is recorded or alive (its kernels were chosen for the other convention)");
@@ -448,6 +449,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "ks_xcd")) *value = ctx->ks_xcd;
     else if (!strcmp(name, "ks_pair14")) *value = ctx->ks_pair14;
     else if (!strcmp(name, "ks_chain")) *value = ctx->ks_chain;
+    else if (!strcmp(name, "mp_bcast")) *value = ctx->mp_bcast;
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
     else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
@@ -888,6 +890,21 @@ static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Bu
     uint64_t *o = O->d + oi * O->item_words;
     const uint64_t *src = A->d + ai * A->item_words;
     // one input ciphertext broadcast over the outputs: it must survive until the last block has read it
+    bool f64 = ctx->use_f64, light = true;
+    for (uint32_t m = 0; m < k; m++) { f64 = f64 && ctx->hc.f64ok[m]; if (ctx->hc.q[m].q >> 44) light = false; }
+    const int pol = f64 && light ? POL_F64L : (f64 ? POL_F64 : POL_U64);
+    if (a_bcast && pstride && count >= 4 && ctx->mp_bcast) {      // one ciphertext x many plaintexts: transform the ciphertext once, the plaintexts inside the product kernel
+        CHECK(ensure_scratch(ctx, al(A->item_words * 8)));
+        uint64_t *ctn = salloc<uint64_t>(ctx, A->item_words);
+        if (!ctn) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply_plain");
+        HIPCHK(hipMemcpyAsync(ctn, src, A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        CHECK(cn_run_ntt(ctx, ctn, A->size * k, 0, k, 0));
+        rr_ops[pol]->mul_plain_bcast(ctx, P->d + (size_t)pi * n, pstride, ctn, o, count, A->size);
+        HIPCHK(hipGetLastError()); launch_count(ctx);
+        ctx->st.ntt_forward_limbs += (uint64_t)A->size * k + (uint64_t)count * A->size * k; ctx->st.ntt_inverse_limbs += (uint64_t)count * A->size * k;
+        ctx->st.PlainMultiplication += count;
+        return 0;
+    }
     const bool alias = a_bcast && src >= o && src < o + (size_t)count * A->item_words;
     CHECK(ensure_scratch(ctx, al((size_t)npt * k * n * 8) + (alias ? al(A->item_words * 8) : 0)));
     uint64_t *lift = salloc<uint64_t>(ctx, (size_t)npt * k * n);
@@ -898,12 +915,10 @@ static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Bu
         src = keep;
     }
     if (!lift) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply_plain");
-    bool f64 = ctx->use_f64, light = true;
-    for (uint32_t m = 0; m < k; m++) { f64 = f64 && ctx->hc.f64ok[m]; if (ctx->hc.q[m].q >> 44) light = false; }
     const uint64_t *pt = P->d + (size_t)pi * n;
     const size_t sstride = a_bcast ? 0 : A->item_words;
     const uint32_t pitch = pstride ? pstride : 1u, ps = pstride ? 1u : 0u;
-    rr_ops[f64 && light ? POL_F64L : (f64 ? POL_F64 : POL_U64)]->mul_plain_fused(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
+    rr_ops[pol]->mul_plain_fused(ctx, pt, pitch, npt, lift, src, sstride, ps, o, count, A->size);
     HIPCHK(hipGetLastError()); launch_count(ctx, 2);
     ctx->st.ntt_forward_limbs += (uint64_t)npt * k + (uint64_t)count * A->size * k; ctx->st.ntt_inverse_limbs += (uint64_t)count * A->size * k;
     ctx->st.PlainMultiplication += count;
@@ -2399,6 +2414,49 @@ static int cn_defer_flush(cn_ctx *ctx) {
                 if (!ok) continue;
                 Gm.out = X.out; Gm.bias = X.b; Gm.level = X.level;
                 dead[x] = 1;
+            }
+        }
+        // ---- scalar products of one term count on different levels of the same flush become ONE launch where nothing stands in the way (round 5).  The
+        // literal PoolLayer pattern puts the outputs that read a fresh encryption of zero (a padded tap) one level behind the others: two GEMM launches per
+        // convolution, the second one a fifth the size and barely half as efficient (k_scalar_gemm<1>: 0.30 ms for 125 outputs against 0.50 ms for 720).
+        // A scalar product may wait for the deepest level that holds others of its kind if, behind its own level, nobody reads or writes its output and
+        // nobody writes its inputs (checked against every queued call, conservatively: any later level counts).  CN_DEFER_MERGE_GEMM=0 switches it off (A/B).
+        static const bool merge_gemm = !(getenv("CN_DEFER_MERGE_GEMM") && !atoi(getenv("CN_DEFER_MERGE_GEMM")));
+        if (merge_gemm) {
+            std::map<uint32_t, std::pair<int32_t, int32_t>> span;          // term count -> (shallowest, deepest) level of its live scalar products
+            for (size_t x = 0; x < ops.size(); x++) if (!dead[x] && ops[x].type == DOP_GEMM1) {
+                auto it = span.find(ops[x].K);
+                if (it == span.end()) span[ops[x].K] = {ops[x].level, ops[x].level};
+                else { it->second.first = std::min(it->second.first, ops[x].level); it->second.second = std::max(it->second.second, ops[x].level); }
+            }
+            bool any = false;
+            for (auto &kv : span) any = any || kv.second.first != kv.second.second;
+            if (any) {
+                struct RW { int32_t r = -1, w = -1; };                      // deepest level at which a queued call reads / writes the array
+                std::unordered_map<const uint64_t *, RW> touch;
+                touch.reserve(ops.size() * 2);
+                auto rd = [&](const uint64_t *p, int32_t lv) { if (p) { RW &t = touch[p]; t.r = std::max(t.r, lv); } };
+                for (size_t x = 0; x < ops.size(); x++) {
+                    if (dead[x]) continue;
+                    const DOp &X = ops[x];
+                    if (X.type == DOP_GEMM1) { for (uint32_t kk = 0; kk < X.K; kk++) rd((const uint64_t *)q->addr[X.terms + kk], X.level); }
+                    else if (X.type == DOP_ADDPLAIN || X.type == DOP_SUBPLAIN || X.type == DOP_MULPLAIN) rd(X.a, X.level);      // (b is a plaintext: never the output of a queued call)
+                    else if (X.type != DOP_ENCRYPT) { rd(X.a, X.level); rd(X.b, X.level); }
+                    RW &t = touch[X.out]; t.w = std::max(t.w, X.level);
+                }
+                for (size_t x = 0; x < ops.size(); x++) {
+                    DOp &X = ops[x];
+                    if (dead[x] || X.type != DOP_GEMM1) continue;
+                    const int32_t deep = span[X.K].second;
+                    if (X.level >= deep) continue;
+                    const RW &to = touch[X.out];
+                    bool ok = to.r <= X.level && to.w <= X.level;
+                    for (uint32_t kk = 0; kk < X.K && ok; kk++) {
+                        const uint64_t *in = (const uint64_t *)q->addr[X.terms + kk];
+                        if (in) { auto it = touch.find(in); ok = it == touch.end() || it->second.w <= X.level; }
+                    }
+                    if (ok) X.level = deep;
+                }
             }
         }
         // ---- launches: level by level, one batched launch per kind (and per term count for the GEMMs)

@@ -70,6 +70,48 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_lift_ntt(const uint64_t *__r
         *reinterpret_cast<ulonglong2 *>(o + tail_index<L>(tid, r)) = w;
     }
 }
+// ONE ciphertext times MANY plaintexts (the row-dot batches of the LoLa dense layers, EncryptedSealBfvMatrix.cs:79-120 -> DotProduct: 5488 rows at CIFAR
+// shapes) in one launch (round 5): the ciphertext's 2k limbs are transformed ONCE (`ctn`: NTT form, canonical, [polys][k][N] - 2 MiB that stay in L2),
+// block = (row, poly, limb j) lifts the row's plaintext into q_j while loading it, transforms IT, multiplies by the ciphertext's NTT words at the positions
+// the thread holds (16 B/lane), transforms back.  INTT(NTT(lift(pt)) . NTT(ct)): the same words as k_lift_ntt + k_mul_plain_fused, which transformed the
+// broadcast ciphertext once per row and carried every lifted plaintext through HBM in NTT form (k limbs written + read twice per row: 5.5 GiB per call at CIFAR
+// shapes) - a launch, a fifth of the transforms and that round trip less.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_bcast(const uint64_t *__restrict__ pt, uint32_t pitch, const uint64_t *__restrict__ ctn, uint64_t *__restrict__ out,
+                                                                    const DevConsts *__restrict__ C, uint32_t polys) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t tid = threadIdx.x, k = C->k, j = blockIdx.x % k, cp = blockIdx.x / k, row = cp / polys, p = cp % polys;
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t *x = pt + (size_t)row * pitch * n, th = C->t_half, inc = C->lift_inc[j];
+    const uint64_t *w = ctn + ((size_t)p * k + j) * n;
+    T v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const uint64_t m = x[pass_index<L, SA, 0>(tid, r)]; v[r] = A.load(m >= th ? m + inc : m); }
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    uint32_t tm = tid;
+    asm volatile("" : "+v"(tm));
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(w + tail_index<L>(tm, r));
+        if constexpr (std::is_same<T, double>::value) {                   // lazy transform output x canonical word: exact (see KsMac)
+            v[r] = ops.mul(v[r], A.load(y.x), A); v[r + 1] = ops.mul(v[r + 1], A.load(y.y), A);
+        } else {
+            v[r] = ops.mul(A.canon(v[r]), y.x, A); v[r + 1] = ops.mul(A.canon(v[r + 1]), y.y, A);
+        }
+    }
+    if (!ntt_tail_local<L>()) __syncthreads();
+    uint32_t ti = tid;
+    asm volatile("" : "+v"(ti));
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, ti);
+    uint64_t *o = out + ((size_t)cp * k + j) * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(ti, r)] = A.scaled(v[r]);
+}
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_fused(const uint64_t *src, size_t src_stride, const uint64_t *__restrict__ ptn, uint32_t pstride,
                                                                     uint64_t *out, const DevConsts *__restrict__ C, uint32_t polys) {

@@ -17,7 +17,7 @@ template <int L> static int set_attrs_l(size_t bytes) {
         CHECK(big_lds(k_square_fused<L, AR>, bytes));
         if constexpr (L <= 13) { CHECK(big_lds(k_square_fused<L, AR, true>, bytes + ((size_t)8 << L))); CHECK(big_lds(k_square_pipe<L, AR>, bytes + ((size_t)8 << L))); }
     }
-    CHECK(big_lds(k_lift_ntt<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_fused<L, AR>, bytes));
+    CHECK(big_lds(k_lift_ntt<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_fused<L, AR>, bytes)); CHECK(big_lds(k_mul_plain_bcast<L, AR>, bytes));
 #ifdef RR_ENC_TAIL
     CHECK(big_lds(k_encrypt_tail<L, AR>, bytes));
 #endif
@@ -81,6 +81,14 @@ template <int L> static void l_mul_plain_fused(cn_ctx *c, const uint64_t *pt, ui
 static bool mul_plain_fused(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint32_t npt, uint64_t *lift, const uint64_t *src, size_t sstride, uint32_t pstride,
                             uint64_t *out, uint32_t count, uint32_t polys) { BY_SIZE(l_mul_plain_fused, c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys) }
 
+// one ciphertext (NTT form in ctn) times `count` plaintexts: one launch
+template <int L> static void l_mul_plain_bcast(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys) {
+    hipLaunchKernelGGL((k_mul_plain_bcast<L, AR>), dim3(count * polys * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, pt, pitch, ctn, out, c->dc, polys);
+}
+static bool mul_plain_bcast(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys) {
+    BY_SIZE(l_mul_plain_bcast, c, pt, pitch, ctn, out, count, polys)
+}
+
 #ifdef RR_ENC_TAIL
 template <int L> static void l_enc_tail(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
     hipLaunchKernelGGL((k_encrypt_tail<L, AR>), dim3(cnt * 2 * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, u, c->pk, pt, pts, out, c->dc,
@@ -104,5 +112,5 @@ static bool enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t 
     BY_SIZE(l_enc_fused, c, us, pt, pts, out, cnt, noise, tab)
 }
 #ifndef __HIP_DEVICE_COMPILE__      // host-side table (in the device pass a const global would be emitted as device data)
-extern const RrOps RR_NAME = {set_attrs, ntt, intt_tensor, square_fused, mul_plain_fused, enc_tail, enc_fused};
+extern const RrOps RR_NAME = {set_attrs, ntt, intt_tensor, square_fused, mul_plain_fused, enc_tail, enc_fused, mul_plain_bcast};
 #endif

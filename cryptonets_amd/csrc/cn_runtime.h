@@ -166,6 +166,7 @@ struct cn_ctx {
     std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
+    bool mp_bcast = true;     // ... one ciphertext x many plaintexts (row-dot batches) as ONE launch that transforms the plaintexts (k_mul_plain_bcast, round 5); 0: the two launches above
     bool gemm_mfma = true;    // scalar GEMMs with >= 16 outputs per gather list on the int8 matrix cores (exact); cn_set_option("gemm_mfma", 0): FP64 kernel
     int cus = 0;              // compute units of the device
     bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per
@@ -210,6 +211,7 @@ struct RrOps {                // register-radix kernels of one arithmetic policy
                             uint64_t *out, uint32_t count, uint32_t polys);
     bool (*enc_tail)(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);   // U64, F64; tab: EncTab[cnt] or null
     bool (*enc_fused)(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);  // all policies, N <= 8192: u (int8) -> transform -> both components in one kernel
+    bool (*mul_plain_bcast)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys);             // ONE ciphertext (NTT form) x count plaintexts
 };
 struct KsOps {
     int (*set_attrs)(uint32_t logn, size_t lds);

@@ -48,38 +48,38 @@ namespace HEWrapper
         public int CtWords(int size = 2) { return (int)(size * K * N); }
 
         // Disposal in batches.  The unchanged layers dispose one vector at a time from many threads (PoolLayer.ReleaseTemp: one Dispose per zero
-        // encryption, PoolLayer.cs:83-90; BaseLayer.GetNext: the columns of a layer's input, BaseLayer.cs:23-49): a released handle is parked in a list of
-        // the calling thread and the list goes to the library 32 handles at a time (cn_free_many: one lock acquisition instead of 32).  What is
-        // left in the lists only holds device memory; it is released when results leave the device (Download / Decrypt call FlushFrees) and by the finalizer.
-        [ThreadStatic] static Dictionary<CnDevice, List<ulong>> parked;
-        static readonly ConcurrentBag<Dictionary<CnDevice, List<ulong>>> allParked = new ConcurrentBag<Dictionary<CnDevice, List<ulong>>>();
-        const int FreeBatch = 32;
+        // encryption, PoolLayer.cs:83-90; BaseLayer.GetNext: the columns of a layer's input, BaseLayer.cs:23-49): a released handle is parked in one of 64
+        // lists OF THIS DEVICE (picked by the calling thread's id: threads rarely meet on a list) and a list goes to the library 32 handles at a time
+        // (cn_free_many: one lock acquisition instead of 32).  What is left in the lists only holds device memory - at most 64 x 31 handles; it is released
+        // when results leave the device (Download / Decrypt call FlushFrees) and dies with the device: nothing static refers to a CnDevice (ADVICE r04: the
+        // round-4 thread-static dictionaries in a static bag kept every device - its HBM, pool and keys - alive for the life of the process).
+        const int FreeBatch = 32, Stripes = 64;
+        readonly List<ulong>[] parked = Enumerable.Range(0, Stripes).Select(_ => new List<ulong>(FreeBatch)).ToArray();
         public void DeferFree(ulong handle)
         {
-            if (parked == null) { parked = new Dictionary<CnDevice, List<ulong>>(); allParked.Add(parked); }
-            List<ulong> list;
-            lock (parked)
+            var list = parked[Thread.CurrentThread.ManagedThreadId & (Stripes - 1)];
+            ulong[] batch = null;
+            lock (list)
             {
-                if (!parked.TryGetValue(this, out list)) { list = new List<ulong>(FreeBatch); parked[this] = list; }
                 list.Add(handle);
-                if (list.Count < FreeBatch) return;
-                var batch = list.ToArray();
-                list.Clear();
-                if (Ctx != IntPtr.Zero) CnHip.cn_free_many(Ctx, batch, (uint)batch.Length);
+                if (list.Count >= FreeBatch) { batch = list.ToArray(); list.Clear(); }
             }
+            if (batch != null && Ctx != IntPtr.Zero) CnHip.cn_free_many(Ctx, batch, (uint)batch.Length);
         }
         /// <summary>releases the parked handles of every thread for this device</summary>
         public void FlushFrees()
         {
-            foreach (var dict in allParked)
-                lock (dict)
+            foreach (var list in parked)
+            {
+                ulong[] batch;
+                lock (list)
                 {
-                    List<ulong> list;
-                    if (!dict.TryGetValue(this, out list) || list.Count == 0) continue;
-                    var batch = list.ToArray();
+                    if (list.Count == 0) continue;
+                    batch = list.ToArray();
                     list.Clear();
-                    if (Ctx != IntPtr.Zero) CnHip.cn_free_many(Ctx, batch, (uint)batch.Length);
                 }
+                if (Ctx != IntPtr.Zero) CnHip.cn_free_many(Ctx, batch, (uint)batch.Length);
+            }
         }
     }
 

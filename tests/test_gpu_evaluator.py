@@ -318,6 +318,22 @@ def test_multiply_plain_fused_kernels_are_the_separate_launches(name, rng):
             g.free(x)
     g.set_option("mp_fused", 1)
     g.free(ph)
+    # four rows or more: ONE launch that transforms the plaintexts and multiplies by the once-transformed ciphertext (k_mul_plain_bcast, round 5) - against the
+    # oracle and against the two-launch form (cn_set_option("mp_bcast", 0)), rows with a stride in the plaintext array, and the integer transform path
+    rows = 5
+    pts5 = np.stack([o.encode(rng.integers(0, o.t, size=o.n, dtype=np.uint64)) for _ in range(rows)])
+    exp5 = np.stack([o.multiply_plain(cts[1], pts5[r]) for r in range(rows)])
+    for gg in (g, get_gpu(name, galois=True, f64=False)):
+        ph5, h, out = gg.pt_alloc(rows), up(gg, cts), gg.ct_alloc(rows)
+        gg.pt_upload(ph5, 0, pts5)
+        for bc in (1, 0):
+            gg.set_option("mp_bcast", bc)
+            gg.rowdot_batch(h, 1, ph5, 0, rows, 1, out, 0)                      # length 1: the products themselves
+            assert np.array_equal(gg.ct_download(out, 0, rows), exp5), (name, bc)
+        gg.set_option("mp_bcast", 1)
+        assert np.array_equal(gg.ct_download(h, 1, 1)[0], cts[1])
+        for x in (ph5, h, out):
+            gg.free(x)
 
 
 @pytest.mark.parametrize("name", ["tiny", "default4096", "c4"])

@@ -125,6 +125,17 @@ def replay_layers(chans, layers):
 
 
 LAST_LAUNCHES = None
+LAST_HOST = None            # host-side accounting of the last measure(): CPU seconds the process used per wall second, CFS bandwidth throttling of its cgroup
+
+
+def _cgroup_cpu_stat():
+    """{nr_periods, nr_throttled, throttled_usec, usage_usec} of this process' cgroup (v2), {} where there is none: a quota of q cores with p >> q runnable
+    threads is spent early in every 100 ms period and ALL threads of the group then wait for the next one - what 256 caller threads on a 16-core quota do"""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            return {k: int(v) for k, v in (line.split() for line in f)}
+    except Exception:
+        return {}
 
 
 def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True, per_step=False):
@@ -146,6 +157,7 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                 for g in ctxs:
                     g.sync()
                 launches0 = sum(g.stats()["kernel_launches"] for g in ctxs)
+                cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
                 t0 = time.perf_counter()
             ts = time.perf_counter()
             out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged)
@@ -157,6 +169,11 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                 for g in ctxs:
                     g.sync()
                 dt = time.perf_counter() - t0
+                cg1 = _cgroup_cpu_stat()
+                global LAST_HOST
+                LAST_HOST = {"cpu_s_per_wall_s": round((time.process_time() - cpu0) / dt, 2),
+                             "cgroup_periods": cg1.get("nr_periods", 0) - cg0.get("nr_periods", 0), "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                             "cgroup_throttled_ms": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1)} if cg0 else {"cpu_s_per_wall_s": round((time.process_time() - cpu0) / dt, 2)}
                 LAST_LAUNCHES = (sum(g.stats()["kernel_launches"] for g in ctxs) - launches0) / steps       # how finely the queue was cut
                 words = [np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[p]]) for p, g in enumerate(ctxs)]
             for p, g in enumerate(ctxs):                 # Decrypt + Dispose of the result matrix
@@ -233,13 +250,13 @@ def main():
         ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, merged=not args.no_merged)
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
         rows.append(dict(caller="unchanged (per-ciphertext calls), deferred submission", threads=t, ms_per_batch=round(ms, 2),
-                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES))
+                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES, host=LAST_HOST))
     for t in [int(x) for x in args.literal_threads.split(",") if x]:
         ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, literal_taps=True, merged=not args.no_merged, per_step=args.per_step)
         dec = decrypt_outputs(chans, words)
         same = all(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t)) for d, ch in zip(dec, chans))
         rows.append(dict(caller="unchanged, padded taps as fresh encryptions of zero (PoolLayer.ElementAt), deferred submission", threads=t, ms_per_batch=round(ms, 2),
-                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES,
+                         images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES, host=LAST_HOST,
                          note="words_identical here = every decrypted slot of every output equals the integer model (fresh randomness: words cannot match)"))
     if args.immediate:
         ms, words = measure(chans, layers, 8, 1, warmup=1, defer=False)
