@@ -285,22 +285,24 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
 #define KS14_PREFETCH 1     // 0: every digit loads its source words at its start (A/B)
 #endif
 // stage 0 of the 2N'-point transform on one (x, y) = (c[e], c[e + N']) pair of source words, the output half `sg` keeps, recentred
-template <class AR, bool XI> struct Ks14Stage0 {
+// WHOLE: every source limb is ONE digit that covers it (2^dbc > q_l: the reference's N = 16384 networks, dbc 60) - the digit is the word itself, no 64-bit
+// variable shift and mask per word (130 of ~2200 vector instructions per digit transform)
+template <class AR, bool XI, bool WHOLE> struct Ks14Stage0 {
     typedef typename AR::T T;
     const DevConsts *C; typename AR::Mod m; double sg, w1; uint64_t mask;
     NTT_DEV T operator()(uint64_t sx, uint64_t sy, uint32_t l, int sh) const {
         if constexpr (XI) { const DMod ql = C->q[l]; const uint64_t xf = C->inv_qhat_q[l]; sx = mulmod(sx, xf, ql); sy = mulmod(sy, xf, ql); }   // digits of xi_l
-        const T X = AR::from_u64((sx >> sh) & mask), Y = AR::from_u64((sy >> sh) & mask);
+        const T X = AR::from_u64(WHOLE ? sx : (sx >> sh) & mask), Y = AR::from_u64(WHOLE ? sy : (sy >> sh) & mask);
         return AR::center(__fma_rn(sg, AR::mulmod(Y, w1, m), X), m);         // x +- w y
     }
 };
 // the hook of ntt_forward_regs_hooked: piece c of the next digit's 16 pairs = registers 4c .. 4c+3, requested at boundary c, parked at boundary c + 1
 // (Measured, not kept: the multiply-accumulate of a digit moved behind the NEXT digit's first pass - its 32 key words requested when that digit starts, the
 // transformed values waiting in the thread's LDS slots meanwhile - to spend the key round trip (3.6 ms of 35 per link) under arithmetic: 37.8 vs 35.9 ms.)
-template <class AR, bool XI> struct Ks14Next {
+template <class AR, bool XI, bool WHOLE> struct Ks14Next {
     typedef typename AR::T T;
     static constexpr uint32_t n2 = 8192, NT = 512;
-    const Ks14Stage0<AR, XI> &st0;
+    const Ks14Stage0<AR, XI, WHOLE> &st0;
     const uint64_t *src; uint32_t l; int sh;          // the next digit: limb, source limb index, shift (src == nullptr: there is none)
     T *park; uint32_t tid;
     uint64_t raw[8];
@@ -318,7 +320,7 @@ template <class AR, bool XI> struct Ks14Next {
         if constexpr (PH < 4) issue<PH>();
     }
 };
-template <class AR, bool XI = false>
+template <class AR, bool XI = false, bool WHOLE = false>
 __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *add0, const uint64_t *add1,
                                                                        size_t add_stride, const void *__restrict__ key_, uint64_t *out, double *__restrict__ stash,
                                                                        const DevConsts *__restrict__ C, int galois, uint32_t accmax, const uint64_t *extra, size_t ex_stride,
@@ -368,7 +370,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
         fwh.w = fwg;
         if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwh, fwg);
         const typename AR::Tw ivh = {(GP)(C->twdh + ((size_t)(j * 2 + 1) * 2 + h) * n2)};
-        const Ks14Stage0<AR, XI> st0{C, A.m, h ? -1.0 : 1.0, ntt_uniform(A.fw.w[1]), (1ull << dbc) - 1};
+        const Ks14Stage0<AR, XI, WHOLE> st0{C, A.m, h ? -1.0 : 1.0, ntt_uniform(A.fw.w[1]), (1ull << dbc) - 1};
         T acc0[16], acc1[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
             uint32_t ln = l, dn = d + 1;
             if (dn == (galois ? C->gk_dig[l] : C->rl_dig[l])) { ln = l + 1; dn = 0; }
             const bool pf = KS14_PREFETCH && !(KS14_DBG & 16);
-            Ks14Next<AR, XI> nx{st0, (pf && g + 1 < tot) ? tgt + (size_t)ln * n : nullptr, ln, dbc * (int)dn, park, tl};
+            Ks14Next<AR, XI, WHOLE> nx{st0, (pf && g + 1 < tot) ? tgt + (size_t)ln * n : nullptr, ln, dbc * (int)dn, park, tl};
             T v[16];
             if (pf && g) {
 #pragma unroll

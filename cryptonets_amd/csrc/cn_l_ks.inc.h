@@ -26,7 +26,8 @@ static int set_attrs(uint32_t logn, size_t bytes) {
         CHECK(set_attrs_l<14>(bytes));
         if constexpr (kF64) {
             CHECK(big_lds(k_keyswitch_split14<AR>, (size_t)ntt_lds_words(8192) * 8)); CHECK(big_lds(k_keyswitch_split14<AR, true>, (size_t)ntt_lds_words(8192) * 8));
-            CHECK(big_lds(k_keyswitch_pair14<AR, false>, PAIR14_LDS)); CHECK(big_lds(k_keyswitch_pair14<AR, true>, PAIR14_LDS));
+            CHECK(big_lds(k_keyswitch_pair14<AR, false, false>, PAIR14_LDS)); CHECK(big_lds(k_keyswitch_pair14<AR, true, false>, PAIR14_LDS));
+            CHECK(big_lds(k_keyswitch_pair14<AR, false, true>, PAIR14_LDS)); CHECK(big_lds(k_keyswitch_pair14<AR, true, true>, PAIR14_LDS));
         }
     }
     return 0;
@@ -94,14 +95,19 @@ static bool split14(cn_ctx *c, const KsArgs &a) {
     return false;
 }
 // N = 16384 in one launch: both halves per (ciphertext, output limb) workgroup (k_keyswitch_pair14); a.target = sigma(c1) for rotations
-template <bool XI> static void launch_pair14(cn_ctx *c, const KsArgs &a) {
+template <bool XI, bool WHOLE> static void launch_pair14(cn_ctx *c, const KsArgs &a) {
     if constexpr (kF64)
-        hipLaunchKernelGGL((k_keyswitch_pair14<AR, XI>), dim3(a.cnt * c->hc.k), dim3(NttPlan<13>::NT), PAIR14_LDS, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride,
+        hipLaunchKernelGGL((k_keyswitch_pair14<AR, XI, WHOLE>), dim3(a.cnt * c->hc.k), dim3(NttPlan<13>::NT), PAIR14_LDS, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride,
                            (const void *)a.key, a.out, (double *)c->ks_part, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.perm_elt, a.next_elt, a.next_out, a.xcd_cts);
 }
 static bool pair14(cn_ctx *c, const KsArgs &a) {
     if constexpr (kF64) {
-        if (c->hc.ks_xi) launch_pair14<true>(c, a); else launch_pair14<false>(c, a);
+        // one digit per source limb that covers the limb (the reference's N = 16384 parameter sets, dbc 60): the digit is the word itself
+        const int dbc = a.galois ? c->hc.gdbc : c->hc.dbc;
+        uint64_t qmax = 0; for (uint32_t j = 0; j < c->hc.k; j++) qmax = std::max(qmax, c->hc.q[j].q);
+        const bool whole = (a.galois ? c->hc.gk_tot : c->hc.rl_tot) == c->hc.k && dbc < 64 && (qmax >> dbc) == 0;
+        if (c->hc.ks_xi) { if (whole) launch_pair14<true, true>(c, a); else launch_pair14<true, false>(c, a); }
+        else { if (whole) launch_pair14<false, true>(c, a); else launch_pair14<false, false>(c, a); }
         return true;
     }
     return false;

@@ -14,7 +14,9 @@ src = [s for s in _native.SOURCES if s.endswith("cn_l_ks_f64.hip")][0]
 def one(mask):
     o = os.path.join(_native.OBJ_DIR, "cn_l_ks_f64_dbg%s.o" % mask)
     extra = [d for d in sys.argv[1:] if d.startswith("-D")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", *_native._unit_flags(src),
+    st = os.environ.get("KS14_SCHED")          # A/B of the compiler's scheduling strategy for this translation unit: "" (default), max-ilp, max-memory-clause, iterative-...
+    unit = _native._unit_flags(src) if st is None else (["-mllvm", "-amdgpu-sched-strategy=" + st] if st else [])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", *unit,
                            "-DKS14_DBG=%s" % mask, *extra, "-c", src, "-o", o])
     lib = os.path.join(os.path.dirname(_native.LIB_PATH), "libcnhip_dbg%s.so" % mask)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "--offload-arch=gfx950", *[o if x.endswith("cn_l_ks_f64.o") else x for x in objs], "-o", lib])
