@@ -799,10 +799,11 @@ def main():
                          "timing": "best of 5 windows of %d steps on BOTH sides of frac_of_batched (skipped_taps, at_visible_cpu_count: best of 3)" % reps,
                          "windows_ms": {"unchanged": [round(x, 2) for x in lwin], "batched": [round(x, 2) for x in bwin]},
                          "frac_of_batched_mean_over_mean": round((sum(bwin) / len(bwin)) / (sum(lwin) / len(lwin)), 3), "at_visible_cpu_count": visible,
-                         "pattern": "PoolLayer.Apply: per (map, corner) [cn_ct_alloc + cn_encrypt(zero) per padded tap] + cn_scalar_dot (K = 25 real handles) + "
-                                    "cn_add_plain + cn_free, ReleaseTemp: cn_free per zero encryption; SquareActivation: per column cn_mul_relin(count 1); every "
-                                    "ciphertext its own handle; 2 x (2855 + 3 x 645) calls per batch; cn_set_option(defer, 1); threads = Defaults.ThreadCount = processor count "
-                                    "(visible CPUs %d, cgroup quota %s)" % (effective_cores()[1], effective_cores()[2]),
+                         "pattern": "PoolLayer.Apply: per (map, corner) [cn_encrypt_zero_new per padded tap (the twin's one-call zero vector)] + cn_ct_alloc + cn_scalar_dot "
+                                    "(K = 25 real handles) + cn_ct_alloc + cn_add_plain + cn_free of the product (at once: the queue folds the bias into the GEMM), ReleaseTemp: "
+                                    "cn_free_many per 32 zero encryptions (CnDevice.DeferFree); SquareActivation: per column cn_mul_relin(count 1); BaseLayer.GetNext: cn_free_many "
+                                    "of the layer's input columns; every ciphertext its own handle; cn_set_option(defer, 1); at flush the scalar products of a layer are ONE launch "
+                                    "per term count (round 5); threads = Defaults.ThreadCount = processor count (visible CPUs %d, cgroup quota %s)" % (effective_cores()[1], effective_cores()[2]),
                          "skipped_taps": {"value": round(8192e3 / ums, 1), "ms_per_step": round(ums, 2), "threads": 4, "frac_of_batched": round(batched_ms / ums, 3),
                                           "words_identical_to_batched": bool(all(np.array_equal(a, b) for a, b in zip(uwords, ref_words)))}}
         except Exception as ex:
