@@ -232,7 +232,7 @@ namespace HEWrapper
         }
 
         /// <summary>what the last SelfTest settled on: "ks_xi=0|1 keys=ntt|coeff" (null: not run)</summary>
-        public string SelfTestReport { get; private set; }
+        public string SelfTestReport { get; internal set; }
         /// <summary>set to false to skip the start-up self-test (a few SEAL evaluator calls + device calls per environment, ~0.1 s)</summary>
         public static bool RunSelfTest = true;
 

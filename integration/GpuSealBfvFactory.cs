@@ -79,7 +79,10 @@ namespace HEWrapper
                 var dst = new AtomicSealBfvEncryptedEnvironment(src);           // shares the SEAL objects
                 dst.device = new CnDevice(src.parameters, src.relinKeys.DecompositionBitCount, src.galoisKeys.DecompositionBitCount, device,
                                           AtomicSealBfvEncryptedEnvironment.DeferredSubmission);
+                // the keys AND the key-switch convention the source's start-up self-test settled on ("ks_xi") arrive together: cn_ctx_broadcast_keys copies both
+                // (round 5, ADVICE r04 - before, a replica kept its own default and returned rc 0 and garbage when the source had flipped the convention)
                 CnHip.Check(CnHip.cn_ctx_broadcast_keys(new IntPtr[] { src.device.Ctx, dst.device.Ctx }, 2));
+                dst.SelfTestReport = src.SelfTestReport;
                 return dst;
             }).ToArray();
             FreeComputationEnv(env);
