@@ -608,3 +608,34 @@ def test_random_programs_deferred_equal_immediate(name, rng):
         assert len(now) == len(later)
         for i, (x, y) in enumerate(zip(now, later)):
             assert np.array_equal(x, y), (seed, i)
+
+
+@pytest.mark.gpu
+def test_deferred_squarings_at_n16384_take_the_one_launch_key_switch(rng):
+    """24 per-ciphertext Multiply + Relinearize calls at the LoLa-CIFAR parameters (N = 16384, k = 8): queued, they are flushed as ONE batched chain whose
+    relinearisation is k_keyswitch_pair14 writing through a table of output addresses (every ciphertext its own array) - the same words as the
+    immediate per-ciphertext calls (two-launch key switch), which tests/test_gpu_evaluator.py holds to the oracle."""
+    o, g = get_oracle("c5", galois=True), get_gpu("c5", galois=True)
+    cnt = 24                                                  # 24 x 8 = 192 (ciphertext, limb) blocks: above the two-launch threshold of 160
+    base = _fresh(o, rng, 3)
+    words = {}
+    for defer in (0, 1):
+        g.set_option("defer", defer)
+        ins, outs = [], []
+        for i in range(cnt):
+            h = g.ct_alloc(1)
+            c = base[i % 3].copy()
+            c[:8] = (c[:8] + np.uint64(i)) % np.uint64(o.q[0])          # 24 distinct operands
+            g.ct_upload(h, 0, c[None, :])
+            ins.append(h)
+        for i in range(cnt):
+            out = g.ct_alloc(1)
+            g.mul_relin(ins[i], 0, ins[i], 0, out, 0, 1)
+            outs.append(out)
+        words[defer] = np.stack([g.ct_download(h, 0, 1)[0] for h in outs])
+        for h in ins + outs:
+            g.free(h)
+    g.set_option("defer", 0)
+    assert np.array_equal(words[0], words[1])
+    exp = o.relinearize(o.multiply(base[0], base[0]))           # operand 0 is base[0] unchanged
+    assert np.array_equal(words[1][0], exp)
