@@ -86,8 +86,15 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * CN_TABLES_ZERO_COPY=0 (small operand tables are copied to the device instead of read from the pinned ring), CN_KS_WIDE_MAX / CN_KS_DIGIT_MAX ((ciphertext,
  * limb) blocks up to which a key switch runs as two launches: 160 / with one workgroup per digit: 10), CN_GEMM_ORDER, CN_DEFER_TRACE=1 (one stderr line
  * per flushed queue level: calls per kind, launches).
- * "ks_xcd": workgroup order of the fused key switch - 0 (ciphertext, limb), 1 the limbs of a ciphertext on one XCD, 2 limb-major (default up to
- * N = 8192: one key slice per XCD L2 at a time).  Environment: CN_LOCK_GRACE_NS / CN_LOCK_COMBINE switch the two context-lock experiments that
+ * "ks_xcd": workgroup order of the fused key switch - 0 (ciphertext, limb), 1 the limbs of a ciphertext on one XCD (default at N = 16384), 2 limb-major
+ * (default up to N = 8192: one key slice per XCD L2 at a time).
+ * N = 16384, batches (round 5): "ks_pair14" = 1 (default) runs a key switch as ONE launch - both 8192-point halves of a limb in one workgroup, the last
+ * inverse stage and the addends applied on the way out, a rotation's c1 permuted once per ciphertext and its c0 inside the kernel; 0 = the three launches of
+ * rounds 1-4 (permutation pass, two workgroups per limb, combining pass).  "ks_chain" = 1 (default): every link of a cn_sum_slots / cn_rowdot_batch
+ * rotate-and-add chain leaves the NEXT link's permuted c1 beside its result (no permutation pass between links).  "mp_bcast" = 1 (default): cn_rowdot_batch
+ * transforms its ONE ciphertext once and the row plaintexts inside the product kernel (one launch); 0 = k_lift_ntt + k_mul_plain_fused.  Environment:
+ * CN_KS_PAIR14, CN_KS_CHAIN (the same switches for a whole process), CN_DEFER_MERGE_GEMM=0 (deferred scalar products of one flush keep their levels:
+ * one launch per level instead of one per term count).  Environment: CN_LOCK_GRACE_NS / CN_LOCK_COMBINE switch the two context-lock experiments that
  * are kept but off (cn_host.cpp).
  * "ks_xi": DECOMPOSITION CONVENTION of the key switch (relinearisation and rotations).  0 (default): base-2^dbc digits of the raw residue c_l of every
  * source limb l; key (l, d) = (-(a s + e) + 2^(dbc d) s' [in limb l only], a) - SURVEY 9.5, the form in which the CRT basis element
@@ -98,7 +105,7 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
 int cn_set_option(cn_ctx *ctx, const char *name, int value);
 /* reads a switch back, or a choice the library made: "behz_small_base" (1: auxiliary primes below 2^49 - the FP64 kernels - k+1 of them,
  * or k+2 where k+1 are too few (N = 16384); 0: SEAL's 61-bit base, taken whenever log2 t + log2 N + log2 q + 2 < log2(B m_sk) does not
- * hold for the small primes or a data prime has 49 bits or more), "behz_f64", "aux_primes" (primes of B plus m_sk), "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "ks_xi", "sq_fused", "sq_pipe", "enc_fused", "mp_fused" */
+ * hold for the small primes or a data prime has 49 bits or more), "behz_f64", "aux_primes" (primes of B plus m_sk), "pending_calls" (deferred calls not yet launched), "f64", "defer", "ks_wide", "ks_xi", "ks_pair14", "ks_chain", "mp_bcast", "sq_fused", "sq_pipe", "enc_fused", "mp_fused" */
 int cn_get_option(cn_ctx *ctx, const char *name, int *value);
 /* SEAL DefaultParams.CoeffModulus128(n) (AtomicSealBfvVector.cs:146); returns count, fills q (<=9) */
 int cn_default_coeff_modulus(uint32_t n, uint64_t *q);
