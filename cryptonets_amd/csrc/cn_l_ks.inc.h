@@ -100,8 +100,18 @@ template <bool XI, bool WHOLE> static void launch_pair14(cn_ctx *c, const KsArgs
         hipLaunchKernelGGL((k_keyswitch_pair14<AR, XI, WHOLE>), dim3(a.cnt * c->hc.k), dim3(NttPlan<13>::NT), PAIR14_LDS, c->stream, a.target, a.tstride, a.add0, a.add1, a.astride,
                            (const void *)a.key, a.out, (double *)c->ks_part, c->dc, a.galois, a.accmax, a.extra, a.xstride, a.out_tab, a.perm_elt, a.next_elt, a.next_out, a.xcd_cts);
 }
-static bool pair14(cn_ctx *c, const KsArgs &a) {
+static bool pair14(cn_ctx *c, const KsArgs &a0) {
     if constexpr (kF64) {
+        // lazy accumulators of THIS kernel: the forward half-transform (L = 13: five stages behind its one recentring) leaves |v| <= 4.82 q, a term
+        // mulmod(v, key) is then at most (1/2 + 0.1875 x 4.82) q = 1.41 q (cn_ntt_core.hip.h), and 2^53 / q >= 16 for q < 2^49: 8 terms (+ the q/2 a recentred
+        // accumulator starts from) stay below 11.8 q.  The generic bound of do_keyswitch (2.1 q per term, sum below 2^52) allows 2 at 49 bits: a recentring of
+        // both accumulator sets every other digit, 2 % of the kernel's FP64 instructions at the reference's N = 16384 parameters.
+        KsArgs a = a0;
+        {
+            uint64_t qm = 0; for (uint32_t j = 0; j < c->hc.k; j++) qm = std::max(qm, c->hc.q[j].q);
+            const int bits = 64 - __builtin_clzll(qm);
+            if (bits >= 45 && bits <= 49) a.accmax = std::max(a.accmax, 1u << (52 - bits));
+        }
         // one digit per source limb that covers the limb (the reference's N = 16384 parameter sets, dbc 60): the digit is the word itself
         const int dbc = a.galois ? c->hc.gdbc : c->hc.dbc;
         uint64_t qmax = 0; for (uint32_t j = 0; j < c->hc.k; j++) qmax = std::max(qmax, c->hc.q[j].q);

@@ -452,8 +452,21 @@ def test_fp64_path_extreme_values():
         out = g.ct_alloc(3)
         g.rotate_rows(h, 0, 1, out, 0, 3)                 # key switch with extreme digits
         got = g.ct_download(out, 0, 3)
+        exp_rot = [o.rotate_rows(cts[i], 1) for i in range(3)]
         for i in range(3):
-            assert np.array_equal(got[i], o.rotate_rows(cts[i], 1))
+            assert np.array_equal(got[i], exp_rot[i])
+        # the same on the BATCH kernels (the fused key switch; at N = 16384 k_keyswitch_pair14 with its lazy accumulators over all 8 digits and the
+        # single-recentring forward transform), and a rotate-and-add chain on the extreme words
+        try:
+            g.set_option("ks_wide", 0)
+            g.rotate_rows(h, 0, 1, out, 0, 3)
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_rot)), name
+            g.copy(h, 0, out, 0, 3)
+            g.sum_slots(out, 0, 3, 4)
+            exp_sum = [o.add(x, o.rotate_rows(x, -2)) for x in [o.add(c, o.rotate_rows(c, -1)) for c in cts]]
+            assert np.array_equal(g.ct_download(out, 0, 3), np.stack(exp_sum)), name
+        finally:
+            g.set_option("ks_wide", -1)
         g.free(h); g.free(out)
 
 
