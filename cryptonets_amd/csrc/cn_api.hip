@@ -2,6 +2,7 @@
 // The compute path is HIP-only: there is no CPU fallback; every entry point fails with CN_ERR_NODEV /
 // CN_ERR_HIP when no gfx950 device is usable.
 #include "cn_runtime.h"
+#include <thread>
 #include "cn_k_elem.hip.h"
 #include <algorithm>
 #include <chrono>
@@ -230,6 +231,9 @@ __global__ void k_spin(uint64_t ticks) {
 }
 static std::mutex g_ctx_reg_mu;
 static std::vector<cn_ctx *> g_ctx_reg;
+// contexts of ONE device are created one after the other (the selection below needs to see every live stream of the device); other devices' creations and
+// every destruction go on meanwhile (round 5, ADVICE r04: the probe used to run under the registry lock - a busy context stalled every create / destroy in the process)
+static std::mutex &device_create_mutex(int device) { static std::mutex mu[64]; return mu[(unsigned)device % 64]; }
 // (both streams idle and nobody else submitting to them: the caller holds the lock of the context that owns `b`)
 static bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
     double best = 1e9;
@@ -243,11 +247,12 @@ static bool streams_share_a_queue(hipStream_t a, hipStream_t b) {
     }
     return best > 150e-6;
 }
-// Caller holds g_ctx_reg_mu (no context is created or destroyed meanwhile).  The stream of another live context is only touched UNDER THAT
+// Caller holds device_create_mutex(c->device).  The contexts to probe are SNAPSHOT under the registry lock and pinned (cn_ctx::probe_pins: cn_ctx_destroy of a
+// pinned context waits for the probe to let go); the registry lock is released before any stream is touched.  The stream of another live context is only touched UNDER THAT
 // CONTEXT'S LOCK, with `capturing` re-read under it: no API call of another thread can submit to it, start recording on it or free it while the two
 // spin kernels run, and a recording stream never sees a foreign launch (the probe used to read o->capturing and launch on o->stream
-// unsynchronised).  Lock order: registry, then ONE context lock at a time; nothing takes them the other way round (cn_ctx_destroy leaves the
-// registry lock before it takes the context's).  A probe waits for the work the other context has queued (at most a few batches); CN_STREAM_PROBE=0
+// unsynchronised).  Lock order: device-create mutex, then (briefly) the registry, then ONE context lock at a time; nothing takes them the other way round
+// (cn_ctx_destroy leaves the registry lock before it takes the context's).  A probe waits for the work the other context has queued (at most a few batches); CN_STREAM_PROBE=0
 // switches the whole selection off.  No early return between the creation of a candidate and the clean-up below: rejected candidates are destroyed on
 // every path.
 static int pick_stream(cn_ctx *c) {
@@ -256,7 +261,11 @@ static int pick_stream(cn_ctx *c) {
     const char *env = getenv("CN_STREAM_PROBE");
     if (env && !atoi(env)) return 0;
     std::vector<cn_ctx *> others;
-    for (cn_ctx *o : g_ctx_reg) if (o->device == c->device) others.push_back(o);
+    {
+        std::lock_guard<std::mutex> reg(g_ctx_reg_mu);
+        for (cn_ctx *o : g_ctx_reg) if (o->device == c->device) { o->probe_pins.fetch_add(1, std::memory_order_acq_rel); others.push_back(o); }
+    }
+    struct Unpin { std::vector<cn_ctx *> &v; ~Unpin() { for (cn_ctx *o : v) o->probe_pins.fetch_sub(1, std::memory_order_acq_rel); } } unpin{others};
     if (others.empty()) return 0;
     hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, (uint64_t)1);          // code object loaded, queue created
     if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }          // (no selection; the context itself will report a broken device)
@@ -300,6 +309,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), c->index_map.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
     c->dq = cn_defer_new();
     c->slabs = new std::vector<Slab>();
+    std::lock_guard<std::mutex> one_at_a_time(device_create_mutex(device));       // until this context is registered: the next creator on this device must see its stream
     const int rc = ctx_init(c, n, k, device, tw);
     if (rc) {                                   // whatever was created so far is released (streams, events, tables); the message of the failing call stays
         (void)hipGetLastError();
@@ -313,10 +323,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
 static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<uint64_t> &tw) {
     c->device = device;
     HIPCHK(hipSetDevice(device));
-    {
-        std::lock_guard<std::mutex> reg(g_ctx_reg_mu);
-        CHECK(pick_stream(c));
-    }
+    CHECK(pick_stream(c));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipMalloc((void **)&c->tw, tw.size() * 8));
     HIPCHK(hipMemcpy(c->tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
@@ -376,6 +383,7 @@ extern "C" int cn_ctx_destroy(cn_ctx *ctx) {
         std::lock_guard<std::mutex> reg(g_ctx_reg_mu);
         g_ctx_reg.erase(std::remove(g_ctx_reg.begin(), g_ctx_reg.end(), ctx), g_ctx_reg.end());
     }
+    while (ctx->probe_pins.load(std::memory_order_acquire) > 0) std::this_thread::yield();      // a cn_ctx_create on this device is measuring this context's stream (pick_stream)
     ctx_teardown(ctx);
     return 0;
 }

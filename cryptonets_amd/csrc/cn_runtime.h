@@ -159,6 +159,7 @@ struct cn_ctx {
     int gemm_order = 1;                          // scalar GEMM (VALU kernels): 1 = slice-major workgroup order (every input slice fetched once per XCD), 0 = group-major
     bool ks_perm_fused = true;                    // rotations through the two-launch key switch apply the automorphism while loading (no k_galois_lds pass)
     int stream_tries = 0;                        // streams created until one had a hardware queue of its own (cn_api.hip: pick_stream)
+    std::atomic<int> probe_pins{0};              // > 0: a cn_ctx_create on this device is measuring this context's stream; cn_ctx_destroy waits
                               // ciphertext on one XCD (share its source limbs in that L2); 2 limb-major (one key slice per XCD L2 at a time)
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
     bool capturing = false;   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
