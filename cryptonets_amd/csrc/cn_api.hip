@@ -1553,8 +1553,24 @@ static int rotate_jobs(cn_ctx *ctx, std::vector<RotJob> &jobs) {
     if (!n) return 0;
     size_t rounds = 0;
     for (RotJob &j : jobs) { CHECK(rotation_hops(ctx, j.steps, j.elts)); rounds = std::max(rounds, j.elts.size()); }
-    bool tables_ok = ctx->ks_perm_fused && ks_planned_mode(ctx, n, 1) != 0;
-    for (uint32_t a = 0; a < n && tables_ok; a++) for (uint32_t b = 0; b < n; b++) if (a != b && (jobs[a].dst == jobs[b].src || jobs[a].dst == jobs[b].dst)) { tables_ok = false; break; }
+    bool aliased = false;
+    for (uint32_t a = 0; a < n && !aliased; a++) for (uint32_t b = 0; b < n; b++) if (a != b && (jobs[a].dst == jobs[b].src || jobs[a].dst == jobs[b].dst)) { aliased = true; break; }
+    bool tables_ok = ctx->ks_perm_fused && !aliased && ks_planned_mode(ctx, n, 1) != 0;
+    if (!tables_ok && !aliased && ctx->ks_perm_fused && n > 1) {
+        // More rotations than ONE table-driven two-launch key switch takes (LoLa-CIFAR's ConvertToColumnVector: 83 maps at N = 16384 - 664 (ciphertext, limb)
+        // blocks against the 160 up to which a key switch runs as two launches): pieces of the largest size that does, each a launch chain of its own, instead
+        // of 83 x ~4 single-ciphertext rotations of two launches each (round 5: 632 -> ~40 launches per plaintext prime and image).  Independent jobs: any order.
+        uint32_t piece = 0;
+        for (uint32_t c = std::min<uint32_t>(n - 1, 64); c >= 2; c--) if (ks_planned_mode(ctx, c, 1) != 0) { piece = c; break; }
+        if (piece) {
+            for (uint32_t s0 = 0; s0 < n; s0 += piece) {
+                std::vector<RotJob> part(jobs.begin() + s0, jobs.begin() + std::min<uint32_t>(n, s0 + piece));
+                for (RotJob &j : part) j.elts.clear();
+                CHECK(rotate_jobs(ctx, part));
+            }
+            return 0;
+        }
+    }
     if (!tables_ok) {                                      // large batches (fused kernel), aliased operands: one after the other
         CHECK(ensure_scratch(ctx, al(ctx->ctw2 * 8)));
         for (RotJob &j : jobs) {

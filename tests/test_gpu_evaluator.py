@@ -1227,7 +1227,7 @@ def test_rotation_with_and_without_the_permutation_pass(name, rng):
 @pytest.mark.parametrize("name", ["tiny", "c4"])
 def test_rotate_rows_many(name, rng):
     """cn_rotate_rows_many: n ciphertexts rotated by n different step counts (direct keys, multi-hop NAF steps, 0) as one launch chain per hop
-    round - words of n cn_rotate_rows calls; in place; more rotations than one two-launch key switch takes (run one after the other); queued
+    round - words of n cn_rotate_rows calls; in place; more rotations than one two-launch key switch takes (run in pieces of the largest size that does); queued
     under deferred submission (rotations of one level share the rounds whatever their step counts); overlapping operands are refused."""
     from cryptonets_amd._native import CnError
     o, g = get_oracle(name, galois=True), get_gpu(name, galois=True)
@@ -1265,7 +1265,10 @@ def test_rotate_rows_many(name, rng):
     big = 40
     idx = [i % len(steps) for i in range(big)]
     hb = g.ct_alloc(big)
+    l0 = g.stats()["kernel_launches"]
     g.rotate_rows_many(h, idx, [steps[i] for i in idx], hb, list(range(big)))
     assert np.array_equal(g.ct_download(hb, 0, big), exp[idx])
+    # ... run as a few table-driven pieces (round 5), not as 40 x hops single-ciphertext key switches of two launches each
+    assert g.stats()["kernel_launches"] - l0 < 40
     for x in (h, out, w, hb):
         g.free(x)
