@@ -1441,7 +1441,12 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
 
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
     uint32_t limbs = count * 2 * ctx->hc.k;
-    if (ks_pair14_ok(ctx, count, 1, it->second)) {           // N = 16384, batch: c1 is permuted once (here unless the caller brings it), c0 inside the key switch
+    // (the one-launch kernel reads c0 of `in` while other workgroups already write `out`: safe when the two arrays are the same or disjoint - a workgroup only touches
+    // its own (ciphertext, limb) - not when they overlap with a shift: those calls keep the permutation pass, which has read all of `in` before anything is written)
+    const bool shifted = in != out && in < out + (size_t)count * ctx->ctw2 && out < in + (size_t)count * ctx->ctw2;
+    const bool acc_shifted = acc && acc != out && acc < out + (size_t)count * ctx->ctw2 && out < acc + (size_t)count * ctx->ctw2;
+    if (acc_shifted) return fail(CN_ERR_ARG, "rotate-and-add: accumulator and result ranges overlap partially (use the same range or disjoint ranges)");
+    if (!shifted && ks_pair14_ok(ctx, count, 1, it->second)) {           // N = 16384, batch: c1 is permuted once (here unless the caller brings it), c0 inside the key switch
         if (!pre) {
             hipLaunchKernelGGL(k_galois_limbs, dim3(count * ctx->hc.k), dim3(1024), (size_t)ctx->hc.n * 8, ctx->stream, in + kn, 2 * kn, tmp, kn, ctx->dc, elt);
             HIPCHK(hipGetLastError()); launch_count(ctx);
@@ -1468,8 +1473,11 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
     if (acc) ctx->st.Addition += count;
     return 0;
 }
+// (a batched rotation reads operand c while another workgroup / a staging copy already writes result c': the same range or disjoint ranges only - like cn_mul_plain)
+static bool shifted_overlap(const Buffer *I, uint32_t ii, const Buffer *O, uint32_t oi, uint32_t count) { return I == O && ii != oi && ii < oi + count && oi < ii + count; }
 static int galois_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, uint64_t elt, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (shifted_overlap(I, ii, O, oi, count)) return fail(CN_ERR_ARG, "rotation: operand and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
@@ -1504,6 +1512,7 @@ static int rotate_rec(cn_ctx *ctx, uint64_t *cur, int steps, uint64_t *tmp, uint
 }
 static int rotate_rows_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (shifted_overlap(I, ii, O, oi, count)) return fail(CN_ERR_ARG, "rotation: operand and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
@@ -1645,6 +1654,8 @@ API_END }
 // fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
 static int rotate_rows_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (shifted_overlap(I, ii, O, oi, count) || shifted_overlap(A, ai, O, oi, count))
+        return fail(CN_ERR_ARG, "rotate-and-add: operand / accumulator and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     const uint64_t *i = I->d + ii * I->item_words, *a = A->d + ai * A->item_words; uint64_t *o = O->d + oi * O->item_words;
     if (steps == 0) {
@@ -1670,6 +1681,8 @@ static int rotate_rows_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, 
 }
 static int rotate_columns_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
+    if (shifted_overlap(I, ii, O, oi, count) || shifted_overlap(A, ai, O, oi, count))
+        return fail(CN_ERR_ARG, "rotate-and-add: operand / accumulator and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);

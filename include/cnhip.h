@@ -228,7 +228,8 @@ int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t a_stride, cn_ha
 /* Evaluator.ApplyGalois: automorphism + key switch of c1 */
 int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t galois_elt, cn_handle out, uint32_t oi, uint32_t count);
 /* Evaluator.RotateRows(/Inplace): NAF decomposition when no key exists for the step
- * (AtomicSealBfvVector.cs:625,631,637,660,864,1420,1458) */
+ * (AtomicSealBfvVector.cs:625,631,637,660,864,1420,1458).  Every batched rotation (this one, cn_apply_galois, cn_rotate_columns and the _add forms): operand /
+ * accumulator and result ranges of ONE handle are the same range (in place) or disjoint; a partial overlap is refused (CN_ERR_ARG), as in cn_mul_plain. */
 int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count);
 /* RotateRows of n ciphertexts by n DIFFERENT step counts: out[oi[i]] = RotateRows(in[ii[i]], steps[i]), same words as n cn_rotate_rows calls.
  * The reference rotates the vectors of an Interleave / a Vectorize one Evaluator.RotateRows at a time (AtomicSealBfvVector.cs:628-688); here the

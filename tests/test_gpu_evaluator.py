@@ -640,6 +640,13 @@ def test_sum_slots_chain_at_n16384(name, rng):
                     assert np.array_equal(g.ct_download(h, 8, 1)[0], reference(cts[8], length))
         g.set_option("ks_pair14", 1); g.set_option("ks_chain", 1); g.set_option("ks_xcd", 0)
         g.ct_upload(h, 0, cts)
+        from cryptonets_amd._native import CnError
+        with pytest.raises(CnError):
+            g.rotate_rows(h, 0, -2, h, 1, 3)                                  # result range = operand range shifted by one ciphertext: refused (like cn_mul_plain)
+        with pytest.raises(CnError):
+            g.rotate_rows_add(h, 4, 1, h, 5, h, 6, 2)                         # accumulator range overlaps the result range with a shift
+        assert np.array_equal(g.ct_download(h, 0, 9), cts)
+        g.ct_upload(h, 0, cts)
         g.rotate_rows_add(h, 0, -2, h, 1, h, 2, 1)                            # three different arrays
         assert np.array_equal(g.ct_download(h, 2, 1)[0], o.add(cts[1], o.rotate_rows(cts[0], -2)))
         g.rotate_columns_add(h, 0, h, 1, h, 1, 1)                             # accumulator in place
