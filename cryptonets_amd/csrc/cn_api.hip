@@ -893,7 +893,11 @@ extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
 API_END }
 // out[c] = a[c * (a_bcast ? 0 : 1)] * pt[c * pstride]; a_bcast: ONE ciphertext against `count` plaintexts (row-dot batches)
 // Dense MultiplyPlain in two launches (k_lift_ntt, k_mul_plain_fused); ranges / zero plaintexts were checked by the caller
-static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
+// A row-dot batch whose SumAllSlots chain follows: the product kernel leaves sigma_elt(c1) of every product in `out` ([row][k][N], the chain's first scratch array) and takes
+// its transformed ciphertext from `ctn` - both inside the scratch arena the caller has sized for the whole call (no ensure_scratch in between: the arena must not move)
+struct BcastNext { uint64_t elt; uint64_t *out, *ctn; };
+static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count,
+                           const BcastNext *nx = nullptr) {
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
     uint64_t *o = O->d + oi * O->item_words;
     const uint64_t *src = A->d + ai * A->item_words;
@@ -902,12 +906,12 @@ static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Bu
     for (uint32_t m = 0; m < k; m++) { f64 = f64 && ctx->hc.f64ok[m]; if (ctx->hc.q[m].q >> 44) light = false; }
     const int pol = f64 && light ? POL_F64L : (f64 ? POL_F64 : POL_U64);
     if (a_bcast && pstride && count >= 4 && ctx->mp_bcast) {      // one ciphertext x many plaintexts: transform the ciphertext once, the plaintexts inside the product kernel
-        CHECK(ensure_scratch(ctx, al(A->item_words * 8)));
-        uint64_t *ctn = salloc<uint64_t>(ctx, A->item_words);
+        uint64_t *ctn = nx ? nx->ctn : nullptr;
+        if (!nx) { CHECK(ensure_scratch(ctx, al(A->item_words * 8))); ctn = salloc<uint64_t>(ctx, A->item_words); }
         if (!ctn) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply_plain");
         HIPCHK(hipMemcpyAsync(ctn, src, A->item_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
         CHECK(cn_run_ntt(ctx, ctn, A->size * k, 0, k, 0));
-        rr_ops[pol]->mul_plain_bcast(ctx, P->d + (size_t)pi * n, pstride, ctn, o, count, A->size);
+        rr_ops[pol]->mul_plain_bcast(ctx, P->d + (size_t)pi * n, pstride, ctn, o, count, A->size, nx ? (uint32_t)nx->elt : 0u, nx ? nx->out : nullptr);
         HIPCHK(hipGetLastError()); launch_count(ctx);
         ctx->st.ntt_forward_limbs += (uint64_t)A->size * k + (uint64_t)count * A->size * k; ctx->st.ntt_inverse_limbs += (uint64_t)count * A->size * k;
         ctx->st.PlainMultiplication += count;
@@ -932,7 +936,9 @@ static int mul_plain_fused(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Bu
     ctx->st.PlainMultiplication += count;
     return 0;
 }
-static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count) {
+static bool mul_plain_takes_bcast(cn_ctx *ctx, uint32_t count) { return ctx->mp_fused && ctx->mp_bcast && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14 && count >= 4; }
+static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buffer *P, uint32_t pi, uint32_t pstride, Buffer *O, uint32_t oi, uint32_t count,
+                          const BcastNext *nx = nullptr) {
     if (!range_ok(A, ai, a_bcast ? 1 : count) || !range_ok(O, oi, count) || !range_ok(P, pi, pstride ? count : 1, pstride ? pstride : 1))
         return fail(CN_ERR_ARG, "index out of range");
     if (!count) return 0;
@@ -940,7 +946,8 @@ static int mul_plain_impl(cn_ctx *ctx, Buffer *A, uint32_t ai, bool a_bcast, Buf
         return fail(CN_ERR_ARG, "multiply_plain: input and output ranges overlap partially (use the same range or disjoint ranges)");
     const uint32_t n = ctx->hc.n, k = ctx->hc.k, npt = pstride ? count : 1;
     for (uint32_t c = 0; c < npt; c++) if (P->pt_zero[pi + c * pstride]) return fail(CN_ERR_ZERO, "plain cannot be zero");
-    if (ctx->mp_fused && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) return mul_plain_fused(ctx, A, ai, a_bcast, P, pi, pstride, O, oi, count);
+    if (ctx->mp_fused && !ctx->legacy_ntt && ctx->hc.logn >= 10 && ctx->hc.logn <= 14) return mul_plain_fused(ctx, A, ai, a_bcast, P, pi, pstride, O, oi, count, nx);
+    if (nx) return fail(CN_ERR_ARG, "internal: chained row-dot batch outside the fused product");
     CHECK(ensure_scratch(ctx, al((size_t)npt * k * n * 8)));
     uint64_t *lift = salloc<uint64_t>(ctx, (size_t)npt * k * n);
     // lift every referenced plaintext into the k limbs (one launch), NTT them
@@ -1710,24 +1717,33 @@ extern "C" int cn_rotate_columns_add(cn_ctx *ctx, cn_handle in, uint32_t ii, cn_
 API_END }
 // SumAllSlots(length) of AtomicSealBfvVector.cs:888-935 on `count` single-block ciphertexts at once, in place: the column swap when
 // length >= N/2, then log2 rotate-and-add steps (RotateRows(-2^s) + AddInplace).  length 0 = all N slots.
-static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count, uint32_t length) {
+// the Galois elements of SumAllSlots(length) if the whole chain runs on the one-launch key switch with every link handing sigma_next(c1) on (N = 16384, batch); else empty
+static std::vector<uint64_t> sum_slots_chain_elts(cn_ctx *ctx, uint32_t count, uint32_t length) {
+    const uint32_t n = ctx->hc.n, half = n / 2;
+    std::vector<uint64_t> elts;
+    bool ok = ctx->ks_chain && count > 0;
+    uint32_t l2 = length ? length : n;
+    if (l2 >= half) { elts.push_back(2ull * n - 1); l2 = half; }
+    for (uint32_t steps = 1; steps < l2 && ok; steps *= 2) { if (has_direct_key(ctx, -(int)steps)) elts.push_back(cn_galois_elt_from_step(ctx, -(int)steps)); else ok = false; }
+    for (uint64_t e : elts) { auto it = ctx->gk.find(e); if (it == ctx->gk.end() || !it->second.d || !ks_pair14_ok(ctx, count, 1, it->second)) { ok = false; break; } }
+    if (!ok || elts.size() < 2) elts.clear();
+    return elts;
+}
+// first_ready: the scratch arena already holds sigma_(elts[0])(c1) of every ciphertext at its start (written by the producer of H: k_mul_plain_bcast) and is large enough
+static int sum_slots_impl(cn_ctx *ctx, Buffer *H, uint32_t first, uint32_t count, uint32_t length, bool first_ready = false) {
     const uint32_t n = ctx->hc.n, half = n / 2;
     uint32_t len = length ? length : n;
     {   // N = 16384, batch: the links of the chain as ONE launch each - link s leaves sigma_(s+1) of its new c1 beside its result (k_keyswitch_pair14), so only the
-        // first link needs a permutation pass.  Same words as the loop below (the same key switches on the same operands).
-        std::vector<uint64_t> elts;
-        bool ok = ctx->ks_chain && count > 0;
-        uint32_t l2 = len;
-        if (l2 >= half) { elts.push_back(2ull * n - 1); l2 = half; }
-        for (uint32_t steps = 1; steps < l2 && ok; steps *= 2) { if (has_direct_key(ctx, -(int)steps)) elts.push_back(cn_galois_elt_from_step(ctx, -(int)steps)); else ok = false; }
-        for (uint64_t e : elts) { auto it = ctx->gk.find(e); if (it == ctx->gk.end() || !it->second.d || !ks_pair14_ok(ctx, count, 1, it->second)) { ok = false; break; } }
-        if (ok && elts.size() > 1) {
+        // first link needs a permutation pass (none when the producer has left it).  Same words as the loop below (the same key switches on the same operands).
+        const std::vector<uint64_t> elts = sum_slots_chain_elts(ctx, count, length);
+        if (elts.empty() && first_ready) return fail(CN_ERR_ARG, "internal: chained row-dot batch without a chain");
+        if (!elts.empty()) {
             const size_t kn = (size_t)ctx->hc.k * n;
-            CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+            if (first_ready) ctx->soff = 0; else CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
             uint64_t *pp[2]; pp[0] = salloc<uint64_t>(ctx, count * ctx->ctw2); pp[1] = pp[0] + (size_t)count * kn;
             uint64_t *h = H->d + first * H->item_words;
             for (size_t s = 0; s < elts.size(); s++)
-                CHECK(do_galois(ctx, h, elts[s], h, pp[s & 1], count, h, s ? pp[s & 1] : nullptr, s + 1 < elts.size() ? elts[s + 1] : 0, pp[(s + 1) & 1]));
+                CHECK(do_galois(ctx, h, elts[s], h, pp[s & 1], count, h, (s || first_ready) ? pp[s & 1] : nullptr, s + 1 < elts.size() ? elts[s + 1] : 0, pp[(s + 1) & 1]));
             return 0;
         }
     }
@@ -1755,6 +1771,19 @@ extern "C" int cn_rowdot_batch(cn_ctx *ctx, cn_handle v, uint32_t vi, cn_handle 
     LOCK; GETCT(V, v, 2); GETCT(O, out, 2); GETPT(P, pt);
     if (!rows) return 0;
     if (V == O && vi >= oi && vi < oi + rows) return fail(CN_ERR_ARG, "row-dot batch cannot overwrite its input");
+    if (length != 1 && mul_plain_takes_bcast(ctx, rows)) {
+        // the product kernel hands the chain its first permuted c1 (no k_galois_limbs pass over the products): one arena for the chain's two scratch arrays and the
+        // transformed ciphertext, sized here and left where it is until the chain has run
+        const std::vector<uint64_t> elts = sum_slots_chain_elts(ctx, rows, length);
+        if (!elts.empty()) {
+            CHECK(ensure_scratch(ctx, al(rows * ctx->ctw2 * 8) + al(V->item_words * 8)));
+            uint64_t *p0 = salloc<uint64_t>(ctx, rows * ctx->ctw2), *ctn = salloc<uint64_t>(ctx, V->item_words);
+            if (!p0 || !ctn) return fail(CN_ERR_HIP, "internal: scratch exhausted in the row-dot batch");
+            const BcastNext nx{elts[0], p0, ctn};
+            CHECK(mul_plain_impl(ctx, V, vi, true, P, pi, 1, O, oi, rows, &nx));
+            return sum_slots_impl(ctx, O, oi, rows, length, true);
+        }
+    }
     CHECK(mul_plain_impl(ctx, V, vi, true, P, pi, 1, O, oi, rows));
     if (length == 1) return 0;
     return sum_slots_impl(ctx, O, oi, rows, length);

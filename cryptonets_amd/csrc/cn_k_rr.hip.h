@@ -76,9 +76,11 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_lift_ntt(const uint64_t *__r
 // the thread holds (16 B/lane), transforms back.  INTT(NTT(lift(pt)) . NTT(ct)): the same words as k_lift_ntt + k_mul_plain_fused, which transformed the
 // broadcast ciphertext once per row and carried every lifted plaintext through HBM in NTT form (k limbs written + read twice per row: 5.5 GiB per call at CIFAR
 // shapes) - a launch, a fifth of the transforms and that round trip less.
+// next_elt != 0: the c1 limbs (poly 1) leave a second time, permuted by the Galois element of the rotation that follows (the first link of the row-dot batch's
+// SumAllSlots chain, k_keyswitch_pair14): next_out[row][k][N] - staged through the exchange image (coalesced stores), no permutation pass in front of the chain.
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_bcast(const uint64_t *__restrict__ pt, uint32_t pitch, const uint64_t *__restrict__ ctn, uint64_t *__restrict__ out,
-                                                                    const DevConsts *__restrict__ C, uint32_t polys) {
+                                                                    const DevConsts *__restrict__ C, uint32_t polys, uint32_t next_elt, uint64_t *__restrict__ next_out) {
     typedef typename AR::T T;
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
@@ -109,8 +111,22 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_bcast(const uint64
     asm volatile("" : "+v"(ti));
     ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, ti);
     uint64_t *o = out + ((size_t)cp * k + j) * n;
+    const bool chain = next_elt && p == 1;
+    uint64_t *win = reinterpret_cast<uint64_t *>(smem);                    // N words: inside the (padded) exchange image
+    if (chain) __syncthreads();                                            // everybody has taken its coefficients out of the image
 #pragma unroll
-    for (int r = 0; r < 16; r++) o[pass_index<L, SA, 0>(ti, r)] = A.scaled(v[r]);
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(ti, r);
+        const uint64_t val = A.scaled(v[r]);
+        o[e] = val;
+        if (chain) { const uint32_t pos = (e * next_elt) & (2 * n - 1); win[pos & (n - 1)] = (pos >> L) ? negmod(val, C->q[j].q) : val; }
+    }
+    if (chain) {
+        __syncthreads();
+        uint64_t *no = next_out + ((size_t)row * k + j) * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) no[ti + NttPlan<L>::NT * (uint32_t)r] = win[ti + NttPlan<L>::NT * (uint32_t)r];
+    }
 }
 template <int L, class AR>
 __global__ void __launch_bounds__(NttPlan<L>::NT) k_mul_plain_fused(const uint64_t *src, size_t src_stride, const uint64_t *__restrict__ ptn, uint32_t pstride,

@@ -82,11 +82,13 @@ static bool mul_plain_fused(cn_ctx *c, const uint64_t *pt, uint32_t pitch, uint3
                             uint64_t *out, uint32_t count, uint32_t polys) { BY_SIZE(l_mul_plain_fused, c, pt, pitch, npt, lift, src, sstride, pstride, out, count, polys) }
 
 // one ciphertext (NTT form in ctn) times `count` plaintexts: one launch
-template <int L> static void l_mul_plain_bcast(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys) {
-    hipLaunchKernelGGL((k_mul_plain_bcast<L, AR>), dim3(count * polys * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, pt, pitch, ctn, out, c->dc, polys);
+template <int L> static void l_mul_plain_bcast(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys, uint32_t next_elt,
+                                               uint64_t *next_out) {
+    hipLaunchKernelGGL((k_mul_plain_bcast<L, AR>), dim3(count * polys * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, pt, pitch, ctn, out, c->dc, polys,
+                       next_elt, next_out);
 }
-static bool mul_plain_bcast(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys) {
-    BY_SIZE(l_mul_plain_bcast, c, pt, pitch, ctn, out, count, polys)
+static bool mul_plain_bcast(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys, uint32_t next_elt, uint64_t *next_out) {
+    BY_SIZE(l_mul_plain_bcast, c, pt, pitch, ctn, out, count, polys, next_elt, next_out)
 }
 
 #ifdef RR_ENC_TAIL

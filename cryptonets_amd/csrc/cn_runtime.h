@@ -212,7 +212,8 @@ struct RrOps {                // register-radix kernels of one arithmetic policy
                             uint64_t *out, uint32_t count, uint32_t polys);
     bool (*enc_tail)(cn_ctx *c, const uint64_t *u, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);   // U64, F64; tab: EncTab[cnt] or null
     bool (*enc_fused)(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);  // all policies, N <= 8192: u (int8) -> transform -> both components in one kernel
-    bool (*mul_plain_bcast)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys);             // ONE ciphertext (NTT form) x count plaintexts
+    bool (*mul_plain_bcast)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys, uint32_t next_elt,
+                            uint64_t *next_out);                                       // ONE ciphertext (NTT form) x count plaintexts (+ sigma_next(c1) of every product on the side)
 };
 struct KsOps {
     int (*set_attrs)(uint32_t logn, size_t lds);

@@ -638,6 +638,27 @@ def test_sum_slots_chain_at_n16384(name, rng):
                 assert np.array_equal(g.ct_download(h, 0, 3), exp), (length, pair, chain, xcd)
                 if xcd:                                                        # 8 ciphertexts in the XCD-aware order + 1 in the plain one
                     assert np.array_equal(g.ct_download(h, 8, 1)[0], reference(cts[8], length))
+        # the row-dot batch: ONE ciphertext x 5 plaintext rows, then the chain - the product kernel hands the chain its first permuted c1 (no permutation pass at all);
+        # against the oracle, with and without the hand-over (mp_bcast 0: two-launch product + k_galois_limbs)
+        rows = 5
+        pts = np.stack([o.encode(rng.integers(0, o.t, size=n, dtype=np.uint64)) for _ in range(rows)])
+        ph, ro = g.pt_alloc(rows), g.ct_alloc(rows)
+        g.pt_upload(ph, 0, pts)
+        g.set_option("ks_pair14", 1); g.set_option("ks_chain", 1); g.set_option("ks_xcd", 1)
+        g.ct_upload(h, 0, cts)
+        for length in (0, 8):
+            exp_rows = np.stack([reference(o.multiply_plain(cts[4], pts[r]), length) for r in range(rows)])
+            for bc in (1, 0):
+                g.set_option("mp_bcast", bc)
+                l0 = g.stats()["kernel_launches"]
+                g.rowdot_batch(h, 4, ph, 0, rows, length, ro, 0)
+                launches = g.stats()["kernel_launches"] - l0
+                assert np.array_equal(g.ct_download(ro, 0, rows), exp_rows), (length, bc)
+                links = 14 if length == 0 else 3
+                assert launches == (links + 2 if bc else links + 3), (length, bc, launches)      # transform of the ciphertext + product (or lift + product + permutation) + one launch per link
+        g.set_option("mp_bcast", 1)
+        assert np.array_equal(g.ct_download(h, 4, 1)[0], cts[4])
+        g.free(ph); g.free(ro)
         g.set_option("ks_pair14", 1); g.set_option("ks_chain", 1); g.set_option("ks_xcd", 0)
         g.ct_upload(h, 0, cts)
         from cryptonets_amd._native import CnError
