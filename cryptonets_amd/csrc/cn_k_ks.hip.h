@@ -278,9 +278,6 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
 #ifndef KS14_DBG
 #define KS14_DBG 0          // timing experiments (tools/build_ks14_dbg.py; results are wrong with any bit set): 1 no c0 staging, 2 no accumulator, 4 no stash,
 #endif                      // 8 no closing arithmetic, 16 synthetic digit sources (no loads), 32 synthetic keys (no loads)
-#ifndef KS14_WARM
-#define KS14_WARM 0
-#endif
 #ifndef KS14_PREFETCH
 #define KS14_PREFETCH 1     // 0: every digit loads its source words at its start (A/B)
 #endif
@@ -350,19 +347,6 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
     const uint32_t tot = galois ? C->gk_tot : C->rl_tot;
     double *stp = stash + ((size_t)ct * k + j) * 2 * n2;
     const uint64_t *tgt = target + (size_t)ct * tgt_stride;
-#if KS14_WARM
-    // (experiment) the closing step touches ~8 arrays this workgroup has not seen before: one word of each now, so that the address translations are in
-    // place when the closing loads arrive
-    uint64_t warm = 0;
-    if (tid < 16) {
-        const uint32_t w = tid & 7;
-        const uint64_t *ob = (out_tab ? out_tab[ct] : out + (size_t)ct * 2 * kn) + (size_t)j * n;
-        const uint64_t *a = w == 0 ? (add0 ? add0 + (size_t)ct * add_stride + (size_t)j * n : ob) : w == 1 ? (add1 ? add1 + (size_t)ct * add_stride + (size_t)j * n : ob)
-                          : w == 2 ? (extra ? extra + (size_t)ct * ex_stride + (size_t)j * n : ob) : w == 3 ? (extra ? extra + (size_t)ct * ex_stride + kn + (size_t)j * n : ob)
-                          : w == 4 ? ob : w == 5 ? ob + kn : w == 6 ? (const uint64_t *)stp : (next_out ? next_out + (size_t)ct * kn + (size_t)j * n : ob);
-        warm = a[(tid >> 3) * (n - 1)];
-    }
-#endif
 #pragma unroll 1
     for (uint32_t h = 0; h < 2; h++) {
         const GP fwg = (GP)(C->twdh + ((size_t)(j * 2 + 0) * 2 + h) * n2);
@@ -481,9 +465,6 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
                 }
             }
             __syncthreads();
-#if KS14_WARM
-            asm volatile("" :: "v"(warm));
-#endif
             if (chain) {
                 NTT_GLOBAL uint64_t *no = (NTT_GLOBAL uint64_t *)next_out + (size_t)ct * kn + (size_t)j * n;
 #pragma unroll 8
