@@ -361,7 +361,8 @@ def cifar_key_switch_block(g, ms_per_image, primes):
     link_ms = chain_ms / links
     blk_ = {"kernel": "k_keyswitch_pair14 (%d ciphertexts x %d output limbs: 2 x %d digit transforms + 4 inverse half-transforms per workgroup, one launch per rotate-and-add link)" % (rows, k, k),
             "bound": "valu issue (fp64)", "ms_per_link": round(link_ms, 3), "links_per_prime": links, "ms_per_chain": round(chain_ms, 2),
-            "share_of_image": round(primes * chain_ms / ms_per_image, 3)}
+            "share_of_image": round(primes * chain_ms / ms_per_image, 3),
+            "share_note": "this chain alone on one stream, timed behind the images (the clock is at its lowest there); inside an image the chains of the plaintext primes run on two hardware queues and fill each other's last partial wave of workgroups"}
     try:
         import glob
         src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ks14_counters.json")))[-1]
