@@ -1004,17 +1004,19 @@ API_END }
 
 // HOT LOOP A
 // weight tiles of a planned GEMM in kernel layout; row(g, m): the K weights (residues mod t) of member m of group g, or null
-template <class ROW> static void pack_gemm_weights(cn_ctx *ctx, uint32_t G, uint32_t M, uint32_t K, bool small, ROW row, uint32_t &MT, std::vector<char> &wbytes) {
+// tap_ok(g, kk): term kk of group g gathers a ciphertext; a padded tap gets the weight 0 whatever the caller passed (k_scalar_gemm_f64 multiplies a valid word
+// by it instead of selecting per lane)
+template <class ROW, class TAP> static void pack_gemm_weights(cn_ctx *ctx, uint32_t G, uint32_t M, uint32_t K, bool small, ROW row, TAP tap_ok, uint32_t &MT, std::vector<char> &wbytes) {
     const uint32_t k = ctx->hc.k; const uint64_t t = ctx->hc.t.q;
     if (small) {
         const uint32_t MTf = M >= 16 ? 20 : (M >= 8 ? 10 : (M >= 3 ? 5 : 1)), mtf = (M + MTf - 1) / MTf;
-        std::vector<double> hWd((size_t)G * mtf * K * MTf + 16 * MTf, 0.0);  // [g][mtile][kk][m], zero padded; + 16 rows: the kernel's software
-                                                                               // pipeline reads (and multiplies by 0) up to 15 terms past a block
+        const uint32_t Kw = gemm_f64_rows(K);
+        std::vector<double> hWd((size_t)G * mtf * Kw * MTf, 0.0);           // [g][mtile][kk < Kw][m], zero padded (gemm_f64_rows)
         for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
             const uint64_t *wr = row(g, m);
             if (!wr) continue;
-            double *dst = &hWd[(((size_t)g * mtf + m / MTf) * K) * MTf + m % MTf];
-            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
+            double *dst = &hWd[(((size_t)g * mtf + m / MTf) * Kw) * MTf + m % MTf];
+            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = tap_ok(g, kk) ? wr[kk] : 0; dst[(size_t)kk * MTf] = w >= ctx->hc.t_half ? -(double)(t - w) : (double)w; }
         }
         MT = MTf;
         wbytes.assign((const char *)hWd.data(), (const char *)(hWd.data() + hWd.size()));
@@ -1025,7 +1027,7 @@ template <class ROW> static void pack_gemm_weights(cn_ctx *ctx, uint32_t G, uint
             const uint64_t *wr = row(g, m);
             if (!wr) continue;
             uint64_t *dst = &hW[((((size_t)j * G + g) * mti + m / MTi) * K) * MTi + m % MTi];
-            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = wr[kk]; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
+            for (uint32_t kk = 0; kk < K; kk++) { uint64_t w = tap_ok(g, kk) ? wr[kk] : 0; dst[(size_t)kk * MTi] = w ? lift_scalar(ctx->hc, w, j) : 0; }
         }
         MT = MTi;
         wbytes.assign((const char *)hW.data(), (const char *)(hW.data() + hW.size()));
@@ -1150,7 +1152,7 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
     if (mfma) {
         P.P = gemm_weight_planes(ctx, W, (size_t)O * K); P.mtiles = (M + 31) / 32; P.ksteps = (K + 31) / 32;
         pack_gemm_mfma(ctx, G, M, K, P.P, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] >= 0; }, wbytes);
-    } else pack_gemm_weights(ctx, G, M, K, small, row, P.MT, wbytes);
+    } else pack_gemm_weights(ctx, G, M, K, small, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] >= 0; }, P.MT, wbytes);
     P.off_oidx = al(hidx.size() * 4); P.off_bidx = P.off_oidx + al(hoidx.size() * 4); P.off_w = P.off_bidx + al(hbidx.size() * 4);
     P.host.assign(P.off_w + al(wbytes.size()), 0);
     memcpy(P.host.data(), hidx.data(), hidx.size() * 4);
@@ -2216,7 +2218,7 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
     if (mfma) {
         for (const DOp *op : ops) WP = std::max(WP, gemm_weight_planes(ctx, &q->wt[op->terms], K));
         pack_gemm_mfma(ctx, G, M, K, WP, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; }, wbytes);
-    } else pack_gemm_weights(ctx, G, M, K, small, row, MT, wbytes);
+    } else pack_gemm_weights(ctx, G, M, K, small, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; }, MT, wbytes);
     const size_t off_oidx = al(hidx.size() * 8), off_bidx = off_oidx + al(hoidx.size() * 8), off_w = off_bidx + al(hbidx.size() * 8);
     std::vector<char> host(off_w + al(wbytes.size()), 0);
     memcpy(host.data(), hidx.data(), hidx.size() * 8);

@@ -11,15 +11,19 @@
 // convolution are 1.5 MiB, which an XCD's 4 MiB L2 holds.  XCD x (blocks b = x mod 8) walks through ALL groups of slice x, then of slice x + 8, ...:
 // every input slice is fetched once per launch, whatever the overlap of the gather lists (5x5 windows at stride 2 share each pixel 6.25 times; in
 // group-major order only the horizontal overlap survived in L2: FETCH_SIZE 2.3 x the input bytes, profiles/r02_pmc_square_gemm.txt).
-DEV void gemm_block_coords(uint32_t b, uint32_t chunks, uint32_t limbs, uint32_t mtiles, uint32_t G, uint32_t &chunk, uint32_t &limb, uint32_t &mt, uint32_t &g, uint32_t order = 0) {
+// order 1 is launched as a 2-D grid (8 * mtiles * G, slices / 8) - x fastest, so workgroup (x, y) still lands on XCD x mod 8: the coordinates of the
+// convolution's workgroups (mtiles = 1; chunks is a power of two) come out of shifts and masks.  (As one linear id they took three divisions by run-time
+// values - ~100 vector instructions of the ~860 a convolution workgroup issues, on a kernel that is bound by its issue slots.)
+DEV void gemm_block_coords(uint32_t bx, uint32_t by, uint32_t chunks, uint32_t limbs, uint32_t mtiles, uint32_t G, uint32_t &chunk, uint32_t &limb, uint32_t &mt, uint32_t &g,
+                           uint32_t order = 0) {
     if (order == 1) {
-        const uint32_t x = b & 7, r = b >> 3;
-        mt = r % mtiles;
-        const uint32_t rr = r / mtiles, sl = (rr / G) * 8 + x;
-        g = rr % G; chunk = sl % chunks; limb = sl / chunks;
+        const uint32_t x = bx & 7, r = bx >> 3;
+        if (mtiles == 1) { mt = 0; g = r; } else { mt = r % mtiles; g = r / mtiles; }
+        const uint32_t sl = by * 8 + x;
+        chunk = sl & (chunks - 1); limb = sl >> (__ffs((int)chunks) - 1);
         return;
     }
-    const uint32_t D = chunks * limbs * G;
+    const uint32_t b = bx, D = chunks * limbs * G;
     uint32_t d;
     if ((D & 7) == 0) { const uint32_t r = b >> 3; mt = r % mtiles; d = (r / mtiles) * 8 + (b & 7); }
     else { d = b % D; mt = b / D; }
@@ -46,7 +50,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
     uint32_t chunk, limb, mt, g;
-    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
+    gemm_block_coords(blockIdx.x, blockIdx.y, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];
@@ -121,12 +125,12 @@ template <int MT, int NL, int LW, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const double *__restrict__ Wd,
                                                          const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order) {
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order, uint32_t Kw) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
     uint32_t chunk, limb, mt, g;
-    gemm_block_coords(blockIdx.x, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
+    gemm_block_coords(blockIdx.x, blockIdx.y, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
     const DMod qm = C->q[j];
@@ -138,7 +142,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         for (int l = 0; l < NL; l++) acc[l][m] = 0.0;
     }
     const TT *gi = idx + (size_t)g * Kp;                                                 // row pitch Kp: 16 B aligned, -1 (ABS: 0) beyond K
-    const double *gw = Wd + ((size_t)g * mtiles + mt) * (size_t)K * MT;                  // [kk][m], zero-padded
+    const double *gw = Wd + ((size_t)g * mtiles + mt) * (size_t)Kw * MT;                 // [kk < Kw][m]: zero rows behind the K terms (gemm_f64_rows)
     const uint32_t mcnt = min((uint32_t)MT, M - mt * MT);
     // fold: value = sum_l acc[l] * 2^(l*LW) mod q_j, in exact FP64 (q_j < 2^49): Horner with one modular multiply per limb.  (The
     // 128-bit integer version - double -> int128 conversions and a Barrett reduction per output - cost more instructions than the 25
@@ -158,8 +162,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     // compiler (the whole 128-bit fold executed every iteration under v_cndmask - 30x the instructions of the 2*MT FMAs)
     // Software pipeline: a term is one dependent scalar load (gather index) + one global load, ~1 us of latency against
     // 2*MT*NL FMAs.  Two register sets ping-pong: the input elements of the NEXT PF terms are requested before the FMAs of the
-    // current PF terms are issued.  Fetch and compute are branch-free (padded taps and terms past the block read as x = 0 and
-    // multiply whatever weight row follows - the table carries 8 spare rows), so the waits stay exact.
+    // current PF terms are issued.  The requests are branch-free (padded taps and terms past K multiply a valid word by the weight 0: every
+    // (group, tile) of the table ends in zero rows, gemm_f64_rows), so the waits stay exact.
 #ifndef GEMM_PF_SMALL
 #define GEMM_PF_SMALL 4       // terms requested ahead per register set for MT <= 5 (convolution windows: 25 taps, 5 maps).  8 - two gather lists of four in flight per
                               // thread, VERDICT r03 next #7 - was measured in round 4 and is NOT the default: 91 instead of 66 VGPRs (5 instead of 7 waves per SIMD),
@@ -167,21 +171,19 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 #endif
     constexpr int PF = (MT <= 5) ? GEMM_PF_SMALL : 4;
     static_assert(PF % 4 == 0, "gather indices travel in 16 B scalar loads of four");
-    auto fetch = [&](uint64_t (&x)[PF], uint32_t kk, uint32_t k1) {
+    // A padded tap (-1 / address 0 in the gather row) and a term past K carry the WEIGHT 0 in the table (pack_gemm_weights) and read a valid word (element
+    // 0 / the fallback ciphertext); a block of `lazy` terms ends on a multiple of 2 PF unless it ends at K: no per-lane select on the 64-bit words.
+    auto fetch = [&](uint64_t (&x)[PF], uint32_t kk) {
         // ONE 16 B scalar load per four gather indices (four dependent s_load_dword + wait chains cost more than the FMAs)
         const uint32_t kc = min(kk, Kp - PF);
-        if constexpr (ABS) {               // addresses: two 16 B scalar loads per four; a padded tap reads (and discards) the fallback ciphertext `in`
+        if constexpr (ABS) {               // addresses: two 16 B scalar loads per four; a padded tap reads (and multiplies by 0) the fallback ciphertext `in`
 #pragma unroll
             for (int c = 0; c < PF; c += 4) {
                 const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + kc + c, 16));
                 const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + kc + c + 2, 16));
                 const uint64_t ad[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const bool ok = kk + c + p < k1 && ad[p] != 0;
-                    const uint64_t v = gmem(ad[p] ? ad[p] : (uint64_t)in)[e];
-                    x[c + p] = ok ? v : 0;
-                }
+                for (int p = 0; p < 4; p++) x[c + p] = gmem(ad[p] ? ad[p] : (uint64_t)in)[e];
             }
         } else {
 #pragma unroll
@@ -189,31 +191,35 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
                 const int4 ids = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + kc + c, 16));
                 const int32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const bool ok = kk + c + p < k1 && id[p] >= 0;
-                    const uint64_t v = in[(size_t)max(id[p], 0) * ctw + e];
-                    x[c + p] = ok ? v : 0;
-                }
+                for (int p = 0; p < 4; p++) x[c + p] = in[(size_t)max(id[p], 0) * ctw + e];
             }
         }
     };
     auto terms = [&](const uint64_t (&x)[PF], uint32_t kk) {
+        // the weights of WB terms (up to 20 doubles = 40 SGPRs) are contiguous: requested together (wide scalar loads, ONE wait) before the first product
+        constexpr int WB = MT >= 20 ? 1 : (MT * PF <= 20 ? PF : 20 / MT);
 #pragma unroll
-        for (int p = 0; p < PF; p++) {
-            double xl[NL];
+        for (int p0 = 0; p0 < PF; p0 += WB) {
+            double w[WB * MT];
+            const double *wp = gw + (size_t)(kk + p0) * MT;
 #pragma unroll
-            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x[p] >> (l * LW)) & ((1ull << LW) - 1));
+            for (int q = 0; q < WB * MT; q++) w[q] = wp[q];
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const double w = gw[(size_t)(kk + p) * MT + m];
+            for (int p = p0; p < p0 + WB; p++) {
+                double xl[NL];
 #pragma unroll
-                for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w, acc[l][m]);
+                for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)(l == NL - 1 ? x[p] >> (l * LW) : (x[p] >> (l * LW)) & ((1ull << LW) - 1));      // canonical residue: below 2^(NL LW)
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+#pragma unroll
+                    for (int l = 0; l < NL; l++) acc[l][m] = __fma_rn(xl[l], w[(p - p0) * MT + m], acc[l][m]);
+                }
             }
         }
     };
     constexpr bool DPPW = GEMM_DPP_W && MT == 20 && PF == 4;
     constexpr int WV = DPPW ? PF * MT / 16 : 1;                    // 4 terms x 20 weights = 5 registers of 16 lanes
-    auto wfetch = [&](double (&wv)[WV], uint32_t kk) {             // rows min(kk, K + 4) .. + 3: inside the 8 spare (zero) rows of the table
+    auto wfetch = [&](double (&wv)[WV], uint32_t kk) {             // rows min(kk, K + 4) .. + 3: inside the zero rows behind the K terms
         const double *wp = gw + (size_t)min(kk, K + 4) * MT + (threadIdx.x & 15);
 #pragma unroll
         for (int v = 0; v < WV; v++) wv[v] = wp[16 * v];
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         for (int p = 0; p < PF; p++) {
             double xl[NL];
 #pragma unroll
-            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)((x[p] >> (l * LW)) & ((1ull << LW) - 1));
+            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)(l == NL - 1 ? x[p] >> (l * LW) : (x[p] >> (l * LW)) & ((1ull << LW) - 1));      // canonical residue: below 2^(NL LW)
             asm volatile("s_nop 1");
 #pragma unroll
             for (int m = 0; m < MT; m++) {
@@ -238,37 +244,68 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         uint64_t xa[PF], xb[PF];
         if constexpr (DPPW) {
             double wa[WV], wb[WV];
-            fetch(xa, k0, k1); wfetch(wa, k0);
+            fetch(xa, k0); wfetch(wa, k0);
             for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
-                fetch(xb, kk + PF, k1); wfetch(wb, kk + PF);
+                fetch(xb, kk + PF); wfetch(wb, kk + PF);
                 terms_dpp(xa, wa);
-                fetch(xa, kk + 2 * PF, k1); wfetch(wa, kk + 2 * PF);
+                fetch(xa, kk + 2 * PF); wfetch(wa, kk + 2 * PF);
                 terms_dpp(xb, wb);
             }
         } else {
-            fetch(xa, k0, k1);
-            for (uint32_t kk = k0; kk < k1; kk += 2 * PF) {
-                fetch(xb, kk + PF, k1);
+            // sets of PF terms in pairs, then the odd set: a window of 25 taps is 7 sets of four, not 8.  ONE exit at the end of the pair loop and no branch
+            // inside it - at a join the compiler's wait counts assume the path with the fewest requests in flight and drain the set requested ahead.
+            const uint32_t sets = (k1 - k0 + PF - 1) / PF;
+            uint32_t kk = k0;
+            fetch(xa, k0);
+            for (uint32_t it = sets >> 1; it; it--, kk += 2 * PF) {
+                fetch(xb, kk + PF);
                 terms(xa, kk);
-                fetch(xa, kk + 2 * PF, k1);
+                fetch(xa, kk + 2 * PF);
                 terms(xb, kk + PF);
             }
+            if (sets & 1) terms(xa, kk);
         }
         fold();
     }
+    // Outputs in sets of OB: the table entries of a set (scalar loads), then its bias words (all requested before the first is used), then the arithmetic and
+    // the stores - one exposed round trip per kind and set.  (One output at a time it was three dependent round trips per output: table entry -> bias entry ->
+    // bias word, ~8 us of a convolution workgroup's ~19 us.)
+    constexpr int OB = MT < 5 ? MT : 5;
+    const uint32_t olast = G * M - 1;
+    const bool hb = (ABS ? bias_idx != nullptr : bias != nullptr) && limb < k;
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
-        const uint32_t o = g * M + mt * MT + m;
-        if constexpr (ABS) {
-            if ((uint32_t)m < mcnt && out_idx[o]) {
-                uint64_t r = BzF::to_u64(res[m], mq);
-                if (bias_idx && bias_idx[o] && limb < k) { const uint64_t bv = gmem(bias_idx[o])[i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
-                gmem_w(out_idx[o])[e] = r;
+    for (int m0 = 0; m0 < MT; m0 += OB) {
+        uint32_t oo[OB];
+        TT oi[OB], bi[OB];
+        bool st[OB];
+        uint64_t bv[OB];
+#pragma unroll
+        for (int u = 0; u < OB; u++) oo[u] = min(g * M + mt * MT + m0 + u, olast);
+#pragma unroll
+        for (int u = 0; u < OB; u++) { oi[u] = out_idx[oo[u]]; bi[u] = 0; bv[u] = 0; }
+        if (hb) {
+#pragma unroll
+            for (int u = 0; u < OB; u++) bi[u] = bias_idx[oo[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < OB; u++) st[u] = (uint32_t)(m0 + u) < mcnt && (ABS ? oi[u] != 0 : (int64_t)oi[u] >= 0);
+        if (hb) {
+#pragma unroll
+            for (int u = 0; u < OB; u++) {
+                if constexpr (ABS) bv[u] = gmem(st[u] && bi[u] ? bi[u] : (uint64_t)in)[i];          // no bias: any readable word, discarded below
+                else bv[u] = bias[(size_t)(st[u] ? bi[u] : (TT)0) * n + i];
             }
-        } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {
-            uint64_t r = BzF::to_u64(res[m], mq);
-            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
-            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
+#pragma unroll
+            for (int u = 0; u < OB; u++) if (!(st[u] && (ABS ? bi[u] != 0 : true))) bv[u] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < OB; u++) {
+            if (!st[u]) continue;
+            uint64_t r = BzF::to_u64(res[m0 + u], mq);
+            // bias: a PoolLayer bias is the constant polynomial - every coefficient but one is zero and scales to zero (skipped wave-uniformly almost everywhere)
+            if (bv[u]) r = addmod(r, scale_plain(C, bv[u], j), qm.q);
+            if constexpr (ABS) gmem_w(oi[u])[e] = r;
+            else out[(size_t)(obase + (uint32_t)oi[u]) * ctw + e] = r;
         }
     }
 }
@@ -290,6 +327,12 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }   // byte n of the result = byte sel[n] of {hi: 4..7, lo: 0..3}
+#ifndef GEMM_MFMA_XCD
+#define GEMM_MFMA_XCD 0
+#endif
+#ifndef GEMM_MFMA_DEPTH
+#define GEMM_MFMA_DEPTH 2          // K steps of input words in flight beside the one being multiplied (1 or 2)
+#endif
 template <int P, bool ABS>
 __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const int8_t *__restrict__ Wf,
                                                              const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
@@ -297,11 +340,21 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
                                                              uint32_t ksteps, uint32_t obase, uint32_t polys) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
-    constexpr int ND = 6, D = ND + P - 1;
-    __shared__ __align__(16) uint32_t frag[2][ND][64][4];          // [buffer][digit plane][lane][slot group q]: 12 KiB
+    constexpr int ND = 6, D = ND + P - 1, NB = GEMM_MFMA_DEPTH + 1;
+    __shared__ __align__(16) uint32_t frag[NB][ND][64][4];         // [buffer][digit plane][lane][slot group q]: 6 KiB each
     const uint32_t n = C->n, k = C->k, limbs = polys * k, ctiles = n >> 5;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    // the wave number as a SCALAR: the gather-table entries of a wave's K slots are then wave-uniform and travel through the scalar cache (lgkmcnt).  As vector
+    // loads they sat on vmcnt IN FRONT of the input loads that need them: every step waited for the table (vmcnt(0) - which also drained whatever input words
+    // were still in flight), then for the inputs: two exposed round trips per K step, 1.9 us of them against 0.2 us of matrix instructions.
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = lane >> 5, col = lane & 31;
     uint32_t b = blockIdx.x;
+#if GEMM_MFMA_XCD
+    {   // workgroup ids are dealt round-robin to the 8 XCDs: XCD x takes a CONTIGUOUS range of work items (adjacent column tiles of one limb run side by side on one
+        // XCD: 64 resident workgroups read 16 KiB runs of every input instead of 256 B pieces 2 KiB apart)
+        const uint32_t nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = b & 7, loc = b >> 3;
+        b = x < r8 ? x * (q8 + 1) + loc : r8 * (q8 + 1) + (x - r8) * q8 + loc;
+    }
+#endif
     const uint32_t ctile = b % ctiles; b /= ctiles;
     const uint32_t limb = b % limbs; b /= limbs;
     const uint32_t mgroups = (mtiles + 3) >> 2, mg = b % mgroups, g = b / mgroups;
@@ -318,37 +371,39 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[d][r] = 0;
     const uint64_t BIAS = 0x0000808080808080ull;
-    auto load_x = [&](uint64_t (&x)[4], uint32_t ks) {          // the 4 input words of this lane's slots 4 wave .. 4 wave + 3
-        if constexpr (ABS) {
-            const ulonglong2 a01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32, 16));
-            const ulonglong2 a23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 2, 16));
-            const ulonglong2 c01 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 16, 16));
-            const ulonglong2 c23 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(gi + ks * 32 + 18, 16));
-            const uint64_t a0[4] = {a01.x, a01.y, a23.x, a23.y}, a1[4] = {c01.x, c01.y, c23.x, c23.y};
+    // Requests behind the last step are NOT skipped but repeat the last step (a few words re-read from L2): with a branch around the loads the compiler's wait
+    // counts at the join assume the path WITHOUT them - "at most 5 younger loads" where 11 are in flight - and every step drained the sets requested ahead.
+    const uint32_t klast = ksteps - 1;
+    auto load_idx = [&](TT (&s)[8], uint32_t ks) {              // table entries of slots 4 wave .. + 3 (lanes 0..31) and 16 + 4 wave .. + 3 (lanes 32..63): scalar loads
+        const TT *t = gi + (size_t)min(ks, klast) * 32;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint64_t ad = half ? a1[u] : a0[u];
-                x[u] = gmem(ad ? ad : (uint64_t)in)[e];              // padded tap: any readable word (its weight digits are 0)
-            }
-        } else {
-            const int4 i0 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32, 16));
-            const int4 i1 = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + ks * 32 + 16, 16));
-            const int32_t a0[4] = {i0.x, i0.y, i0.z, i0.w}, a1[4] = {i1.x, i1.y, i1.z, i1.w};
+        for (int u = 0; u < 4; u++) { s[u] = t[u]; s[4 + u] = t[16 + u]; }
+    };
+    auto load_x = [&](uint64_t (&x)[4], const TT (&s)[8]) {     // the 4 input words of this lane's slots
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int32_t id = half ? a1[u] : a0[u];
-                x[u] = in[(size_t)max(id, 0) * ctw + e];
+        for (int u = 0; u < 4; u++) {
+            if constexpr (ABS) {
+                const uint64_t a0 = s[u] ? s[u] : (uint64_t)in, a1 = s[4 + u] ? s[4 + u] : (uint64_t)in;      // padded tap: any readable word (its weight digits are 0)
+                x[u] = gmem(half ? a1 : a0)[e];
+            } else {
+                const size_t o0 = (size_t)max(s[u], 0) * ctw, o1 = (size_t)max(s[4 + u], 0) * ctw;
+                x[u] = in[(half ? o1 : o0) + e];
             }
         }
     };
     auto load_a = [&](v4i_t (&af)[P], uint32_t ks) {
 #pragma unroll
-        for (int p = 0; p < P; p++) af[p] = *reinterpret_cast<const v4i_t *>(wf + ((size_t)p * mtiles * ksteps + ks) * 1024);
+        for (int p = 0; p < P; p++) af[p] = *reinterpret_cast<const v4i_t *>(wf + ((size_t)p * mtiles * ksteps + min(ks, klast)) * 1024);
     };
-    uint64_t xa[4], xb[4];
-    v4i_t afa[P], afb[P];
-    load_x(xa, 0); load_a(afa, 0);
-    auto step = [&](uint64_t (&x)[4], v4i_t (&af)[P], uint64_t (&xn)[4], v4i_t (&afn)[P], uint32_t ks) {
+    // x / af: NB register sets in a ring - set (ks mod NB) holds step ks, requested GEMM_MFMA_DEPTH steps ahead; `nidx` = the table entries of the step whose
+    // inputs are requested next (asked for one step before they are needed; refilled right after use)
+    uint64_t xs[NB][4];
+    v4i_t afs[NB][P];
+    TT nidx[8];
+    load_idx(nidx, 0);
+#pragma unroll
+    for (int s = 0; s < GEMM_MFMA_DEPTH; s++) { load_x(xs[s], nidx); load_a(afs[s], s); load_idx(nidx, s + 1); }
+    auto step = [&](uint64_t (&x)[4], v4i_t (&af)[P], uint64_t (&xn)[4], v4i_t (&afn)[P], uint32_t ks, uint32_t (*fb)[64][4]) {
         // recode: byte i of y = signed digit i; transpose the 4 words into one dword per digit plane; publish
         uint32_t lo[4], hi[4];
 #pragma unroll
@@ -356,14 +411,14 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
         const uint32_t ab02 = byte_perm(lo[1], lo[0], 0x06020400u), cd02 = byte_perm(lo[3], lo[2], 0x06020400u);     // (a0 b0 a2 b2), (c0 d0 c2 d2)
         const uint32_t ab13 = byte_perm(lo[1], lo[0], 0x07030501u), cd13 = byte_perm(lo[3], lo[2], 0x07030501u);     // (a1 b1 a3 b3), (c1 d1 c3 d3)
         const uint32_t hab = byte_perm(hi[1], hi[0], 0x05010400u), hcd = byte_perm(hi[3], hi[2], 0x05010400u);       // (a4 b4 a5 b5), (c4 d4 c5 d5)
-        uint32_t (*fb)[64][4] = frag[ks & 1];
         fb[0][lane][wave] = byte_perm(cd02, ab02, 0x05040100u);          // a0 b0 c0 d0
         fb[1][lane][wave] = byte_perm(cd13, ab13, 0x05040100u);
         fb[2][lane][wave] = byte_perm(cd02, ab02, 0x07060302u);          // a2 b2 c2 d2
         fb[3][lane][wave] = byte_perm(cd13, ab13, 0x07060302u);
         fb[4][lane][wave] = byte_perm(hcd, hab, 0x05040100u);
         fb[5][lane][wave] = byte_perm(hcd, hab, 0x07060302u);
-        if (ks + 1 < ksteps) { load_x(xn, ks + 1); load_a(afn, ks + 1); }      // in flight over the barrier and the matrix instructions
+        load_x(xn, nidx); load_a(afn, ks + GEMM_MFMA_DEPTH);             // in flight over the barriers and matrix instructions of the next GEMM_MFMA_DEPTH steps
+        load_idx(nidx, ks + GEMM_MFMA_DEPTH + 1);
         __syncthreads();
         if (active) {
             v4i_t bf[ND];
@@ -376,10 +431,16 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
                 for (int i = 0; i < ND; i++) acc[i + p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[p], bf[i], acc[i + p], 0, 0, 0);
         }
     };
-    for (uint32_t ks = 0; ks < ksteps; ks += 2) {
-        step(xa, afa, xb, afb, ks);
-        if (ks + 1 < ksteps) step(xb, afb, xa, afa, ks + 1);
+    // the set that step ks refills is the one step ks - 1 consumed
+    // (for the same reason the loop has ONE exit, at its end: whole turns of the ring, then the ksteps mod NB steps left over)
+    uint32_t ks = 0;
+    for (; ks + NB <= ksteps; ks += NB) {
+#pragma unroll
+        for (int s = 0; s < NB; s++) step(xs[s], afs[s], xs[(s + GEMM_MFMA_DEPTH) % NB], afs[(s + GEMM_MFMA_DEPTH) % NB], ks + s, frag[s]);
     }
+#pragma unroll
+    for (int s = 0; s < NB - 1; s++)
+        if (ks + s < ksteps) step(xs[s], afs[s], xs[(s + GEMM_MFMA_DEPTH) % NB], afs[(s + GEMM_MFMA_DEPTH) % NB], ks + s, frag[s]);
     if (!active) return;
     // ---- fold the diagonals: value = sum_d acc_d 256^d mod q_j (exact FP64), bias, store
     const BzF::Mod mq = {C->qd[j], C->qinvd[j]};

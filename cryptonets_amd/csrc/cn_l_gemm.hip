@@ -3,19 +3,27 @@
 #include <algorithm>
 #include "cn_k_gemm.hip.h"
 
+// order 1 (slice-major) needs the slices in multiples of 8 and is launched as a 2-D grid: x = (XCD, output tile, group), y = slice / 8 (gemm_block_coords)
+struct GemmGrid { dim3 grid; uint32_t order; };
+static GemmGrid gemm_grid(cn_ctx *c, const GemmLaunch &g, uint32_t mtiles) {
+    const uint32_t slices = c->chunks * g.polys * c->hc.k;
+    if (g.order == 1 && (slices & 7) == 0 && (c->chunks & (c->chunks - 1)) == 0 && (uint64_t)8 * mtiles * g.G < (1ull << 31) && slices / 8 < 65536)
+        return {dim3(8 * mtiles * g.G, slices / 8), 1u};
+    return {dim3((uint32_t)((size_t)slices * mtiles * g.G)), 0u};
+}
 template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
-    const size_t blocks = (size_t)c->chunks * g.polys * c->hc.k * mtiles * g.G;
-    hipLaunchKernelGGL((k_scalar_gemm<MT, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const uint64_t *)g.W, g.oidx, g.bias, g.bidx, g.out, c->dc,
-                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, ((c->chunks * g.polys * c->hc.k) & 7) == 0 ? g.order : 0u);
+    const GemmGrid gg = gemm_grid(c, g, mtiles);
+    hipLaunchKernelGGL((k_scalar_gemm<MT, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const uint64_t *)g.W, g.oidx, g.bias, g.bidx, g.out, c->dc,
+                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order);
 }
 template <int MT, bool ABS> static void launch_f64(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
-    const size_t blocks = (size_t)c->chunks * g.polys * c->hc.k * mtiles * g.G;
-    if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, ((c->chunks * g.polys * c->hc.k) & 7) == 0 ? g.order : 0u);
-    else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), dim3((uint32_t)blocks), dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, ((c->chunks * g.polys * c->hc.k) & 7) == 0 ? g.order : 0u);
+    const GemmGrid gg = gemm_grid(c, g, mtiles);
+    if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
+    else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
+                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
 }
 template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
     if (g.small) {

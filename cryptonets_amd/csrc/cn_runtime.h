@@ -238,6 +238,9 @@ struct GemmLaunch {
     uint32_t polys = 2;                              // ciphertext size of inputs and outputs (3: unrelinearized products)
     uint32_t order = 0;                              // workgroup order of the VALU kernels: 0 group-major, 1 slice-major (gemm_block_coords)
 };
+// k_scalar_gemm_f64: rows of the weight table per (group, output tile) - K terms + zero rows up to a multiple of 16 + 16: the kernel's sets of 4 (or 8) terms run past K
+// and multiply whatever word the padded gather entry reads by these zeros
+inline uint32_t gemm_f64_rows(uint32_t K) { return ((K + 15) & ~15u) + 16; }
 int cn_l_gemm(cn_ctx *c, const GemmLaunch &g);
 int cn_l_gemm_mfma(cn_ctx *c, const GemmLaunch &g);   // k_scalar_gemm_mfma: W = weight digit fragments, idx rows of ksteps * 32 entries
 
