@@ -386,7 +386,10 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
                 const uint64_t a0 = s[u] ? s[u] : (uint64_t)in, a1 = s[4 + u] ? s[4 + u] : (uint64_t)in;      // padded tap: any readable word (its weight digits are 0)
                 x[u] = gmem(half ? a1 : a0)[e];
             } else {
-                const size_t o0 = (size_t)max(s[u], 0) * ctw, o1 = (size_t)max(s[4 + u], 0) * ctw;
+                // both products on the scalar unit, THEN the per-lane choice (left alone the compiler chooses first and multiplies per lane: two quarter-rate
+                // v_mad_u64_u32 per word)
+                size_t o0 = (size_t)max(s[u], 0) * ctw, o1 = (size_t)max(s[4 + u], 0) * ctw;
+                asm volatile("" : "+s"(o0), "+s"(o1));
                 x[u] = in[(half ? o1 : o0) + e];
             }
         }
@@ -445,17 +448,21 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
     // ---- fold the diagonals: value = sum_d acc_d 256^d mod q_j (exact FP64), bias, store
     const BzF::Mod mq = {C->qd[j], C->qinvd[j]};
     const DMod qm = C->q[j];
-    double cpow[D];
-    cpow[0] = 1.0;
-#pragma unroll
-    for (int d = 1; d < D; d++) cpow[d] = BzF::center(__dmul_rn(cpow[d - 1], 256.0), mq);          // 256^d mod q_j, centred (exact: |x| <= q/2 times 256 < 2^53)
+    // three neighbouring diagonals at a time: a_d + 256 a_(d+1) + 65536 a_(d+2) is an exact double (|a| < 2^31: below 2^47.1), so a row costs two modular
+    // products (by 2^24 and 2^48 mod q_j) instead of one per diagonal
+    const double c24 = BzF::center(16777216.0, mq), c48 = BzF::center(__dmul_rn(c24, 16777216.0), mq);       // exact: |c24| <= 2^24
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const uint32_t row = (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * half, o = g * M + mt * 32 + row;
         if (mt * 32 + row >= M) continue;
-        double v = (double)acc[0][r];
-#pragma unroll
-        for (int d = 1; d < D; d++) v = __dadd_rn(v, BzF::mulmod((double)acc[d][r], cpow[d], mq));
+        auto group = [&](int d0) {
+            double t = (double)acc[d0][r];
+            if (d0 + 1 < D) t = __fma_rn((double)acc[d0 + 1 < D ? d0 + 1 : d0][r], 256.0, t);
+            if (d0 + 2 < D) t = __fma_rn((double)acc[d0 + 2 < D ? d0 + 2 : d0][r], 65536.0, t);
+            return t;
+        };
+        double v = __dadd_rn(group(0), BzF::mulmod(group(3), c24, mq));
+        if (D > 6) v = __dadd_rn(v, BzF::mulmod(group(6), c48, mq));
         uint64_t res = BzF::to_u64(v, mq);
         if constexpr (ABS) {
             if (!out_idx[o]) continue;
