@@ -47,6 +47,11 @@ template <class FW0> struct KsPassA<FW0, true> { typedef ArPassA<FW0> P; };
 #ifndef KS_PRE_SYNC
 #define KS_PRE_SYNC 1       // the "image is free again" barrier of a digit sits behind the next digit's first pass (ntt_forward_regs<.., PRE>)
 #endif
+#ifndef KS_SRC_AHEAD
+#define KS_SRC_AHEAD 0      // k_keyswitch_rr: the source words of the next limb requested a limb ahead (250 instead of 212 VGPRs, no spills).  Measured in round 5
+                            // (tools/gpu_r05_aa.sh, alternating runs on one box) and NOT the default: 3.29-3.33 against 3.25-3.29 ms per 845-ciphertext launch - the
+                            // round trip at the start of a limb is not what the kernel waits for
+#endif
 #ifndef KS_MAC_FENCE
 #define KS_MAC_FENCE 0      // FP64 path: letting the scheduler interleave key loads with the MACs measured 11-14 % faster (same VGPRs)
 #endif
@@ -103,16 +108,26 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, MINW) k_keyswitch_rr(const uin
     if constexpr (HasPassA<FW>::value) ntt_load_pass_a<SA>(fwt, A.fw.w);
     const T *kp = reinterpret_cast<const T *>(key_);
     uint32_t terms = 0;
+    uint64_t raw[16];                              // the source words of limb l stay in registers for all of its digits
+    // AHEAD (KS_SRC_AHEAD, off): the source words of limb l + 1 requested when limb l starts.  Unconditional (the last limb requests itself again): a request
+    // under an `if` would make the compiler's wait counts at the join assume the path without it.
+    constexpr bool AHEAD = KS_SRC_AHEAD && MINW == 1 && L <= 13;
+    uint64_t nraw[AHEAD ? 16 : 1];
+    auto request = [&](uint64_t (&w)[16], uint32_t l) {
+        uint32_t t0 = tid;
+        asm volatile("" : "+v"(t0));
+        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) w[r] = src[pass_index<L, SA, 0>(t0, r)];
+    };
+    if constexpr (AHEAD) request(nraw, 0);
     for (uint32_t l = 0; l < k; l++) {
         const uint32_t nd = galois ? C->gk_dig[l] : C->rl_dig[l];
-        const uint64_t *src = target + (size_t)ct * tgt_stride + (size_t)l * n;
-        uint64_t raw[16];                          // the source words of limb l stay in registers for all of its digits
-        {
-            uint32_t t0 = tid;
-            asm volatile("" : "+v"(t0));
+        if constexpr (AHEAD) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) raw[r] = src[pass_index<L, SA, 0>(t0, r)];
-        }
+            for (int r = 0; r < 16; r++) raw[r] = nraw[r];
+            request(nraw, min(l + 1, k - 1));
+        } else request(raw, l);
         if constexpr (XI) {
             const DMod ql = C->q[l]; const uint64_t xf = C->inv_qhat_q[l];
 #pragma unroll

@@ -76,15 +76,22 @@ def structure(obj=None, kernel=KERNEL):
     # the kernel has two loop nests with FP64 work: (limb loop > digit loop), which the compiler rotates onto ONE header with two back
     # edges (digit: the nearer one, limb: the farther one), and behind it the loop over the two inverse transforms
     big = sorted((h, sorted(e)) for h, e in loops(ins).items() if within(h, max(e)) > 100)
-    if len(big) != 2 or len(big[0][1]) != 2:
+    if len(big) == 3 and len(big[0][1]) == 1 and len(big[1][1]) == 2 and big[0][0] < big[1][0] and max(big[1][1]) < big[0][1][0]:
+        # since the source words of a limb are requested a limb ahead (round 5) the limb loop has a header of its own: limb loop > digit loop with two back
+        # edges (the nearer one: next digit; the farther one: the end of the recentring block that runs every `accmax` terms - counted once per limb, as before)
+        (h0, (limb_end,)), (h1, (digit_end, _settle_end)), (h2, e2) = big
+    elif len(big) == 2 and len(big[0][1]) == 2:
+        (h1, (digit_end, limb_end)), (h2, e2) = big
+        h0 = h1
+    else:
         raise RuntimeError("unrecognised loop structure in the key-switch kernel: %s" % [(hex(h), [hex(x) for x in e]) for h, e in big])
-    (h1, (digit_end, limb_end)), (h2, e2) = big
     tail_end = max(e2)
+    limb_only = lambda f: f(h0, limb_end) - f(h1, digit_end)
     return dict(kernel="k_keyswitch_rr<13, ArF64T<0>, 1, true, false>", instructions=len(ins), fp64_total=len(f64),
-                fp64_digit_loop=within(h1, digit_end), fp64_limb_loop_only=within(digit_end + 1, limb_end),
-                fp64_tail_loop=within(h2, tail_end), fp64_once=len(f64) - within(h1, limb_end) - within(h2, tail_end),
-                valu_digit_loop=owithin(h1, digit_end), valu_limb_loop_only=owithin(digit_end + 1, limb_end),
-                valu_tail_loop=owithin(h2, tail_end), valu_once=len(other) - owithin(h1, limb_end) - owithin(h2, tail_end))
+                fp64_digit_loop=within(h1, digit_end), fp64_limb_loop_only=limb_only(within),
+                fp64_tail_loop=within(h2, tail_end), fp64_once=len(f64) - within(h0, limb_end) - within(h2, tail_end),
+                valu_digit_loop=owithin(h1, digit_end), valu_limb_loop_only=limb_only(owithin),
+                valu_tail_loop=owithin(h2, tail_end), valu_once=len(other) - owithin(h0, limb_end) - owithin(h2, tail_end))
 
 
 def fp64_per_thread(k, digits_per_limb, obj=None, kernel=KERNEL):
