@@ -495,6 +495,36 @@ def test_scalar_gemm_small_signed_weights(name, rng):
     g.free(h)
 
 
+@pytest.mark.parametrize("name", ["tiny", "c3"])
+def test_scalar_gemm_term_counts_of_the_small_weight_kernel(name, rng):
+    """k_scalar_gemm_f64 walks a gather list in sets of four terms, two sets per loop turn and an odd set behind the loop; padded taps and the terms past K
+    multiply a valid word by a ZERO the weight table carries (whatever weight the caller passed for a padded tap).  Term counts around the set and pair
+    boundaries, 1 / 4 / 5 / 9 outputs per list (register tiles of 1, 5, 5 and 10), padded taps with non-zero weights, against the oracle."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    n_in = 6
+    vals, cts = enc_batch(o, rng, n_in)
+    cts[5] = np.concatenate([np.full(o.n, qj - 1, dtype=np.uint64) for _ in range(2) for qj in o.q])
+    h = up(g, cts)
+    for M in (1, 4, 5, 9):
+        for K in (1, 3, 4, 5, 8, 9, 12, 13, 25, 26):
+            lists = 2
+            O = M * lists
+            idx = np.empty((O, K), dtype=np.int32)
+            for c in range(lists):
+                idx[c::lists] = rng.integers(0, n_in, size=K, dtype=np.int32)
+            if K > 1:
+                idx[0::lists, K // 2] = -1                             # a padded tap in the first list ...
+            Ws = rng.integers(-1000, 1001, size=(O, K))
+            Ws[:, 0] = np.where(Ws[:, 0] == 0, 1, Ws[:, 0])           # ... whose (non-zero) weight must not count; every row keeps a real term
+            W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
+            exp = o.scalar_gemm(cts, W, idx)
+            out = g.ct_alloc(O + 1)
+            g.scalar_gemm(h, W, out, 1, idx=idx)
+            assert np.array_equal(g.ct_download(out, 1, O), exp), (name, M, K)
+            g.free(out)
+    g.free(h)
+
+
 @pytest.mark.parametrize("name", ["tiny", "c2", "c4"])
 def test_scalar_gemm_matrix_core_kernel(name, rng):
     """Scalar GEMMs with >= 16 outputs per gather list run on the int8 matrix cores (k_scalar_gemm_mfma: signed base-256 digits of the
@@ -513,7 +543,8 @@ def test_scalar_gemm_matrix_core_kernel(name, rng):
     bh = g.pt_alloc(3)
     g.pt_upload(bh, 0, bias_plain)
     half = (o.t - 1) // 2
-    for O, K, wmax in ((16, 5, 127), (33, 32, 128), (100, 33, 32639), (130, 70, 32640), (17, 64, 2 ** 20 - 1), (40, 1, 100)):
+    # (18, 100) / (20, 130): 4 and 5 K steps = one turn of the kernel's three-set register ring + 1 / 2 steps left over
+    for O, K, wmax in ((16, 5, 127), (33, 32, 128), (100, 33, 32639), (130, 70, 32640), (17, 64, 2 ** 20 - 1), (40, 1, 100), (18, 100, 1000), (20, 130, 77)):
         wmax = min(wmax, half)
         idx = rng.integers(0, n_in, size=(O, K), dtype=np.int32)
         idx[:, :] = idx[0]                                            # one gather list ...
