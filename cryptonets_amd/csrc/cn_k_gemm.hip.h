@@ -320,16 +320,14 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 // inputs x 32 columns per K step) is the same for the four waves, so they build it TOGETHER: wave w loads the input words of K slots
 // 4w .. 4w+3 of its lanes' half (4 loads of 256 contiguous bytes per half-wave instead of 16), recodes them, transposes their bytes with
 // v_perm_b32 into one dword per digit plane, and publishes the six dwords in LDS; after one barrier every wave reads its complete
-// fragments back as 16 B per lane and plane.  Two LDS buffers and a one-step-ahead prefetch of the input words and of the A fragments
-// (weight digits, laid out in fragment order by the plan: one 16 B load per lane and plane) keep one barrier per K step.
+// fragments back as 16 B per lane and plane.  Three LDS buffers and a ring of three register sets keep one barrier per K step with the input words and
+// the A fragments (weight digits, laid out in fragment order by the plan: one 16 B load per lane and plane) of the next TWO steps in flight; the gather-table
+// entries of a wave's slots are wave-uniform and arrive through the scalar cache, a step ahead of the loads that use them (round 5).
 // K-slot convention: lane l, byte t of an operand <-> k = 32 ks + 16 (l >> 5) + t for BOTH operands (the instruction pairs equal slots,
 // so any convention shared by A and B is correct).  C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }   // byte n of the result = byte sel[n] of {hi: 4..7, lo: 0..3}
-#ifndef GEMM_MFMA_XCD
-#define GEMM_MFMA_XCD 0
-#endif
 #ifndef GEMM_MFMA_DEPTH
 #define GEMM_MFMA_DEPTH 2          // K steps of input words in flight beside the one being multiplied (1 or 2)
 #endif
@@ -348,13 +346,6 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
     // were still in flight), then for the inputs: two exposed round trips per K step, 1.9 us of them against 0.2 us of matrix instructions.
     const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = lane >> 5, col = lane & 31;
     uint32_t b = blockIdx.x;
-#if GEMM_MFMA_XCD
-    {   // workgroup ids are dealt round-robin to the 8 XCDs: XCD x takes a CONTIGUOUS range of work items (adjacent column tiles of one limb run side by side on one
-        // XCD: 64 resident workgroups read 16 KiB runs of every input instead of 256 B pieces 2 KiB apart)
-        const uint32_t nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = b & 7, loc = b >> 3;
-        b = x < r8 ? x * (q8 + 1) + loc : r8 * (q8 + 1) + (x - r8) * q8 + loc;
-    }
-#endif
     const uint32_t ctile = b % ctiles; b /= ctiles;
     const uint32_t limb = b % limbs; b /= limbs;
     const uint32_t mgroups = (mtiles + 3) >> 2, mg = b % mgroups, g = b / mgroups;
