@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 #pragma unroll
         for (int u = 0; u < OB; u++) {
             if (!st[u]) continue;
-            uint64_t r = BzF::to_u64(res[m0 + u], mq);
+            // res left the last fold recentred (|res| <= q/2 + 1 ulp of the quotient): canonical residue without a second quotient
+            const double rc = res[m0 + u] < 0.0 ? __dadd_rn(res[m0 + u], mq.q) : res[m0 + u];
+            uint64_t r = (uint64_t)__double_as_longlong(__dadd_rn(rc, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull;
             // bias: a PoolLayer bias is the constant polynomial - every coefficient but one is zero and scales to zero (skipped wave-uniformly almost everywhere)
             if (bv[u]) r = addmod(r, scale_plain(C, bv[u], j), qm.q);
             if constexpr (ABS) gmem_w(oi[u])[e] = r;
