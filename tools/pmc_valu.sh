@@ -4,15 +4,16 @@ OUT=gpurun_out/pmc_valu
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $R/$OUT/p1 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-unchanged-caller --serialize > $R/$OUT/run1.txt 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS -f csv -d $R/$OUT/p2 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-unchanged-caller --serialize > $R/$OUT/run2.txt 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY -f csv -d $R/$OUT/p3 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-unchanged-caller --serialize > $R/$OUT/run3.txt 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $R/$OUT/p1 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-unchanged-caller --no-single-image --no-relinearize-late --serialize > $R/$OUT/run1.txt 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS -f csv -d $R/$OUT/p2 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-unchanged-caller --no-single-image --no-relinearize-late --serialize > $R/$OUT/run2.txt 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY -f csv -d $R/$OUT/p3 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-unchanged-caller --no-single-image --no-relinearize-late --serialize > $R/$OUT/run3.txt 2>&1)
 python - <<'PY'
 import csv, glob, collections
 for p in ("p1", "p2", "p3"):
     f = glob.glob("gpurun_out/pmc_valu/%s/**/*counter_collection.csv" % p, recursive=True)
     if not f:
         print(p, "no counter file"); continue
+    f.sort(key=lambda x: -__import__("os").path.getsize(x))          # the batch process, not a helper's
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f[0])):
         k = (r["Kernel_Name"].split("(")[0].replace("void ", "")[:44], r["Grid_Size"])
