@@ -1054,6 +1054,25 @@ static GemmArith gemm_arith(cn_ctx *ctx, bool weights_small) {
     return g;
 }
 
+// One-limb form of the small-weight kernel: sum_k w_k x_k with x_k < q_max is an exact double as long as (sum_k |w_k| + 1) q_max <= 2^53 for every output row
+// (all partial sums are integers below 2^53; the + 1 leaves room for the recentred carry of the fold) - the words are then not split into limbs at all: ONE FMA
+// per MAC instead of two, no masks and shifts, one recentring per output.  True for the CryptoNets convolution (row sums <= 373 with the trained weights,
+// 44-bit moduli); the dense layers have larger row sums and keep the two-limb form (or the matrix cores).  Needs the whole term list in one block (K <= lazy).
+template <class ROW, class TAP> static bool gemm_one_limb(cn_ctx *ctx, const GemmArith &ar, uint32_t G, uint32_t M, uint32_t K, ROW row, TAP tap_ok) {
+    static const bool on = !(getenv("CN_GEMM_ONE_LIMB") && !atoi(getenv("CN_GEMM_ONE_LIMB")));
+    if (!on || !ar.small || ar.bits > 49 || K > ar.lazy) return false;
+    uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+    const uint64_t room = (1ull << 53) / qmax;                 // sum |w| + 1 <= room
+    const uint64_t t = ctx->hc.t.q;
+    for (uint32_t g = 0; g < G; g++) for (uint32_t m = 0; m < M; m++) {
+        const uint64_t *wr = row(g, m);
+        if (!wr) continue;
+        uint64_t sum = 1;
+        for (uint32_t kk = 0; kk < K; kk++) if (tap_ok(g, kk)) { const uint64_t w = wr[kk]; sum += w >= ctx->hc.t_half ? t - w : w; if (sum > room) return false; }
+    }
+    return true;
+}
+
 // ---- the matrix-core form of a scalar GEMM (k_scalar_gemm_mfma): eligibility, weight digit planes, A fragments
 // 6 signed base-256 digits cover residues below 2^46 (x + 0x80..80 must stay below 2^48); i32 accumulators hold K * P * 2^14 < 2^31
 static bool gemm_mfma_ok(cn_ctx *ctx, const GemmArith &ar, uint32_t M, uint32_t K) {
@@ -1090,7 +1109,7 @@ template <class ROW, class TAP> static void pack_gemm_mfma(cn_ctx *ctx, uint32_t
 // inference only launches) or in the per-call scratch (cn_scalar_gemm).
 struct GemmPlan {
     uint32_t O = 0, K = 0, Kp = 0, G = 0, M = 0, MT = 0, lazy = 0, max_in = 0;
-    bool small = false, two = false, has_bias = false, mfma = false;
+    bool small = false, two = false, one = false, has_bias = false, mfma = false;
     uint32_t P = 0, mtiles = 0, ksteps = 0;  // matrix-core form: weight digit planes, 32-row output tiles, 32-term steps
     cn_handle bias_pt = 0; uint32_t bias_count = 0;
     uint64_t nnz = 0;                        // non-zero, non-padded terms (statistics)
@@ -1152,7 +1171,11 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
     if (mfma) {
         P.P = gemm_weight_planes(ctx, W, (size_t)O * K); P.mtiles = (M + 31) / 32; P.ksteps = (K + 31) / 32;
         pack_gemm_mfma(ctx, G, M, K, P.P, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] >= 0; }, wbytes);
-    } else pack_gemm_weights(ctx, G, M, K, small, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] >= 0; }, P.MT, wbytes);
+    } else {
+        auto tap = [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] >= 0; };
+        pack_gemm_weights(ctx, G, M, K, small, row, tap, P.MT, wbytes);
+        P.one = gemm_one_limb(ctx, ar, G, M, K, row, tap);
+    }
     P.off_oidx = al(hidx.size() * 4); P.off_bidx = P.off_oidx + al(hoidx.size() * 4); P.off_w = P.off_bidx + al(hbidx.size() * 4);
     P.host.assign(P.off_w + al(wbytes.size()), 0);
     memcpy(P.host.data(), hidx.data(), hidx.size() * 4);
@@ -1176,7 +1199,7 @@ static int run_gemm_plan(cn_ctx *ctx, const GemmPlan &P, const char *tables, Buf
         bias = BP->d;
     }
     GemmLaunch gl{P.small, P.two, false, P.MT, I->d, tables, tables + P.off_w, tables + P.off_oidx, bias, tables + P.off_bidx, OB->d,
-                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps, I->size, (uint32_t)ctx->gemm_order};
+                  P.G, P.M, P.K, P.lazy, P.Kp, oi, P.P, P.mtiles, P.ksteps, I->size, (uint32_t)ctx->gemm_order, P.one};
     CHECK(P.mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl));
     ctx->st.PlainMultiplication += P.nnz; ctx->st.Addition += P.nnz - P.O;
     if (P.has_bias) ctx->st.PlainAddition += P.O;
@@ -2213,12 +2236,17 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
         }
     }
     const bool small = ar.small, two = ar.two; const uint32_t lazy = ar.lazy; uint32_t MT = 1, WP = 0;
+    bool one = false;
     std::vector<char> wbytes;
     auto row = [&](uint32_t g, uint32_t m) -> const uint64_t * { const DOp *op = member[(size_t)g * M + m]; return op ? &q->wt[op->terms] : nullptr; };
     if (mfma) {
         for (const DOp *op : ops) WP = std::max(WP, gemm_weight_planes(ctx, &q->wt[op->terms], K));
         pack_gemm_mfma(ctx, G, M, K, WP, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; }, wbytes);
-    } else pack_gemm_weights(ctx, G, M, K, small, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; }, MT, wbytes);
+    } else {
+        auto tap = [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; };
+        pack_gemm_weights(ctx, G, M, K, small, row, tap, MT, wbytes);
+        one = gemm_one_limb(ctx, ar, G, M, K, row, tap);
+    }
     const size_t off_oidx = al(hidx.size() * 8), off_bidx = off_oidx + al(hoidx.size() * 8), off_w = off_bidx + al(hbidx.size() * 8);
     std::vector<char> host(off_w + al(wbytes.size()), 0);
     memcpy(host.data(), hidx.data(), hidx.size() * 8);
@@ -2228,7 +2256,7 @@ static int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const 
     CHECK(ensure_scratch(ctx, al(host.size())));
     char *tables; CHECK(upload_tmp(ctx, host.data(), host.size(), &tables));
     GemmLaunch gl{small, two, true, MT, fallback, tables, tables + off_w, tables + off_oidx, nullptr, any_bias ? tables + off_bidx : nullptr, nullptr,
-                  G, M, K, lazy, Kp, 0, WP, (M + 31) / 32, (K + 31) / 32, 2, (uint32_t)ctx->gemm_order};
+                  G, M, K, lazy, Kp, 0, WP, (M + 31) / 32, (K + 31) / 32, 2, (uint32_t)ctx->gemm_order, one};
     return mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl);
 }
 static int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, int type) {

@@ -109,6 +109,12 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
 #ifndef GEMM_DPP_W
 #define GEMM_DPP_W 1
 #endif
+// limb l of a canonical residue (below 2^(NL LW)) as an exact double; the top limb needs no mask.  NL = 1: the WHOLE word (v | 2^52's exponent, minus 2^52: two
+// instructions) - the launcher picks that form when every row's sum of |weights| times q_max stays below 2^53 (gemm_one_limb): one FMA per MAC and nothing to fold
+template <int NL, int LW> DEV double gemm_limb(uint64_t x, int l) {
+    if constexpr (NL == 1) return BzF::from_u64(x);
+    else return (double)(uint32_t)(l == NL - 1 ? x >> (l * LW) : (x >> (l * LW)) & ((1ull << LW) - 1));
+}
 template <int LANE> DEV void fmac_bcast(double &acc, double w, double x) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x), "n"(LANE));
 }
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             for (int p = p0; p < p0 + WB; p++) {
                 double xl[NL];
 #pragma unroll
-                for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)(l == NL - 1 ? x[p] >> (l * LW) : (x[p] >> (l * LW)) & ((1ull << LW) - 1));      // canonical residue: below 2^(NL LW)
+                for (int l = 0; l < NL; l++) xl[l] = gemm_limb<NL, LW>(x[p], l);
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
 #pragma unroll
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
         for (int p = 0; p < PF; p++) {
             double xl[NL];
 #pragma unroll
-            for (int l = 0; l < NL; l++) xl[l] = (double)(uint32_t)(l == NL - 1 ? x[p] >> (l * LW) : (x[p] >> (l * LW)) & ((1ull << LW) - 1));      // canonical residue: below 2^(NL LW)
+            for (int l = 0; l < NL; l++) xl[l] = gemm_limb<NL, LW>(x[p], l);
             asm volatile("s_nop 1");
 #pragma unroll
             for (int m = 0; m < MT; m++) {

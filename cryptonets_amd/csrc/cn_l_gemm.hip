@@ -20,7 +20,9 @@ template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &
 template <int MT, bool ABS> static void launch_f64(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
     const GemmGrid gg = gemm_grid(c, g, mtiles);
-    if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
+    if (g.one) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 1, 0, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
+    else if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
                                   g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
     else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
                             g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));

@@ -237,6 +237,7 @@ struct GemmLaunch {
     uint32_t P = 0, mtiles = 0, ksteps = 0;          // matrix-core kernel: weight digit planes, 32-row output tiles, 32-term K steps
     uint32_t polys = 2;                              // ciphertext size of inputs and outputs (3: unrelinearized products)
     uint32_t order = 0;                              // workgroup order of the VALU kernels: 0 group-major, 1 slice-major (gemm_block_coords)
+    bool one = false;                                // k_scalar_gemm_f64<MT, 1, 0>: the words are not split (gemm_one_limb)
 };
 // k_scalar_gemm_f64: rows of the weight table per (group, output tile) - K terms + zero rows up to a multiple of 16 + 16: the kernel's sets of 4 (or 8) terms run past K
 // and multiply whatever word the padded gather entry reads by these zeros

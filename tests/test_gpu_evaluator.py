@@ -522,6 +522,26 @@ def test_scalar_gemm_term_counts_of_the_small_weight_kernel(name, rng):
             g.scalar_gemm(h, W, out, 1, idx=idx)
             assert np.array_equal(g.ct_download(out, 1, O), exp), (name, M, K)
             g.free(out)
+    # the one-limb form (words not split: one FMA per term) is chosen when (sum |w| + 1) q_max <= 2^53 for every row: rows AT the bound over inputs whose
+    # words are all q_j - 1 (every partial sum as large as it gets), all weights of one sign; and one weight more, where the two-limb form must take over
+    room = (1 << 53) // max(int(x) for x in o.q)
+    half = (o.t - 1) // 2
+    K = 25
+    per = min((room - 1) // K, half)
+    if per >= 1:
+        for extra in (0, 1):
+            Ws = np.full((5, K), per, dtype=np.int64)
+            Ws[:, 0] += min((room - 1) - per * K, half - per) + extra
+            Ws[1] = -Ws[1]
+            Ws[3, 1::2] = -Ws[3, 1::2]
+            W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
+            idx = np.full((5, K), 5, dtype=np.int32)                  # the all-(q_j - 1) ciphertext in every tap
+            idx[:, 3] = 2
+            exp = o.scalar_gemm(cts, W, idx)
+            out = g.ct_alloc(6)
+            g.scalar_gemm(h, W, out, 1, idx=idx)
+            assert np.array_equal(g.ct_download(out, 1, 5), exp), (name, "row sum at the one-limb bound", extra)
+            g.free(out)
     g.free(h)
 
 
