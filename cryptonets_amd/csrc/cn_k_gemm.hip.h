@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 #ifndef GEMM_PF_SMALL
 #define GEMM_PF_SMALL 4       // terms requested ahead per register set for MT <= 5 (convolution windows: 25 taps, 5 maps).  8 - two gather lists of four in flight per
                               // thread, VERDICT r03 next #7 - was measured in round 4 and is NOT the default: 91 instead of 66 VGPRs (5 instead of 7 waves per SIMD),
-                              // 476 against 462 us for the CryptoNets convolution (profiles/HISTORY.md, round 4): the layer is not waiting for its loads
+                              // 476 against 462 us for the CryptoNets convolution (profiles/HISTORY.md, round 4); again on the round-5 kernel (80 VGPRs, 26 spilled
+                              // SGPRs for the weights of a set): 451-455 against 382-386 us
 #endif
     constexpr int PF = (MT <= 5) ? GEMM_PF_SMALL : 4;
     static_assert(PF % 4 == 0, "gather indices travel in 16 B scalar loads of four");
