@@ -367,6 +367,7 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
+    if (getenv("CN_GEMM_PAIR")) c->gemm_pair = atoi(getenv("CN_GEMM_PAIR")) != 0;
     if (getenv("CN_GEMM_ORDER")) c->gemm_order = atoi(getenv("CN_GEMM_ORDER"));
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
@@ -430,6 +431,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
     if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value != 0; return 0; }
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
+    if (!strcmp(name, "gemm_pair")) { ctx->gemm_pair = value != 0; return 0; }        // likewise
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
     if (!strcmp(name, "ks_wide")) { ctx->ks_wide = value; return 0; }
     if (!strcmp(name, "ks_split14")) { ctx->ks_split14 = value != 0; return 0; }
@@ -461,6 +463,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "sq_fused")) *value = ctx->sq_fused;
     else if (!strcmp(name, "mp_fused")) *value = ctx->mp_fused;
     else if (!strcmp(name, "gemm_mfma")) *value = ctx->gemm_mfma;
+    else if (!strcmp(name, "gemm_pair")) *value = ctx->gemm_pair;
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
     else if (!strcmp(name, "enc_fused")) *value = ctx->enc_fused;
@@ -1121,6 +1124,65 @@ static int free_gemm_plan(cn_ctx *ctx, Buffer &b) {
     if (b.plan && b.plan->dev) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.plan->dev)); b.plan->dev = nullptr; }
     return 0;
 }
+// Gather lists that overlap are merged in PAIRS (round 5).  A convolution window of 25 taps shares 15 of them with its neighbour; as two gather lists every shared
+// input word travels from L2 to a CU twice - and that traffic, not HBM and not instruction issue, is what the layer waits for (profiles/HISTORY.md, round 5: the
+// CryptoNets convolution 370-380 us with one list per window, 300-320 us with the windows in pairs; wider tiles lose again: their outputs no longer fit the
+// 10-output register tile).  Two lists that share at least half of their inputs become ONE list (the union, 35 entries for two neighbouring 5 x 5 windows at stride
+// 2) whose outputs carry the weight 0 for the entries of the other list: a zero weight is "no term" in DenseMatrixBySparseVectorMultiply, the outputs are the same
+// words.  Only for small signed weights (the FP64 kernels), lists of at most 64 entries without repeated inputs and at most 5 outputs each (a pair then fills the
+// 10-output tile).  gidx / W2 / K are rewritten in place; returns false when nothing was merged.
+static bool pair_gather_lists(uint32_t O, uint32_t &K, std::vector<int32_t> &gidx, const uint64_t *W, std::vector<uint64_t> &W2) {
+    if (K > 64 || O < 2) return false;
+    std::map<std::vector<int32_t>, std::vector<uint32_t>> groups;
+    for (uint32_t o = 0; o < O; o++) groups[std::vector<int32_t>(gidx.begin() + (size_t)o * K, gidx.begin() + (size_t)(o + 1) * K)].push_back(o);
+    const size_t G = groups.size();
+    if (G < 2 || G > 65536) return false;
+    struct L { std::vector<int32_t> in; const std::vector<uint32_t> *outs; const std::vector<int32_t> *list; int32_t mate = -1; };
+    std::vector<L> ls; ls.reserve(G);
+    for (auto &kv : groups) {
+        if (kv.second.size() > 5) return false;
+        L l; l.outs = &kv.second; l.list = &kv.first;
+        for (int32_t id : kv.first) if (id >= 0) l.in.push_back(id);
+        std::sort(l.in.begin(), l.in.end());
+        if (std::adjacent_find(l.in.begin(), l.in.end()) != l.in.end()) return false;       // an input twice in one list: its two weights would have to be added
+        ls.push_back(std::move(l));
+    }
+    std::unordered_map<int32_t, std::vector<uint32_t>> where;                               // input -> lists that gather it
+    for (uint32_t i = 0; i < G; i++) for (int32_t id : ls[i].in) where[id].push_back(i);
+    bool any = false;
+    std::vector<uint32_t> cnt(G, 0), touched;
+    for (uint32_t i = 0; i < G; i++) {
+        if (ls[i].mate >= 0) continue;
+        touched.clear();
+        for (int32_t id : ls[i].in) for (uint32_t j : where[id]) if (j > i && ls[j].mate < 0) { if (!cnt[j]++) touched.push_back(j); }
+        uint32_t best = 0; int32_t bj = -1;
+        for (uint32_t j : touched) { if (cnt[j] > best || (cnt[j] == best && (int32_t)j < bj)) { best = cnt[j]; bj = (int32_t)j; } cnt[j] = 0; }
+        if (bj >= 0 && 2 * best >= std::min(ls[i].in.size(), ls[bj].in.size()) && ls[i].in.size() + ls[bj].in.size() - best <= 64) { ls[i].mate = bj; ls[bj].mate = (int32_t)i; any = true; }
+    }
+    if (!any) return false;
+    // the union of a pair: the first list's entries in their order, then the second list's new ones; K2 = the longest list after merging
+    std::vector<std::vector<int32_t>> uni(G);
+    uint32_t K2 = 0;
+    for (uint32_t i = 0; i < G; i++) {
+        const int32_t m = ls[i].mate;
+        if (m >= 0 && (uint32_t)m < i) { uni[i] = uni[m]; continue; }
+        for (int32_t id : *ls[i].list) if (id >= 0) uni[i].push_back(id);
+        if (m >= 0) for (int32_t id : *ls[m].list) if (id >= 0 && !std::binary_search(ls[i].in.begin(), ls[i].in.end(), id)) uni[i].push_back(id);
+        K2 = std::max<uint32_t>(K2, (uint32_t)uni[i].size());
+    }
+    std::vector<int32_t> g2((size_t)O * K2, -1);
+    W2.assign((size_t)O * K2, 0);
+    for (uint32_t i = 0; i < G; i++) {
+        std::unordered_map<int32_t, uint32_t> pos;
+        for (uint32_t x = 0; x < uni[i].size(); x++) pos[uni[i][x]] = x;
+        for (uint32_t o : *ls[i].outs) {
+            for (uint32_t x = 0; x < uni[i].size(); x++) g2[(size_t)o * K2 + x] = uni[i][x];
+            for (uint32_t kk = 0; kk < K; kk++) { const int32_t id = gidx[(size_t)o * K + kk]; if (id >= 0) W2[(size_t)o * K2 + pos[id]] = W[(size_t)o * K + kk]; }
+        }
+    }
+    gidx.swap(g2); K = K2;
+    return true;
+}
 static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, uint32_t O, uint32_t K, Buffer *BP, cn_handle bias_pt, const int32_t *bias_idx,
                            GemmPlan &P) {
     if (!O || !K || !W) return fail(CN_ERR_ARG, "empty scalar GEMM");
@@ -1141,6 +1203,8 @@ static int build_gemm_plan(cn_ctx *ctx, const int32_t *idx, const uint64_t *W, u
         if (!any) return fail(CN_ERR_ARG, "output %u has no non-zero term (AddMany of nothing)", o);
         if (BP && (bias_idx[o] < 0 || (uint32_t)bias_idx[o] >= BP->count)) return fail(CN_ERR_ARG, "bias index out of range");
     }
+    std::vector<uint64_t> W2;
+    if (ctx->gemm_pair && gemm_arith(ctx, gemm_weights_small(ctx, W, (size_t)O * K)).small && pair_gather_lists(O, K, gidx, W, W2)) W = W2.data();
     // group outputs that gather the same inputs (PoolLayer: every map of one corner shares its patch)
     std::map<std::vector<int32_t>, std::vector<uint32_t>> groups;
     for (uint32_t o = 0; o < O; o++) groups[std::vector<int32_t>(gidx.begin() + (size_t)o * K, gidx.begin() + (size_t)(o + 1) * K)].push_back(o);

@@ -202,15 +202,24 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             }
         }
     };
-    auto terms = [&](const uint64_t (&x)[PF], uint32_t kk) {
-        // the weights of WB terms (up to 20 doubles = 40 SGPRs) are contiguous: requested together (wide scalar loads, ONE wait) before the first product
-        constexpr int WB = MT >= 20 ? 1 : (MT * PF <= 20 ? PF : 20 / MT);
+    // the weights of WB terms (up to 20 doubles = 40 SGPRs) are contiguous: requested together (wide scalar loads, ONE wait) before the first product.
+    // WSET (the whole set fits: MT <= 5): they are requested BEFORE the gather entries of the set behind it (wload in front of fetch), so that the one
+    // lgkmcnt(0) in front of that set's input requests covers them too - one scalar round trip per set on a wave's chain of dependent requests instead of two
+    constexpr int WB = MT >= 20 ? 1 : (MT * PF <= 20 ? PF : 20 / MT);
+    constexpr bool WSET = WB == PF;
+    auto wload = [&](double (&w)[WB * MT], uint32_t kk) {
+        const double *wp = gw + (size_t)kk * MT;
+#pragma unroll
+        for (int q = 0; q < WB * MT; q++) w[q] = wp[q];
+    };
+    auto terms = [&](const uint64_t (&x)[PF], uint32_t kk, const double (&w0)[WB * MT]) {
 #pragma unroll
         for (int p0 = 0; p0 < PF; p0 += WB) {
             double w[WB * MT];
-            const double *wp = gw + (size_t)(kk + p0) * MT;
+            if constexpr (WSET) {
 #pragma unroll
-            for (int q = 0; q < WB * MT; q++) w[q] = wp[q];
+                for (int q = 0; q < WB * MT; q++) w[q] = w0[q];
+            } else wload(w, kk + p0);
 #pragma unroll
             for (int p = p0; p < p0 + WB; p++) {
                 double xl[NL];
@@ -263,14 +272,17 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             // inside it - at a join the compiler's wait counts assume the path with the fewest requests in flight and drain the set requested ahead.
             const uint32_t sets = (k1 - k0 + PF - 1) / PF;
             uint32_t kk = k0;
+            double wa[WB * MT], wb[WB * MT];
             fetch(xa, k0);
             for (uint32_t it = sets >> 1; it; it--, kk += 2 * PF) {
+                if constexpr (WSET) { wload(wa, kk); __builtin_amdgcn_sched_barrier(0); }      // (the scheduler sinks the request behind the input requests otherwise)
                 fetch(xb, kk + PF);
-                terms(xa, kk);
+                terms(xa, kk, wa);
+                if constexpr (WSET) { wload(wb, kk + PF); __builtin_amdgcn_sched_barrier(0); }
                 fetch(xa, kk + 2 * PF);
-                terms(xb, kk + PF);
+                terms(xb, kk + PF, wb);
             }
-            if (sets & 1) terms(xa, kk);
+            if (sets & 1) { if constexpr (WSET) wload(wa, kk); terms(xa, kk, wa); }
         }
         fold();
     }

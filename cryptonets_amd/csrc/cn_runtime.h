@@ -168,6 +168,7 @@ struct cn_ctx {
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
     bool mp_fused = true;     // dense MultiplyPlain as k_lift_ntt + k_mul_plain_fused; cn_set_option("mp_fused", 0) = the six separate launches
     bool mp_bcast = true;     // ... one ciphertext x many plaintexts (row-dot batches) as ONE launch that transforms the plaintexts (k_mul_plain_bcast, round 5); 0: the two launches above
+    bool gemm_pair = true;    // planned scalar GEMMs: gather lists that share at least half of their inputs are merged in pairs (pair_gather_lists); cn_set_option("gemm_pair", 0): the caller's lists
     bool gemm_mfma = true;    // scalar GEMMs with >= 16 outputs per gather list on the int8 matrix cores (exact); cn_set_option("gemm_mfma", 0): FP64 kernel
     int cus = 0;              // compute units of the device
     bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per

@@ -68,7 +68,10 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * pipelined resident kernel (k_square_pipe: one workgroup per CU and modulus, inverse root table in LDS, next operand prefetched), 0 = k_square_fused; "enc_fused" = 1 (default) runs Encryptor.Encrypt behind the samplers as ONE kernel (N <= 8192: the ternary u goes from the sampler's int8
  * polynomial through one transform and stays in registers for both components), 0 = expansion + batched transform + tail kernel;
  * "gemm_mfma" = 1 (default) runs wide scalar GEMMs (cn_scalar_gemm / cn_scalar_dot batches with >= 16 outputs) on the int8 matrix
- * cores.  All variants produce identical words. */
+ * cores; "gemm_pair" = 1 (default) lets cn_scalar_gemm / cn_gemm_plan_create merge gather lists that share at least half of their inputs in pairs
+ * (small signed weights, lists of <= 64 entries and <= 5 outputs: the windows of a convolution - every shared input then travels to a CU once, not twice),
+ * 0 = the caller's lists as they are (environment: CN_GEMM_PAIR; CN_GEMM_ONE_LIMB=0 keeps the small-weight kernel on its two-limb form).
+ * All variants produce identical words. */
 /* "defer" = 1: DEFERRED SUBMISSION for callers that issue one evaluator call per ciphertext from many threads - the unchanged
  * NeuralNetworks layers of the reference (PoolLayer.cs:67-80,113-121,182,214; EncryptedSealBfvMatrix.cs:79-120,140-154; LLInterleaveLayer.cs;
  * Utils.cs:46-88).  cn_scalar_dot, cn_add, cn_sub, cn_add_plain, cn_mul_relin, cn_encrypt and - on up to 4 ciphertexts per call - cn_mul_plain,

@@ -545,6 +545,49 @@ def test_scalar_gemm_term_counts_of_the_small_weight_kernel(name, rng):
     g.free(h)
 
 
+@pytest.mark.parametrize("name", ["tiny", "c3"])
+def test_scalar_gemm_pairs_overlapping_gather_lists(name, rng):
+    """cn_gemm_plan_create / cn_scalar_gemm merge gather lists that share at least half of their inputs in pairs (the union list, weight 0 for the other list's
+    entries - a zero weight is no term): sliding windows of 6 taps at stride 2 (4 shared), 1 / 3 / 5 outputs per window, an odd number of windows, padded taps at
+    the border, a 2-D 3 x 3 / stride 1 case, and lists that must NOT be merged (more than five outputs; an input twice in one list) - same words as the oracle and
+    as the caller's own lists (cn_set_option("gemm_pair", 0))."""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    n_in = 24
+    vals, cts = enc_batch(o, rng, n_in)
+    cts[23] = np.concatenate([np.full(o.n, qj - 1, dtype=np.uint64) for _ in range(2) for qj in o.q])
+    h = up(g, cts)
+    cases = []
+    for maps in (1, 3, 5, 6):                                          # 6 outputs per list: left alone
+        wins = [[(2 * c + t) if 2 * c + t < n_in else -1 for t in range(6)] for c in range(11)]          # the last windows hang over the border
+        cases.append((np.array([w for w in wins for _ in range(maps)], dtype=np.int32), "1-D windows x %d maps" % maps))
+    grid = np.arange(20).reshape(4, 5)
+    wins = [[int(grid[r + a, c + b]) for a in range(3) for b in range(3)] for r in range(2) for c in range(3)]
+    cases.append((np.array([w for w in wins for _ in range(2)], dtype=np.int32), "3 x 3 windows at stride 1"))
+    dup = np.array([[0, 1, 2, 1], [1, 2, 3, 4], [1, 2, 3, 4]], dtype=np.int32)
+    cases.append((dup, "an input twice in one list"))
+    try:
+        for idx, what in cases:
+            O, K = idx.shape
+            Ws = rng.integers(-300, 301, size=(O, K))
+            Ws[:, 0] = np.where(Ws[:, 0] == 0, 7, Ws[:, 0])
+            Ws[idx < 0] = 99                                           # weights of padded taps do not count
+            W = np.where(Ws < 0, o.t + Ws, Ws).astype(np.uint64)
+            exp = o.scalar_gemm(cts, W, idx)
+            for pair in (1, 0):
+                g.set_option("gemm_pair", pair)
+                out = g.ct_alloc(O)
+                g.scalar_gemm(h, W, out, 0, idx=idx)
+                assert np.array_equal(g.ct_download(out, 0, O), exp), (name, what, pair)
+                plan = g.gemm_plan(W, idx=idx)
+                out2 = g.ct_alloc(O)
+                g.gemm_apply(plan, h, out2, 0)
+                assert np.array_equal(g.ct_download(out2, 0, O), exp), (name, what, pair, "planned")
+                g.free(plan); g.free(out); g.free(out2)
+    finally:
+        g.set_option("gemm_pair", 1)
+    g.free(h)
+
+
 @pytest.mark.parametrize("name", ["tiny", "c2", "c4"])
 def test_scalar_gemm_matrix_core_kernel(name, rng):
     """Scalar GEMMs with >= 16 outputs per gather list run on the int8 matrix cores (k_scalar_gemm_mfma: signed base-256 digits of the

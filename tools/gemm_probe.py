@@ -16,6 +16,8 @@ tile = os.environ.get("BENCH_CONV_TILE", "1")
 tile = tuple(int(x) for x in tile.split("x")) if "x" in tile else int(tile)
 layers = cm.layer_tables(*cm.synthetic_weights(1), conv_tile=tile)
 g = Context(cm.N, cm.PLAIN_PRIMES[0], dbc=10, gdbc=20)
+if os.environ.get("PROBE_GEMM_MFMA"):
+    g.set_option("gemm_mfma", int(os.environ["PROBE_GEMM_MFMA"]))      # 0: tiled convolutions (BENCH_CONV_TILE) stay on the VALU kernel
 ch = cm.CryptoNetsChannel(g, layers, cm.constant_plaintext(cm.N))
 rng = np.random.default_rng(3)
 n, k = g.n, g.k
