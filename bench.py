@@ -795,6 +795,12 @@ def main():
             if not args.caller_threads and effective_cores()[1] != nthreads:
                 vms = min(rp.measure(chans, layers, effective_cores()[1], reps, warmup=2, literal_taps=True)[0] for _ in range(3))
                 visible = {"threads": effective_cores()[1], "ms_per_step": round(vms, 2), "frac_of_batched": round(batched_ms / vms, 3)}
+            locked = None                                                  # the same literal pattern with every deferred call under the context lock (defer = 1)
+            try:
+                kms = min(rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True, lockfree=False)[0] for _ in range(3))
+                locked = {"threads": nthreads, "ms_per_step": round(kms, 2), "frac_of_batched": round(batched_ms / kms, 3)}
+            except Exception as ex:
+                locked = {"error": str(ex)[:200]}
             unchanged = {"value": round(8192e3 / lms, 1), "unit": "images/s", "ms_per_step": round(lms, 2), "threads": nthreads,
                          "frac_of_batched": round(batched_ms / lms, 3), "verified_against_integer_model": lok, "verified_slots": 8192 * 10 * len(chans),
                          "timing": "best of 5 windows of %d steps on BOTH sides of frac_of_batched (skipped_taps, at_visible_cpu_count: best of 3)" % reps,
@@ -803,8 +809,11 @@ def main():
                          "pattern": "PoolLayer.Apply: per (map, corner) [cn_encrypt_zero_new per padded tap (the twin's one-call zero vector)] + cn_ct_alloc + cn_scalar_dot "
                                     "(K = 25 real handles) + cn_ct_alloc + cn_add_plain + cn_free of the product (at once: the queue folds the bias into the GEMM), ReleaseTemp: "
                                     "cn_free_many per 32 zero encryptions (CnDevice.DeferFree); SquareActivation: per column cn_mul_relin(count 1); BaseLayer.GetNext: cn_free_many "
-                                    "of the layer's input columns; every ciphertext its own handle; cn_set_option(defer, 1); at flush the scalar products of a layer are ONE launch "
-                                    "per term count (round 5); threads = Defaults.ThreadCount = processor count (visible CPUs %d, cgroup quota %s)" % (effective_cores()[1], effective_cores()[2]),
+                                    "of the layer's input columns; every ciphertext its own handle; cn_set_option(defer, 2): the deferrable calls are published to the context's "
+                                    "submission ring without taking its lock and executed in claim order by whoever finds the lock free (round 6; `locked`: defer = 1, every call "
+                                    "under the lock, rounds 2-5); at flush the scalar products of a layer are ONE launch per term count; threads = Defaults.ThreadCount = processor "
+                                    "count (visible CPUs %d, cgroup quota %s)" % (effective_cores()[1], effective_cores()[2]),
+                         "locked": locked,
                          "skipped_taps": {"value": round(8192e3 / ums, 1), "ms_per_step": round(ums, 2), "threads": 4, "frac_of_batched": round(batched_ms / ums, 3),
                                           "words_identical_to_batched": bool(all(np.array_equal(a, b) for a, b in zip(uwords, ref_words)))}}
         except Exception as ex:
@@ -850,10 +859,15 @@ def main():
                "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
                                       "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; weights: " + args.weights,
+                          "padded_taps": "elided",     # the batched program of `value` skips the 645 x 2 zero-weighted padded convolution taps per batch the reference encrypts and
+                                                       # multiplies inside its timed window (PoolLayer.cs:67-80); `literal_call_sequence` / `unchanged_caller` = the reference's literal sequence
                           "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world,
                           "arithmetic": "exact modular integers over 43-49-bit RNS primes (results are u64 words, bit-identical to the integer "
                                         "oracle); products evaluated with error-free FP64 instruction sequences where the modulus is below 2^49, "
                                         "64-bit integer instructions otherwise"},
+               # the figure for the reference's LITERAL call sequence (padded taps as fresh encryptions of zero, one call per ciphertext from Defaults.ThreadCount threads), next to `value`
+               "literal_call_sequence": ({"value": unchanged.get("value"), "unit": "images/s", "ms_per_step": unchanged.get("ms_per_step"), "frac_of_value_program": unchanged.get("frac_of_batched"),
+                                          "verified_against_integer_model": unchanged.get("verified_against_integer_model")} if isinstance(unchanged, dict) and "value" in unchanged else None),
                "roofline": roofline, "key_switch": key_switch, "square": square, "unchanged_caller": unchanged, "relinearize_late": late,
                # the WHOLE batch against HBM (inputs read once + outputs written once per layer, 640 KiB per ciphertext, per prime:
                # conv (784+845), square 845 x 2, dense (845+100), square 100 x 2, dense (100+10)): the path is FP64-issue bound, not HBM bound

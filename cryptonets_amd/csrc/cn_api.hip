@@ -175,10 +175,13 @@ static int range_ok(const Buffer *b, uint32_t first, uint32_t count, uint32_t st
 // every entry point takes the context lock; all but the deferrable ones (cn_defer.hip) first drain the queue of deferred calls
 // (the function bodies that start with LOCK / LOCK_ONLY run inside CnMutex::run - see API_BODY below: under the context lock, on the calling
 // thread or, when the lock is held, on the holder's thread)
-#define LOCK_ONLY CHECK(use(ctx))
+// Lock-free submission ("defer" = 2, cn_submit.h): every entry point that takes the lock first executes the records other threads have published up to
+// this moment (ring_sync: in claim order, waiting for a slot that is claimed but not yet written); LOCK additionally reports the first error one of them ran into.
+static int ring_sync(cn_ctx *ctx, bool report);
+#define LOCK_ONLY CHECK(use(ctx)); CHECK(ring_sync(ctx, false))
 #define API_BODY return ctx->mu.run([&]() -> int {
 #define API_END });
-#define LOCK LOCK_ONLY; CHECK(cn_defer_flush(ctx))
+#define LOCK CHECK(use(ctx)); CHECK(ring_sync(ctx, true)); CHECK(cn_defer_flush(ctx))
 
 #define launch_count cn_launch_count
 
@@ -308,6 +311,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     c->index_map.assign(n, 0);
     if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), c->index_map.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
     c->dq = cn_defer_new();
+    c->ring = new SubmitRing(); c->ready = new ReadyRing();
     c->slabs = new std::vector<Slab>();
     std::lock_guard<std::mutex> one_at_a_time(device_create_mutex(device));       // until this context is registered: the next creator on this device must see its stream
     const int rc = ctx_init(c, n, k, device, tw);
@@ -372,7 +376,7 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     if (getenv("CN_MP_FUSED")) c->mp_fused = atoi(getenv("CN_MP_FUSED")) != 0;          // A/B switch of the fused squaring kernel
     size_t lds = (size_t)ntt_lds_words(n) * 8;
     if (lds > 48 * 1024) {                 // N >= 8192: the padded LDS image exceeds the default dynamic-LDS limit
-        CHECK(big_lds(k_ntt, lds)); CHECK(big_lds(k_galois_lds, (size_t)n * 8));
+        CHECK(big_lds(k_ntt, lds)); CHECK(big_lds(k_galois_lds, (size_t)n * 8)); CHECK(big_lds(k_galois_limbs, (size_t)n * 8));
         CHECK(set_ks_attr<8>(lds)); CHECK(set_ks_attr<16>(lds));
     }
     for (int pol = 0; pol < 3; pol++) { CHECK(rr_ops[pol]->set_attrs(c->hc.logn, lds)); CHECK(ks_ops[pol]->set_attrs(c->hc.logn, lds)); }
@@ -395,6 +399,7 @@ static void ctx_teardown(cn_ctx *ctx) {
         // calls were pending - go back to the pool and are released with it)
         CnGuard lk(ctx->mu);
         if (ctx->capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(ctx->stream, &g); if (g) (void)hipGraphDestroy(g); ctx->capturing = false; }
+        (void)ring_sync(ctx, false);
         (void)cn_defer_flush(ctx);
     }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -415,8 +420,10 @@ static void ctx_teardown(cn_ctx *ctx) {
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     cn_defer_delete(ctx->dq);
+    delete ctx->ring; delete ctx->ready;
     delete ctx;
 }
+static int free_body(cn_ctx *ctx, cn_handle h);
 extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BODY
     LOCK;
     if (!name) return fail(CN_ERR_ARG, "null option name");
@@ -438,7 +445,15 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "ks_pair14")) { ctx->ks_pair14 = value != 0; return 0; }
     if (!strcmp(name, "ks_chain")) { ctx->ks_chain = value != 0; return 0; }
     if (!strcmp(name, "mp_bcast")) { ctx->mp_bcast = value != 0; return 0; }
-    if (!strcmp(name, "defer")) { ctx->defer = value != 0; return 0; }          // the queue was drained by LOCK
+    if (!strcmp(name, "defer")) {                // 0 immediate, 1 queued under the context lock, 2 queued through the lock-free submission ring; the queue was drained by LOCK
+        if (value < 0 || value > 2) return fail(CN_ERR_ARG, "defer: 0, 1 or 2");
+        ctx->defer.store(value, std::memory_order_release);
+        if (value != 2) {                        // the ready single-ciphertext arrays of the lock-free mode go back to the pool
+            while (const cn_handle h = ctx->ready->pop()) CHECK(free_body(ctx, h));
+            ctx->ready->misses.store(0, std::memory_order_relaxed);
+        }
+        return 0;
+    }
     if (!strcmp(name, "ks_xi")) {                // decomposition convention of the key switch (DevConsts::ks_xi); the keys must be of the same convention
         if (ctx->capturing || ctx->graphs_alive) return fail(CN_ERR_ARG, "ks_xi cannot change while a graph is recorded or alive (its kernels were chosen for the other convention)");
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -453,7 +468,8 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     LOCK_ONLY;
     if (!name || !value) return fail(CN_ERR_ARG, "null argument");
     if (!strcmp(name, "f64")) *value = ctx->use_f64;
-    else if (!strcmp(name, "defer")) *value = ctx->defer;
+    else if (!strcmp(name, "defer")) *value = ctx->defer.load(std::memory_order_relaxed);
+    else if (!strcmp(name, "ready_handles")) *value = (int)ctx->ready->size();          // allocated single-ciphertext arrays waiting for a lock-free cn_ct_alloc
     else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
     else if (!strcmp(name, "ks_xi")) *value = (int)ctx->hc.ks_xi;
     else if (!strcmp(name, "ks_xcd")) *value = ctx->ks_xcd;
@@ -606,12 +622,30 @@ static int alloc_buf(cn_ctx *ctx, int kind, uint32_t count, uint32_t size, cn_ha
     *out = ctx->bufs.insert(std::move(b));
     return 0;
 }
-extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) { API_BODY
-    LOCK_ONLY; if (size < 2 || size > 3) return fail(CN_ERR_ARG, "ciphertext size must be 2 or 3"); return alloc_buf(ctx, 0, count, size, out);
+// ---- lock-free submission ("defer" = 2): producer side.  A deferrable entry point builds a record and publishes it; the records are executed by ring_drain
+// (behind the deferred queue, further down).  submit_async: is the context in that mode?  (read without the lock: the mode changes only through
+// cn_set_option, which drains the ring first; a call that races with the change is executed in its claim order either way)
+static bool submit_async(const cn_ctx *ctx) { return ctx->defer.load(std::memory_order_relaxed) == 2 && !ctx->capturing.load(std::memory_order_relaxed); }
+static int ring_push(cn_ctx *ctx, uint32_t type, uint32_t count, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t x, uint64_t arg);
+static void ready_refill(cn_ctx *ctx);
+extern "C" int cn_ct_alloc(cn_ctx *ctx, uint32_t count, uint32_t size, cn_handle *out) {
+    if (out && count == 1 && size == 2 && submit_async(ctx)) {          // AllocateCiphertext of a per-ciphertext caller: a ready handle, no lock
+        const cn_handle h = ctx->ready->pop();
+        if (h) { *out = h; return 0; }
+    }
+    API_BODY
+    LOCK_ONLY; if (size < 2 || size > 3) return fail(CN_ERR_ARG, "ciphertext size must be 2 or 3");
+    CHECK(alloc_buf(ctx, 0, count, size, out));
+    if (count == 1 && size == 2 && ctx->defer.load(std::memory_order_relaxed) == 2) ready_refill(ctx);      // the ring had run dry: fill it while the lock is held anyway
+    return 0;
 API_END }
 extern "C" int cn_pt_alloc(cn_ctx *ctx, uint32_t count, cn_handle *out) { API_BODY LOCK_ONLY; return alloc_buf(ctx, 1, count, 1, out); API_END }
-extern "C" int cn_free(cn_ctx *ctx, cn_handle h) { API_BODY
-    LOCK_ONLY;
+static int free_body(cn_ctx *ctx, cn_handle h);
+extern "C" int cn_free(cn_ctx *ctx, cn_handle h) {
+    if (submit_async(ctx)) return ring_push(ctx, SUB_FREE, 1, h, 0, 0, 0, 0, 0, 0, 0);      // (a release must not overtake the published calls that read the array)
+    API_BODY LOCK_ONLY; return free_body(ctx, h); API_END
+}
+static int free_body(cn_ctx *ctx, cn_handle h) {
     Buffer *it = ctx->bufs.find(h);
     if (!it) return fail(CN_ERR_ARG, "invalid handle");
     if (it->kind == 2) { NOT_CAPTURING("releasing a GEMM plan"); CHECK(cn_defer_flush(ctx)); CHECK(free_gemm_plan(ctx, *it)); }
@@ -620,11 +654,20 @@ extern "C" int cn_free(cn_ctx *ctx, cn_handle h) { API_BODY
     else CHECK(dev_release(ctx, it->d, it->item_words * 8 * it->count));
     ctx->bufs.erase(h);
     return 0;
-API_END }
+}
 // n handles in one call (ReleaseTemp of the unchanged PoolLayer: one Dispose per zero encryption, PoolLayer.cs:83-90; BaseLayer.GetNext: one per column of a
 // layer's input, BaseLayer.cs:23-49): the handles are checked first - nothing is released when one of them is invalid - then released like n cn_free calls
-extern "C" int cn_free_many(cn_ctx *ctx, const cn_handle *h, uint32_t n) { API_BODY
-    LOCK_ONLY;
+static int free_many_body(cn_ctx *ctx, const cn_handle *h, uint32_t n);
+extern "C" int cn_free_many(cn_ctx *ctx, const cn_handle *h, uint32_t n) {
+    if (submit_async(ctx) && h && n) {
+        cn_handle *blk = (cn_handle *)malloc((size_t)n * sizeof(cn_handle));
+        if (!blk) return fail(CN_ERR_ARG, "out of host memory");
+        memcpy(blk, h, (size_t)n * sizeof(cn_handle));
+        return ring_push(ctx, SUB_FREE_MANY, 1, 0, 0, 0, 0, 0, 0, n, (uint64_t)(uintptr_t)blk);
+    }
+    API_BODY LOCK_ONLY; return free_many_body(ctx, h, n); API_END
+}
+static int free_many_body(cn_ctx *ctx, const cn_handle *h, uint32_t n) {
     if (!h && n) return fail(CN_ERR_ARG, "null argument");
     bool heavy = false;
     for (uint32_t i = 0; i < n; i++) {
@@ -649,7 +692,7 @@ extern "C" int cn_free_many(cn_ctx *ctx, const cn_handle *h, uint32_t n) { API_B
         ctx->bufs.erase(h[i]);
     }
     return 0;
-API_END }
+}
 // ---- captured sequences: the launch-bound chains of small kernels of a single-image inference (LoLa: ~235 launches per plaintext
 // prime) are recorded once on the context stream and replayed with one hipGraphLaunch - no per-launch host work, dependent kernels
 // back to back on the device.  Recording rules: the same sequence must have run once before (so that every temporary comes out of
@@ -710,7 +753,7 @@ extern "C" int cn_graph_launch(cn_ctx *ctx, cn_handle graph) { API_BODY
     ctx->st.kernel_launches += 1;
     return 0;
 API_END }
-extern "C" int cn_live_handles(cn_ctx *ctx) { CnGuard lk(ctx->mu); return (int)ctx->bufs.size(); }
+extern "C" int cn_live_handles(cn_ctx *ctx) { CnGuard lk(ctx->mu); (void)ring_sync(ctx, false); return (int)ctx->bufs.size() - (int)ctx->ready->size(); }   // (ready handles belong to nobody yet)
 extern "C" int cn_ct_upload(cn_ctx *ctx, cn_handle h, uint32_t first, uint32_t count, const uint64_t *host) { API_BODY
     LOCK; NOT_CAPTURING("cn_ct_upload"); GETCT(b, h, 0);
     if (!range_ok(b, first, count)) return fail(CN_ERR_ARG, "index out of range");
@@ -853,16 +896,20 @@ static bool deferring(cn_ctx *ctx);
 static int defer_addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op);
 static int defer_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count);
 static int defer_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out, uint32_t oi, uint32_t count);
-extern "C" int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
-    LOCK_ONLY;
-    if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, 0); if (rc <= 0) return rc; }      // > 0: not deferrable (size-3 operands)
-    CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 0)); ctx->st.Addition += count; return 0;
-API_END }
-extern "C" int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
-    LOCK_ONLY;
-    if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, 1); if (rc <= 0) return rc; }
-    CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, 1)); ctx->st.Subtraction += count; return 0;
-API_END }
+static int addsub_body(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op) {
+    if (deferring(ctx)) { int rc = defer_addsub(ctx, a, ai, b, bi, out, oi, count, op); if (rc <= 0) return rc; }      // > 0: not deferrable (size-3 operands)
+    CHECK(cn_defer_flush(ctx)); CHECK(addsub(ctx, a, ai, b, bi, out, oi, count, op));
+    if (op) ctx->st.Subtraction += count; else ctx->st.Addition += count;
+    return 0;
+}
+extern "C" int cn_add(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
+    if (submit_async(ctx) && count <= DEFER_STAGED_MAX) return ring_push(ctx, SUB_ADD, count, a, ai, b, bi, out, oi, 0, 0);
+    API_BODY LOCK_ONLY; return addsub_body(ctx, a, ai, b, bi, out, oi, count, 0); API_END
+}
+extern "C" int cn_sub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count) {
+    if (submit_async(ctx) && count <= DEFER_STAGED_MAX) return ring_push(ctx, SUB_SUB, count, a, ai, b, bi, out, oi, 0, 0);
+    API_BODY LOCK_ONLY; return addsub_body(ctx, a, ai, b, bi, out, oi, count, 1); API_END
+}
 extern "C" int cn_negate(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
     LOCK; return addsub(ctx, a, ai, a, ai, out, oi, count, 2);
 API_END }
@@ -880,8 +927,12 @@ extern "C" int cn_add_many(cn_ctx *ctx, cn_handle in, const uint32_t *idx, uint3
     ctx->st.AddMany += 1; ctx->st.AddManyItemCount += n_idx;
     return 0;
 API_END }
-extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) { API_BODY
-    LOCK_ONLY;
+static int add_plain_body(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count);
+extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) {
+    if (submit_async(ctx) && count <= DEFER_STAGED_MAX) return ring_push(ctx, SUB_ADD_PLAIN, count, a, ai, pt, pi, out, oi, subtract ? 1u : 0u, 0);
+    API_BODY LOCK_ONLY; return add_plain_body(ctx, a, ai, pt, pi, subtract, out, oi, count); API_END
+}
+static int add_plain_body(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt, uint32_t pi, int subtract, cn_handle out, uint32_t oi, uint32_t count) {
     if (deferring(ctx)) { int rc = defer_add_plain(ctx, a, ai, pt, pi, subtract, out, oi, count); if (rc <= 0) return rc; }
     CHECK(cn_defer_flush(ctx));
     GETCT(A, a, 0); GETCT(O, out, A->size); GETPT(P, pt);
@@ -893,7 +944,7 @@ extern "C" int cn_add_plain(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle pt,
     HIPCHK(hipGetLastError()); launch_count(ctx);
     if (subtract) ctx->st.PlainSubtraction += count; else ctx->st.PlainAddition += count;
     return 0;
-API_END }
+}
 // out[c] = a[c * (a_bcast ? 0 : 1)] * pt[c * pstride]; a_bcast: ONE ciphertext against `count` plaintexts (row-dot batches)
 // Dense MultiplyPlain in two launches (k_lift_ntt, k_mul_plain_fused); ranges / zero plaintexts were checked by the caller
 // A row-dot batch whose SumAllSlots chain follows: the product kernel leaves sigma_elt(c1) of every product in `out` ([row][k][N], the chain's first scratch array) and takes
@@ -1500,9 +1551,13 @@ extern "C" int cn_relinearize(cn_ctx *ctx, cn_handle in3, uint32_t ii, cn_handle
     ctx->st.Relinarization += count;
     return 0;
 API_END }
+static int mul_relin_body(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out, uint32_t oi, uint32_t count);
 extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out,
-                            uint32_t oi, uint32_t count) { API_BODY
-    LOCK_ONLY;
+                            uint32_t oi, uint32_t count) {
+    if (submit_async(ctx) && count <= DEFER_STAGED_MAX) return ring_push(ctx, SUB_MUL_RELIN, count, a, ai, b, bi, out, oi, astride, bstride);      // PointwiseMultiply of one column
+    API_BODY LOCK_ONLY; return mul_relin_body(ctx, a, ai, astride, b, bi, bstride, out, oi, count); API_END
+}
+static int mul_relin_body(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_handle b, uint32_t bi, uint32_t bstride, cn_handle out, uint32_t oi, uint32_t count) {
     if (deferring(ctx)) return defer_mul_relin(ctx, a, ai, astride, b, bi, bstride, out, oi, count);
     CHECK(cn_defer_flush(ctx));
     GETCT(A, a, 2); GETCT(B, b, 2); GETCT(O, out, 2);
@@ -1524,7 +1579,7 @@ extern "C" int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astr
     }
     ctx->st.Relinarization += count;
     return 0;
-API_END }
+}
 
 // ---------------------------------------------------------------- rotations
 // in/out device pointers to size-2 ciphertext arrays; tmp holds count size-2 ciphertexts
@@ -2089,8 +2144,13 @@ static int encrypt_chain(cn_ctx *ctx, uint32_t cnt, const uint64_t *ptd, uint32_
     return 0;
 }
 static int defer_encrypt(cn_ctx *ctx, const uint64_t *ptd, uint32_t pt_stride_words, Buffer *O, uint32_t oi, uint32_t count, uint64_t seed);
-extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) { API_BODY
-    LOCK_ONLY; NOT_CAPTURING("cn_encrypt (a replayed graph would reuse its randomness)"); GETCT(O, out, 2);
+static int encrypt_body(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed);
+extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) {
+    if (submit_async(ctx) && count && count <= 4) return ring_push(ctx, SUB_ENCRYPT, count, 0, 0, pt, pi, out, oi, pt_stride, seed);
+    API_BODY LOCK_ONLY; return encrypt_body(ctx, pt, pi, pt_stride, out, oi, count, seed); API_END
+}
+static int encrypt_body(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_stride, cn_handle out, uint32_t oi, uint32_t count, uint64_t seed) {
+    NOT_CAPTURING("cn_encrypt (a replayed graph would reuse its randomness)"); GETCT(O, out, 2);
     if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
     if (!range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
     if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
@@ -2101,16 +2161,22 @@ extern "C" int cn_encrypt(cn_ctx *ctx, cn_handle pt, uint32_t pi, uint32_t pt_st
     if (deferring(ctx) && count <= 4) return defer_encrypt(ctx, ptd, pt_stride ? ctx->hc.n : 0, O, oi, count, seed);
     CHECK(cn_defer_flush(ctx));
     return encrypt_chain(ctx, count, ptd, pt_stride ? ctx->hc.n : 0, O->d + oi * O->item_words, seed, nullptr);
-API_END }
+}
 // AllocateCiphertext + Encryptor.Encrypt(PlainZero) in ONE call (the unchanged PoolLayer does both per padded convolution tap, PoolLayer.cs:67-80,
 // AtomicSealBfvVector.cs:566): one lock acquisition instead of two, same queue entry / same words as cn_ct_alloc followed by cn_encrypt(pt = 0)
-extern "C" int cn_encrypt_zero_new(cn_ctx *ctx, uint64_t seed, cn_handle *out) { API_BODY
+extern "C" int cn_encrypt_zero_new(cn_ctx *ctx, uint64_t seed, cn_handle *out) {
+    if (out && submit_async(ctx)) {                     // a ready handle + one record (same queue entry as the locked path below)
+        const cn_handle h = ctx->ready->pop();
+        if (h) { *out = h; return ring_push(ctx, SUB_ENCRYPT_ZERO, 1, 0, 0, 0, 0, h, 0, 0, seed); }
+    }
+    API_BODY
     LOCK_ONLY; NOT_CAPTURING("cn_encrypt_zero_new (a replayed graph would reuse its randomness)");
     if (!out) return fail(CN_ERR_ARG, "null argument");
     if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
     if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
     cn_handle h = 0;
     CHECK(alloc_buf(ctx, 0, 1, 2, &h));
+    if (ctx->defer.load(std::memory_order_relaxed) == 2) ready_refill(ctx);          // (the ring of ready handles had run dry)
     Buffer *O = ctx->bufs.find(h);
     int rc;
     if (deferring(ctx)) rc = defer_encrypt(ctx, nullptr, 0, O, 0, 1, seed);
@@ -2654,8 +2720,19 @@ static int cn_defer_flush(cn_ctx *ctx) {
 static bool deferring(cn_ctx *ctx) { return ctx->defer && !ctx->capturing; }
 
 /* DenseMatrixBySparseVectorMultiply for ONE output block whose K input ciphertexts are separate objects (see include/cnhip.h) */
-extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi) { API_BODY
-    LOCK_ONLY; GETCT(O, out, 2);
+static int scalar_dot_body(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi);
+extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi) {
+    if (submit_async(ctx) && K && in && w) {            // the call's lists travel in one block: K handles, K weights, K indices (if any)
+        char *blk = (char *)malloc((size_t)K * (in_idx ? 20 : 16));
+        if (!blk) return fail(CN_ERR_ARG, "out of host memory");
+        memcpy(blk, in, (size_t)K * 8); memcpy(blk + (size_t)K * 8, w, (size_t)K * 8);
+        if (in_idx) memcpy(blk + (size_t)K * 16, in_idx, (size_t)K * 4);
+        return ring_push(ctx, SUB_SCALAR_DOT, 1, 0, in_idx ? 1u : 0u, 0, 0, out, oi, K, (uint64_t)(uintptr_t)blk);
+    }
+    API_BODY LOCK_ONLY; return scalar_dot_body(ctx, in, in_idx, w, K, out, oi); API_END
+}
+static int scalar_dot_body(cn_ctx *ctx, const cn_handle *in, const uint32_t *in_idx, const uint64_t *w, uint32_t K, cn_handle out, uint32_t oi) {
+    GETCT(O, out, 2);
     if (!K || !in || !w) return fail(CN_ERR_ARG, "empty scalar product");
     if (oi >= O->count) return fail(CN_ERR_ARG, "index out of range");
     DeferQueue *q = ctx->dq;
@@ -2689,7 +2766,7 @@ extern "C" int cn_scalar_dot(cn_ctx *ctx, const cn_handle *in, const uint32_t *i
     ctx->st.PlainMultiplication += nnz; ctx->st.Addition += nnz - 1;
     if (!deferring(ctx)) return cn_defer_flush(ctx);
     return 0;
-API_END }
+}
 
 // ---- the deferrable forms of the per-ciphertext entry points (arguments are checked now, the work is queued)
 static int defer_addsub(cn_ctx *ctx, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t count, int op) {
@@ -2729,6 +2806,88 @@ static int defer_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astri
         CHECK(defer_push(ctx, DOp{DOP_MULRELIN, 0, O->d + (size_t)(oi + c) * O->item_words, pa, pb, 0, 0, nullptr}, ins, 2));
     }
     ctx->st.Relinarization += count;          // (Multiplication is counted by the batched multiply at flush time)
+    return 0;
+}
+
+// ---------------------------------------------------------------- lock-free submission ("defer" = 2, cn_submit.h): the consumer side
+// ready_refill (lock held): single-ciphertext arrays for the lock-free cn_ct_alloc / cn_encrypt_zero_new.  The target starts small and doubles whenever
+// a caller found the ring empty since the last refill (a flush that holds the lock for a millisecond is outrun by ~1 000 allocations).
+static void ready_refill(cn_ctx *ctx) {
+    ReadyRing &r = *ctx->ready;
+    if (ctx->capturing) return;
+    if (r.misses.exchange(0, std::memory_order_relaxed)) r.target = std::min<uint32_t>(r.target * 2, (uint32_t)ReadyRing::CAP / 2);
+    while (r.size() < r.target) {
+        cn_handle h = 0;
+        if (alloc_buf(ctx, 0, 1, 2, &h)) return;                 // out of memory: the callers fall back to the locked path and see the error there
+        if (!r.push(h)) { Buffer *b = ctx->bufs.find(h); (void)dev_release(ctx, b->d, b->item_words * 8); ctx->bufs.erase(h); return; }
+    }
+}
+static int ring_exec(cn_ctx *ctx, const SubRec &r) {
+    switch (r.type) {
+    case SUB_FREE: return free_body(ctx, r.a);
+    case SUB_FREE_MANY: { cn_handle *blk = (cn_handle *)(uintptr_t)r.arg; const int rc = free_many_body(ctx, blk, r.x); free(blk); return rc; }
+    case SUB_SCALAR_DOT: {
+        char *blk = (char *)(uintptr_t)r.arg; const uint32_t K = r.x;
+        const int rc = scalar_dot_body(ctx, (const cn_handle *)blk, r.ai ? (const uint32_t *)(blk + (size_t)K * 16) : nullptr, (const uint64_t *)(blk + (size_t)K * 8), K, r.out, r.oi);
+        free(blk);
+        return rc;
+    }
+    case SUB_ADD: return addsub_body(ctx, r.a, r.ai, r.b, r.bi, r.out, r.oi, r.count, 0);
+    case SUB_SUB: return addsub_body(ctx, r.a, r.ai, r.b, r.bi, r.out, r.oi, r.count, 1);
+    case SUB_ADD_PLAIN: return add_plain_body(ctx, r.a, r.ai, r.b, r.bi, (int)r.x, r.out, r.oi, r.count);
+    case SUB_MUL_RELIN: return mul_relin_body(ctx, r.a, r.ai, r.x, r.b, r.bi, (uint32_t)r.arg, r.out, r.oi, r.count);
+    case SUB_ENCRYPT: return encrypt_body(ctx, r.b, r.bi, r.x, r.out, r.oi, r.count, r.arg);
+    case SUB_ENCRYPT_ZERO: {
+        Buffer *O = ctx->bufs.find(r.out);
+        if (!O || O->kind != 0 || O->size != 2) return fail(CN_ERR_ARG, "invalid ciphertext handle");
+        if (!ctx->pk) return fail(CN_ERR_NOKEY, "public key not set");
+        if (ctx->hc.logn < 10 || ctx->hc.logn > 14) return fail(CN_ERR_ARG, "device encryption needs 1024 <= N <= 16384");
+        return defer_encrypt(ctx, nullptr, 0, O, 0, 1, r.arg);
+    }
+    default: return fail(CN_ERR_ARG, "internal: submission record of type %u", r.type);
+    }
+}
+// lock held.  Executes published records in claim order; upto = ~0: as far as they are published (an opportunistic drain stops at a slot that is claimed
+// but not written yet), else every record claimed before position `upto` (waiting for a writer that was descheduled between its claim and its publication).
+static void ring_drain(cn_ctx *ctx, uint64_t upto) {
+    SubmitRing &q = *ctx->ring;
+    (void)hipSetDevice(ctx->device);
+    uint64_t done = 0;
+    for (;;) {
+        SubRec *r = q.peek();
+        if (!r) {
+            if (upto == ~0ull || q.head.load(std::memory_order_relaxed) >= upto) break;
+            for (int spins = 0; !(r = q.peek()); spins++) { if (spins < 256) __builtin_ia32_pause(); else sched_yield(); }
+        }
+        const int rc = ring_exec(ctx, *r);
+        if (rc && !ctx->async_rc) { ctx->async_rc = rc; ctx->async_msg = cn_last_error(); }
+        q.pop();
+        done++;
+    }
+    if (done && ctx->defer.load(std::memory_order_relaxed) == 2) ready_refill(ctx);
+}
+static int ring_sync(cn_ctx *ctx, bool report) {
+    SubmitRing &q = *ctx->ring;
+    const uint64_t t = q.tail.load(std::memory_order_acquire);
+    if (q.head.load(std::memory_order_relaxed) != t) ring_drain(ctx, t);
+    if (report && ctx->async_rc) {
+        const int rc = ctx->async_rc; ctx->async_rc = 0;
+        return fail(rc, "a call submitted without the lock (defer = 2) failed when it was executed: %s", ctx->async_msg.c_str());
+    }
+    return 0;
+}
+// producer: claim, write, publish; then drain if nobody else is (nobody waits for the lock here)
+static int ring_push(cn_ctx *ctx, uint32_t type, uint32_t count, cn_handle a, uint32_t ai, cn_handle b, uint32_t bi, cn_handle out, uint32_t oi, uint32_t x, uint64_t arg) {
+    SubmitRing &q = *ctx->ring;
+    const uint64_t pos = q.claim();
+    for (int spins = 0; !q.writable(pos); spins++) {           // a full lap ahead of the consumer: help
+        if (ctx->mu.try_lock()) { ring_drain(ctx, ~0ull); ctx->mu.unlock_now(); }
+        else if (spins < 64) __builtin_ia32_pause(); else sched_yield();
+    }
+    SubRec &r = q.slot(pos);
+    r.type = type; r.count = count; r.a = a; r.b = b; r.out = out; r.ai = ai; r.bi = bi; r.oi = oi; r.x = x; r.arg = arg;
+    q.publish(pos);
+    while (q.peek_published() && ctx->mu.try_lock()) { ring_drain(ctx, ~0ull); ctx->mu.unlock_now(); }
     return 0;
 }
 

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
 // limb l of a canonical residue (below 2^(NL LW)) as an exact double; the top limb needs no mask.  NL = 1: the WHOLE word (v | 2^52's exponent, minus 2^52: two
 // instructions) - the launcher picks that form when every row's sum of |weights| times q_max stays below 2^53 (gemm_one_limb): one FMA per MAC and nothing to fold
 template <int NL, int LW> DEV double gemm_limb(uint64_t x, int l) {
-    if constexpr (NL == 1) return BzF::from_u64(x);
+    if constexpr (NL == 1) return BzF::from_u64(x & 0x000FFFFFFFFFFFFFull);   // (masked: a padded tap multiplies whatever word it reads by the weight 0 - an unwritten array
+                                                                               // may hold bits 52..62, which would land in the exponent: 0 x NaN poisons the sum; one v_and_b32 per term)
     else return (double)(uint32_t)(l == NL - 1 ? x >> (l * LW) : (x >> (l * LW)) & ((1ull << LW) - 1));
 }
 template <int LANE> DEV void fmac_bcast(double &acc, double w, double x) {

@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/cnhip.h"
 #include "cn_internal.h"
+#include "cn_submit.h"
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <map>
@@ -94,6 +95,10 @@ public:
         r.arg = (void *)&f; r.err[0] = 0;
         return submit(r);
     }
+    // the lock-free submission path (cn_submit.h): whoever finds the lock free drains the ring; nobody waits
+    bool try_lock() { return try_take_me(); }
+    void unlock_now() { release(); }
+    bool is_held() const { return held.load(std::memory_order_relaxed) != 0; }
 private:
     std::atomic<int> held{0};
     std::atomic<int> spinners{0};      // waiters that spin; the others sleep on wake_seq (cn_host.cpp)
@@ -162,7 +167,7 @@ struct cn_ctx {
     std::atomic<int> probe_pins{0};              // > 0: a cn_ctx_create on this device is measuring this context's stream; cn_ctx_destroy waits
                               // ciphertext on one XCD (share its source limbs in that L2); 2 limb-major (one key slice per XCD L2 at a time)
     bool ks_tight = false;    // CN_KS_TIGHT=1: 128-VGPR key-switch variant (2 workgroups per CU, accumulators spill to scratch)
-    bool capturing = false;   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
+    std::atomic<bool> capturing{false};   // between cn_graph_begin and cn_graph_end: work is recorded on the stream, nothing that synchronises or allocates may run
     std::vector<std::unique_ptr<char[]>> cap_staged;                 // host blocks of the upload nodes recorded so far
     std::vector<std::pair<uint64_t *, size_t>> cap_allocs;           // arrays handed out while recording
     int graphs_alive = 0;     // graphs carry the addresses of the scratch arenas: those must not move while one exists
@@ -176,9 +181,13 @@ struct cn_ctx {
     bool enc_fused = true;    // Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
     int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
-    // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches
-    bool defer = false;
+    // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches; 2: ... and submitted without the
+    // context lock through `ring` (cn_submit.h), executed by whoever drains it
+    std::atomic<int> defer{0};
     DeferQueue *dq = nullptr;
+    SubmitRing *ring = nullptr;
+    ReadyRing *ready = nullptr;
+    int async_rc = 0; std::string async_msg;        // first error of a record executed from the ring: reported by the next synchronising call
 };
 
 // ---------------------------------------------------------------- kernel launchers (cn_l_*.hip)

@@ -1,4 +1,4 @@
-"""Deferred submission (`cn_set_option("defer", 1)`) and the unchanged caller of the reference.
+"""Deferred submission (`cn_set_option("defer", 1)`; 2 = through the lock-free submission ring, round 6) and the unchanged caller of the reference.
 
 The reference's layers issue one evaluator call per ciphertext from many threads (PoolLayer.cs:113-121,182,214;
 EncryptedSealBfvMatrix.cs:140-154; Utils.cs:46-88).  libcnhip queues such calls and launches them batched; every test here holds the
@@ -89,10 +89,11 @@ def test_deferred_program_equals_immediate(name, rng):
     pts = np.stack([o.encode(rng.integers(0, 9, size=o.n, dtype=np.uint64)) for _ in range(3)])
     for seed in (1, 2, 3):
         now = _program(g, o, cts, pts, seed, defer=False)
-        later = _program(g, o, cts, pts, seed, defer=True)
-        assert len(now) == len(later)
-        for x, y in zip(now, later):
-            assert np.array_equal(x, y)
+        for mode in (1, 2):                              # queued under the lock / published to the submission ring
+            later = _program(g, o, cts, pts, seed, defer=mode)
+            assert len(now) == len(later)
+            for x, y in zip(now, later):
+                assert np.array_equal(x, y), "defer=%d" % mode
 
 
 @pytest.mark.gpu
@@ -164,6 +165,74 @@ def test_deferred_argument_errors_are_immediate():
         g.set_option("defer", 0)
 
 
+@pytest.mark.gpu
+def test_lockfree_submission_reports_errors_at_the_next_synchronising_call(rng):
+    """"defer" = 2: a deferrable call is published without the lock and checked when it is executed - a bad argument comes back from the next call that
+    synchronises with the context (once), the calls around it are executed, the context stays usable"""
+    from cryptonets_amd._native import CnError
+    o, g = get_oracle("tiny", galois=False), get_gpu("tiny", galois=False)
+    cts = _fresh(o, rng, 2)
+    g.set_option("defer", 2)
+    try:
+        a, b = g.ct_alloc(1), g.ct_alloc(1)
+        g.ct_upload(a, 0, cts[0][None, :])
+        g.ct_upload(b, 0, cts[1][None, :])
+        out, out2 = g.ct_alloc(1), g.ct_alloc(1)                       # (lock-free allocations once the ring of ready handles is filled)
+        g.add(a, 0, b, 0, out, 0)
+        g.add(a, 0, b, 7, out2, 0)                                     # index out of range: returns at once, fails when executed
+        g.sub(a, 0, b, 0, out2, 0)
+        with pytest.raises(CnError, match="defer = 2"):
+            g.sync()
+        g.sync()                                                       # reported once
+        assert np.array_equal(g.ct_download(out, 0, 1)[0], o.add(cts[0], cts[1]))
+        assert np.array_equal(g.ct_download(out2, 0, 1)[0], o.sub(cts[0], cts[1]))
+        with pytest.raises(CnError):                                   # the entry points that take the lock still check at the call
+            g.rotate_rows(a, 0, 1, out, 5)
+        for h in (a, b, out, out2):
+            g.free(h)
+        g.sync()
+        assert g.get_option("ready_handles") > 0
+        assert g.live_handles() >= 0
+    finally:
+        g.set_option("defer", 0)
+
+
+@pytest.mark.gpu
+def test_lockfree_submission_from_many_threads(rng):
+    """the C++ per-ciphertext caller from 64 threads on "defer" = 2 (every deferrable call published without the context lock, whoever finds the lock free
+    executes the records in claim order): the batched path's words, five times in a row (allocations from the ready ring, releases as records)"""
+    import replay_reference_calls as rp
+    o, g = get_oracle("tiny", galois=False), get_gpu("tiny", galois=False)
+    n_in = 40
+    cts = _fresh(o, rng, n_in)
+    layers = _small_network(n_in, rng, o.t)
+    bias = np.stack([o.encode(np.full(o.n, b, dtype=np.uint64)) for b in (3, 11)])
+    ph = g.pt_alloc(2)
+    g.pt_upload(ph, 0, bias)
+    hin = g.ct_alloc(n_in)
+    g.ct_upload(hin, 0, cts)
+    lin = o.add_plain_batch(o.scalar_gemm(cts, layers[0]["W"], idx=layers[0]["idx"]), bias[layers[0]["bias_idx"]])
+    sq = o.mul_relin_batch(lin, lin)
+    exp = o.add_plain_batch(o.scalar_gemm(sq, layers[1]["W"], idx=layers[1]["idx"]), bias[layers[1]["bias_idx"]])
+    ins = rp.split_columns(g, hin, n_in)[None, :]
+    net = rp.Replay([g], [dict(idx=L["idx"], W=[L["W"]], bias_pt=[ph], bias_idx=L["bias_idx"], square=L["square"]) for L in layers])
+    live0 = g.live_handles()
+    g.set_option("defer", 2)
+    try:
+        for rep in range(5):
+            out = net.run(ins, 64, merged=bool(rep & 1))
+            got = np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[0]])
+            for h in out[0]:
+                g.free(int(h))
+            assert np.array_equal(got, exp), rep
+        g.sync()
+        assert g.live_handles() == live0                               # nothing leaked (ready handles are not counted: they belong to nobody)
+    finally:
+        g.set_option("defer", 0)
+    for h in list(ins[0]) + [hin, ph]:
+        g.free(int(h))
+
+
 def _small_network(n_in, rng, t):
     """two PoolLayers with a SquareActivation between them on a 1-d 'image': conv (K=5, stride 2, 3 maps, one padded tap at the border)
     then dense; weights signed, one exact zero"""
@@ -201,7 +270,7 @@ def test_unchanged_caller_replay_small(threads, rng):
     # the unchanged caller
     ins = rp.split_columns(g, hin, n_in)[None, :]
     net = rp.Replay([g], [dict(idx=L["idx"], W=[L["W"]], bias_pt=[ph], bias_idx=L["bias_idx"], square=L["square"]) for L in layers])
-    for defer in (1, 0):
+    for defer in (2, 1, 0):
         g.set_option("defer", defer)
         try:
             out = net.run(ins, threads)
@@ -524,7 +593,7 @@ def _random_program(g, o, cts, pts, seed, defer, length=120):
     caller) plus one 4-ciphertext array: reads and writes collide at random (RAW, WAR, WAW, in place), handles are freed and re-allocated
     while calls are pending.  Returns the words of every live ciphertext at the end, in a canonical order."""
     r = np.random.default_rng(seed)
-    g.set_option("defer", 1 if defer else 0)
+    g.set_option("defer", int(defer))
     try:
         pool = []
         for c in cts:
@@ -603,11 +672,12 @@ def test_random_programs_deferred_equal_immediate(name, rng):
     pts = np.stack([o.encode(rng.integers(1, 5, size=o.n, dtype=np.uint64)) for _ in range(3)])
     for seed in range(16 if name == "tiny" else 4):
         now, _ = _random_program(g, o, cts, pts, seed, defer=False, length=300)
-        later, pending = _random_program(g, o, cts, pts, seed, defer=True, length=300)
-        assert pending >= 40, pending
-        assert len(now) == len(later)
-        for i, (x, y) in enumerate(zip(now, later)):
-            assert np.array_equal(x, y), (seed, i)
+        for mode in (1, 2):                              # 2: the element-wise calls, scalar products, allocations and releases go through the submission ring, the rest under the lock
+            later, pending = _random_program(g, o, cts, pts, seed, defer=mode, length=300)
+            assert pending >= 40, pending
+            assert len(now) == len(later)
+            for i, (x, y) in enumerate(zip(now, later)):
+                assert np.array_equal(x, y), (seed, i, mode)
 
 
 @pytest.mark.gpu

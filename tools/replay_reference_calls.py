@@ -138,16 +138,19 @@ def _cgroup_cpu_stat():
         return {}
 
 
-def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True, per_step=False):
+def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True, per_step=False, lockfree=None):
     """images/s of the unchanged caller on the inputs resident in chans[p].h_in; returns (ms per batch, output words [primes][O][...]).
     literal_taps: padded taps are fresh encryptions of zero (PoolLayer.cs:67-80) - the words then differ from the batched path's (fresh
-    randomness), the DECRYPTED outputs must not (decrypt_outputs)"""
+    randomness), the DECRYPTED outputs must not (decrypt_outputs).  lockfree: cn_set_option("defer", 2) - the calls are published to the context's submission
+    ring without taking its lock (round 6; default on, REPLAY_LOCKFREE=0 or lockfree=False: "defer" = 1, every call under the lock)"""
+    if lockfree is None:
+        lockfree = os.environ.get("REPLAY_LOCKFREE", "1") != "0"
     ctxs = [ch.g for ch in chans]
     rp = Replay(ctxs, replay_layers(chans, layers))
     n_in = 784
     ins = np.stack([split_columns(g, ch.h_in, n_in) for g, ch in zip(ctxs, chans)])
     for g in ctxs:
-        g.set_option("defer", int(defer))
+        g.set_option("defer", (2 if lockfree else 1) if defer else 0)
         g.sync()
     words = None
     global LAST_LAUNCHES
@@ -211,6 +214,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2, help="untimed batches in front of every measurement (the first one or two batches behind a new set of input handles carry a "
                     "one-time ~55 ms - arenas and slabs settling - profiles/HISTORY.md round 4; bench.py warms up with 2 as well)")
     ap.add_argument("--per-step", action="store_true", help="print the wall time of every timed batch of the literal measurements (a sync after each)")
+    ap.add_argument("--locked", action="store_true", help="cn_set_option(defer, 1): every deferred call under the context lock (rounds 2-5) instead of the lock-free submission ring")
     ap.add_argument("--no-merged", action="store_true", help="the twin's round-3 calls: cn_ct_alloc + cn_encrypt per zero vector, one cn_free per disposed array")
     args = ap.parse_args()
     from cryptonets_amd._native import Context
@@ -247,12 +251,12 @@ def main():
     ref = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
     rows = [dict(caller="batched (bench.py)", threads=1, ms_per_batch=round(batched_ms, 2), images_per_s=round(8192e3 / batched_ms, 1), words_identical=True)]
     for t in [int(x) for x in args.threads.split(",")]:
-        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, merged=not args.no_merged)
+        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, merged=not args.no_merged, lockfree=not args.locked)
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
         rows.append(dict(caller="unchanged (per-ciphertext calls), deferred submission", threads=t, ms_per_batch=round(ms, 2),
                          images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES, host=LAST_HOST))
     for t in [int(x) for x in args.literal_threads.split(",") if x]:
-        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, literal_taps=True, merged=not args.no_merged, per_step=args.per_step)
+        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, literal_taps=True, merged=not args.no_merged, per_step=args.per_step, lockfree=not args.locked)
         dec = decrypt_outputs(chans, words)
         same = all(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t)) for d, ch in zip(dec, chans))
         rows.append(dict(caller="unchanged, padded taps as fresh encryptions of zero (PoolLayer.ElementAt), deferred submission", threads=t, ms_per_batch=round(ms, 2),
