@@ -31,6 +31,7 @@ struct DOp {
     const uint64_t *bias;          // GEMM1: plaintext polynomial added to the result (an AddPlain folded in at flush time), or null
     uint64_t nonce = 0, item = 0;  // ENCRYPT: the call's seed and the sampler item of this ciphertext (a = plaintext polynomial or null)
     int64_t arg = 0;               // staged kinds: rotation steps (ROT, ROTADD) / slot count (SUMSLOTS); MULPLAIN: b = plaintext polynomial; ROTADD / COLSADD: b = accumulator
+    int32_t fold_first = -1; uint32_t fold_count = 0;   // GEMM1: terms [fold_first, +fold_count) of DeferQueue::folds - zero encryptions folded onto this output (cn_defer_flush)
 };
 struct DeferQueue {
     std::vector<DOp> ops;
@@ -64,6 +65,8 @@ struct DeferQueue {
     } haz;
     int32_t maxlevel = -1;
     std::vector<std::pair<uint64_t *, size_t>> frees;      // arrays released by the caller while calls were pending: back to the pool after the flush
+    struct Fold { int32_t enc; uint64_t w; };               // a zero encryption (index of its DOp) folded into a scalar product with weight w (residue mod t)
+    std::vector<Fold> folds;
 };
 // Small arrays (a per-ciphertext caller allocates every Ciphertext on its own: thousands of 640 KiB arrays per layer) are carved out of
 // slabs - one hipMalloc per SLAB_PIECES arrays, neighbours in the address space - and only ever travel between the handles and the pool;
@@ -76,6 +79,8 @@ static bool in_slab(cn_ctx *ctx, const void *p) {
     return false;
 }
 static bool deferring(cn_ctx *ctx);
+static bool zero_fold_ok(cn_ctx *ctx);
+static int flush_zero_folds(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> &gemms);
 static int defer_staged(cn_ctx *ctx, int type, Buffer *A, uint32_t ai, Buffer *B, uint32_t bi, const uint64_t *plain, uint32_t pstride_words, Buffer *O, uint32_t oi,
                         uint32_t count, int64_t arg);
 static const uint32_t DEFER_STAGED_MAX = 4;       // per-ciphertext callers: calls on up to this many ciphertexts are queued, larger ones run at once
@@ -369,6 +374,7 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
     if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED")) != 0;
+    if (getenv("CN_FOLD_ZERO")) c->fold_zero = atoi(getenv("CN_FOLD_ZERO")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
     if (getenv("CN_GEMM_PAIR")) c->gemm_pair = atoi(getenv("CN_GEMM_PAIR")) != 0;
@@ -437,6 +443,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
     if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value != 0; return 0; }
+    if (!strcmp(name, "fold_zero")) { ctx->fold_zero = value != 0; return 0; }      // queued zero encryptions that only feed a queued scalar product: folded by linearity (default 1)
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
     if (!strcmp(name, "gemm_pair")) { ctx->gemm_pair = value != 0; return 0; }        // likewise
     if (!strcmp(name, "mp_fused")) { ctx->mp_fused = value != 0; return 0; }
@@ -483,6 +490,8 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
     else if (!strcmp(name, "enc_fused")) *value = ctx->enc_fused;
+    else if (!strcmp(name, "fold_zero")) *value = ctx->fold_zero;
+    else if (!strcmp(name, "folded_zero_encryptions")) *value = (int)std::min<uint64_t>(ctx->folded_zero, 0x7fffffff);    // zero encryptions folded so far (tests)
     else if (!strcmp(name, "behz_small_base")) *value = ctx->hc.bsk[ctx->hc.kb - 1].q < (1ull << 49);     // auxiliary primes below 2^49 (FP64 kernels) instead of SEAL's 61-bit ones
     else if (!strcmp(name, "behz_f64")) *value = ctx->hc.behz_f64 && ctx->use_f64;
     else if (!strcmp(name, "aux_primes")) *value = (int)ctx->hc.kb;
@@ -2590,6 +2599,39 @@ static int flush_encrypt_group(cn_ctx *ctx, const std::vector<const DOp *> &ops)
     }
     return 0;
 }
+// the weighted sums of folded zero encryptions (cn_defer_flush), added onto the outputs of the scalar products `gemms` (launched just before): the samplers draw
+// u, e1, e2 of every folded encryption exactly as flush_encrypt_group would have (its nonce, its item), k_encrypt_fold does the rest
+static bool zero_fold_ok(cn_ctx *ctx) {
+    return ctx->pk && ctx->enc_fused && !ctx->legacy_ntt && ctx->use_f64 && ctx->hc.q_f64 && ctx->hc.logn >= 10 && ctx->hc.logn <= 13;
+}
+static int flush_zero_folds(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> &gemms) {
+    const uint32_t n = ctx->hc.n;
+    std::vector<EncTab> tab; std::vector<FoldOut> fo; std::vector<FoldTerm> ft;
+    const uint64_t t = ctx->hc.t.q, t_half = ctx->hc.t_half;
+    for (const DOp *G : gemms) {
+        fo.push_back({G->out, (uint32_t)ft.size(), G->fold_count});
+        for (uint32_t f = 0; f < G->fold_count; f++) {
+            const DeferQueue::Fold &fd = q->folds[(size_t)G->fold_first + f];
+            const DOp &E = q->ops[fd.enc];
+            tab.push_back({nullptr, nullptr, E.nonce, E.item});
+            ft.push_back({fd.w >= t_half ? -(double)(t - fd.w) : (double)fd.w, (uint32_t)tab.size() - 1, 0});
+        }
+    }
+    const uint32_t cnt = (uint32_t)tab.size();
+    CHECK(ensure_scratch(ctx, al((size_t)cnt * n) + al((size_t)cnt * 2 * n) + al(cnt * sizeof(EncTab)) + al(fo.size() * sizeof(FoldOut)) + al(ft.size() * sizeof(FoldTerm)) + 1024));
+    int8_t *us = salloc<int8_t>(ctx, (size_t)cnt * n), *es = salloc<int8_t>(ctx, (size_t)cnt * 2 * n);
+    if (!us || !es) return fail(CN_ERR_HIP, "internal: scratch exhausted in the zero-encryption fold");
+    EncTab *dtab; FoldOut *dfo; FoldTerm *dft;
+    CHECK(upload_tmp(ctx, tab.data(), tab.size(), &dtab)); CHECK(upload_tmp(ctx, fo.data(), fo.size(), &dfo)); CHECK(upload_tmp(ctx, ft.data(), ft.size(), &dft));
+    const RngKey key = rng_key_of(ctx);
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, 0ull, 0u, 0ull, (const EncTab *)dtab);
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, 0ull, 1u, 0ull, (const EncTab *)dtab);
+    uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
+    if (!rr_ops[(qmax >> 44) ? POL_F64 : POL_F64L]->enc_fold(ctx, us, es, dfo, dft, (uint32_t)fo.size())) return fail(CN_ERR_ARG, "internal: zero-encryption fold without a kernel");
+    HIPCHK(hipGetLastError()); launch_count(ctx, 3);
+    ctx->st.ntt_forward_limbs += (uint64_t)fo.size() * ctx->hc.k; ctx->st.ntt_inverse_limbs += (uint64_t)fo.size() * 2 * ctx->hc.k;
+    return 0;
+}
 static int defer_encrypt(cn_ctx *ctx, const uint64_t *ptd, uint32_t pt_stride_words, Buffer *O, uint32_t oi, uint32_t count, uint64_t seed) {
     for (uint32_t c = 0; c < count; c++) {
         DOp op{DOP_ENCRYPT, 0, O->d + (size_t)(oi + c) * O->item_words, ptd ? ptd + (size_t)c * pt_stride_words : nullptr, nullptr, 0, 0, nullptr};
@@ -2617,9 +2659,9 @@ static int cn_defer_flush(cn_ctx *ctx) {
         // then runs at the AddPlain's level and writes its output: safe when nothing else reads the intermediate and no later call
         // overwrites the GEMM's inputs
         std::vector<uint8_t> dead(ops.size(), 0);
+        std::unordered_map<const uint64_t *, int> freed;
+        for (auto &f : q->frees) freed[f.first] = 1;
         {
-            std::unordered_map<const uint64_t *, int> freed;
-            for (auto &f : q->frees) freed[f.first] = 1;
             for (size_t x = 0; x < ops.size(); x++) {
                 DOp &X = ops[x];
                 if (X.type != DOP_ADDPLAIN || X.a == X.out) continue;
@@ -2640,6 +2682,44 @@ static int cn_defer_flush(cn_ctx *ctx) {
                 if (!ok) continue;
                 Gm.out = X.out; Gm.bias = X.b; Gm.level = X.level;
                 dead[x] = 1;
+            }
+        }
+        // ---- fresh encryptions of ZERO that only feed one queued scalar product and have been released (PoolLayer.ElementAt / ReleaseTemp, PoolLayer.cs:67-90) are
+        // not materialised: their weighted sum is folded onto the scalar product's output by linearity (k_encrypt_fold: same words, a fifth of the transforms, the
+        // scalar product reads no extra ciphertexts and the outputs of a border patch share their gather list again).  Conditions, all on whole arrays: the
+        // encryption is the last writer of its array, exactly one queued call reads it - a scalar product on a deeper level - and the caller has released it.
+        if (ctx->fold_zero && zero_fold_ok(ctx)) {
+            std::unordered_map<const uint64_t *, int32_t> cand;
+            for (size_t x = 0; x < ops.size(); x++) {
+                const DOp &E = ops[x];
+                if (dead[x] || E.type != DOP_ENCRYPT || E.a) continue;
+                const DeferQueue::Haz *h = q->haz.find(E.out);
+                if (h && h->wop == (int32_t)x && h->readers == 1 && freed.count(E.out)) cand[E.out] = (int32_t)x;
+            }
+            const uint64_t t_half = ctx->hc.t_half, max_terms = (1ull << 52) / std::max<uint64_t>(1, t_half * 20);
+            if (!cand.empty()) for (size_t x = 0; x < ops.size(); x++) {
+                DOp &G = ops[x];
+                if (dead[x] || G.type != DOP_GEMM1 || G.level == 0) continue;
+                uint32_t nf = 0, left = 0;
+                for (uint32_t kk = 0; kk < G.K; kk++) {
+                    const uint64_t a = q->addr[G.terms + kk];
+                    if (!a) continue;
+                    auto it = cand.find((const uint64_t *)a);
+                    if (it != cand.end() && ops[it->second].level < G.level) nf++; else if (q->wt[G.terms + kk]) left++;
+                }
+                if (!nf || !left || nf > max_terms) continue;              // (a scalar product keeps at least one real term: its launch writes the output the fold adds onto)
+                G.fold_first = (int32_t)q->folds.size();
+                for (uint32_t kk = 0; kk < G.K; kk++) {
+                    const uint64_t a = q->addr[G.terms + kk];
+                    if (!a) continue;
+                    auto it = cand.find((const uint64_t *)a);
+                    if (it == cand.end() || ops[it->second].level >= G.level) continue;
+                    if (q->wt[G.terms + kk]) { q->folds.push_back({it->second, q->wt[G.terms + kk]}); G.fold_count++; }      // (weight 0: the term contributes nothing, AtomicSealBfvVector.cs:468)
+                    q->addr[G.terms + kk] = 0; q->wt[G.terms + kk] = 0;
+                    dead[it->second] = 2;
+                    cand.erase(it);
+                }
+                ctx->folded_zero += nf;
             }
         }
         // ---- scalar products of one term count on different levels of the same flush become ONE launch where nothing stands in the way (round 5).  The
@@ -2704,6 +2784,9 @@ static int cn_defer_flush(cn_ctx *ctx) {
                 std::map<uint32_t, std::vector<const DOp *>> byK;
                 for (const DOp *op : by_type[DOP_GEMM1]) byK[op->K].push_back(op);
                 for (auto &kv : byK) if (!rc) rc = flush_gemm_group(ctx, q, kv.second, kv.first);
+                std::vector<const DOp *> folded;
+                for (const DOp *op : by_type[DOP_GEMM1]) if (op->fold_count) folded.push_back(op);
+                if (!rc && !folded.empty()) rc = flush_zero_folds(ctx, q, folded);
             }
             for (int t : {DOP_ADD, DOP_SUB, DOP_ADDPLAIN, DOP_SUBPLAIN}) if (!rc && !by_type[t].empty()) rc = flush_elementwise_group(ctx, by_type[t], t);
             if (!rc && !by_type[DOP_ENCRYPT].empty()) rc = flush_encrypt_group(ctx, by_type[DOP_ENCRYPT]);
@@ -2711,7 +2794,7 @@ static int cn_defer_flush(cn_ctx *ctx) {
             if (!rc && !by_type[DOP_MULRELIN].empty()) rc = flush_mulrelin_group(ctx, by_type[DOP_MULRELIN]);
         }
     }
-    q->ops.clear(); q->addr.clear(); q->wt.clear(); q->haz.clear(); q->maxlevel = -1;
+    q->ops.clear(); q->addr.clear(); q->wt.clear(); q->haz.clear(); q->maxlevel = -1; q->folds.clear();
     for (auto &f : q->frees) { int r2 = dev_release(ctx, f.first, f.second); if (!rc) rc = r2; }
     q->frees.clear();
     return rc;

@@ -501,3 +501,74 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fused(const int8_t *
         }
     }
 }
+
+// Weighted sums of FRESH ENCRYPTIONS OF ZERO that nobody else ever reads, folded by linearity (round 6; FP64 policies).  The unchanged PoolLayer makes a fresh
+// Encrypt(0) per padded convolution tap (PoolLayer.cs:67-80), multiplies it by the tap's weight inside DenseMatrixBySparseVectorMultiply and disposes of it after the
+// layer: 645 encryptions per plaintext prime and batch that exist only as terms of 125 scalar products.  With E_t = (pk0 u_t + e1_t, pk1 u_t + e2_t):
+//     sum_t w_t E_t = (pk0 (sum_t w_t u_t) + sum_t w_t e1_t,  pk1 (sum_t w_t u_t) + sum_t w_t e2_t)   mod q_j, EXACTLY
+// - every operation is exact modular arithmetic and the results are canonical residues, so the output words are those of the literal evaluation (same sampler
+// draws: every folded encryption keeps its nonce and item) while one forward and two inverse transforms serve all padded taps of an output instead of three per
+// tap, and the scalar product no longer reads 645 extra ciphertexts.  Block = (folded output, limb j): U = sum_t w_t u_t from the samplers' int8 polynomials
+// (|w_t| <= t/2 as a centred double, |u| <= 1, |e| <= 19: the host checks terms * t/2 * 20 < 2^52), recentred, transformed once, both components added ONTO the
+// output the scalar product (and its folded bias) wrote in the launch before.  tests/test_deferred.py: words identical with the fold switched off.
+// (FoldOut / FoldTerm: cn_runtime.h)
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fold(const int8_t *__restrict__ us, const uint64_t *__restrict__ pk, const DevConsts *__restrict__ C,
+                                                                 const int8_t *__restrict__ noise, const FoldOut *__restrict__ fout, const FoldTerm *__restrict__ terms) {
+    typedef typename AR::T T;
+    static_assert(std::is_same<T, double>::value, "FP64 policies only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, ct = blockIdx.x / k;
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t q = C->q[j].q;
+    const FoldOut fo = fout[ct];
+    const FoldTerm *tt = terms + fo.first;
+    T U[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) U[r] = 0.0;
+#pragma unroll 1
+    for (uint32_t t = 0; t < fo.count; t++) {
+        const double w = tt[t].w;
+        const int8_t *uu = us + (size_t)tt[t].enc * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) U[r] = __fma_rn(w, (double)(int32_t)uu[pass_index<L, SA, 0>(tid, r)], U[r]);
+    }
+    AR::renorm(U, A.m);                                                       // |U| <= q/2: a transform input
+    ntt_forward_regs<AR, L>(U, s, A.fw, A.m, tid);
+    AR::renorm(U, A.m);
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        const uint64_t *pp = pk + ((size_t)p * k + j) * n;
+        T v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(pp + tail_index<L>(tl, r));
+            v[r] = ops.mul(U[r], A.load(y.x), A); v[r + 1] = ops.mul(U[r + 1], A.load(y.y), A);
+        }
+        if (p || !ntt_tail_local<L>()) __syncthreads();
+        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
+        T E[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) E[r] = 0.0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < fo.count; t++) {
+            const double w = tt[t].w;
+            const int8_t *ee = noise + ((size_t)tt[t].enc * 2 + p) * n;
+#pragma unroll
+            for (int r = 0; r < 16; r++) E[r] = __fma_rn(w, (double)(int32_t)ee[pass_index<L, SA, 0>(tl, r)], E[r]);
+        }
+        NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)fo.out + ((size_t)p * k + j) * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t e = pass_index<L, SA, 0>(tl, r);
+            uint64_t val = addmod(A.scaled(v[r]), A.canon(E[r]), q);
+            o[e] = addmod(val, o[e], q);
+        }
+    }
+}

@@ -22,6 +22,7 @@ template <int L> static int set_attrs_l(size_t bytes) {
     CHECK(big_lds(k_encrypt_tail<L, AR>, bytes));
 #endif
     if constexpr (L <= 13) CHECK(big_lds(k_encrypt_fused<L, AR>, bytes));
+    if constexpr (L <= 13 && kF64) CHECK(big_lds(k_encrypt_fold<L, AR>, bytes));
     return 0;
 }
 static int set_attrs(uint32_t logn, size_t bytes) {      // transforms whose padded LDS image exceeds the default dynamic-LDS limit (N >= 8192)
@@ -113,6 +114,16 @@ static bool enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t 
     if (c->hc.logn > 13) return false;
     BY_SIZE(l_enc_fused, c, us, pt, pts, out, cnt, noise, tab)
 }
+// weighted sums of fresh zero encryptions folded onto scalar-product outputs (k_encrypt_fold; FP64 policies, N <= 8192)
+template <int L> static void l_enc_fold(cn_ctx *c, const int8_t *us, const int8_t *noise, const void *fout, const void *terms, uint32_t outputs) {
+    if constexpr (L <= 13 && kF64)
+        hipLaunchKernelGGL((k_encrypt_fold<L, AR>), dim3(outputs * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, c->dc, noise,
+                           (const FoldOut *)fout, (const FoldTerm *)terms);
+}
+static bool enc_fold(cn_ctx *c, const int8_t *us, const int8_t *noise, const void *fout, const void *terms, uint32_t outputs) {
+    if (!kF64 || c->hc.logn > 13) return false;
+    BY_SIZE(l_enc_fold, c, us, noise, fout, terms, outputs)
+}
 #ifndef __HIP_DEVICE_COMPILE__      // host-side table (in the device pass a const global would be emitted as device data)
-extern const RrOps RR_NAME = {set_attrs, ntt, intt_tensor, square_fused, mul_plain_fused, enc_tail, enc_fused, mul_plain_bcast};
+extern const RrOps RR_NAME = {set_attrs, ntt, intt_tensor, square_fused, mul_plain_fused, enc_tail, enc_fused, mul_plain_bcast, enc_fold};
 #endif

@@ -178,6 +178,8 @@ struct cn_ctx {
     int cus = 0;              // compute units of the device
     bool sq_lds = true;       // fused squaring with the NTT-form operand parked in LDS (N <= 8192) - HBM traffic = the algorithmic 2 reads + 3 writes per
                               // block (profiles/r02_pmc_square_gemm.txt); cn_set_option("sq_lds", 0): parked in the outputs' place (two workgroups per CU)
+    uint64_t folded_zero = 0;  // zero encryptions folded so far
+    bool fold_zero = true;    // queued fresh encryptions of zero whose only reader is a queued scalar product and which have been released: folded by linearity (k_encrypt_fold, round 6); cn_set_option("fold_zero", 0): materialised
     bool enc_fused = true;    // Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
     int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
@@ -213,6 +215,9 @@ struct KsArgs {
                               // k_keyswitch_pair14: target = sigma(c1) already, add0 = the UNPERMUTED c0 (permuted through LDS by the workgroup that owns the limb)
     uint32_t next_elt = 0; uint64_t *next_out = nullptr;   // k_keyswitch_pair14: the new c1 leaves a second time as sigma_next(c1) -> next_out[ct][k][N] (rotate-and-add chains)
 };
+// k_encrypt_fold (cn_k_rr.hip.h): a scalar-product output that receives the weighted sum of `count` folded zero encryptions, and the terms of all outputs
+struct FoldOut { uint64_t *out; uint32_t first, count; };               // terms [first, first + count) of the term table
+struct FoldTerm { double w; uint32_t enc, pad; };                       // centred weight (|w| <= t/2), index of the encryption in the samplers' int8 arrays
 struct RrOps {                // register-radix kernels of one arithmetic policy; every launcher returns false when the size has no kernel
     int (*set_attrs)(uint32_t logn, size_t lds);
     bool (*ntt)(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse);
@@ -224,6 +229,7 @@ struct RrOps {                // register-radix kernels of one arithmetic policy
     bool (*enc_fused)(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab);  // all policies, N <= 8192: u (int8) -> transform -> both components in one kernel
     bool (*mul_plain_bcast)(cn_ctx *c, const uint64_t *pt, uint32_t pitch, const uint64_t *ctn, uint64_t *out, uint32_t count, uint32_t polys, uint32_t next_elt,
                             uint64_t *next_out);                                       // ONE ciphertext (NTT form) x count plaintexts (+ sigma_next(c1) of every product on the side)
+    bool (*enc_fold)(cn_ctx *c, const int8_t *us, const int8_t *noise, const void *fout, const void *terms, uint32_t outputs);   // FP64 policies, N <= 8192: k_encrypt_fold
 };
 struct KsOps {
     int (*set_attrs)(uint32_t logn, size_t lds);

@@ -432,6 +432,68 @@ def test_deferred_encryptions_equal_immediate_ones(rng):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_zero_encryptions_folded_into_scalar_products_give_the_literal_words(mode, rng):
+    """Round 6: a queued fresh Encrypt(0) whose only reader is a queued scalar product and which the caller has released (PoolLayer.ElementAt / ReleaseTemp,
+    PoolLayer.cs:67-90) is not materialised - sum_t w_t Enc_t(0) is added onto the scalar product's output by linearity (k_encrypt_fold).  Exact modular
+    arithmetic on the same sampler draws: the output WORDS are those of the literal evaluation (cn_set_option("fold_zero", 0)), at one caller thread (the
+    sampler items follow the call order); from several threads the decrypted slots are the integer model's."""
+    import replay_reference_calls as rp
+    from cryptonets_amd._native import Context
+    p = PARAMS["tiny"]
+    n_in = 13                                                             # the last corner of the 1-d convolution has two padded taps
+    layers = _small_network(n_in, np.random.default_rng(5), p["t"])
+    x = rng.integers(0, 12, size=(n_in, 8), dtype=np.uint64)
+    t = p["t"]
+    words, slots = {}, {}
+    for fold in (1, 0):
+        g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
+        g.keygen(42, galois=False)
+        g.set_option("fold_zero", fold)
+        bias = g.pt_alloc(2)
+        g.encode_batch(np.array([[3] * p["n"], [11] * p["n"]], dtype=np.uint64), bias, 0)
+        ph, hin = g.pt_alloc(n_in), g.ct_alloc(n_in)
+        g.encode_batch(x, ph, 0)
+        g.encrypt(ph, 0, hin, 0, n_in, seed=5)
+        ins = rp.split_columns(g, hin, n_in)[None, :]
+        net = rp.Replay([g], [dict(idx=L["idx"], W=[L["W"]], bias_pt=[bias], bias_idx=L["bias_idx"], square=L["square"]) for L in layers])
+        g.set_option("defer", mode)
+        try:
+            for threads in (1, 6):
+                out = net.run(ins, threads, literal_taps=True, nonce0=900 + threads, merged=True, direct_free=True)
+                w = np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[0]])
+                dh = g.pt_alloc(len(out[0]))
+                for i, h in enumerate(out[0]):
+                    g.decrypt(int(h), 0, 1, dh, i)
+                    g.free(int(h))
+                slots[fold, threads] = g.decode_batch(dh, 0, len(out[0]))[:, :8]
+                g.free(dh)
+                words[fold, threads] = w
+        finally:
+            g.set_option("defer", 0)
+        nf = g.get_option("folded_zero_encryptions")
+        assert (nf == 2 * 3 * 2) if fold else (nf == 0), nf                # two padded taps x three maps, two runs
+        g.close()
+    assert np.array_equal(words[1, 1], words[0, 1])                        # one caller thread: the same draws -> the same words, folded or not
+    # the integer model of the two layers (weights are residues mod t)
+    X = [[int(v) for v in row] for row in x]
+    def dense(L, cols, b):
+        out = []
+        for o in range(L["idx"].shape[0]):
+            acc = [int(b[int(L["bias_idx"][o])])] * 8
+            for kk, c in enumerate(L["idx"][o]):
+                if c >= 0:
+                    acc = [(a + int(L["W"][o, kk]) * v) % t for a, v in zip(acc, cols[int(c)])]
+            out.append(acc)
+        return out
+    l0 = dense(layers[0], X, (3, 11))
+    l1 = dense(layers[1], [[v * v % t for v in col] for col in l0], (3, 11))
+    want = np.array(l1, dtype=np.uint64)
+    for key, got in slots.items():
+        assert np.array_equal(got, want), key
+
+
+@pytest.mark.gpu
 def test_literal_padded_taps_in_the_unchanged_caller(rng):
     """The LITERAL PoolLayer.ElementAt: every padded convolution tap is a fresh encryption of zero (device, queued), K = 25 real handles per
     output.  Convolution layer of CryptoNets alone (N = 8192, one plaintext prime): outputs without a padded tap carry the batched path's

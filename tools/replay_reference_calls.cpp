@@ -128,8 +128,9 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
                        int literal_taps, uint64_t nonce0, char *errmsg, size_t errlen) {
     Err err;
     const bool merged = (literal_taps & 2) != 0;                                     // the twin's one-call zero vectors and batched disposal (see FreeBins)
-    literal_taps &= 1;
-    auto release = [&](cn_ctx *c, cn_handle h) { return merged ? defer_free(c, h) : cn_free(c, h); };
+    const bool direct_free = (literal_taps & 4) != 0;                                // ... on a lock-free context ("defer" = 2) Dispose() is one published record: nothing is parked, the
+    literal_taps &= 1;                                                               // library sees every release where the caller made it (and can tell which zero vectors are dead)
+    auto release = [&](cn_ctx *c, cn_handle h) { return merged && !direct_free ? defer_free(c, h) : cn_free(c, h); };
     std::atomic<uint64_t> nonce{nonce0};
     std::vector<std::vector<cn_handle>> cur(nprimes);
     for (int p = 0; p < nprimes; p++) cur[p].assign(in + (size_t)p * n_in, in + (size_t)(p + 1) * n_in);

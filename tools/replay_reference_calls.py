@@ -90,16 +90,17 @@ class Replay:
         self.n_out = int(self.arr[len(layers) - 1].O)
         self.hctx = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
 
-    def run(self, in_handles, threads, literal_taps=False, nonce0=1, merged=False):
+    def run(self, in_handles, threads, literal_taps=False, nonce0=1, merged=False, direct_free=False):
         """in_handles: uint64 [primes, n_in] (one count-1 handle per input column) -> uint64 [primes, O_last] handles (caller frees).
         literal_taps: a padded convolution tap is a fresh device encryption of zero, as PoolLayer.ElementAt makes it (the contexts need
         their public key); nonce0: first nonce of those encryptions (consecutive values are used); merged: the twin makes a zero vector with one
-        library call (cn_encrypt_zero_new) and releases disposed arrays 32 at a time (cn_free_many) - same words"""
+        library call (cn_encrypt_zero_new) and releases disposed arrays 32 at a time (cn_free_many) - same words; direct_free: ... releases every disposed array
+        at once (cn_free: on a lock-free context a published record, no lock to save)"""
         ih = np.ascontiguousarray(in_handles, dtype=np.uint64)
         out = np.zeros((len(self.ctxs), self.n_out), dtype=np.uint64)
         msg = C.create_string_buffer(512)
         rc = lib().rp_run2(self.hctx, len(self.ctxs), self.arr, len(self.arr), ih.ctypes.data_as(C.POINTER(C.c_uint64)), ih.shape[1],
-                           out.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads), int(bool(literal_taps)) | (2 if merged else 0), int(nonce0), msg, 512)
+                           out.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads), int(bool(literal_taps)) | (2 if merged else 0) | (4 if direct_free else 0), int(nonce0), msg, 512)
         if rc:
             raise RuntimeError("replay failed (%d): %s" % (rc, msg.value.decode()))
         return out
@@ -163,7 +164,7 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                 cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
                 t0 = time.perf_counter()
             ts = time.perf_counter()
-            out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged)
+            out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged, direct_free=bool(defer and lockfree))
             if per_step:
                 for g in ctxs:
                     g.sync()
