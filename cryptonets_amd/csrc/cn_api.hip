@@ -373,6 +373,7 @@ static int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<u
     if (getenv("CN_SQ_FUSED")) c->sq_fused = atoi(getenv("CN_SQ_FUSED")) != 0;
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
+    if (getenv("CN_SQ_OVERLAP")) c->sq_overlap = atoi(getenv("CN_SQ_OVERLAP")) != 0;
     if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED")) != 0;
     if (getenv("CN_FOLD_ZERO")) c->fold_zero = atoi(getenv("CN_FOLD_ZERO")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -424,6 +425,9 @@ static void ctx_teardown(cn_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     cn_defer_delete(ctx->dq);
     delete ctx->ring; delete ctx->ready;
@@ -442,6 +446,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_fused")) { ctx->sq_fused = value != 0; return 0; }
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
+    if (!strcmp(name, "sq_overlap")) { ctx->sq_overlap = value != 0; return 0; }
     if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value != 0; return 0; }
     if (!strcmp(name, "fold_zero")) { ctx->fold_zero = value != 0; return 0; }      // queued zero encryptions that only feed a queued scalar product: folded by linearity (default 1)
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
@@ -489,6 +494,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "gemm_pair")) *value = ctx->gemm_pair;
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
+    else if (!strcmp(name, "sq_overlap")) *value = ctx->sq_overlap;
     else if (!strcmp(name, "enc_fused")) *value = ctx->enc_fused;
     else if (!strcmp(name, "fold_zero")) *value = ctx->fold_zero;
     else if (!strcmp(name, "folded_zero_encryptions")) *value = (int)std::min<uint64_t>(ctx->folded_zero, 0x7fffffff);    // zero encryptions folded so far (tests)
@@ -1391,6 +1397,26 @@ static void run_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, const
     launch_count(c);
     c->st.ntt_forward_limbs += (uint64_t)cnt * 2 * Lm; c->st.ntt_inverse_limbs += (uint64_t)cnt * 3 * Lm;
 }
+// the context's second stream (squaring overlap): created on first use, kept only if it runs beside the context's own stream (a hardware queue of its own)
+static bool aux_stream_ready(cn_ctx *ctx) {
+    if (ctx->stream2) return true;
+    if (ctx->stream2_failed) return false;
+    hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+    int got = -1;
+    for (int i = 0; i < 4 && got < 0; i++) {
+        if (hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); cand[i] = nullptr; break; }
+        if (!streams_share_a_queue(cand[i], ctx->stream)) got = i;
+    }
+    for (int i = 0; i < 4; i++) if (cand[i] && i != got) (void)hipStreamDestroy(cand[i]);
+    if (got < 0 || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (got >= 0) (void)hipStreamDestroy(cand[got]);
+        ctx->stream2_failed = true;
+        return false;
+    }
+    ctx->stream2 = cand[got];
+    return true;
+}
 static size_t mul_scratch_per_ct(cn_ctx *c, bool square) {
     size_t n = c->hc.n, k = c->hc.k, kb = c->hc.kb;
     size_t w = (square ? 1 : 2) * 2 * (k + kb) * n + 3 * (k + kb) * n;
@@ -1411,10 +1437,24 @@ static int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const u
     if (!square) { bq = salloc<uint64_t>(ctx, (size_t)cnt * 2 * k * n); bb = salloc<uint64_t>(ctx, (size_t)cnt * 2 * kb * n); }
     uint64_t *dq = salloc<uint64_t>(ctx, (size_t)cnt * 3 * k * n), *db = salloc<uint64_t>(ctx, (size_t)cnt * 3 * kb * n);
     if ((!fused && !aq) || !ab || (!square && (!bq || !bb)) || !dq || !db) return fail(CN_ERR_HIP, "internal: scratch exhausted in multiply");
+    // Squaring of a batch, "sq_overlap": the q-side transform kernel needs only the input, the Bsk side needs k_behz_extend's output - so the q side runs on a second
+    // stream of the context beside [extend -> Bsk side] and joins in front of k_behz_floor (round 6).  The two resident transform kernels cannot share a CU
+    // (130 KiB of LDS each), but the HBM-bound base extension (no LDS, few registers) runs beside the q side's workgroups instead of in front of them.
+    const bool overlap = fused && ctx->sq_overlap && !ctx->capturing && cnt >= 64 && aux_stream_ready(ctx);
+    if (overlap) {
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        std::swap(ctx->stream, ctx->stream2);
+        run_square_fused(ctx, a, (size_t)astride * 2 * k * n, atab, dq, cnt, 0, k, lq);
+        std::swap(ctx->stream, ctx->stream2);
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
     CHECK(cn_l_behz_extend(ctx, a, astride, atab, aq, ab, cnt));
     if (!square) CHECK(cn_l_behz_extend(ctx, b, bstride, btab, bq, bb, cnt));
     if (fused) {
-        run_square_fused(ctx, a, (size_t)astride * 2 * k * n, atab, dq, cnt, 0, k, lq); run_square_fused(ctx, ab, (size_t)2 * kb * n, nullptr, db, cnt, k, kb, lb);
+        if (!overlap) run_square_fused(ctx, a, (size_t)astride * 2 * k * n, atab, dq, cnt, 0, k, lq);
+        run_square_fused(ctx, ab, (size_t)2 * kb * n, nullptr, db, cnt, k, kb, lb);
+        if (overlap) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     } else {
     CHECK(cn_run_ntt(ctx, aq, cnt * 2 * k, 0, k, 0)); CHECK(cn_run_ntt(ctx, ab, cnt * 2 * kb, k, kb, 0));
     if (!square) { CHECK(cn_run_ntt(ctx, bq, cnt * 2 * k, 0, k, 0)); CHECK(cn_run_ntt(ctx, bb, cnt * 2 * kb, k, kb, 0)); }

@@ -530,13 +530,34 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fold(const int8_t *_
     T U[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) U[r] = 0.0;
+    // (three terms' byte loads in flight at a time: a term is 16 dependent-free one-byte loads and one round trip; a border output of the 5x5 stride-2 convolution has 5 or 9)
+    auto accumulate = [&](T (&X)[16], const int8_t *base, size_t pitch, size_t off, uint32_t tl) {
+        uint32_t t = 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < fo.count; t++) {
-        const double w = tt[t].w;
-        const int8_t *uu = us + (size_t)tt[t].enc * n;
+        for (; t + 3 <= fo.count; t += 3) {
+            int8_t b[3][16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) U[r] = __fma_rn(w, (double)(int32_t)uu[pass_index<L, SA, 0>(tid, r)], U[r]);
-    }
+            for (int c = 0; c < 3; c++) {
+                const int8_t *pp = base + (size_t)tt[t + c].enc * pitch + off;
+#pragma unroll
+                for (int r = 0; r < 16; r++) b[c][r] = pp[pass_index<L, SA, 0>(tl, r)];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double w = tt[t + c].w;
+#pragma unroll
+                for (int r = 0; r < 16; r++) X[r] = __fma_rn(w, (double)(int32_t)b[c][r], X[r]);
+            }
+        }
+#pragma unroll 1
+        for (; t < fo.count; t++) {
+            const double w = tt[t].w;
+            const int8_t *pp = base + (size_t)tt[t].enc * pitch + off;
+#pragma unroll
+            for (int r = 0; r < 16; r++) X[r] = __fma_rn(w, (double)(int32_t)pp[pass_index<L, SA, 0>(tl, r)], X[r]);
+        }
+    };
+    accumulate(U, us, n, 0, tid);
     AR::renorm(U, A.m);                                                       // |U| <= q/2: a transform input
     ntt_forward_regs<AR, L>(U, s, A.fw, A.m, tid);
     AR::renorm(U, A.m);
@@ -556,13 +577,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fold(const int8_t *_
         T E[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) E[r] = 0.0;
-#pragma unroll 1
-        for (uint32_t t = 0; t < fo.count; t++) {
-            const double w = tt[t].w;
-            const int8_t *ee = noise + ((size_t)tt[t].enc * 2 + p) * n;
-#pragma unroll
-            for (int r = 0; r < 16; r++) E[r] = __fma_rn(w, (double)(int32_t)ee[pass_index<L, SA, 0>(tl, r)], E[r]);
-        }
+        accumulate(E, noise, (size_t)2 * n, (size_t)p * n, tl);
         NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)fo.out + ((size_t)p * k + j) * n;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
