@@ -489,14 +489,22 @@ def stub_workload(args, rank, world, result_fd):
     if d is not None:
         d.barrier()
     dt = max_over_ranks(time.perf_counter() - t0, "cpu", d)
+    cover = sorted(mine) == list(range(args.steps)) if world == 1 else None
     if d is not None:
         flag = torch.tensor([1 if ok and len(mine) == args.steps else 0], dtype=torch.int32)
         d.all_reduce(flag, op=d.ReduceOp.MIN)
         ok = bool(flag.item())
+        shards = [None] * world                                                        # shard cover: every batch of the job on exactly one rank
+        d.all_gather_object(shards, [int(b) for b in mine])
+        cover = sorted(b for sh in shards for b in sh) == list(range(args.steps * world))
+    # what the real run does beside the timed region, and on which ranks: the CPU baseline, the single-image children and the unchanged caller are rank-0,
+    # world-1 work (main(): `rank == 0 and world == 1`) - at N > 1 no rank runs them, so the driver's SCALE lines time the sharded batches only
+    side = {"cpu_baseline": rank == 0 and world == 1, "single_image_children": rank == 0 and world == 1, "unchanged_caller": rank == 0 and world == 1}
     if rank == 0:
         out = {"metric": "encrypted images/sec (CryptoNets-MNIST, N=8192)", "stub": True, "value": round(8192 * args.steps * world / dt, 1), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (launcher stub)", "plumbing_ok": ok,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (launcher stub)", "plumbing_ok": ok, "shard_cover_ok": bool(cover),
+               "rank0_side_work": side,
                "config": {"workload": "STUB: no device work - launcher, gloo rendezvous, key broadcast, barrier and MAX-over-ranks timing only"}}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if d is not None:

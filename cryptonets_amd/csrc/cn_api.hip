@@ -1659,7 +1659,7 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
     }
     if (pre || next_elt) return fail(CN_ERR_ARG, "internal: rotation chain outside the one-launch key switch");
     // small batches (two-launch key switch): no permutation pass - the key-switch kernels apply the automorphism while they load c1 and c0
-    if (ctx->ks_perm_fused && ks_planned_mode(ctx, count, 1) != 0) {
+    if (!shifted && ctx->ks_perm_fused && ks_planned_mode(ctx, count, 1) != 0) {
         CHECK(do_keyswitch(ctx, in + kn, 2 * kn, in, nullptr, 2 * kn, it->second, out, count, 1, acc, ctx->ctw2, nullptr, (uint32_t)elt));
         ctx->st.Rotation += count;
         if (acc) ctx->st.Addition += count;
@@ -1673,11 +1673,13 @@ static int do_galois(cn_ctx *ctx, const uint64_t *in, uint64_t elt, uint64_t *ou
     if (acc) ctx->st.Addition += count;
     return 0;
 }
-// (a batched rotation reads operand c while another workgroup / a staging copy already writes result c': the same range or disjoint ranges only - like cn_mul_plain)
+// A rotation whose result range overlaps its operand range with a SHIFT (the same handle, different first indices): the kernels that apply the automorphism while they
+// load (one-launch N = 16384 kernel, two-launch small-batch kernels) would read ciphertext c after another workgroup has written c' over it - such calls take the
+// permutation pass (do_galois: `shifted`), which has read the whole operand before anything is written (they used to be refused on every path).  Only the
+// rotate-and-ADD forms still refuse a partially overlapping ACCUMULATOR: no path reads it ahead of the stores.
 static bool shifted_overlap(const Buffer *I, uint32_t ii, const Buffer *O, uint32_t oi, uint32_t count) { return I == O && ii != oi && ii < oi + count && oi < ii + count; }
 static int galois_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, uint64_t elt, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
-    if (shifted_overlap(I, ii, O, oi, count)) return fail(CN_ERR_ARG, "rotation: operand and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
@@ -1712,13 +1714,17 @@ static int rotate_rec(cn_ctx *ctx, uint64_t *cur, int steps, uint64_t *tmp, uint
 }
 static int rotate_rows_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
-    if (shifted_overlap(I, ii, O, oi, count)) return fail(CN_ERR_ARG, "rotation: operand and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
-    CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
+    const bool shifted = shifted_overlap(I, ii, O, oi, count);
+    CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8) * (shifted ? 2 : 1)));
     uint64_t *tmp = salloc<uint64_t>(ctx, count * ctx->ctw2);
     uint64_t *o = O->d + oi * O->item_words; const uint64_t *i = I->d + ii * I->item_words;
     if (steps != 0 && has_direct_key(ctx, steps)) return do_galois(ctx, i, cn_galois_elt_from_step(ctx, steps), o, tmp, count);   // one hop: no staging copy
-    if (o != i) HIPCHK(hipMemcpyAsync(o, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (shifted) {                                    // overlapping ranges: through a staging array (a device-to-device copy between overlapping ranges is undefined)
+        uint64_t *stage = salloc<uint64_t>(ctx, count * ctx->ctw2);
+        HIPCHK(hipMemcpyAsync(stage, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(o, stage, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (o != i) HIPCHK(hipMemcpyAsync(o, i, count * ctx->ctw2 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return rotate_rec(ctx, o, steps, tmp, count);
 }
 // can RotateRows(steps) run with the keys this context holds (direct key, or every hop of the NAF decomposition)?  Queued rotations are
@@ -1854,7 +1860,7 @@ API_END }
 // fused into the last kernel of the key switch.  Same words as cn_rotate_rows followed by cn_add.
 static int rotate_rows_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
-    if (shifted_overlap(I, ii, O, oi, count) || shifted_overlap(A, ai, O, oi, count))
+    if (shifted_overlap(I, ii, O, oi, count) || shifted_overlap(A, ai, O, oi, count))          // (the fused accumulator is read where the result is stored: no path reads it ahead)
         return fail(CN_ERR_ARG, "rotate-and-add: operand / accumulator and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     const uint64_t *i = I->d + ii * I->item_words, *a = A->d + ai * A->item_words; uint64_t *o = O->d + oi * O->item_words;
@@ -1881,7 +1887,7 @@ static int rotate_rows_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, int steps, 
 }
 static int rotate_columns_add_impl(cn_ctx *ctx, Buffer *I, uint32_t ii, Buffer *A, uint32_t ai, Buffer *O, uint32_t oi, uint32_t count) {
     if (!range_ok(I, ii, count) || !range_ok(A, ai, count) || !range_ok(O, oi, count)) return fail(CN_ERR_ARG, "index out of range");
-    if (shifted_overlap(I, ii, O, oi, count) || shifted_overlap(A, ai, O, oi, count))
+    if (shifted_overlap(I, ii, O, oi, count) || shifted_overlap(A, ai, O, oi, count))          // (the fused accumulator is read where the result is stored: no path reads it ahead)
         return fail(CN_ERR_ARG, "rotate-and-add: operand / accumulator and result ranges overlap partially (use the same range or disjoint ranges)");
     if (!count) return 0;
     CHECK(ensure_scratch(ctx, al(count * ctx->ctw2 * 8)));
@@ -3120,6 +3126,15 @@ done:
                 (void)hipSetDevice(ctxs[i]->device);
                 ctxs[i]->hc.ks_xi = root->hc.ks_xi;
                 if (hipMemcpy(ctxs[i]->dc, &ctxs[i]->hc, sizeof(DevConsts), hipMemcpyHostToDevice) != hipSuccess) rc = fail(CN_ERR_HIP, "constant upload failed on context %d", i);
+                // the keys this replica already holds were made for the OTHER convention: those the broadcast does not overwrite are dropped (a rotation by one of
+                // their elements then fails with CN_ERR_NOKEY instead of returning rc 0 and garbage - ADVICE r05)
+                if (!rc) {
+                    auto carried = [&](bool galois, uint64_t elt) { for (const Item &it : items) if (it.galois == galois && (!galois || it.elt == elt)) return true; return false; };
+                    if (ctxs[i]->rlk.d && !carried(false, 0)) { if (ctxs[i]->rlk.owned) (void)hipFree(ctxs[i]->rlk.d); ctxs[i]->rlk = KsKey{nullptr, false, false}; }
+                    for (auto it = ctxs[i]->gk.begin(); it != ctxs[i]->gk.end();) {
+                        if (!carried(true, it->first)) { if (it->second.owned && it->second.d) (void)hipFree(it->second.d); it = ctxs[i]->gk.erase(it); } else ++it;
+                    }
+                }
             }
         }
         for (size_t x = 0; x < items.size(); x++) {

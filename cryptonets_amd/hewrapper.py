@@ -269,6 +269,9 @@ class AtomicSealBfvEncryptedEnvironment:
                                     "does not implement this evaluator's arithmetic; no key convention can repair that" % (op, t))
                 warnings.append("%s: ciphertext words differ from the client's evaluator, decrypted slots are equal (another valid representative; "
                                 "not an interoperability property)" % op)
+                # never silent: the operator sees at start-up that this device and the client's evaluator disagree on words
+                import sys as _sys
+                print("libcnhip self-test warning (plaintext modulus %d): %s" % (t, warnings[-1]), file=_sys.stderr)
             ks_ops = [op for op in ("Relinearize", "RotateRows(1)", "RotateRows(-1)", "RotateColumns") if op in want]
 
             # Key-switching operations: WORDS again - unless the product itself already differs in words (then Relinearize inherits the difference and only

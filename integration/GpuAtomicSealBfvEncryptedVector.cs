@@ -331,6 +331,7 @@ namespace HEWrapper
                         if (decryptor == null || !slots(got, size).SequenceEqual(slots(exp, size)))
                             throw new Exception(String.Format("libcnhip self-test: {0} differs from SEAL's Evaluator (plaintext modulus {1}), words AND decrypted slots - the device does not implement this SEAL's arithmetic; no key convention can repair that", op, t));
                         warnings.Add(op + ": words differ, decrypted slots equal");
+                        Console.Error.WriteLine("libcnhip self-test warning: " + warnings[warnings.Count - 1]);      // never silent (ADVICE r05)
                     }
                     bool rotations = galoisKeys != null && galoisKeys.Data.Any(k => k.Any());
                     var ksOps = rotations ? new[] { "Relinearize", "RotateRows(1)", "RotateRows(-1)", "RotateColumns" } : new[] { "Relinearize" };

@@ -48,3 +48,15 @@ def test_default_is_one_rank():
     r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "0", "--stub"], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert _one_line(r.stdout)["n_gpus"] == 1
+
+
+def test_gpus_8_stub_covers_every_shard_once():
+    """the driver's 8-GPU launch, on gloo: eight ranks rendezvous on 127.0.0.1, every batch of the job runs on exactly one rank, the line carries the MAX over
+    ranks (rank 7 sleeps 80 ms per step) and n_gpus = 8; the side work of the N = 1 line (CPU baseline, single-image children, unchanged caller) runs on no rank"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "0", "--stub"], env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = _one_line(r.stdout)
+    assert line["n_gpus"] == 8 and line["plumbing_ok"] is True and line["shard_cover_ok"] is True
+    assert line["ms_per_step"] >= 79.0, line
+    assert not any(line["rank0_side_work"].values())

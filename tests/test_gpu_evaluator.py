@@ -756,8 +756,16 @@ def test_sum_slots_chain_at_n16384(name, rng):
         g.set_option("ks_pair14", 1); g.set_option("ks_chain", 1); g.set_option("ks_xcd", 0)
         g.ct_upload(h, 0, cts)
         from cryptonets_amd._native import CnError
-        with pytest.raises(CnError):
-            g.rotate_rows(h, 0, -2, h, 1, 3)                                  # result range = operand range shifted by one ciphertext: refused (like cn_mul_plain)
+        g.rotate_rows(h, 0, -2, h, 1, 3)                                      # result range = operand range shifted by one ciphertext: the permutation pass reads the
+        assert np.array_equal(g.ct_download(h, 1, 3), np.stack([o.rotate_rows(c, -2) for c in cts[:3]]))      # whole operand before anything is written
+        assert np.array_equal(g.ct_download(h, 0, 1)[0], cts[0]) and np.array_equal(g.ct_download(h, 4, 5), cts[4:])
+        g.ct_upload(h, 0, cts)
+        g.rotate_rows(h, 1, 5, h, 0, 3)                                       # ... a multi-hop step count (NAF 4 + 1), shifted the other way: through a staging array
+        assert np.array_equal(g.ct_download(h, 0, 3), np.stack([o.rotate_rows(c, 5) for c in cts[1:4]]))
+        g.ct_upload(h, 0, cts)
+        g.rotate_columns(h, 2, h, 3, 2)
+        assert np.array_equal(g.ct_download(h, 3, 2), np.stack([o.rotate_columns(c) for c in cts[2:4]]))
+        g.ct_upload(h, 0, cts)
         with pytest.raises(CnError):
             g.rotate_rows_add(h, 4, 1, h, 5, h, 6, 2)                         # accumulator range overlaps the result range with a shift
         assert np.array_equal(g.ct_download(h, 0, 9), cts)
