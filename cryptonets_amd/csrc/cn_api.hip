@@ -2736,12 +2736,18 @@ static int cn_defer_flush(cn_ctx *ctx) {
         // encryption is the last writer of its array, exactly one queued call reads it - a scalar product on a deeper level - and the caller has released it.
         if (ctx->fold_zero && zero_fold_ok(ctx)) {
             std::unordered_map<const uint64_t *, int32_t> cand;
+            size_t zero_encs = 0;
             for (size_t x = 0; x < ops.size(); x++) {
                 const DOp &E = ops[x];
                 if (dead[x] || E.type != DOP_ENCRYPT || E.a) continue;
+                zero_encs++;
                 const DeferQueue::Haz *h = q->haz.find(E.out);
                 if (h && h->wop == (int32_t)x && h->readers == 1 && freed.count(E.out)) cand[E.out] = (int32_t)x;
             }
+            // all or nothing: a caller that parks its releases (cn_free_many of 32 at a time, the locked twin of rounds 3-5) leaves some of a layer's zero vectors alive at
+            // the flush - folding the rest would run BOTH chains (samplers + k_encrypt_fused for the live ones, samplers + k_encrypt_fold for the others) and cut the scalar
+            // products of a layer into more gather groups: 17.4 against 15.8 ms per batch (profiles/r06_bench_default_flags.json, `locked`)
+            if (cand.size() != zero_encs) cand.clear();
             const uint64_t t_half = ctx->hc.t_half, max_terms = (1ull << 52) / std::max<uint64_t>(1, t_half * 20);
             if (!cand.empty()) for (size_t x = 0; x < ops.size(); x++) {
                 DOp &G = ops[x];

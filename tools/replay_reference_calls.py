@@ -139,13 +139,15 @@ def _cgroup_cpu_stat():
         return {}
 
 
-def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True, per_step=False, lockfree=None):
+def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=False, merged=True, per_step=False, lockfree=None, direct_free=None):
     """images/s of the unchanged caller on the inputs resident in chans[p].h_in; returns (ms per batch, output words [primes][O][...]).
     literal_taps: padded taps are fresh encryptions of zero (PoolLayer.cs:67-80) - the words then differ from the batched path's (fresh
     randomness), the DECRYPTED outputs must not (decrypt_outputs).  lockfree: cn_set_option("defer", 2) - the calls are published to the context's submission
     ring without taking its lock (round 6; default on, REPLAY_LOCKFREE=0 or lockfree=False: "defer" = 1, every call under the lock)"""
     if lockfree is None:
         lockfree = os.environ.get("REPLAY_LOCKFREE", "1") != "0"
+    if direct_free is None:               # Dispose() = one cn_free at once (the round-6 twin) instead of the per-thread lists released 32 at a time (rounds 3-5: halves the lock acquisitions)
+        direct_free = bool(defer and lockfree)
     ctxs = [ch.g for ch in chans]
     rp = Replay(ctxs, replay_layers(chans, layers))
     n_in = 784
@@ -164,7 +166,7 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                 cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
                 t0 = time.perf_counter()
             ts = time.perf_counter()
-            out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged, direct_free=bool(defer and lockfree))
+            out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged, direct_free=bool(direct_free))
             if per_step:
                 for g in ctxs:
                     g.sync()
@@ -216,6 +218,7 @@ def main():
                     "one-time ~55 ms - arenas and slabs settling - profiles/HISTORY.md round 4; bench.py warms up with 2 as well)")
     ap.add_argument("--per-step", action="store_true", help="print the wall time of every timed batch of the literal measurements (a sync after each)")
     ap.add_argument("--locked", action="store_true", help="cn_set_option(defer, 1): every deferred call under the context lock (rounds 2-5) instead of the lock-free submission ring")
+    ap.add_argument("--direct-free", action="store_true", help="with --locked: release every disposed array at once (the lock-free twin's calls) instead of 32 at a time")
     ap.add_argument("--no-merged", action="store_true", help="the twin's round-3 calls: cn_ct_alloc + cn_encrypt per zero vector, one cn_free per disposed array")
     args = ap.parse_args()
     from cryptonets_amd._native import Context
@@ -252,12 +255,12 @@ def main():
     ref = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
     rows = [dict(caller="batched (bench.py)", threads=1, ms_per_batch=round(batched_ms, 2), images_per_s=round(8192e3 / batched_ms, 1), words_identical=True)]
     for t in [int(x) for x in args.threads.split(",")]:
-        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, merged=not args.no_merged, lockfree=not args.locked)
+        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, merged=not args.no_merged, lockfree=not args.locked, direct_free=True if args.direct_free else None)
         same = all(np.array_equal(a, b) for a, b in zip(words, ref))
         rows.append(dict(caller="unchanged (per-ciphertext calls), deferred submission", threads=t, ms_per_batch=round(ms, 2),
                          images_per_s=round(8192e3 / ms, 1), frac_of_batched=round(batched_ms / ms, 3), words_identical=same, launches_per_batch=LAST_LAUNCHES, host=LAST_HOST))
     for t in [int(x) for x in args.literal_threads.split(",") if x]:
-        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, literal_taps=True, merged=not args.no_merged, per_step=args.per_step, lockfree=not args.locked)
+        ms, words = measure(chans, layers, t, args.steps, warmup=args.warmup, literal_taps=True, merged=not args.no_merged, per_step=args.per_step, lockfree=not args.locked, direct_free=True if args.direct_free else None)
         dec = decrypt_outputs(chans, words)
         same = all(np.array_equal(d, cm.model_mod_p_dense(x_int, layers, ch.g.t)) for d, ch in zip(dec, chans))
         rows.append(dict(caller="unchanged, padded taps as fresh encryptions of zero (PoolLayer.ElementAt), deferred submission", threads=t, ms_per_batch=round(ms, 2),
