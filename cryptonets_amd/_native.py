@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libcnhip.so")
 CSRC = os.path.join(_PKG, "csrc")
 # one translation unit per kernel family: hipcc compiles them in parallel (the register-radix kernels alone are ~180 instantiations)
 SOURCES = [os.path.join(CSRC, f) for f in (
-    "cn_api.hip", "cn_host.cpp", "cn_tables.cpp", "cn_l_gemm.hip", "cn_l_behz.hip",
+    "cn_api.hip", "cn_eval.hip", "cn_client.hip", "cn_defer.hip", "cn_multi.hip", "cn_host.cpp", "cn_tables.cpp", "cn_l_gemm.hip", "cn_l_behz.hip",
     "cn_l_rr_u64.hip", "cn_l_rr_f64.hip", "cn_l_rr_f64l.hip", "cn_l_ks_u64.hip", "cn_l_ks_f64.hip", "cn_l_ks_f64l.hip")]
 OBJ_DIR = os.path.join(_PKG, "lib", "obj")
 

@@ -1,5 +1,5 @@
 // Element-wise kernels, the radix-2 LDS transform (sizes without a register-radix kernel), Galois permutations, the legacy key switch
-// and the client-side (keygen / decrypt) element-wise kernels.  Included by cn_api.hip only.
+// and the client-side (keygen / decrypt) element-wise kernels.  Included (through cn_api_shared.h) by the runtime units; the kernels have internal linkage - every unit carries the ones it launches.
 #pragma once
 #include "cn_dev_common.hip.h"
 
@@ -46,7 +46,7 @@ DEV void ntt_inv_lds(uint64_t *s, const uint64_t *__restrict__ iw, const uint64_
     }
 }
 // batched in-place NTT: block b transforms limb b; modulus = base_off + (b % nmod)
-__global__ void __launch_bounds__(1024) k_ntt(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
+static __global__ void __launch_bounds__(1024) k_ntt(uint64_t *data, const DevConsts *__restrict__ C, uint32_t base_off, uint32_t nmod, int inverse) {
     extern __shared__ uint64_t s[];
     const uint32_t n = C->n, mod = base_off + blockIdx.x % nmod;
     const uint64_t q = mod < C->k ? C->q[mod].q : (mod < C->k + C->kb ? C->bsk[mod - C->k].q : C->t.q);
@@ -67,14 +67,14 @@ __global__ void __launch_bounds__(1024) k_ntt(uint64_t *data, const DevConsts *_
 // ------------------------------------------------------------------ element-wise kernels
 // grid.x = limbs * chunks ; limb index is block-uniform so moduli come from scalar loads.
 // op: 0 add, 1 sub, 2 negate(a).  a,b,out point at ciphertext arrays with `polys` polys each.
-__global__ void k_addsub(const uint64_t *a, const uint64_t *b, uint64_t *out, const DevConsts *__restrict__ C, uint32_t chunks, int op) {
+static __global__ void k_addsub(const uint64_t *a, const uint64_t *b, uint64_t *out, const DevConsts *__restrict__ C, uint32_t chunks, int op) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint64_t q = C->q[limb % C->k].q; size_t o = (size_t)limb * C->n + i;
     uint64_t x = a[o];
     out[o] = op == 0 ? addmod(x, b[o], q) : (op == 1 ? submod(x, b[o], q) : negmod(x, q));
 }
 // out = sum_i in[idx[i]] ; limbs = polys*k of ONE ciphertext
-__global__ void k_add_many(const uint64_t *in, const uint32_t *__restrict__ idx, uint32_t n_idx, size_t ct_words, uint64_t *out,
+static __global__ void k_add_many(const uint64_t *in, const uint32_t *__restrict__ idx, uint32_t n_idx, size_t ct_words, uint64_t *out,
                            const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint64_t q = C->q[limb % C->k].q; size_t o = (size_t)limb * C->n + i;
@@ -83,7 +83,7 @@ __global__ void k_add_many(const uint64_t *in, const uint32_t *__restrict__ idx,
     out[o] = acc;
 }
 // a: [count][polys][k][N]; pt: [..][N]; grid over count*polys*k limbs
-__global__ void k_add_plain(const uint64_t *a, const uint64_t *pt, uint32_t pt_stride_words, uint64_t *out, const DevConsts *__restrict__ C,
+static __global__ void k_add_plain(const uint64_t *a, const uint64_t *pt, uint32_t pt_stride_words, uint64_t *out, const DevConsts *__restrict__ C,
                             uint32_t chunks, uint32_t polys, int subtract) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t k = C->k, j = limb % k, p = (limb / k) % polys, ct = limb / (k * polys);
@@ -96,21 +96,21 @@ __global__ void k_add_plain(const uint64_t *a, const uint64_t *pt, uint32_t pt_s
     out[o] = x;
 }
 // lifted[pi][j][i] = fast plain lift of pt[pi][i] into q_j (multiply_plain)
-__global__ void k_lift_plain(const uint64_t *pt, uint64_t *lifted, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t pitch) {
+static __global__ void k_lift_plain(const uint64_t *pt, uint64_t *lifted, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t pitch) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t k = C->k, j = limb % k, pi = limb / k;
     uint64_t m = pt[(size_t)pi * pitch * C->n + i];          // plaintext pi of the batch sits `pitch` plaintexts after plaintext pi-1
     lifted[(size_t)limb * C->n + i] = m >= C->t_half ? m + C->lift_inc[j] : m;
 }
 // x[ct][p][j][i] *= ptn[(ct*pstride)][j][i]   (both in NTT form)
-__global__ void k_dyadic_pt(uint64_t *x, const uint64_t *ptn, uint32_t pstride, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t polys) {
+static __global__ void k_dyadic_pt(uint64_t *x, const uint64_t *ptn, uint32_t pstride, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t polys) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t k = C->k, j = limb % k, ct = limb / (k * polys);
     size_t o = (size_t)limb * C->n + i;
     x[o] = mulmod(x[o], ptn[((size_t)ct * pstride * k + j) * C->n + i], C->q[j]);
 }
 // out[ct] = a[ct] * lifted scalar sc[ct*sstride*k + j]   (constant-plaintext multiply_plain)
-__global__ void k_mul_scalar(const uint64_t *a, const uint64_t *__restrict__ sc, uint32_t sstride, uint64_t *out, const DevConsts *__restrict__ C,
+static __global__ void k_mul_scalar(const uint64_t *a, const uint64_t *__restrict__ sc, uint32_t sstride, uint64_t *out, const DevConsts *__restrict__ C,
                              uint32_t chunks, uint32_t polys) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t k = C->k, j = limb % k, ct = limb / (k * polys);
@@ -118,7 +118,7 @@ __global__ void k_mul_scalar(const uint64_t *a, const uint64_t *__restrict__ sc,
     out[o] = mulmod(a[o], sc[(size_t)ct * sstride * k + j], C->q[j]);
 }
 // Step 2: tensor product in NTT form; A,B: [cnt][2][L][N], D: [cnt][3][L][N]; L limbs with moduli base_off..
-__global__ void k_tensor(const uint64_t *__restrict__ A, const uint64_t *__restrict__ B, uint64_t *__restrict__ D, const DevConsts *__restrict__ C,
+static __global__ void k_tensor(const uint64_t *__restrict__ A, const uint64_t *__restrict__ B, uint64_t *__restrict__ D, const DevConsts *__restrict__ C,
                          uint32_t chunks, uint32_t L, uint32_t base_off) {
     uint32_t limb, i; decode(chunks, limb, i);                       // limb = ct*L + l
     const uint32_t n = C->n, l = limb % L, ct = limb / L, mod = base_off + l;
@@ -135,7 +135,7 @@ __global__ void k_tensor(const uint64_t *__restrict__ A, const uint64_t *__restr
 // registers; finally INTT both accumulators and add them to add0/add1.  The digit polynomials never touch HBM.
 // block = NT threads, EPT = N/NT accumulators per thread per output poly.
 template <int EPT>
-__global__ void __launch_bounds__(1024) k_keyswitch(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
+static __global__ void __launch_bounds__(1024) k_keyswitch(const uint64_t *__restrict__ target, size_t tgt_stride, const uint64_t *__restrict__ add0,
                                                     const uint64_t *__restrict__ add1, size_t add_stride, const uint64_t *__restrict__ key,
                                                     uint64_t *__restrict__ out, const DevConsts *__restrict__ C, int galois, uint64_t *const *__restrict__ out_tab) {
     extern __shared__ uint64_t s[];
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(1024) k_keyswitch(const uint64_t *__restrict__
     }
 }
 // Galois automorphism x -> x^elt on coefficient-form limbs: dst[(i*elt) mod N] = +-src[i]
-__global__ void k_galois(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, const DevConsts *__restrict__ C, uint32_t chunks, uint64_t elt) {
+static __global__ void k_galois(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, const DevConsts *__restrict__ C, uint32_t chunks, uint64_t elt) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t n = C->n;
     const uint64_t q = C->q[limb % C->k].q;
@@ -210,7 +210,7 @@ __global__ void k_galois(const uint64_t *__restrict__ src, uint64_t *__restrict_
 // The same permutation with both global accesses coalesced: one workgroup per limb stages it in LDS - coalesced 8 B/lane loads, LDS
 // writes at the permuted positions (odd stride -> bank-conflict free), barrier, linear LDS reads, coalesced stores.  The scattered
 // global stores of k_galois reach 1.6 TB/s (a 64 B sector per lane and instruction); a batched rotation at N = 16384 spent 21 % there.
-__global__ void __launch_bounds__(1024) k_galois_lds(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, const DevConsts *__restrict__ C, uint64_t elt) {
+static __global__ void __launch_bounds__(1024) k_galois_lds(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, const DevConsts *__restrict__ C, uint64_t elt) {
     extern __shared__ uint64_t gs[];
     const uint32_t n = C->n, limb = blockIdx.x, logn = C->logn;
     const uint64_t q = C->q[limb % C->k].q;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(1024) k_galois_lds(const uint64_t *__restrict_
 }
 // The permutation of a rotation on SELECTED limbs (k_galois_lds, which permutes whole ciphertexts, with a stride): limb (ct, j) of
 // src + ct*sstride -> dst + ct*dstride.  In front of k_keyswitch_pair14 only c1 is permuted ahead of time.
-__global__ void __launch_bounds__(1024) k_galois_limbs(const uint64_t *__restrict__ src, size_t sstride, uint64_t *__restrict__ dst, size_t dstride,
+static __global__ void __launch_bounds__(1024) k_galois_limbs(const uint64_t *__restrict__ src, size_t sstride, uint64_t *__restrict__ dst, size_t dstride,
                                                        const DevConsts *__restrict__ C, uint64_t elt) {
     extern __shared__ uint64_t gsl[];
     const uint32_t n = C->n, k = C->k, ct = blockIdx.x / k, j = blockIdx.x % k, logn = C->logn;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(1024) k_galois_limbs(const uint64_t *__restric
     uint64_t *o = dst + (size_t)ct * dstride + (size_t)j * n;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = gsl[i];
 }
-__global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict__ half, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
+static __global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict__ half, const uint64_t *__restrict__ add0, const uint64_t *__restrict__ add1,
                                                        size_t add_stride, uint64_t *out, const DevConsts *__restrict__ C, const uint64_t *extra,
                                                        size_t ex_stride, uint64_t *const *__restrict__ out_tab) {
     const uint32_t n = C->n, n2 = n >> 1, k = C->k, chunks = n2 / 256;
@@ -262,18 +262,18 @@ __global__ void __launch_bounds__(256) k_ks_combine14(const uint64_t *__restrict
     o[i] = lo; o[i + n2] = hi;
 }
 // in-place conversion of key words to the FP64 form used by k_keyswitch_rr<L, ArF64> (exact: residues < 2^49)
-__global__ void k_u64_to_f64(uint64_t *p, size_t words) {
+static __global__ void k_u64_to_f64(uint64_t *p, size_t words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < words) { double d = (double)(long long)p[i]; reinterpret_cast<double *>(p)[i] = d; }
 }
 // the way back (a key that arrived as an FP64 image in a context that runs the integer kernels: cn_ctx_broadcast_keys)
-__global__ void k_f64_to_u64(uint64_t *p, size_t words) {
+static __global__ void k_f64_to_u64(uint64_t *p, size_t words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < words) { double d = reinterpret_cast<double *>(p)[i]; p[i] = (uint64_t)(long long)d; }
 }
 // ---- samplers (ChaCha20 DRBG, cn_dev_common.hip.h).  Secrets and noise are drawn once per coefficient into int8 arrays.
 // small[it][p][i], it < items, p < polys: kind 0 ternary {-1, 0, 1} (stream0 + p), kind 1 clipped normal (stream0 + p)
-__global__ void k_sample_small(int8_t *__restrict__ small, uint32_t n, int kind, uint32_t polys, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream0,
+static __global__ void k_sample_small(int8_t *__restrict__ small, uint32_t n, int kind, uint32_t polys, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream0,
                                uint64_t item0, const EncTab *__restrict__ tab) {
     const uint32_t per = kind == 0 ? 16u : 8u, bpp = n / per;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,20 +294,20 @@ __global__ void k_sample_small(int8_t *__restrict__ small, uint32_t n, int kind,
     }
 }
 // one raw generator block (known-answer self-test, cn_rng_selftest)
-__global__ void k_rng_block(RngKey key, uint64_t counter, uint64_t nonce, uint32_t *out) {
+static __global__ void k_rng_block(RngKey key, uint64_t counter, uint64_t nonce, uint32_t *out) {
     uint32_t w[16];
     chacha20_block(key, counter, nonce, w);
     for (int i = 0; i < 16; i++) out[i] = w[i];
 }
 // out[it][j][i] = small[it][i] as a residue mod q_j
-__global__ void k_expand_small(const int8_t *__restrict__ small, uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks) {
+static __global__ void k_expand_small(const int8_t *__restrict__ small, uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t k = C->k, j = limb % k; const uint64_t q = C->q[j].q;
     const int32_t s = small[(size_t)(limb / k) * C->n + i];
     out[(size_t)limb * C->n + i] = s >= 0 ? (uint64_t)s : q - (uint64_t)(-s);
 }
 // out[it][j][i]: uniform residues mod q_j (the `a` component of keys, directly in the NTT domain); thread = 8 coefficients of one limb
-__global__ void k_sample_uniform(uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream, uint64_t item0) {
+static __global__ void k_sample_uniform(uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream, uint64_t item0) {
     const uint32_t n = C->n, k = C->k, bpl = n / 8;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (uint64_t)items * k * bpl) return;
@@ -320,7 +320,7 @@ __global__ void k_sample_uniform(uint64_t *__restrict__ out, const DevConsts *__
 // b = -(a s + e) + f[limb] snew: the first component of a public key (f all zero) or of key-switch key (l, d) - f = 2^(dbc d) in limb l and zero
 // elsewhere, or (q/q_l) 2^(dbc d) mod q_j under cn_set_option("ks_xi", 1) (again zero unless j == l: q_j divides q/q_l)
 struct KeyFactors { uint64_t f[CN_MAXK]; };
-__global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, KeyFactors fac, uint64_t *b,
+static __global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s, const uint64_t *snew, KeyFactors fac, uint64_t *b,
                         const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);
     const DMod qm = C->q[limb]; size_t o = (size_t)limb * C->n + i;
@@ -329,12 +329,12 @@ __global__ void k_key_b(const uint64_t *a, const uint64_t *e, const uint64_t *s,
     if (factor) v = addmod(v, mulmod(snew[o], factor, qm), qm.q);
     b[o] = v;
 }
-__global__ void k_mul_limbs(const uint64_t *a, const uint64_t *b, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {   // NTT-form product, [k][N]
+static __global__ void k_mul_limbs(const uint64_t *a, const uint64_t *b, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {   // NTT-form product, [k][N]
     uint32_t limb, i; decode(chunks, limb, i);
     size_t x = (size_t)limb * C->n + i; o[x] = mulmod(a[x], b[x], C->q[limb % C->k]);
 }
 // o[ct][j] = a[ct][j] * b[j] (+ add[ct][j]): b broadcast over ciphertexts, NTT form
-__global__ void k_mul_limbs_bcast(const uint64_t *a, const uint64_t *b, const uint64_t *add, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {
+static __global__ void k_mul_limbs_bcast(const uint64_t *a, const uint64_t *b, const uint64_t *add, uint64_t *o, const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t j = limb % C->k; const DMod qm = C->q[j];
     size_t x = (size_t)limb * C->n + i;
@@ -342,7 +342,7 @@ __global__ void k_mul_limbs_bcast(const uint64_t *a, const uint64_t *b, const ui
     o[x] = add ? addmod(v, add[x], qm.q) : v;
 }
 // noise probe: acc[ct][j] <- t * (c0[ct][j] + acc[ct][j]) mod q_j  (the polynomial whose centred norm InvariantNoiseBudget measures)
-__global__ void k_noise_poly(const uint64_t *__restrict__ c0, size_t ct_stride, uint64_t *__restrict__ acc, const DevConsts *__restrict__ C, uint32_t chunks) {
+static __global__ void k_noise_poly(const uint64_t *__restrict__ c0, size_t ct_stride, uint64_t *__restrict__ acc, const DevConsts *__restrict__ C, uint32_t chunks) {
     uint32_t limb, i; decode(chunks, limb, i);
     const uint32_t j = limb % C->k, ct = limb / C->k; const DMod qm = C->q[j];
     const size_t x = (size_t)limb * C->n + i;
@@ -350,7 +350,7 @@ __global__ void k_noise_poly(const uint64_t *__restrict__ c0, size_t ct_stride, 
 }
 // decryption tail: x_j = c0_j + acc_j (coefficient form), then m = round(t*x/q) mod t by the {t, gamma} trick
 template <int K>
-__global__ void __launch_bounds__(256) k_decrypt_scale(const uint64_t *__restrict__ c0, size_t ct_stride, const uint64_t *__restrict__ acc, uint64_t *__restrict__ plain,
+static __global__ void __launch_bounds__(256) k_decrypt_scale(const uint64_t *__restrict__ c0, size_t ct_stride, const uint64_t *__restrict__ acc, uint64_t *__restrict__ plain,
                                                        const DevConsts *__restrict__ C, uint32_t chunks) {
     const uint32_t n = C->n;
     const uint32_t ct = blockIdx.x / chunks, i = (blockIdx.x % chunks) * blockDim.x + threadIdx.x;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) k_decrypt_scale(const uint64_t *__restric
 // FP64 issue-rate probe (cn_fp64_issue_time): ILP independent chains of the 6-instruction exact modular multiply per thread, nothing else -
 // the rate at which the FP64 pipe issues under the power state of the moment (the key switch's floor in bench.py is priced with it).
 template <int ILP>
-__global__ void __launch_bounds__(512) k_fp64_probe(double *out, double w, double q, double qinv, int iters) {
+static __global__ void __launch_bounds__(512) k_fp64_probe(double *out, double w, double q, double qinv, int iters) {
     extern __shared__ double probe_lds[];               // (dynamic LDS only pins the occupancy: one workgroup per CU, two waves per SIMD)
     double a[ILP];
 #pragma unroll
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512) k_fp64_probe(double *out, double w, doubl
 }
 // the same for full-rate 32-bit VALU instructions (add / xor / shift-add / and-or: what the key switch runs besides FP64 - digit extraction,
 // addressing, selects): 4 interleaved chains x 6 instructions per iteration, written out so that the count is exact
-__global__ void __launch_bounds__(512) k_valu_probe(double *out, uint32_t c1, uint32_t c2, int iters) {
+static __global__ void __launch_bounds__(512) k_valu_probe(double *out, uint32_t c1, uint32_t c2, int iters) {
     extern __shared__ double probe_lds[];
     uint32_t a0 = threadIdx.x, a1 = threadIdx.x * 3 + 1, a2 = threadIdx.x * 5 + 2, a3 = threadIdx.x * 7 + 3;
     for (int it = 0; it < iters; it++)

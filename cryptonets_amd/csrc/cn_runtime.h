@@ -1,4 +1,4 @@
-// Host-side structures of libcnhip.so shared by the runtime (cn_api.hip) and the kernel-launch translation units
+// Host-side structures of libcnhip.so shared by the runtime units (cn_api.hip, cn_eval.hip, cn_client.hip, cn_defer.hip, cn_multi.hip: cn_api_shared.h) and the kernel-launch translation units
 // (cn_l_*.hip).  The library is built from several translation units so that hipcc compiles the kernel families in parallel: the
 // register-radix kernels alone are ~180 instantiations (5 transform sizes x 3 arithmetic policies x 12 kernels).
 #pragma once
@@ -121,7 +121,7 @@ struct CnGuard {
     CnGuard &operator=(const CnGuard &) = delete;
 };
 
-struct DeferQueue;            // cn_api.hip, second half
+struct DeferQueue;            // cn_api_shared.h / cn_defer.hip
 struct cn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -182,7 +182,7 @@ struct cn_ctx {
     bool fold_zero = true;    // queued fresh encryptions of zero whose only reader is a queued scalar product and which have been released: folded by linearity (k_encrypt_fold, round 6); cn_set_option("fold_zero", 0): materialised
     bool enc_fused = true;    // Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
     int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
-    bool sq_overlap = false;  // squaring of a batch: the q-side transform kernel on a second stream beside [k_behz_extend -> Bsk side] (cn_api.hip: do_multiply); CN_SQ_OVERLAP / cn_set_option
+    bool sq_overlap = false;  // squaring of a batch: the q-side transform kernel on a second stream beside [k_behz_extend -> Bsk side] (cn_eval.hip: do_multiply); CN_SQ_OVERLAP / cn_set_option
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool stream2_failed = false;
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
     // deferred submission (cn_set_option("defer", 1)): per-ciphertext calls are queued and flushed as batched launches; 2: ... and submitted without the
