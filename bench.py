@@ -805,11 +805,10 @@ def main():
                 visible = {"threads": effective_cores()[1], "ms_per_step": round(vms, 2), "frac_of_batched": round(batched_ms / vms, 3)}
             locked = None                                                  # the same literal pattern with every deferred call under the context lock (defer = 1)
             try:
-                kms = min(rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True, lockfree=False, direct_free=True)[0] for _ in range(3))
-                pms = min(rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True, lockfree=False)[0] for _ in range(3))
+                kms = min(rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True, lockfree=False)[0] for _ in range(3))
                 locked = {"threads": nthreads, "ms_per_step": round(kms, 2), "frac_of_batched": round(batched_ms / kms, 3),
-                          "rounds_3_to_5_twin": {"ms_per_step": round(pms, 2), "frac_of_batched": round(batched_ms / pms, 3),
-                                                 "note": "disposed arrays parked per thread and released 32 at a time (cn_free_many): some zero vectors are still alive at the flush, nothing is folded"}}
+                          "note": "the rounds 3-5 twin: every deferred call under the context lock, disposed arrays parked per thread and released 32 at a time (cn_free_many) - some zero "
+                                  "vectors are still alive at the flush, nothing is folded; run behind the lock-free windows in the same process"}
             except Exception as ex:
                 locked = {"error": str(ex)[:200]}
             unchanged = {"value": round(8192e3 / lms, 1), "unit": "images/s", "ms_per_step": round(lms, 2), "threads": nthreads,

@@ -264,6 +264,7 @@ int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<uint64_t
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
     if (getenv("CN_SQ_OVERLAP")) c->sq_overlap = atoi(getenv("CN_SQ_OVERLAP")) != 0;
+    if (getenv("CN_DEFER_STAGGER")) c->defer_stagger = atoi(getenv("CN_DEFER_STAGGER")) != 0;
     if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED")) != 0;
     if (getenv("CN_FOLD_ZERO")) c->fold_zero = atoi(getenv("CN_FOLD_ZERO")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -315,6 +316,8 @@ void ctx_teardown(cn_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    cn_stagger_forget(ctx);
+    if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -336,6 +339,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
     if (!strcmp(name, "sq_overlap")) { ctx->sq_overlap = value != 0; return 0; }
+    if (!strcmp(name, "defer_stagger")) { ctx->defer_stagger = value != 0; return 0; }
     if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value != 0; return 0; }
     if (!strcmp(name, "fold_zero")) { ctx->fold_zero = value != 0; return 0; }      // queued zero encryptions that only feed a queued scalar product: folded by linearity (default 1)
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
@@ -384,6 +388,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
     else if (!strcmp(name, "sq_overlap")) *value = ctx->sq_overlap;
+    else if (!strcmp(name, "defer_stagger")) *value = ctx->defer_stagger;
     else if (!strcmp(name, "enc_fused")) *value = ctx->enc_fused;
     else if (!strcmp(name, "fold_zero")) *value = ctx->fold_zero;
     else if (!strcmp(name, "folded_zero_encryptions")) *value = (int)std::min<uint64_t>(ctx->folded_zero, 0x7fffffff);    // zero encryptions folded so far (tests)

@@ -162,6 +162,36 @@ int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, in
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;
 }
+// Staggered plaintext-prime channels for the UNCHANGED caller (round 6).  The reference runs the same layer on every plaintext prime from the same caller threads
+// (EncryptedSealBfvVector.cs:225-236), so the contexts of a device flush their big squaring layers within microseconds of each other and their kernel chains run in
+// lock step - key switch beside key switch (both FP64-issue bound), element-wise BEHZ steps beside each other (both HBM bound).  The batched bench staggers its two
+// channels by half a batch with cn_ctx_wait_for (12.4 against 13.0 ms per batch, profiles/r06_stagger_ab.txt); here the library does it by itself: the Multiply part
+// ("front") of a big group waits - on the device, no host wait - for the front of the context that flushed such a group LAST on this device, so it runs beside that
+// context's key switch.  Only the most recent front event of ANOTHER context is waited for (already complete when the flushes are far apart); one context never waits.
+namespace {
+struct FrontSlot { cn_ctx *owner = nullptr; hipEvent_t ev = nullptr; };
+std::mutex g_front_mu;
+FrontSlot g_front[64];               // per device: who recorded the latest front event
+}
+static const uint32_t STAGGER_MIN_CTS = 256;
+void cn_stagger_forget(cn_ctx *ctx) {             // a context that goes away takes its event with it
+    std::lock_guard<std::mutex> lk(g_front_mu);
+    FrontSlot &f = g_front[(unsigned)ctx->device % 64];
+    if (f.owner == ctx) f = FrontSlot();
+}
+static int stagger_front_begin(cn_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_front_mu);
+    const FrontSlot &f = g_front[(unsigned)ctx->device % 64];
+    if (f.owner && f.owner != ctx && f.ev) HIPCHK(hipStreamWaitEvent(ctx->stream, f.ev, 0));
+    return 0;
+}
+static int stagger_front_end(cn_ctx *ctx) {
+    if (!ctx->ev_front) HIPCHK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
+    std::lock_guard<std::mutex> lk(g_front_mu);
+    HIPCHK(hipEventRecord(ctx->ev_front, ctx->stream));
+    g_front[(unsigned)ctx->device % 64] = FrontSlot{ctx, ctx->ev_front};
+    return 0;
+}
 // all queued Multiply + Relinearize calls of one level: the batched BEHZ pipeline + ONE key switch, operands and results through tables
 int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all) {
     const size_t kn = (size_t)ctx->hc.k * ctx->hc.n;
@@ -182,7 +212,10 @@ int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all) {
             CHECK(upload_tmp(ctx, ho.data(), c, &dout));
             uint64_t *t3 = salloc<uint64_t>(ctx, (size_t)c * 3 * kn);
             if (!t3) return fail(CN_ERR_HIP, "internal: scratch exhausted in deferred multiply");
+            const bool stagger = ctx->defer_stagger && c >= STAGGER_MIN_CTS && !ctx->capturing;
+            if (stagger) CHECK(stagger_front_begin(ctx));
             CHECK(do_multiply(ctx, nullptr, 1, nullptr, 1, t3, c, da, sq ? da : db));
+            if (stagger) CHECK(stagger_front_end(ctx));
             CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk, nullptr, c, 0, nullptr, 0, dout));
         }
     }

@@ -81,6 +81,22 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * (cn_sync, downloads, ...) needs the results.  Same words as immediate calls; argument errors (ranges, zero plaintexts, missing Galois keys) are
  * reported by the call that made them, device errors by the call that triggered the flush.  cn_free of a handle with pending readers is safe
  * (the array returns to the pool after the flush).
+ * "defer" = 2 (round 6): the same queue, fed WITHOUT THE CONTEXT LOCK.  cn_scalar_dot, cn_add, cn_sub, cn_add_plain, cn_mul_relin (up to 4 ciphertexts per
+ * call), cn_encrypt (up to 4), cn_encrypt_zero_new, cn_free, cn_free_many and cn_ct_alloc(1, 2) do not take the lock: a call claims the next slot of a
+ * multi-producer ring with one atomic add, writes a 64-byte record (handles and indices as passed) and returns 0; whoever finds the lock free executes
+ * the published records in claim order - a total order consistent with happens-before between the caller's threads, which is what the dependence
+ * tracking needs.  Single-ciphertext allocations come from a ring of ready handles the executing thread keeps filled.  Every other entry point takes the
+ * lock and first executes what was published before it.  DIFFERENCE TO "defer" = 1: the arguments of a published call are checked when it is executed -
+ * an error is reported ONCE by the next call that synchronises with the context (cn_sync, downloads, cn_stats_get, any non-deferrable entry point:
+ * "a call submitted without the lock (defer = 2) failed ..."), the calls around it are executed.  For callers that come from Defaults.ThreadCount =
+ * Environment.ProcessorCount threads (HE Wrapper/Defaults.cs:11-15, Utils.cs:46-88): the unchanged CryptoNets layers run at the same rate from 4, 16 and
+ * 256 threads.  cn_live_handles does not count the ready handles; "ready_handles" reads their number.
+ * "fold_zero" = 1 (default, round 6): a queued fresh encryption of zero (cn_encrypt with pt = 0 / cn_encrypt_zero_new) that only feeds ONE queued scalar
+ * product and has been released by the caller (PoolLayer.ElementAt / ReleaseTemp, PoolLayer.cs:67-90) is not materialised: sum_t w_t Enc_t(0) is
+ * added onto the scalar product's output by linearity - exact modular arithmetic on the same sampler draws (nonce, item), the SAME words as with
+ * "fold_zero" = 0, a fifth of the transforms.  All or nothing per flush (every queued zero encryption must qualify).  "folded_zero_encryptions" reads the count.
+ * "sq_overlap" = 0 (default; 1: the q-side transform kernel of a batched squaring on a second stream beside the base extension - measured slower in
+ * the two-context batch, profiles/r06_square_overlap.txt).
  * "gemm_order" = 1 (default): slice-major workgroup order of the VALU scalar GEMM (every input slice fetched once per XCD), 0 = group-major.
  * "ks_perm_fused" = 1 (default): a rotation of a small batch (two-launch key switch) has no permutation pass - the key-switch kernels apply the
  * automorphism while they load c1 and c0; 0 = k_galois_lds in front of them.  "stream_tries" (read only): streams cn_ctx_create tried until one had a
@@ -231,8 +247,10 @@ int cn_mul_relin(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t a_stride, cn_ha
 /* Evaluator.ApplyGalois: automorphism + key switch of c1 */
 int cn_apply_galois(cn_ctx *ctx, cn_handle in, uint32_t ii, uint64_t galois_elt, cn_handle out, uint32_t oi, uint32_t count);
 /* Evaluator.RotateRows(/Inplace): NAF decomposition when no key exists for the step
- * (AtomicSealBfvVector.cs:625,631,637,660,864,1420,1458).  Every batched rotation (this one, cn_apply_galois, cn_rotate_columns and the _add forms): operand /
- * accumulator and result ranges of ONE handle are the same range (in place) or disjoint; a partial overlap is refused (CN_ERR_ARG), as in cn_mul_plain. */
+ * (AtomicSealBfvVector.cs:625,631,637,660,864,1420,1458).  Operand and result ranges of ONE handle may be the same range (in place), disjoint, or
+ * overlap with a shift (cn_rotate_rows, cn_apply_galois, cn_rotate_columns: such a call takes the permutation pass / a staging copy, which reads the whole
+ * operand before anything is written).  The _add forms refuse a partial overlap of operand or accumulator with the result (CN_ERR_ARG): their fused
+ * accumulator is read where the result is stored. */
 int cn_rotate_rows(cn_ctx *ctx, cn_handle in, uint32_t ii, int steps, cn_handle out, uint32_t oi, uint32_t count);
 /* RotateRows of n ciphertexts by n DIFFERENT step counts: out[oi[i]] = RotateRows(in[ii[i]], steps[i]), same words as n cn_rotate_rows calls.
  * The reference rotates the vectors of an Interleave / a Vectorize one Evaluator.RotateRows at a time (AtomicSealBfvVector.cs:628-688); here the
