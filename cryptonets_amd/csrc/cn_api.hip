@@ -265,7 +265,7 @@ int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<uint64_t
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
     if (getenv("CN_SQ_OVERLAP")) c->sq_overlap = atoi(getenv("CN_SQ_OVERLAP")) != 0;
     if (getenv("CN_DEFER_STAGGER")) c->defer_stagger = atoi(getenv("CN_DEFER_STAGGER")) != 0;
-    if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED")) != 0;
+    if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED"));
     if (getenv("CN_FOLD_ZERO")) c->fold_zero = atoi(getenv("CN_FOLD_ZERO")) != 0;
     HIPCHK(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (getenv("CN_GEMM_MFMA")) c->gemm_mfma = atoi(getenv("CN_GEMM_MFMA")) != 0;
@@ -340,7 +340,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
     if (!strcmp(name, "sq_overlap")) { ctx->sq_overlap = value != 0; return 0; }
     if (!strcmp(name, "defer_stagger")) { ctx->defer_stagger = value != 0; return 0; }
-    if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value != 0; return 0; }
+    if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value; return 0; }          // 0 three launches, 1 k_encrypt_fused, 2 k_encrypt_split
     if (!strcmp(name, "fold_zero")) { ctx->fold_zero = value != 0; return 0; }      // queued zero encryptions that only feed a queued scalar product: folded by linearity (default 1)
     if (!strcmp(name, "gemm_mfma")) { ctx->gemm_mfma = value != 0; return 0; }        // affects GEMMs planned AFTER the call
     if (!strcmp(name, "gemm_pair")) { ctx->gemm_pair = value != 0; return 0; }        // likewise

@@ -403,6 +403,30 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 2) k_square_pipe(const uint64_
         }
     }
 }
+// One output word of an encryption: v N^-1 + e (+ Delta m + r_t(q) in the upper half) as a canonical residue.  FP64 policies (round 6): the whole sum in exact doubles and ONE
+// canonicalisation - Delta_j m is an error-free FP64 product (m < t < q_j < 2^49) instead of a 64 x 64 -> 128-bit multiply and a Barrett reduction per coefficient (~12 quarter-rate
+// v_mad_u64_u32: with a dense plaintext the integer epilogue was a fourth transform's worth of issue slots - 659 us per 784 ciphertexts against 447 at the rate of the zero vectors).
+template <class AR> struct EncTail {
+    typedef typename AR::T T;
+    const ArCtx<AR> &A; const DevConsts *C; uint32_t j; uint64_t q, t_half; double dlt, rtq;
+    NTT_DEV EncTail(const ArCtx<AR> &A_, const DevConsts *C_, uint32_t j_, uint64_t q_) : A(A_), C(C_), j(j_), q(q_), t_half(C_->t_half), dlt((double)C_->delta[j_]), rtq((double)C_->rtq[j_]) {}
+    NTT_DEV uint64_t word(T v, int32_t ns, bool has_m, uint64_t mw) const {
+        if constexpr (std::is_same<T, double>::value) {
+            double x = __dadd_rn(AR::mulmod(v, A.ni, A.m), (double)ns);
+            if (has_m) {
+                double y = AR::mulmod(AR::from_u64(mw), dlt, A.m);
+                if (mw >= t_half) y = __dadd_rn(y, rtq);
+                x = __dadd_rn(x, y);
+            }
+            return AR::to_u64(x, A.m);
+        } else {
+            uint64_t val = A.scaled(v);
+            val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
+            if (has_m) val = addmod(val, scale_plain(C, mw, j), q);
+            return val;
+        }
+    }
+};
 // encryption tail: out[ct][p][j] = INTT(u[ct][j] * pk[p][j]) + e_p (+ Delta*m for p = 0); u in NTT form, e = the int8 noise polynomials
 // [ct][2][N] of k_sample_small.  tab: per-ciphertext output address and plaintext (deferred per-ciphertext calls), else out + ct*2kN and
 // pt + ct*pt_stride_words (pt null: encryptions of zero)
@@ -431,14 +455,12 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_tail(const uint64_t 
     const NTT_GLOBAL uint64_t *m = tab ? tab[ct].pt : (pt ? (const NTT_GLOBAL uint64_t *)pt + (size_t)ct * pt_stride_words : nullptr);
     const int8_t *ee = noise + ((size_t)ct * 2 + p) * n;
     const uint64_t q = C->q[j].q;
+    const EncTail<AR> tail(A, C, j, q);
+    const bool has_m = p == 0 && m;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const uint32_t e = pass_index<L, SA, 0>(tid, r);
-        uint64_t val = A.scaled(v[r]);
-        const int32_t ns = ee[e];
-        val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
-        if (p == 0 && m) val = addmod(val, scale_plain(C, m[e], j), q);
-        o[e] = val;
+        o[e] = tail.word(v[r], ee[e], has_m, has_m ? m[e] : 0);
     }
 }
 
@@ -490,15 +512,62 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fused(const int8_t *
         ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
         NTT_GLOBAL uint64_t *o = obase + ((size_t)p * k + j) * n;
         const int8_t *ee = noise + ((size_t)ct * 2 + p) * n;
+        const EncTail<AR> tail(A, C, j, q);
+        const bool has_m = p == 0 && m;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t e = pass_index<L, SA, 0>(tl, r);
-            uint64_t val = A.scaled(v[r]);
-            const int32_t ns = ee[e];
-            val = addmod(val, ns >= 0 ? (uint64_t)ns : q - (uint64_t)(-ns), q);
-            if (p == 0 && m) val = addmod(val, scale_plain(C, m[e], j), q);
-            o[e] = val;
+            o[e] = tail.word(v[r], ee[e], has_m, has_m ? m[e] : 0);
         }
+    }
+}
+
+// The same encryption with a block per (ciphertext, COMPONENT, limb) (round 6; cn_set_option("enc_fused", 2), the default of the FP64 policies: 784 dense plaintexts
+// 420 us against 542 for k_encrypt_fused and 534 for the three launches, 645 zero vectors 311 / 372 / 401 - profiles/r06_encrypt_probe.txt): every block transforms u itself (4 transforms
+// per (ciphertext, limb) instead of 3) but nothing has to survive an inverse transform - ~100 instead of 198 VGPRs, so TWO workgroups share a CU and each other's
+// memory round trips and barriers.  Same words.
+template <int L, class AR>
+__global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_encrypt_split(const int8_t *__restrict__ us, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pt,
+                                                                     uint32_t pt_stride_words, uint64_t *__restrict__ out, const DevConsts *__restrict__ C,
+                                                                     const int8_t *__restrict__ noise, const EncTab *__restrict__ tab) {
+    typedef typename AR::T T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *s = reinterpret_cast<T *>(smem);
+    constexpr uint32_t n = 1u << L;
+    constexpr int SA = NttPlan<L>::SA;
+    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, p = (blockIdx.x / k) & 1, ct = blockIdx.x / (2 * k);
+    const ArCtx<AR> A(C, j);
+    const TensorOps<AR> ops(C, j);
+    const uint64_t q = C->q[j].q;
+    T v[16];
+    {
+        const int8_t *uu = us + (size_t)ct * n;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const int32_t x = uu[pass_index<L, SA, 0>(tid, r)]; v[r] = A.load(x >= 0 ? (uint64_t)x : q - (uint64_t)(-x)); }
+        ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+        if constexpr (std::is_same<T, double>::value) AR::renorm(v, A.m);
+        else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = A.canon(v[r]);
+        }
+    }
+    const uint64_t *pp = pk + ((size_t)p * k + j) * n;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(pp + tail_index<L>(tid, r));
+        v[r] = ops.mul(v[r], A.load(y.x), A); v[r + 1] = ops.mul(v[r + 1], A.load(y.y), A);
+    }
+    if (!ntt_tail_local<L>()) __syncthreads();
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    NTT_GLOBAL uint64_t *o = (tab ? tab[ct].out : (NTT_GLOBAL uint64_t *)out + (size_t)ct * 2 * k * n) + ((size_t)p * k + j) * n;
+    const NTT_GLOBAL uint64_t *m = tab ? tab[ct].pt : (pt ? (const NTT_GLOBAL uint64_t *)pt + (size_t)ct * pt_stride_words : nullptr);
+    const int8_t *ee = noise + ((size_t)ct * 2 + p) * n;
+    const EncTail<AR> tail(A, C, j, q);
+    const bool has_m = p == 0 && m;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(tid, r);
+        o[e] = tail.word(v[r], ee[e], has_m, has_m ? m[e] : 0);
     }
 }
 

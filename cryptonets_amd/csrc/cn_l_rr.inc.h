@@ -21,7 +21,7 @@ template <int L> static int set_attrs_l(size_t bytes) {
 #ifdef RR_ENC_TAIL
     CHECK(big_lds(k_encrypt_tail<L, AR>, bytes));
 #endif
-    if constexpr (L <= 13) CHECK(big_lds(k_encrypt_fused<L, AR>, bytes));
+    if constexpr (L <= 13) { CHECK(big_lds(k_encrypt_fused<L, AR>, bytes)); CHECK(big_lds(k_encrypt_split<L, AR>, bytes)); }
     if constexpr (L <= 13 && kF64) CHECK(big_lds(k_encrypt_fold<L, AR>, bytes));
     return 0;
 }
@@ -106,9 +106,14 @@ static bool enc_tail(cn_ctx *, const uint64_t *, const uint64_t *, uint32_t, uin
 
 // Encryptor.Encrypt behind the samplers as ONE kernel (N <= 8192; N = 16384 keeps the three-launch chain: 1024-thread workgroups have 128 VGPRs per thread)
 template <int L> static void l_enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
-    if constexpr (L <= 13)
-        hipLaunchKernelGGL((k_encrypt_fused<L, AR>), dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, pt, pts, out, c->dc,
-                           noise, (const EncTab *)tab);
+    if constexpr (L <= 13) {
+        if (c->enc_fused == 2 && kF64)               // (the integer policy spills 17-21 registers at 128: it keeps the one-block form)
+            hipLaunchKernelGGL((k_encrypt_split<L, AR>), dim3(cnt * 2 * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, pt, pts, out, c->dc,
+                               noise, (const EncTab *)tab);
+        else
+            hipLaunchKernelGGL((k_encrypt_fused<L, AR>), dim3(cnt * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, pt, pts, out, c->dc,
+                               noise, (const EncTab *)tab);
+    }
 }
 static bool enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t pts, uint64_t *out, uint32_t cnt, const int8_t *noise, const void *tab) {
     if (c->hc.logn > 13) return false;

@@ -180,7 +180,7 @@ struct cn_ctx {
                               // block (profiles/r02_pmc_square_gemm.txt); cn_set_option("sq_lds", 0): parked in the outputs' place (two workgroups per CU)
     uint64_t folded_zero = 0;  // zero encryptions folded so far
     bool fold_zero = true;    // queued fresh encryptions of zero whose only reader is a queued scalar product and which have been released: folded by linearity (k_encrypt_fold, round 6); cn_set_option("fold_zero", 0): materialised
-    bool enc_fused = true;    // Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
+    int enc_fused = 2;        // 2 (default, round 6): a block per (ciphertext, component, limb) - k_encrypt_split, two workgroups per CU: 420 against 542 us per 784 ciphertexts; 1: Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
     int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
     bool defer_stagger = true; hipEvent_t ev_front = nullptr;   // deferred flush of a big Multiply + Relinearize group: its Multiply waits for the front of the context that flushed one last
                                                                 // on this device (cn_defer.hip: staggered plaintext-prime channels); cn_set_option("defer_stagger", 0) / CN_DEFER_STAGGER=0

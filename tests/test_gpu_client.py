@@ -471,7 +471,7 @@ def test_fused_encryption_kernel_is_the_three_launch_chain(name, f64, rng):
     from cryptonets_amd._native import Context
     p = PARAMS[name]
     words = {}
-    for fused in (1, 0):
+    for fused in (1, 0, 2):                                      # 2: a block per (ciphertext, component, limb) - k_encrypt_split (round 6)
         g = Context(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], device=0)
         if not f64:
             g.set_option("f64", 0)
@@ -491,7 +491,7 @@ def test_fused_encryption_kernel_is_the_three_launch_chain(name, f64, rng):
         g.set_option("defer", 0)
         w = [g.ct_download(ch, 0, 12)] + [g.ct_download(h, 0, 1) for h in z]
         words[fused] = np.concatenate(w)
-        if fused:
+        if fused == 1:
             o = get_oracle(name, galois=False)
             from oracle.cno import Oracle
             oo = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"])
@@ -501,4 +501,4 @@ def test_fused_encryption_kernel_is_the_three_launch_chain(name, f64, rng):
             assert all(np.array_equal(a, b) for a, b in zip(dec, want))
             assert not np.array_equal(words[1][8], words[1][9])
         g.close()
-    assert np.array_equal(words[0], words[1])
+    assert np.array_equal(words[0], words[1]) and np.array_equal(words[2], words[1])
