@@ -205,6 +205,7 @@ extern "C" int cn_ctx_create(uint32_t n, const uint64_t *q, uint32_t k, uint64_t
     char err[256];
     c->index_map.assign(n, 0);
     if (cn_build_consts(&c->hc, n, q, k, t, dbc, gdbc, tw.data(), c->index_map.data(), err, sizeof err)) { delete c; return fail(CN_ERR_ARG, "%s", err); }
+    { static std::atomic<uint64_t> next_uid{1}; c->uid = next_uid.fetch_add(1, std::memory_order_relaxed); }
     c->dq = cn_defer_new();
     c->ring = new SubmitRing(); c->ready = new ReadyRing();
     c->slabs = new std::vector<Slab>();

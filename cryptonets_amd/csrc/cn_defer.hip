@@ -162,14 +162,18 @@ int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, in
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;
 }
-// Staggered plaintext-prime channels for the UNCHANGED caller (round 6).  The reference runs the same layer on every plaintext prime from the same caller threads
+// Staggered plaintext-prime channels for the UNCHANGED caller (round 6; MEASURED WITHOUT A GAIN AND OFF BY DEFAULT - cn_set_option("defer_stagger", 1), profiles/r06_stagger_ab.txt).  The reference runs the same layer on every plaintext prime from the same caller threads
 // (EncryptedSealBfvVector.cs:225-236), so the contexts of a device flush their big squaring layers within microseconds of each other and their kernel chains run in
 // lock step - key switch beside key switch (both FP64-issue bound), element-wise BEHZ steps beside each other (both HBM bound).  The batched bench staggers its two
 // channels by half a batch with cn_ctx_wait_for (12.4 against 13.0 ms per batch, profiles/r06_stagger_ab.txt); here the library does it by itself: the Multiply part
 // ("front") of a big group waits - on the device, no host wait - for the front of the context that flushed such a group LAST on this device, so it runs beside that
-// context's key switch.  Only the most recent front event of ANOTHER context is waited for (already complete when the flushes are far apart); one context never waits.
+// context's key switch.  Only the most recent front event of an OLDER context (created earlier: the device's first context never waits) is waited for - with symmetric waits a
+// context that led one batch and flushes second in the next would wait for the trailing context's front, i.e. for work ~2.5 ms behind its own stream: half of the batches paid for
+// a leader swap and the mean gain was nil (profiles/r06_stagger_ab.txt, visit K).  A front event of a batch long gone is complete and costs nothing.  With the fixed leader the
+// literal caller measured 14.27-14.73 ms per batch against 13.81-14.31 without any stagger (three alternating pairs): the flushes of the two contexts do not line up the way the
+// batched program's two halves do (the convolution, dense and second squaring layers are flushed on their own), and a delayed front is then simply a delayed front.
 namespace {
-struct FrontSlot { cn_ctx *owner = nullptr; hipEvent_t ev = nullptr; };
+struct FrontSlot { cn_ctx *owner = nullptr; hipEvent_t ev = nullptr; uint64_t uid = 0; };
 std::mutex g_front_mu;
 FrontSlot g_front[64];               // per device: who recorded the latest front event
 }
@@ -182,14 +186,15 @@ void cn_stagger_forget(cn_ctx *ctx) {             // a context that goes away ta
 static int stagger_front_begin(cn_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_front_mu);
     const FrontSlot &f = g_front[(unsigned)ctx->device % 64];
-    if (f.owner && f.owner != ctx && f.ev) HIPCHK(hipStreamWaitEvent(ctx->stream, f.ev, 0));
+    if (f.owner && f.owner != ctx && f.ev && f.uid < ctx->uid) HIPCHK(hipStreamWaitEvent(ctx->stream, f.ev, 0));
     return 0;
 }
 static int stagger_front_end(cn_ctx *ctx) {
     if (!ctx->ev_front) HIPCHK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     std::lock_guard<std::mutex> lk(g_front_mu);
     HIPCHK(hipEventRecord(ctx->ev_front, ctx->stream));
-    g_front[(unsigned)ctx->device % 64] = FrontSlot{ctx, ctx->ev_front};
+    FrontSlot &f = g_front[(unsigned)ctx->device % 64];
+    if (!f.owner || f.owner == ctx || ctx->uid <= f.uid) f = FrontSlot{ctx, ctx->ev_front, ctx->uid};       // the slot belongs to the oldest context that staggers on this device
     return 0;
 }
 // all queued Multiply + Relinearize calls of one level: the batched BEHZ pipeline + ONE key switch, operands and results through tables

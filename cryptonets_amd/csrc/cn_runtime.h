@@ -182,8 +182,9 @@ struct cn_ctx {
     bool fold_zero = true;    // queued fresh encryptions of zero whose only reader is a queued scalar product and which have been released: folded by linearity (k_encrypt_fold, round 6); cn_set_option("fold_zero", 0): materialised
     int enc_fused = 2;        // 2 (default, round 6): a block per (ciphertext, component, limb) - k_encrypt_split, two workgroups per CU: 420 against 542 us per 784 ciphertexts; 1: Encryptor.Encrypt behind the samplers as one kernel (k_encrypt_fused, N <= 8192); cn_set_option("enc_fused", 0): expand + batched transform + k_encrypt_tail
     int sq_pipe = 1;          // 1: fused squaring of a batch (>= 4 blocks per resident workgroup) on the pipelined resident kernel k_square_pipe; 0: k_square_fused; 2: k_square_pipe for any count (tests)
-    bool defer_stagger = true; hipEvent_t ev_front = nullptr;   // deferred flush of a big Multiply + Relinearize group: its Multiply waits for the front of the context that flushed one last
-                                                                // on this device (cn_defer.hip: staggered plaintext-prime channels); cn_set_option("defer_stagger", 0) / CN_DEFER_STAGGER=0
+    uint64_t uid = 0;         // creation order within the process (cn_ctx_create)
+    bool defer_stagger = false; hipEvent_t ev_front = nullptr;   // deferred flush of a big Multiply + Relinearize group: its Multiply waits for the front of the context that flushed one last
+                                                                // on this device (cn_defer.hip: staggered plaintext-prime channels); measured, no gain - OFF by default: cn_set_option("defer_stagger", 1) / CN_DEFER_STAGGER=1
     bool sq_overlap = false;  // squaring of a batch: the q-side transform kernel on a second stream beside [k_behz_extend -> Bsk side] (cn_eval.hip: do_multiply); CN_SQ_OVERLAP / cn_set_option
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool stream2_failed = false;
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches
