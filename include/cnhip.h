@@ -65,8 +65,9 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * of a squaring (Multiply(a, a): SquareActivation) as one kernel per base, 0 = separate launches; "mp_fused" = 1 (default) runs a dense
  * MultiplyPlain as two launches (lift + transform of the plaintexts; transform, product, inverse transform of the ciphertext limbs),
  * 0 = six; "sq_lds" = 1 (default) parks the NTT-form operand of a fused squaring in LDS (N <= 8192), 0 = in the outputs' place; "sq_pipe" = 1 (default) runs the fused squaring of a batch on the
- * pipelined resident kernel (k_square_pipe: one workgroup per CU and modulus, inverse root table in LDS, next operand prefetched), 0 = k_square_fused; "enc_fused" = 1 (default) runs Encryptor.Encrypt behind the samplers as ONE kernel (N <= 8192: the ternary u goes from the sampler's int8
- * polynomial through one transform and stays in registers for both components), 0 = expansion + batched transform + tail kernel;
+ * pipelined resident kernel (k_square_pipe: one workgroup per CU and modulus, inverse root table in LDS, next operand prefetched), 0 = k_square_fused; "enc_fused" = 2 (default, round 6) runs Encryptor.Encrypt behind the samplers as ONE kernel with a block per (ciphertext, component, limb) (N <= 8192,
+ * FP64 policies: two workgroups per CU), 1 = a block per (ciphertext, limb) (the ternary u goes from the sampler's int8 polynomial through one transform and stays in registers
+ * for both components), 0 = expansion + batched transform + tail kernel;
  * "gemm_mfma" = 1 (default) runs wide scalar GEMMs (cn_scalar_gemm / cn_scalar_dot batches with >= 16 outputs) on the int8 matrix
  * cores; "gemm_pair" = 1 (default) lets cn_scalar_gemm / cn_gemm_plan_create merge gather lists that share at least half of their inputs in pairs
  * (small signed weights, lists of <= 64 entries and <= 5 outputs: the windows of a convolution - every shared input then travels to a CU once, not twice),
@@ -95,6 +96,8 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * product and has been released by the caller (PoolLayer.ElementAt / ReleaseTemp, PoolLayer.cs:67-90) is not materialised: sum_t w_t Enc_t(0) is
  * added onto the scalar product's output by linearity - exact modular arithmetic on the same sampler draws (nonce, item), the SAME words as with
  * "fold_zero" = 0, a fifth of the transforms.  All or nothing per flush (every queued zero encryption must qualify).  "folded_zero_encryptions" reads the count.
+ * "defer_stagger" = 0 (default; 1: the Multiply of a queued squaring group of >= 256 ciphertexts waits on the device for the Multiply of an older context of the same device -
+ * measured without a gain, profiles/r06_stagger_ab.txt).
  * "sq_overlap" = 0 (default; 1: the q-side transform kernel of a batched squaring on a second stream beside the base extension - measured slower in
  * the two-context batch, profiles/r06_square_overlap.txt).
  * "gemm_order" = 1 (default): slice-major workgroup order of the VALU scalar GEMM (every input slice fetched once per XCD), 0 = group-major.
