@@ -614,7 +614,8 @@ def main():
             # channel runs beside the HBM-bound layers of the other, which fit into the registers and issue slots it leaves free.
             for i, ch in enumerate(chans):
                 ch.front()
-                chans[(i + 1) % len(chans)].g.wait_for(ch.g)          # the next channel('s next batch) starts where this one's key switch starts
+                if not os.environ.get("BENCH_STAGGER_NOWAIT"):        # (A/B: the two halves without the device-side ordering)
+                    chans[(i + 1) % len(chans)].g.wait_for(ch.g)      # the next channel('s next batch) starts where this one's key switch starts
                 ch.back()
             return
         for ch in chans:

@@ -162,39 +162,78 @@ int flush_elementwise_group(cn_ctx *ctx, const std::vector<const DOp *> &ops, in
     HIPCHK(hipGetLastError()); launch_count(ctx);
     return 0;
 }
-// Staggered plaintext-prime channels for the UNCHANGED caller (round 6; MEASURED WITHOUT A GAIN AND OFF BY DEFAULT - cn_set_option("defer_stagger", 1), profiles/r06_stagger_ab.txt).  The reference runs the same layer on every plaintext prime from the same caller threads
-// (EncryptedSealBfvVector.cs:225-236), so the contexts of a device flush their big squaring layers within microseconds of each other and their kernel chains run in
-// lock step - key switch beside key switch (both FP64-issue bound), element-wise BEHZ steps beside each other (both HBM bound).  The batched bench staggers its two
-// channels by half a batch with cn_ctx_wait_for (12.4 against 13.0 ms per batch, profiles/r06_stagger_ab.txt); here the library does it by itself: the Multiply part
-// ("front") of a big group waits - on the device, no host wait - for the front of the context that flushed such a group LAST on this device, so it runs beside that
-// context's key switch.  Only the most recent front event of an OLDER context (created earlier: the device's first context never waits) is waited for - with symmetric waits a
-// context that led one batch and flushes second in the next would wait for the trailing context's front, i.e. for work ~2.5 ms behind its own stream: half of the batches paid for
-// a leader swap and the mean gain was nil (profiles/r06_stagger_ab.txt, visit K).  A front event of a batch long gone is complete and costs nothing.  With the fixed leader the
-// literal caller measured 14.27-14.73 ms per batch against 13.81-14.31 without any stagger (three alternating pairs): the flushes of the two contexts do not line up the way the
-// batched program's two halves do (the convolution, dense and second squaring layers are flushed on their own), and a delayed front is then simply a delayed front.
+// Staggered plaintext-prime channels for the UNCHANGED caller (round 6, `defer_stagger`; THREE FORMS MEASURED, NONE WITH A GAIN - OFF BY DEFAULT, profiles/r06_stagger_ab.txt).  The reference runs the same layer on every plaintext prime from the same caller threads
+// (EncryptedSealBfvVector.cs:225-236), so the two contexts of a CryptoNets device flush their big squaring layers within microseconds of each other and their kernel chains run in
+// lock step - key switch beside key switch (both FP64-issue bound), element-wise BEHZ steps beside each other (both HBM bound).  The batched bench alternates the two channels'
+// "fronts" (convolution + Multiply) with cn_ctx_wait_for, so that a front always runs beside the OTHER channel's key switch: 12.0-12.2 against 12.7-12.9 ms per batch, and it is the
+// device-side ordering that does it, not the split into two calls (profiles/r06_stagger_ab.txt, visit N).  Here the library does the same for queued squaring groups of >= 256
+// ciphertexts when exactly two contexts of a device take part: front #k of the first context (A) waits for front #(k-1) of the second (B), B's #k for A's #k - device-side events,
+// strict alternation A0 B0 A1 B1 ... whatever order the host flushes them in.  When the partner has not ENQUEUED the front that is waited for yet (the two flushes are triggered
+// microseconds apart by different threads), the flushing thread waits for it on the host, at most STAGGER_HOST_WAIT_US - a partner that never comes is skipped, counts that drift
+// apart re-pair.  Two earlier forms measured no gain and are gone: waiting for whoever flushed last (a leader swap stalls the leader for the trailing context's front), and a fixed
+// leader without the host wait (B's flush often precedes A's: no stagger, or a delayed front that is just a delay).  This third form engages (14 device-side waits in 16 fronts,
+// one host wait ran out) and still measures 14.1-14.8 against 13.9 ms per batch (taps skipped, 16 threads, three alternating pairs): what the batched program gains from the same
+// alternation does not carry over to the flush pattern of the unchanged caller (its convolution, dense and second squaring layers are flushed on their own, ahead of the fronts).
 namespace {
-struct FrontSlot { cn_ctx *owner = nullptr; hipEvent_t ev = nullptr; uint64_t uid = 0; };
+struct StaggerPair {
+    cn_ctx *c[2] = {nullptr, nullptr}; uint64_t n[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr};
+    bool off = false;                 // more than two contexts stagger on this device: nobody waits
+    uint64_t waits = 0, timeouts = 0, ahead = 0, first = 0;      // CN_DEFER_TRACE: device-side waits placed / host waits that ran out / partner ahead / nothing to wait for
+};
 std::mutex g_front_mu;
-FrontSlot g_front[64];               // per device: who recorded the latest front event
+StaggerPair g_pair[64];              // per device
 }
 static const uint32_t STAGGER_MIN_CTS = 256;
-void cn_stagger_forget(cn_ctx *ctx) {             // a context that goes away takes its event with it
+static const int STAGGER_HOST_WAIT_US = 400;
+void cn_stagger_forget(cn_ctx *ctx) {             // a context that goes away takes its events with it: the pairing of its device starts over
     std::lock_guard<std::mutex> lk(g_front_mu);
-    FrontSlot &f = g_front[(unsigned)ctx->device % 64];
-    if (f.owner == ctx) f = FrontSlot();
+    StaggerPair &p = g_pair[(unsigned)ctx->device % 64];
+    if (p.c[0] == ctx || p.c[1] == ctx) {
+        if (getenv("CN_DEFER_TRACE") && (p.waits || p.timeouts)) fprintf(stderr, "stagger device %d: %llu device-side waits, %llu host waits ran out, %llu partner ahead, %llu first, fronts %llu / %llu\n",
+            ctx->device, (unsigned long long)p.waits, (unsigned long long)p.timeouts, (unsigned long long)p.ahead, (unsigned long long)p.first, (unsigned long long)p.n[0], (unsigned long long)p.n[1]);
+        p = StaggerPair();
+    }
+}
+static int stagger_slot(StaggerPair &p, cn_ctx *ctx) {      // (mutex held) 0 / 1, or -1: not a participant
+    if (p.off) return -1;
+    for (int i = 0; i < 2; i++) if (p.c[i] == ctx) return i;
+    for (int i = 0; i < 2; i++) if (!p.c[i]) {        // a late joiner lines up with its partner's latest front: A's #k follows B's #(k-1), B's #k follows A's #k
+        p.c[i] = ctx;
+        p.n[i] = i == 0 ? p.n[1] : (p.n[0] ? p.n[0] - 1 : 0);
+        return i;
+    }
+    p.off = true;
+    return -1;
 }
 static int stagger_front_begin(cn_ctx *ctx) {
-    std::lock_guard<std::mutex> lk(g_front_mu);
-    const FrontSlot &f = g_front[(unsigned)ctx->device % 64];
-    if (f.owner && f.owner != ctx && f.ev && f.uid < ctx->uid) HIPCHK(hipStreamWaitEvent(ctx->stream, f.ev, 0));
-    return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(g_front_mu);
+            StaggerPair &p = g_pair[(unsigned)ctx->device % 64];
+            const int i = stagger_slot(p, ctx);
+            if (i < 0 || !p.c[1 - i]) return 0;
+            const uint64_t k = p.n[i], need = i == 0 ? k : k + 1, have = p.n[1 - i];       // A's #k follows B's #(k-1): B has recorded k fronts; B's #k follows A's #k: A has recorded k + 1
+            if (need == 0) { p.first++; return 0; }
+            if (have == need) { if (p.ev[1 - i]) HIPCHK(hipStreamWaitEvent(ctx->stream, p.ev[1 - i], 0)); p.waits++; return 0; }
+            if (have > need) { p.ahead++; if (have > need + 2) { p.n[0] = p.n[1] = 0; } return 0; }   // the partner is ahead: nothing to wait for (far ahead: the counts drifted - re-pair)
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > STAGGER_HOST_WAIT_US) { p.timeouts++; return 0; }
+        }
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 4 * STAGGER_HOST_WAIT_US) return 0;
+        std::this_thread::yield();                // the partner's flush is microseconds away (another thread, the other context's lock)
+    }
 }
 static int stagger_front_end(cn_ctx *ctx) {
     if (!ctx->ev_front) HIPCHK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     std::lock_guard<std::mutex> lk(g_front_mu);
+    StaggerPair &p = g_pair[(unsigned)ctx->device % 64];
+    const int i = stagger_slot(p, ctx);
+    if (i < 0) return 0;
     HIPCHK(hipEventRecord(ctx->ev_front, ctx->stream));
-    FrontSlot &f = g_front[(unsigned)ctx->device % 64];
-    if (!f.owner || f.owner == ctx || ctx->uid <= f.uid) f = FrontSlot{ctx, ctx->ev_front, ctx->uid};       // the slot belongs to the oldest context that staggers on this device
+    p.ev[i] = ctx->ev_front; p.n[i]++;
+    static const bool trace = getenv("CN_DEFER_TRACE") != nullptr;
+    if (trace && i == 1 && p.n[i] % 4 == 0) fprintf(stderr, "stagger device %d: fronts %llu / %llu, %llu device-side waits, %llu host waits ran out, %llu partner ahead, %llu first\n", ctx->device,
+        (unsigned long long)p.n[0], (unsigned long long)p.n[1], (unsigned long long)p.waits, (unsigned long long)p.timeouts, (unsigned long long)p.ahead, (unsigned long long)p.first);
     return 0;
 }
 // all queued Multiply + Relinearize calls of one level: the batched BEHZ pipeline + ONE key switch, operands and results through tables

@@ -95,6 +95,40 @@ def test_broadcast_keys_carry_the_key_switch_convention(rng):
 
 
 @pytest.mark.gpu
+def test_broadcast_drops_a_replicas_keys_of_the_other_convention(rng):
+    """a replica that adopts the root's key-switch convention must not keep keys it generated / received under the other one - a Galois key the
+    broadcast does not overwrite would keep returning rc 0 and garbage.  The root holds the relinearisation key and ONE Galois key (convention 1); the replica
+    holds a full key set of convention 0: after the broadcast the replica rotates with the root's element and refuses every other one (no key)."""
+    from cryptonets_amd import _native
+    from oracle.cno import Oracle
+    p = PARAMS["tiny"]
+    o1 = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"], ks_xi=True)
+    o1.keygen(41, galois=True)
+    o0 = Oracle(p["n"], p["t"], q=p["q"], dbc=p["dbc"], gdbc=p["gdbc"])
+    o0.keygen(43, galois=True)
+    root, replica = _ctx("tiny"), _ctx("tiny")
+    root.set_option("ks_xi", 1)
+    root.set_relin_key(o1.relin_key())
+    elts = list(o1.galois_elts())
+    root.set_galois_key(elts[1], o1.galois_key(1))                 # one element only
+    replica.set_relin_key(o0.relin_key())
+    for i, e in enumerate(o0.galois_elts()):
+        replica.set_galois_key(e, o0.galois_key(i))
+    assert replica.has_galois_key(elts[2])
+    _native.broadcast_keys([root, replica])
+    assert replica.get_option("ks_xi") == 1
+    assert replica.has_galois_key(elts[1]) and not replica.has_galois_key(elts[2]) and not replica.has_galois_key(elts[0])
+    ct = o1.encrypt(o1.encode(rng.integers(0, 50, size=o1.n, dtype=np.uint64)))
+    h, out = replica.ct_alloc(1), replica.ct_alloc(1)
+    replica.ct_upload(h, 0, ct[None, :])
+    replica.apply_galois(h, 0, elts[1], out, 0, 1)
+    assert np.array_equal(replica.ct_download(out, 0, 1)[0], o1.apply_galois(ct, elts[1]))
+    with pytest.raises(_native.CnError):
+        replica.apply_galois(h, 0, elts[2], out, 0, 1)
+    root.close(), replica.close()
+
+
+@pytest.mark.gpu
 def test_broadcast_keys_argument_errors():
     from cryptonets_amd import _native
     a, b = _ctx("tiny"), _ctx("default4096")
