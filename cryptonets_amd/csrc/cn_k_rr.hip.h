@@ -582,25 +582,23 @@ __global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_encrypt_split(const int8_
 // output the scalar product (and its folded bias) wrote in the launch before.  tests/test_deferred.py: words identical with the fold switched off.
 // (FoldOut / FoldTerm: cn_runtime.h)
 template <int L, class AR>
-__global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fold(const int8_t *__restrict__ us, const uint64_t *__restrict__ pk, const DevConsts *__restrict__ C,
-                                                                 const int8_t *__restrict__ noise, const FoldOut *__restrict__ fout, const FoldTerm *__restrict__ terms) {
+__global__ void __launch_bounds__(NttPlan<L>::NT, 4) k_encrypt_fold(const int8_t *__restrict__ us, const uint64_t *__restrict__ pk, const DevConsts *__restrict__ C,
+                                                                    const int8_t *__restrict__ noise, const FoldOut *__restrict__ fout, const FoldTerm *__restrict__ terms) {
+    // block = (folded output, component p, limb j) since the closing visit of round 6: like k_encrypt_split every block forms and transforms U itself, nothing survives the inverse
+    // transform, 128 VGPRs, two workgroups per CU (one block for both components: 232 VGPRs, 468 us per 125 outputs beside the other prime's kernels)
     typedef typename AR::T T;
     static_assert(std::is_same<T, double>::value, "FP64 policies only");
     extern __shared__ __align__(16) unsigned char smem[];
     T *s = reinterpret_cast<T *>(smem);
     constexpr uint32_t n = 1u << L;
     constexpr int SA = NttPlan<L>::SA;
-    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, ct = blockIdx.x / k;
+    const uint32_t k = C->k, tid = threadIdx.x, j = blockIdx.x % k, p = (blockIdx.x / k) & 1, ct = blockIdx.x / (2 * k);
     const ArCtx<AR> A(C, j);
     const TensorOps<AR> ops(C, j);
-    const uint64_t q = C->q[j].q;
     const FoldOut fo = fout[ct];
     const FoldTerm *tt = terms + fo.first;
-    T U[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) U[r] = 0.0;
     // (three terms' byte loads in flight at a time: a term is 16 dependent-free one-byte loads and one round trip; a border output of the 5x5 stride-2 convolution has 5 or 9)
-    auto accumulate = [&](T (&X)[16], const int8_t *base, size_t pitch, size_t off, uint32_t tl) {
+    auto accumulate = [&](T (&X)[16], const int8_t *base, size_t pitch, size_t off) {
         uint32_t t = 0;
 #pragma unroll 1
         for (; t + 3 <= fo.count; t += 3) {
@@ -609,7 +607,7 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fold(const int8_t *_
             for (int c = 0; c < 3; c++) {
                 const int8_t *pp = base + (size_t)tt[t + c].enc * pitch + off;
 #pragma unroll
-                for (int r = 0; r < 16; r++) b[c][r] = pp[pass_index<L, SA, 0>(tl, r)];
+                for (int r = 0; r < 16; r++) b[c][r] = pp[pass_index<L, SA, 0>(tid, r)];
             }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -623,36 +621,34 @@ __global__ void __launch_bounds__(NttPlan<L>::NT) k_encrypt_fold(const int8_t *_
             const double w = tt[t].w;
             const int8_t *pp = base + (size_t)tt[t].enc * pitch + off;
 #pragma unroll
-            for (int r = 0; r < 16; r++) X[r] = __fma_rn(w, (double)(int32_t)pp[pass_index<L, SA, 0>(tl, r)], X[r]);
+            for (int r = 0; r < 16; r++) X[r] = __fma_rn(w, (double)(int32_t)pp[pass_index<L, SA, 0>(tid, r)], X[r]);
         }
     };
-    accumulate(U, us, n, 0, tid);
-    AR::renorm(U, A.m);                                                       // |U| <= q/2: a transform input
-    ntt_forward_regs<AR, L>(U, s, A.fw, A.m, tid);
-    AR::renorm(U, A.m);
-#pragma unroll 1
-    for (int p = 0; p < 2; p++) {
-        uint32_t tl = tid;
-        asm volatile("" : "+v"(tl));
-        const uint64_t *pp = pk + ((size_t)p * k + j) * n;
-        T v[16];
+    T v[16];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(pp + tail_index<L>(tl, r));
-            v[r] = ops.mul(U[r], A.load(y.x), A); v[r + 1] = ops.mul(U[r + 1], A.load(y.y), A);
-        }
-        if (p || !ntt_tail_local<L>()) __syncthreads();
-        ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tl);
-        T E[16];
+    for (int r = 0; r < 16; r++) v[r] = 0.0;
+    accumulate(v, us, n, 0);
+    AR::renorm(v, A.m);                                                       // |U| <= q/2: a transform input
+    ntt_forward_regs<AR, L>(v, s, A.fw, A.m, tid);
+    AR::renorm(v, A.m);
+    const uint64_t *pp = pk + ((size_t)p * k + j) * n;
 #pragma unroll
-        for (int r = 0; r < 16; r++) E[r] = 0.0;
-        accumulate(E, noise, (size_t)2 * n, (size_t)p * n, tl);
-        NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)fo.out + ((size_t)p * k + j) * n;
+    for (int r = 0; r < 16; r += 2) {
+        const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(pp + tail_index<L>(tid, r));
+        v[r] = ops.mul(v[r], A.load(y.x), A); v[r + 1] = ops.mul(v[r + 1], A.load(y.y), A);
+    }
+    if (!ntt_tail_local<L>()) __syncthreads();
+    ntt_inverse_regs<AR, L>(v, s, A.iv, A.m, tid);
+    T E[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint32_t e = pass_index<L, SA, 0>(tl, r);
-            uint64_t val = addmod(A.scaled(v[r]), A.canon(E[r]), q);
-            o[e] = addmod(val, o[e], q);
-        }
+    for (int r = 0; r < 16; r++) E[r] = 0.0;
+    accumulate(E, noise, (size_t)2 * n, (size_t)p * n);
+    NTT_GLOBAL uint64_t *o = (NTT_GLOBAL uint64_t *)fo.out + ((size_t)p * k + j) * n;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t e = pass_index<L, SA, 0>(tid, r);
+        // v N^-1 + E + the word the scalar product wrote: exact doubles (|E| < 2^47, the word < q), one canonicalisation
+        const double x = __dadd_rn(__dadd_rn(AR::mulmod(v[r], A.ni, A.m), AR::center(E[r], A.m)), AR::from_u64(o[e]));
+        o[e] = AR::to_u64(x, A.m);
     }
 }

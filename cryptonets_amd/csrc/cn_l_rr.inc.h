@@ -122,7 +122,7 @@ static bool enc_fused(cn_ctx *c, const int8_t *us, const uint64_t *pt, uint32_t 
 // weighted sums of fresh zero encryptions folded onto scalar-product outputs (k_encrypt_fold; FP64 policies, N <= 8192)
 template <int L> static void l_enc_fold(cn_ctx *c, const int8_t *us, const int8_t *noise, const void *fout, const void *terms, uint32_t outputs) {
     if constexpr (L <= 13 && kF64)
-        hipLaunchKernelGGL((k_encrypt_fold<L, AR>), dim3(outputs * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, c->dc, noise,
+        hipLaunchKernelGGL((k_encrypt_fold<L, AR>), dim3(outputs * 2 * c->hc.k), dim3(NttPlan<L>::NT), (size_t)ntt_lds_words(1u << L) * 8, c->stream, us, c->pk, c->dc, noise,
                            (const FoldOut *)fout, (const FoldTerm *)terms);
 }
 static bool enc_fold(cn_ctx *c, const int8_t *us, const int8_t *noise, const void *fout, const void *terms, uint32_t outputs) {
