@@ -293,6 +293,11 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_split14(const uin
 #ifndef KS14_DBG
 #define KS14_DBG 0          // timing experiments (tools/build_ks14_dbg.py; results are wrong with any bit set): 1 no c0 staging, 2 no accumulator, 4 no stash,
 #endif                      // 8 no closing arithmetic, 16 synthetic digit sources (no loads), 32 synthetic keys (no loads)
+#ifndef KS14_NT
+#define KS14_NT 0           // non-temporal hints of the closing step (A/B, tools/build_ks14_nt.py): 1 result stores, 2 addend / accumulator loads, 4 the parked half (store + load), 8 the next link's c1
+#endif
+template <class P, class V> NTT_DEV void ks14_store(P *p, V v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+template <class P> NTT_DEV auto ks14_load(const P *p, bool nt) -> typename std::remove_cv<P>::type { return nt ? __builtin_nontemporal_load(p) : *p; }
 #ifndef KS14_PREFETCH
 #define KS14_PREFETCH 1     // 0: every digit loads its source words at its start (A/B)
 #endif
@@ -424,7 +429,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
             double *st = stp + (size_t)p * n2;
             if (h == 0) {                                              // parked: |u| <= q/2, this thread reads it back
 #pragma unroll
-                for (int r = 0; r < 16; r++) if (!(KS14_DBG & 4)) st[pass_index<L, SA, 0>(tl, r)] = AR::center(v[r], A.m);
+                for (int r = 0; r < 16; r++) if (!(KS14_DBG & 4)) ks14_store(&st[pass_index<L, SA, 0>(tl, r)], AR::center(v[r], A.m), (KS14_NT & 4) != 0);
                 __syncthreads();
                 continue;
             }
@@ -453,17 +458,17 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 double u[8], alo[8], ahi[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { u[r] = (KS14_DBG & 4) ? v[(r0 + r) ^ 1] : st[pass_index<L, SA, 0>(tl, r0 + r)]; alo[r] = 0; ahi[r] = 0; }
+                for (int r = 0; r < 8; r++) { u[r] = (KS14_DBG & 4) ? v[(r0 + r) ^ 1] : ks14_load(&st[pass_index<L, SA, 0>(tl, r0 + r)], (KS14_NT & 4) != 0); alo[r] = 0; ahi[r] = 0; }
                 if (ex) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = AR::from_u64(ex[e]); ahi[r] = AR::from_u64(ex[e + n2]); }
+                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = AR::from_u64(ks14_load(&ex[e], (KS14_NT & 2) != 0)); ahi[r] = AR::from_u64(ks14_load(&ex[e + n2], (KS14_NT & 2) != 0)); }
                 }
                 if (staged) {
 #pragma unroll
                     for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = __dadd_rn(alo[r], AR::from_u64(win[e])); ahi[r] = __dadd_rn(ahi[r], AR::from_u64(win[e + n2])); }
                 } else if (ad) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = __dadd_rn(alo[r], AR::from_u64(ad[e])); ahi[r] = __dadd_rn(ahi[r], AR::from_u64(ad[e + n2])); }
+                    for (int r = 0; r < 8; r++) { const uint32_t e = pass_index<L, SA, 0>(tl, r0 + r); alo[r] = __dadd_rn(alo[r], AR::from_u64(ks14_load(&ad[e], (KS14_NT & 2) != 0))); ahi[r] = __dadd_rn(ahi[r], AR::from_u64(ks14_load(&ad[e + n2], (KS14_NT & 2) != 0))); }
                 }
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
@@ -471,7 +476,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
                     const double w = AR::center(v[r0 + r], A.m);
                     uint64_t lo = AR::to_u64(__dadd_rn(AR::mulmod(__dadd_rn(u[r], w), ni, A.m), alo[r]), A.m), hi = AR::to_u64(__dadd_rn(AR::mulmod(__dadd_rn(u[r], -w), niw, A.m), ahi[r]), A.m);
                     if (KS14_DBG & 8) { lo = (uint64_t)__double_as_longlong(u[r]); hi = (uint64_t)__double_as_longlong(v[r0 + r]); }
-                    o[e] = lo; o[e + n2] = hi;
+                    ks14_store(&o[e], lo, (KS14_NT & 1) != 0); ks14_store(&o[e + n2], hi, (KS14_NT & 1) != 0);
                     if (chain) {                                       // the new c1 limb once more, permuted for the next link of the chain
                         const uint32_t pl = (e * next_elt) & (2 * n - 1), ph = ((e + n2) * next_elt) & (2 * n - 1);
                         win[pl & (n - 1)] = (pl >> (L + 1)) ? negmod(lo, qm.q) : lo;
@@ -483,7 +488,7 @@ __global__ void __launch_bounds__(NttPlan<13>::NT) k_keyswitch_pair14(const uint
             if (chain) {
                 NTT_GLOBAL uint64_t *no = (NTT_GLOBAL uint64_t *)next_out + (size_t)ct * kn + (size_t)j * n;
 #pragma unroll 8
-                for (int r = 0; r < 32; r++) no[tl + NT * (uint32_t)r] = win[tl + NT * (uint32_t)r];
+                for (int r = 0; r < 32; r++) ks14_store(&no[tl + NT * (uint32_t)r], win[tl + NT * (uint32_t)r], (KS14_NT & 8) != 0);
             }
         }
     }

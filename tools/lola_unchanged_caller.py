@@ -31,7 +31,8 @@ def _apply_chain(layers, enc):
     return m
 
 
-def measure(name="LoLa", reps=20, device=0, image_seed=1234):
+def measure(name="LoLa", reps=20, device=0, image_seed=1234, only=None):
+    """only = "batched" | "literal": just that call pattern, replayed from free-running C++ threads (for a kernel trace of one pattern: tools/gpu_r06_q.sh)"""
     import call_trace
     from cryptonets_amd import cryptonets_mnist as cm, hewrapper, networks
     from cryptonets_amd.distributed import crt_join_over_ranks
@@ -84,19 +85,21 @@ def measure(name="LoLa", reps=20, device=0, image_seed=1234):
 
     rows = []
     for literal in (False, True):
+        if only and (only == "literal") != literal:
+            continue
         hewrapper.set_literal(literal)
         try:
             for _ in range(2):                                     # warm: masks / plaintext forms cached, arenas sized, pool filled
                 _apply_chain(layers, fresh()).Dispose()
             sync()
-            encs = [fresh() for _ in range(reps)]
+            encs = [fresh() for _ in range(2 if only else reps)]
             sync()
             t0 = time.perf_counter()
             outs = []
             for e in encs:
                 outs.append(_apply_chain(layers, e))
                 sync()
-            py_ms = 1e3 * (time.perf_counter() - t0) / reps
+            py_ms = 1e3 * (time.perf_counter() - t0) / len(encs)
             ok = True
             for o in outs[-2:]:
                 col, firsts, count, sparse = result_of(o)
@@ -119,13 +122,15 @@ def measure(name="LoLa", reps=20, device=0, image_seed=1234):
             assert all(rid[0] == "new" for rid in rids), rids
             calls = [len(r.records) for r in recs]
             out.Dispose()
-            for defer in ((0, 1) if literal else (0,)):
+            for defer in ((1,) if only and literal else (0, 1) if literal else (0,)):
                 # defer = 1: libcnhip's deferred submission (what the C# twin switches on): the per-row calls are queued and merged level by level
                 for c in ctxs:
                     c.set_option("defer", defer)
                 try:
                     for mode, host in ((0, "C++ replay, one host thread, contexts call by call"), (1, "C++ replay, one thread per plaintext prime, joined after every call"),
                                        (2, "C++ replay, one free-running thread per plaintext prime")):
+                        if only and mode != 2:
+                            continue
                         l0 = sum(c.stats()["kernel_launches"] for c in ctxs)
                         ms, handles = call_trace.replay(recs, reps, mode, rids, warmup=2)
                         launches = (sum(c.stats()["kernel_launches"] for c in ctxs) - l0) / (reps + 2) / len(ctxs)
@@ -146,6 +151,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("network", nargs="?", default="LoLa")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", choices=["batched", "literal"], default=None, help="one call pattern only, replayed from free-running C++ threads (kernel traces)")
     a = ap.parse_args()
-    for r in measure(a.network, a.reps):
+    for r in measure(a.network, a.reps, only=a.only):
         print(json.dumps(r))
