@@ -99,19 +99,49 @@ __global__ void k_add_plain_tab(const Tab3 *__restrict__ tab, const DevConsts *_
 
 // all queued DenseMatrixBySparseVectorMultiply calls of one level with K terms each: ONE scalar GEMM over address tables
 int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> &ops, uint32_t K) {
-    // group the outputs that gather the same inputs (PoolLayer: every map of one corner shares its patch; a dense layer: one group)
-    std::map<std::vector<uint64_t>, std::vector<const DOp *>> groups;
-    for (const DOp *op : ops) groups[std::vector<uint64_t>(q->addr.begin() + op->terms, q->addr.begin() + op->terms + K)].push_back(op);
-    const uint32_t G = (uint32_t)groups.size();
-    uint32_t M = 0;
-    for (auto &g : groups) M = std::max<uint32_t>(M, (uint32_t)g.second.size());
+    const uint32_t O = (uint32_t)ops.size();
     bool wsmall = true;
     for (const DOp *op : ops) wsmall = wsmall && gemm_weights_small(ctx, &q->wt[op->terms], K);
     const GemmArith ar = gemm_arith(ctx, wsmall);
+    // the calls' lists, contiguous: A[o][kk] = address of term kk of output o (0 = padded tap), Wt[o][kk] its weight
+    std::vector<uint64_t> A((size_t)O * K), Wt((size_t)O * K);
+    for (uint32_t o = 0; o < O; o++) {
+        memcpy(&A[(size_t)o * K], &q->addr[ops[o]->terms], (size_t)K * 8);
+        memcpy(&Wt[(size_t)o * K], &q->wt[ops[o]->terms], (size_t)K * 8);
+    }
+    // Windows that share at least half of their inputs are merged in pairs, like cn_gemm_plan_create does for the batched path (pair_gather_lists: every shared input then
+    // travels from L2 to a CU once - the CryptoNets convolution 371 -> 299 us).  Round 5 measured this inside the flush as a LOSS (16.1-17.7 against 15.1-15.5 ms per batch: the
+    // pairing ran on the flushing thread under the lock every caller waited for).  Round 6, with the flush off the callers' path (lock-free submission): still no gain - literal
+    // caller 14.4-14.6 against 14.0-14.2 ms per batch, taps skipped 13.6-13.8 against 13.5-13.7 (three alternating pairs, profiles/r06_defer_pair_ab.txt): the address-table kernel does
+    // not profit from the 35-entry union the way the index-table kernel of a plan does.  OFF unless CN_DEFER_PAIR=1.
+    static const bool pair_on = getenv("CN_DEFER_PAIR") && atoi(getenv("CN_DEFER_PAIR"));
+    if (pair_on && ctx->gemm_pair && ar.small && K <= 64 && O >= 2) {
+        std::unordered_map<uint64_t, int32_t> id_of; std::vector<uint64_t> addr_of;
+        std::vector<int32_t> gidx((size_t)O * K);
+        for (size_t x = 0; x < A.size(); x++) {
+            if (!A[x]) { gidx[x] = -1; continue; }
+            auto it = id_of.find(A[x]);
+            if (it == id_of.end()) { it = id_of.emplace(A[x], (int32_t)addr_of.size()).first; addr_of.push_back(A[x]); }
+            gidx[x] = it->second;
+        }
+        std::vector<uint64_t> W2; uint32_t K2 = K;
+        if (pair_gather_lists(O, K2, gidx, Wt.data(), W2)) {
+            K = K2; Wt.swap(W2);
+            A.assign((size_t)O * K, 0);
+            for (size_t x = 0; x < A.size(); x++) if (gidx[x] >= 0) A[x] = addr_of[gidx[x]];
+        }
+    }
+    // group the outputs that gather the same inputs (PoolLayer: every map of one corner shares its patch; a dense layer: one group)
+    std::map<std::vector<uint64_t>, std::vector<uint32_t>> groups;
+    for (uint32_t o = 0; o < O; o++) groups[std::vector<uint64_t>(A.begin() + (size_t)o * K, A.begin() + (size_t)(o + 1) * K)].push_back(o);
+    const uint32_t G = (uint32_t)groups.size();
+    uint32_t M = 0;
+    for (auto &g : groups) M = std::max<uint32_t>(M, (uint32_t)g.second.size());
     const bool mfma = gemm_mfma_ok(ctx, ar, M, K);
     const uint32_t Kp = mfma ? ((K + 31) / 32) * 32 : ((K + 15) & ~15u) + 16;       // gather rows: 16 spare entries (the VALU kernels request up to 2 x 8 terms ahead)
+    const uint32_t NONE = 0xffffffffu;
     std::vector<uint64_t> hidx((size_t)G * Kp, 0), hoidx((size_t)G * M, 0), hbidx((size_t)G * M, 0);
-    std::vector<const DOp *> member((size_t)G * M, nullptr);
+    std::vector<uint32_t> member((size_t)G * M, NONE);
     bool any_bias = false;
     const uint64_t *fallback = nullptr;
     {
@@ -119,8 +149,8 @@ int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
         for (auto &kv : groups) {
             memcpy(&hidx[(size_t)g * Kp], kv.first.data(), (size_t)K * 8);
             for (uint32_t m = 0; m < kv.second.size(); m++) {
-                const DOp *op = kv.second[m];
-                member[(size_t)g * M + m] = op; hoidx[(size_t)g * M + m] = (uint64_t)op->out; hbidx[(size_t)g * M + m] = (uint64_t)op->bias;
+                const DOp *op = ops[kv.second[m]];
+                member[(size_t)g * M + m] = kv.second[m]; hoidx[(size_t)g * M + m] = (uint64_t)op->out; hbidx[(size_t)g * M + m] = (uint64_t)op->bias;
                 any_bias = any_bias || op->bias;
             }
             for (uint64_t a : kv.first) if (a && !fallback) fallback = (const uint64_t *)a;
@@ -130,9 +160,9 @@ int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
     const bool small = ar.small, two = ar.two; const uint32_t lazy = ar.lazy; uint32_t MT = 1, WP = 0;
     bool one = false;
     std::vector<char> wbytes;
-    auto row = [&](uint32_t g, uint32_t m) -> const uint64_t * { const DOp *op = member[(size_t)g * M + m]; return op ? &q->wt[op->terms] : nullptr; };
+    auto row = [&](uint32_t g, uint32_t m) -> const uint64_t * { const uint32_t o = member[(size_t)g * M + m]; return o == NONE ? nullptr : &Wt[(size_t)o * K]; };
     if (mfma) {
-        for (const DOp *op : ops) WP = std::max(WP, gemm_weight_planes(ctx, &q->wt[op->terms], K));
+        WP = gemm_weight_planes(ctx, Wt.data(), Wt.size());
         pack_gemm_mfma(ctx, G, M, K, WP, row, [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; }, wbytes);
     } else {
         auto tap = [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; };
