@@ -869,7 +869,8 @@ def main():
                "launcher": os.environ.get("BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"), "process_group": "nccl" if dist is not None else None,
                "config": {"workload": "CryptoNets-MNIST 5-layer (conv 5x5 s2 x5 maps, square, dense 845->100, square, dense 100->10), "
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
-                                      "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; weights: " + args.weights,
+                                      "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; batched program with the zero-weighted padded "
+                                      "convolution taps elided (the reference's literal call sequence: literal_call_sequence); weights: " + args.weights,
                           "padded_taps": "elided",     # the batched program of `value` skips the 645 x 2 zero-weighted padded convolution taps per batch the reference encrypts and
                                                        # multiplies inside its timed window (PoolLayer.cs:67-80); `literal_call_sequence` / `unchanged_caller` = the reference's literal sequence
                           "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world,
