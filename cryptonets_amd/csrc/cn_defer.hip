@@ -111,9 +111,9 @@ int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
     }
     // Windows that share at least half of their inputs are merged in pairs, like cn_gemm_plan_create does for the batched path (pair_gather_lists: every shared input then
     // travels from L2 to a CU once - the CryptoNets convolution 371 -> 299 us).  Round 5 measured this inside the flush as a LOSS (16.1-17.7 against 15.1-15.5 ms per batch: the
-    // pairing ran on the flushing thread under the lock every caller waited for).  Round 6, with the flush off the callers' path (lock-free submission): still no gain - literal
-    // caller 14.4-14.6 against 14.0-14.2 ms per batch, taps skipped 13.6-13.8 against 13.5-13.7 (three alternating pairs, profiles/r06_defer_pair_ab.txt): the address-table kernel does
-    // not profit from the 35-entry union the way the index-table kernel of a plan does.  OFF unless CN_DEFER_PAIR=1.
+    // pairing ran on the flushing thread under the lock every caller waited for).  Round 6, with the flush off the callers' path and index tables (below): alone on the device the paired
+    // convolution is as fast as a plan's (310 against 500 us unpaired), end to end nothing moves and the pairing's host time sits at the head of a batch (profiles/r06_defer_pair_ab.txt).
+    // OFF unless CN_DEFER_PAIR=1.
     static const bool pair_on = getenv("CN_DEFER_PAIR") && atoi(getenv("CN_DEFER_PAIR"));
     if (pair_on && ctx->gemm_pair && ar.small && K <= 64 && O >= 2) {
         std::unordered_map<uint64_t, int32_t> id_of; std::vector<uint64_t> addr_of;
@@ -142,7 +142,7 @@ int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
     const uint32_t NONE = 0xffffffffu;
     std::vector<uint64_t> hidx((size_t)G * Kp, 0), hoidx((size_t)G * M, 0), hbidx((size_t)G * M, 0);
     std::vector<uint32_t> member((size_t)G * M, NONE);
-    bool any_bias = false;
+    bool any_bias = false, all_bias = true;
     const uint64_t *fallback = nullptr;
     {
         uint32_t g = 0;
@@ -151,7 +151,7 @@ int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
             for (uint32_t m = 0; m < kv.second.size(); m++) {
                 const DOp *op = ops[kv.second[m]];
                 member[(size_t)g * M + m] = kv.second[m]; hoidx[(size_t)g * M + m] = (uint64_t)op->out; hbidx[(size_t)g * M + m] = (uint64_t)op->bias;
-                any_bias = any_bias || op->bias;
+                any_bias = any_bias || op->bias; all_bias = all_bias && op->bias;
             }
             for (uint64_t a : kv.first) if (a && !fallback) fallback = (const uint64_t *)a;
             g++;
@@ -168,6 +168,41 @@ int flush_gemm_group(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
         auto tap = [&](uint32_t g, uint32_t kk) { return hidx[(size_t)g * Kp + kk] != 0; };
         pack_gemm_weights(ctx, G, M, K, small, row, tap, MT, wbytes);
         one = gemm_one_limb(ctx, ar, G, M, K, row, tap);
+    }
+    // Index tables instead of address tables (round 6).  Every array the library hands out starts on a 256-byte boundary, so the operands of a flush group are 32-bit offsets in units
+    // of 32 words from the lowest address among them - the INDEX-table kernels of a plan (one 16-byte scalar load per four gather entries, offsets multiplied on the scalar unit)
+    // instead of the address-table variants (two loads per four, a 64-bit select per term): dense layer 242 -> 221 us alone on the device, convolution 506 -> 492
+    // (310 with CN_DEFER_PAIR=1; profiles/r06_defer_pair_ab.txt); end to end neutral.  Needs a bias on every output or on none; CN_DEFER_REL=0 keeps the address tables (A/B).
+    static const bool rel_on = !(getenv("CN_DEFER_REL") && !atoi(getenv("CN_DEFER_REL")));
+    uint64_t ibase = ~0ull, obase_a = ~0ull, bbase = ~0ull;
+    bool rel = rel_on && (!any_bias || all_bias);
+    if (rel) {
+        for (uint64_t a : hidx) if (a) ibase = std::min(ibase, a);
+        for (uint64_t a : hoidx) if (a) obase_a = std::min(obase_a, a);
+        for (uint64_t a : hbidx) if (a) bbase = std::min(bbase, a);
+        auto fits = [](uint64_t a, uint64_t base) { return !a || (((a - base) & 255) == 0 && ((a - base) >> 8) < 0x7fffffffull); };
+        for (uint64_t a : hidx) rel = rel && fits(a, ibase);
+        for (uint64_t a : hoidx) rel = rel && fits(a, obase_a);
+        for (uint64_t a : hbidx) rel = rel && fits(a, bbase);
+        rel = rel && ibase != ~0ull && obase_a != ~0ull;
+    }
+    if (rel) {
+        std::vector<int32_t> ridx(hidx.size(), -1), roidx(hoidx.size(), -1), rbidx(hbidx.size(), 0);
+        for (size_t x = 0; x < hidx.size(); x++) if (hidx[x]) ridx[x] = (int32_t)((hidx[x] - ibase) >> 8);
+        for (size_t x = 0; x < hoidx.size(); x++) if (hoidx[x]) roidx[x] = (int32_t)((hoidx[x] - obase_a) >> 8);
+        if (any_bias) for (size_t x = 0; x < hbidx.size(); x++) if (hbidx[x]) rbidx[x] = (int32_t)((hbidx[x] - bbase) >> 8);
+        const size_t off_oidx = al(ridx.size() * 4), off_bidx = off_oidx + al(roidx.size() * 4), off_w = off_bidx + al(rbidx.size() * 4);
+        std::vector<char> host(off_w + al(wbytes.size()), 0);
+        memcpy(host.data(), ridx.data(), ridx.size() * 4);
+        memcpy(host.data() + off_oidx, roidx.data(), roidx.size() * 4);
+        memcpy(host.data() + off_bidx, rbidx.data(), rbidx.size() * 4);
+        memcpy(host.data() + off_w, wbytes.data(), wbytes.size());
+        CHECK(ensure_scratch(ctx, al(host.size())));
+        char *tables; CHECK(upload_tmp(ctx, host.data(), host.size(), &tables));
+        GemmLaunch gl{small, two, false, MT, (const uint64_t *)ibase, tables, tables + off_w, tables + off_oidx, any_bias ? (const uint64_t *)bbase : nullptr, tables + off_bidx,
+                      (uint64_t *)obase_a, G, M, K, lazy, Kp, 0, WP, (M + 31) / 32, (K + 31) / 32, 2, (uint32_t)ctx->gemm_order, one};
+        gl.in_unit = gl.out_unit = gl.bias_unit = 32;
+        return mfma ? cn_l_gemm_mfma(ctx, gl) : cn_l_gemm(ctx, gl);
     }
     const size_t off_oidx = al(hidx.size() * 8), off_bidx = off_oidx + al(hoidx.size() * 8), off_w = off_bidx + al(hbidx.size() * 8);
     std::vector<char> host(off_w + al(wbytes.size()), 0);

@@ -39,13 +39,17 @@ DEV void gemm_block_coords(uint32_t bx, uint32_t by, uint32_t chunks, uint32_t l
 // kernels of the deferred calls ran 30-60 % behind their index-table twins).
 DEV const NTT_GLOBAL uint64_t *gmem(uint64_t a) { return (const NTT_GLOBAL uint64_t *)a; }
 DEV NTT_GLOBAL uint64_t *gmem_w(uint64_t a) { return (NTT_GLOBAL uint64_t *)a; }
+// Index units of the table-driven (non-ABS) kernels, in words: input / output index x unit = word offset from `in` / `out`, bias index x unit from `bias`.  0 = the defaults (one
+// ciphertext / one plaintext per index: the arrays of a plan).  The deferred per-ciphertext calls - every ciphertext its own array - hand in 32-bit offsets in units of 32 words
+// (256 B: the allocation granule) from the lowest address of their flush group (round 6): the same index-table kernels as a plan instead of 64-bit address tables.
+struct GemmUnits { uint32_t in, out, bias; };
 template <bool ABS> struct GemmTab { typedef int32_t T; };
 template <> struct GemmTab<true> { typedef uint64_t T; };
 template <int MT, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const uint64_t *__restrict__ Wl,
                                                      const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                      uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order) {
+                                                     uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order, GemmUnits U) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
@@ -53,6 +57,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
     gemm_block_coords(blockIdx.x, blockIdx.y, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
+    const size_t iu = U.in ? U.in : ctw, ou = U.out ? U.out : ctw, bu = U.bias ? U.bias : n;
     const DMod qm = C->q[j];
     u128 acc[MT];
 #pragma unroll
@@ -65,7 +70,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
         for (uint32_t kk = k0; kk < k1; kk++) {
             uint64_t x;
             if constexpr (ABS) { const uint64_t a = gi[kk]; if (!a) continue; x = gmem(a)[e]; }
-            else { const int32_t id = gi[kk]; if (id < 0) continue; x = in[(size_t)id * ctw + e]; }
+            else { const int32_t id = gi[kk]; if (id < 0) continue; x = in[(size_t)id * iu + e]; }
 #pragma unroll
             for (int m = 0; m < MT; m++) acc[m] += (u128)x * gw[(size_t)kk * MT + m];       // zero-padded beyond mcnt
         }
@@ -87,8 +92,8 @@ __global__ void __launch_bounds__(256) k_scalar_gemm(const uint64_t *__restrict_
             }
         } else if ((uint32_t)m < mcnt && out_idx[o] >= 0) {                     // -1: padding member of a smaller group
             uint64_t r = bred128(acc[m], qm);
-            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
-            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = r;
+            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * bu + i]; if (bv) r = addmod(r, scale_plain(C, bv, j), qm.q); }
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ou + e] = r;
         }
     }
 }
@@ -132,7 +137,7 @@ template <int MT, int NL, int LW, bool ABS = false>
 __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const double *__restrict__ Wd,
                                                          const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                          uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t chunks, uint32_t G, uint32_t M,
-                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order, uint32_t Kw) {
+                                                         uint32_t K, uint32_t mtiles, uint32_t lazy, uint32_t Kp, uint32_t obase, uint32_t polys, uint32_t order, uint32_t Kw, GemmUnits U) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     const uint32_t n = C->n, k = C->k, limbs = polys * k;       // polys = ciphertext size: 2, or 3 for unrelinearized products (Evaluator::multiply_plain / add accept both)
@@ -140,6 +145,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
     gemm_block_coords(blockIdx.x, blockIdx.y, chunks, limbs, mtiles, G, chunk, limb, mt, g, order);
     const uint32_t j = limb % k, i = chunk * blockDim.x + threadIdx.x;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + i;
+    const size_t iu = U.in ? U.in : ctw, ou = U.out ? U.out : ctw, bu = U.bias ? U.bias : n;
     const DMod qm = C->q[j];
     double acc[NL][MT], res[MT];
 #pragma unroll
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
                 const int4 ids = *reinterpret_cast<const int4 *>(__builtin_assume_aligned(gi + kc + c, 16));
                 const int32_t id[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-                for (int p = 0; p < 4; p++) x[c + p] = in[(size_t)max(id[p], 0) * ctw + e];
+                for (int p = 0; p < 4; p++) x[c + p] = in[(size_t)max(id[p], 0) * iu + e];
             }
         }
     };
@@ -313,7 +319,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
 #pragma unroll
             for (int u = 0; u < OB; u++) {
                 if constexpr (ABS) bv[u] = gmem(st[u] && bi[u] ? bi[u] : (uint64_t)in)[i];          // no bias: any readable word, discarded below
-                else bv[u] = bias[(size_t)(st[u] ? bi[u] : (TT)0) * n + i];
+                else bv[u] = bias[(size_t)(st[u] ? bi[u] : (TT)0) * bu + i];
             }
 #pragma unroll
             for (int u = 0; u < OB; u++) if (!(st[u] && (ABS ? bi[u] != 0 : true))) bv[u] = 0;
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(256) k_scalar_gemm_f64(const uint64_t *__restr
             // bias: a PoolLayer bias is the constant polynomial - every coefficient but one is zero and scales to zero (skipped wave-uniformly almost everywhere)
             if (bv[u]) r = addmod(r, scale_plain(C, bv[u], j), qm.q);
             if constexpr (ABS) gmem_w(oi[u])[e] = r;
-            else out[(size_t)(obase + (uint32_t)oi[u]) * ctw + e] = r;
+            else out[(size_t)(obase + (uint32_t)oi[u]) * ou + e] = r;
         }
     }
 }
@@ -357,7 +363,7 @@ template <int P, bool ABS>
 __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__restrict__ in, const void *__restrict__ idx_, const int8_t *__restrict__ Wf,
                                                              const void *__restrict__ out_idx_, const uint64_t *__restrict__ bias, const void *__restrict__ bias_idx_,
                                                              uint64_t *__restrict__ out, const DevConsts *__restrict__ C, uint32_t G, uint32_t M, uint32_t mtiles,
-                                                             uint32_t ksteps, uint32_t obase, uint32_t polys) {
+                                                             uint32_t ksteps, uint32_t obase, uint32_t polys, GemmUnits U) {
     typedef typename GemmTab<ABS>::T TT;
     const TT *idx = (const TT *)idx_, *out_idx = (const TT *)out_idx_, *bias_idx = (const TT *)bias_idx_;
     constexpr int ND = 6, D = ND + P - 1, NB = GEMM_MFMA_DEPTH + 1;
@@ -375,6 +381,7 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
     const bool active = mt < mtiles;                           // a wave without an output tile still loads its share of the B operand
     const uint32_t j = limb % k;
     const size_t ctw = (size_t)limbs * n, e = (size_t)limb * n + (size_t)ctile * 32 + col;
+    const size_t iu = U.in ? U.in : ctw, ou = U.out ? U.out : ctw, bu = U.bias ? U.bias : n;
     const uint32_t Kp = ksteps * 32;
     const TT *gi = idx + (size_t)g * Kp + 4 * wave;            // + 32 ks + 16 half + u
     const int8_t *wf = Wf + ((((size_t)g * P) * mtiles + (active ? mt : 0)) * ksteps) * 1024 + (size_t)lane * 16;       // + (p * mtiles * ksteps + ks) * 1024
@@ -401,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
             } else {
                 // both products on the scalar unit, THEN the per-lane choice (left alone the compiler chooses first and multiplies per lane: two quarter-rate
                 // v_mad_u64_u32 per word)
-                size_t o0 = (size_t)max(s[u], 0) * ctw, o1 = (size_t)max(s[4 + u], 0) * ctw;
+                size_t o0 = (size_t)max(s[u], 0) * iu, o1 = (size_t)max(s[4 + u], 0) * iu;
                 asm volatile("" : "+s"(o0), "+s"(o1));
                 x[u] = in[(half ? o1 : o0) + e];
             }
@@ -483,8 +490,8 @@ __global__ void __launch_bounds__(256, 2) k_scalar_gemm_mfma(const uint64_t *__r
             gmem_w(out_idx[o])[e] = res;
         } else {
             if (out_idx[o] < 0) continue;
-            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * n + (size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }
-            out[(size_t)(obase + (uint32_t)out_idx[o]) * ctw + e] = res;
+            if (bias && limb < k) { const uint64_t bv = bias[(size_t)bias_idx[o] * bu + (size_t)ctile * 32 + col]; if (bv) res = addmod(res, scale_plain(C, bv, j), qm.q); }
+            out[(size_t)(obase + (uint32_t)out_idx[o]) * ou + e] = res;
         }
     }
 }

@@ -15,17 +15,17 @@ template <int MT, bool ABS> static void launch_int(cn_ctx *c, const GemmLaunch &
     const uint32_t mtiles = (g.M + MT - 1) / MT;
     const GemmGrid gg = gemm_grid(c, g, mtiles);
     hipLaunchKernelGGL((k_scalar_gemm<MT, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const uint64_t *)g.W, g.oidx, g.bias, g.bidx, g.out, c->dc,
-                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order);
+                       c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, GemmUnits{g.in_unit, g.out_unit, g.bias_unit});
 }
 template <int MT, bool ABS> static void launch_f64(cn_ctx *c, const GemmLaunch &g) {
     const uint32_t mtiles = (g.M + MT - 1) / MT;
     const GemmGrid gg = gemm_grid(c, g, mtiles);
     if (g.one) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 1, 0, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K), GemmUnits{g.in_unit, g.out_unit, g.bias_unit});
     else if (g.two) hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 2, 22, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
+                                  g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K), GemmUnits{g.in_unit, g.out_unit, g.bias_unit});
     else hipLaunchKernelGGL((k_scalar_gemm_f64<MT, 3, 17, ABS>), gg.grid, dim3(c->bs), 0, c->stream, g.in, g.idx, (const double *)g.W, g.oidx, g.bias,
-                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K));
+                            g.bidx, g.out, c->dc, c->chunks, g.G, g.M, g.K, mtiles, g.lazy, g.Kp, g.obase, g.polys, gg.order, gemm_f64_rows(g.K), GemmUnits{g.in_unit, g.out_unit, g.bias_unit});
 }
 template <bool ABS> static int launch(cn_ctx *c, const GemmLaunch &g) {
     if (g.small) {
@@ -54,7 +54,7 @@ template <int P, bool ABS> static void launch_mfma(cn_ctx *c, const GemmLaunch &
     const uint32_t mgroups = (g.mtiles + 3) / 4;
     const size_t blocks = (size_t)g.G * mgroups * g.polys * c->hc.k * (c->hc.n / 32);
     hipLaunchKernelGGL((k_scalar_gemm_mfma<P, ABS>), dim3((uint32_t)blocks), dim3(256), 0, c->stream, g.in, g.idx, (const int8_t *)g.W, g.oidx, g.bias, g.bidx, g.out,
-                       c->dc, g.G, g.M, g.mtiles, g.ksteps, g.obase, g.polys);
+                       c->dc, g.G, g.M, g.mtiles, g.ksteps, g.obase, g.polys, GemmUnits{g.in_unit, g.out_unit, g.bias_unit});
 }
 template <bool ABS> static int launch_mfma_p(cn_ctx *c, const GemmLaunch &g) {
     switch (g.P) {

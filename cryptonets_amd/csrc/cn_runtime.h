@@ -259,6 +259,7 @@ struct GemmLaunch {
     uint32_t polys = 2;                              // ciphertext size of inputs and outputs (3: unrelinearized products)
     uint32_t order = 0;                              // workgroup order of the VALU kernels: 0 group-major, 1 slice-major (gemm_block_coords)
     bool one = false;                                // k_scalar_gemm_f64<MT, 1, 0>: the words are not split (gemm_one_limb)
+    uint32_t in_unit = 0, out_unit = 0, bias_unit = 0;   // words per index unit of the table-driven kernels; 0 = one ciphertext / one plaintext (plans).  Deferred calls: 32 (256 B offsets from the lowest address)
 };
 // k_scalar_gemm_f64: rows of the weight table per (group, output tile) - K terms + zero rows up to a multiple of 16 + 16: the kernel's sets of 4 (or 8) terms run past K
 // and multiply whatever word the padded gather entry reads by these zeros
