@@ -780,7 +780,7 @@ def main():
             import replay_reference_calls as rp
             ref_words = [ch.g.ct_download(ch.h5, 0, 10) for ch in chans]
             nthreads = args.caller_threads or effective_cores()[0]
-            reps = max(2, min(args.steps, 5))
+            reps = max(2, min(args.steps, 20))           # (windows of up to 20 batches since round 6: filling and draining the queues of a window costs the unchanged caller ~2.5 ms - 0.5 ms per batch in a 5-batch window)
             # the SAME statistic on both sides of the ratio: best of five windows of `reps` steps for the batched path too (the headline
             # `value` stays the mean over all timed steps)
             bwin = []
