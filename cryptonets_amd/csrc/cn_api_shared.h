@@ -106,6 +106,7 @@ struct RotJob { const uint64_t *src; uint64_t *dst; int steps; std::vector<uint6
 // ---- functions defined in one unit and used by the others
 int cn_run_ntt(cn_ctx *c, uint64_t *data, uint32_t limbs, uint32_t base_off, uint32_t nmod, int inverse);
 void cn_stagger_forget(cn_ctx *ctx);
+const NoiseTab &cn_noise_table();          // thresholds of the noise sampler (cn_client.hip)
 std::vector<Slab> &slabs_of(cn_ctx *ctx);
 bool in_slab(cn_ctx *ctx, const void *p);
 int use(cn_ctx *c);

@@ -42,6 +42,19 @@ extern "C" int cn_get_key(cn_ctx *ctx, int which, uint64_t elt, uint64_t *host, 
     return 0;
 API_END }
 RngKey rng_key_of(const cn_ctx *ctx) { RngKey k; memcpy(k.k, ctx->rng_key, sizeof k.k); return k; }
+// thresholds of sample_noise8 (cn_dev_common.hip.h): cumulative distribution of |x|, x ~ N(0, 3.2^2) conditioned on |x| <= 19.2 (SEAL 3.2: noise_standard_deviation 3.20, noise_max_deviation 6 sigma)
+const NoiseTab &cn_noise_table() {
+    static const NoiseTab tab = [] {
+        NoiseTab t;
+        const long double sigma = 3.2L, root2 = 1.41421356237309504880168872420969808L, norm = erfl(19.2L / (sigma * root2));
+        for (int i = 0; i < 19; i++) {
+            const long double c = erfl((long double)(i + 1) / (sigma * root2)) / norm;             // P(|x| < i + 1 | clipped)
+            t.thr[i] = c >= 1.0L ? 0x7fffffffffffffffull : (uint64_t)floorl(c * 9223372036854775808.0L);
+        }
+        return t;
+    }();
+    return tab;
+}
 // `polys` polynomials [polys][k][N] of residues: kind 0 ternary, 1 clipped normal (both drawn ONCE per coefficient into an int8 array in
 // scratch - the caller's ensure_scratch leaves room for polys * N bytes - and expanded to the k limbs), 2 uniform per limb
 int sample_poly(cn_ctx *ctx, uint64_t *dst, uint32_t polys, int kind, uint64_t seed, uint64_t stream) {
@@ -55,7 +68,7 @@ int sample_poly(cn_ctx *ctx, uint64_t *dst, uint32_t polys, int kind, uint64_t s
         if (!small) return fail(CN_ERR_HIP, "internal: scratch exhausted in the sampler");
         const uint64_t threads = (uint64_t)polys * (n / (kind == 0 ? 16 : 8));
         hipLaunchKernelGGL(k_sample_small, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, small, n, kind, 1u, polys, rng_key_of(ctx), seed, (uint32_t)stream,
-                           ctx->rng_item, (const EncTab *)nullptr);
+                           ctx->rng_item, (const EncTab *)nullptr, cn_noise_table());
         hipLaunchKernelGGL(k_expand_small, dim3(polys * k * ctx->chunks), dim3(ctx->bs), 0, ctx->stream, small, dst, ctx->dc, ctx->chunks);
         launch_count(ctx);
     }
@@ -181,8 +194,8 @@ int encrypt_chain(cn_ctx *ctx, uint32_t cnt, const uint64_t *ptd, uint32_t pt_st
     if (!u || !us || !es) return fail(CN_ERR_HIP, "internal: scratch exhausted in encrypt");
     const RngKey key = rng_key_of(ctx);
     const uint64_t item0 = ctx->rng_item;
-    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, seed, 0u, item0, (const EncTab *)dtab);
-    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, seed, 1u, item0, (const EncTab *)dtab);
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, seed, 0u, item0, (const EncTab *)dtab, cn_noise_table());
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, seed, 1u, item0, (const EncTab *)dtab, cn_noise_table());
     if (!htab) ctx->rng_item += cnt;
     const bool f64 = ctx->use_f64 && ctx->hc.q_f64;
     if (ctx->enc_fused && !ctx->legacy_ntt) {                 // one kernel behind the samplers: u stays in registers between its transform and the two components

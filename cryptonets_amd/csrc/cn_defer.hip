@@ -518,8 +518,8 @@ int flush_zero_folds(cn_ctx *ctx, DeferQueue *q, const std::vector<const DOp *> 
     EncTab *dtab; FoldOut *dfo; FoldTerm *dft;
     CHECK(upload_tmp(ctx, tab.data(), tab.size(), &dtab)); CHECK(upload_tmp(ctx, fo.data(), fo.size(), &dfo)); CHECK(upload_tmp(ctx, ft.data(), ft.size(), &dft));
     const RngKey key = rng_key_of(ctx);
-    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, 0ull, 0u, 0ull, (const EncTab *)dtab);
-    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, 0ull, 1u, 0ull, (const EncTab *)dtab);
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * (n / 16) + 255) / 256)), dim3(256), 0, ctx->stream, us, n, 0, 1u, cnt, key, 0ull, 0u, 0ull, (const EncTab *)dtab, cn_noise_table());
+    hipLaunchKernelGGL(k_sample_small, dim3((unsigned)(((uint64_t)cnt * 2 * (n / 8) + 255) / 256)), dim3(256), 0, ctx->stream, es, n, 1, 2u, cnt, key, 0ull, 1u, 0ull, (const EncTab *)dtab, cn_noise_table());
     uint64_t qmax = 0; for (uint32_t j = 0; j < ctx->hc.k; j++) qmax = std::max(qmax, ctx->hc.q[j].q);
     if (!rr_ops[(qmax >> 44) ? POL_F64 : POL_F64L]->enc_fold(ctx, us, es, dfo, dft, (uint32_t)fo.size())) return fail(CN_ERR_ARG, "internal: zero-encryption fold without a kernel");
     HIPCHK(hipGetLastError()); launch_count(ctx, 3);

@@ -274,7 +274,7 @@ static __global__ void k_f64_to_u64(uint64_t *p, size_t words) {
 // ---- samplers (ChaCha20 DRBG, cn_dev_common.hip.h).  Secrets and noise are drawn once per coefficient into int8 arrays.
 // small[it][p][i], it < items, p < polys: kind 0 ternary {-1, 0, 1} (stream0 + p), kind 1 clipped normal (stream0 + p)
 static __global__ void k_sample_small(int8_t *__restrict__ small, uint32_t n, int kind, uint32_t polys, uint32_t items, RngKey key, uint64_t nonce, uint32_t stream0,
-                               uint64_t item0, const EncTab *__restrict__ tab) {
+                               uint64_t item0, const EncTab *__restrict__ tab, NoiseTab nt) {
     const uint32_t per = kind == 0 ? 16u : 8u, bpp = n / per;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (uint64_t)items * polys * bpp) return;
@@ -288,7 +288,7 @@ static __global__ void k_sample_small(int8_t *__restrict__ small, uint32_t n, in
         for (int c = 0; c < 16; c++) o[c] = v[c];
     } else {
         int8_t v[8];
-        sample_noise8(key, nc, stream0 + p, item, blk, v);
+        sample_noise8(key, nc, stream0 + p, item, blk, nt, v);
 #pragma unroll
         for (int c = 0; c < 8; c++) o[c] = v[c];
     }
