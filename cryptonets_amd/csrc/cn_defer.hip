@@ -396,7 +396,12 @@ int flush_staged_group(cn_ctx *ctx, const std::vector<const DOp *> &all, int typ
         // an operand whose addresses are equally spaced already IS the array the batched implementation wants (always so for a single call -
         // 12 rotations by 12 different step counts are 12 groups of one): it is used in place; only scattered operands are gathered
         auto spaced = [&](auto get, size_t words) { for (uint32_t i = 1; i < cnt; i++) if (get(ops[i]) != get(ops[0]) + (size_t)i * words) return false; return true; };
-        const bool da = spaced([](const DOp *o) { return o->a; }, ctw), db = has_b && spaced([](const DOp *o) { return o->b; }, ctw),
+        // MultiplyPlain of ONE ciphertext by the plaintexts of several rows (the per-row DotProduct of a dense layer: every row multiplies the same vector): the broadcast form -
+        // the ciphertext is transformed once, not once per row, and nothing is gathered (round 6)
+        bool same_a = has_p && cnt >= 2;
+        for (uint32_t i = 1; i < cnt && same_a; i++) same_a = ops[i]->a == ops[0]->a;
+        for (uint32_t i = 0; i < cnt && same_a; i++) same_a = (const uint64_t *)ops[i]->out != ops[0]->a;      // (the shared operand is nobody's result)
+        const bool da = same_a || spaced([](const DOp *o) { return o->a; }, ctw), db = has_b && spaced([](const DOp *o) { return o->b; }, ctw),
                    dp = has_p && spaced([](const DOp *o) { return o->b; }, n), dout = spaced([](const DOp *o) { return (const uint64_t *)o->out; }, ctw);
         std::vector<Tab2> gin, gpt, gout;
         for (uint32_t i = 0; i < cnt; i++) {
@@ -418,7 +423,7 @@ int flush_staged_group(cn_ctx *ctx, const std::vector<const DOp *> &all, int typ
         if (has_p) fp.pt_zero.assign(cnt, 0);                 // zero plaintexts were refused when the calls were queued
         int rc = 0;
         switch (type) {
-        case DOP_MULPLAIN: rc = mul_plain_impl(ctx, &fa, 0, false, &fp, 0, 1, &fo, 0, cnt); break;
+        case DOP_MULPLAIN: if (same_a) fa.count = 1; rc = mul_plain_impl(ctx, &fa, 0, same_a, &fp, 0, 1, &fo, 0, cnt); break;
         case DOP_ROT: rc = rotate_rows_impl(ctx, &fa, 0, (int)kv.first, &fo, 0, cnt); break;
         case DOP_ROTADD: rc = rotate_rows_add_impl(ctx, &fa, 0, (int)kv.first, &fb, 0, &fo, 0, cnt); break;
         case DOP_COLS: rc = galois_impl(ctx, &fa, 0, 2ull * n - 1, &fo, 0, cnt); break;
