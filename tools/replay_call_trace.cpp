@@ -113,10 +113,19 @@ extern "C" int ct_replay(cn_ctx **ctx, int n, const uint64_t *const *traces, con
             std::vector<std::thread> th;
             for (int c = 0; c < n; c++) th.emplace_back([&, c] {
                 for (uint64_t i = 0; i < T[c].recs.size(); i++) { if (!err) fail(run_one(T[c], T[c].recs[i]), c, i); if (mode == 1) bar.wait(); }
+                // the caller reads the result of every inference: Decrypt follows, and the reference runs it - like every operation of the CRT layer - as one task per plaintext
+                // prime (EncryptedSealBfvVector.cs:225-236).  Round 6: the wait belongs to the prime's own thread.  (It used to be a loop over the contexts behind the join: with
+                // deferred submission the LAST queue segment of a prime is launched by its cn_sync, so the four final segments ran one after the other - 2-3 ms per image
+                // of an artefact of this harness, profiles/r06_lola_unchanged_queue_gaps.txt.)
+                if (!err) fail(cn_sync(ctx[c]), c, 0);
             });
             for (auto &x : th) x.join();
         }
-        for (int c = 0; c < n; c++) cn_sync(ctx[c]);      // the caller reads the result of every inference (Decrypt follows)
+        if (mode == 0) {                                   // one host thread: launch what every context has queued (cn_stats_get flushes without waiting), THEN wait
+            cn_stats st;
+            for (int c = 0; c < n; c++) cn_stats_get(ctx[c], &st, 0);
+        }
+        for (int c = 0; c < n; c++) cn_sync(ctx[c]);
         const bool last = rep == warmup + reps - 1;
         for (int c = 0; c < n; c++) { int rc = cleanup(T[c], results[c], last); if (rc) fail(rc, c, 0); }
     }
