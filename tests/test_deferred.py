@@ -771,3 +771,19 @@ def test_deferred_squarings_at_n16384_take_the_one_launch_key_switch(rng):
     assert np.array_equal(words[0], words[1])
     exp = o.relinearize(o.multiply(base[0], base[0]))           # operand 0 is base[0] unchanged
     assert np.array_equal(words[1][0], exp)
+
+
+@pytest.mark.gpu
+def test_soak_of_random_caller_configurations():
+    """tools/soak_lockfree.py for 150 seeds: random CryptoNets-shaped networks, 1-200 caller threads, one or two contexts, "defer" 0 / 1 / 2, literal zero
+    encryptions folded or materialised, releases at once or parked - slots against the integer model, words against the batched entry points, handle
+    counts (profiles/r06_soak_lockfree.txt: 188 591 such runs in eight minutes)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import soak_lockfree as sk
+    chans = [sk.Chan(42), sk.Chan(43)]
+    try:
+        runs = sum(sk.one(chans, seed, 0) for seed in range(31000, 31150))
+    finally:
+        for c in chans:
+            c.g.close()
+    assert runs >= 150

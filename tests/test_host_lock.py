@@ -28,3 +28,15 @@ def test_submission_ring_stress():
     assert r.returncode == 0, r.stdout.decode()
     lines = r.stdout.decode().splitlines()
     assert len(lines) == 6 and all(" bad 0" in ln for ln in lines), lines
+
+
+def test_replay_pool_regions():
+    """the thread pool of the C++ per-ciphertext caller (tools/replay_reference_calls.cpp, the stand-in for Utils.ParallelProcessInEnv): regions of changing
+    width - every item once, no body alive after its region returned.  (Round 6: generation and width lived in two atomics; a pool thread could take part
+    in one region twice and the region returned early - found by tools/soak_lockfree.py on the GPU box as an 'invalid handle' / a crash of the HARNESS.)"""
+    import ctypes, sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import replay_reference_calls as rp
+    L = ctypes.CDLL(rp.build())
+    L.rp_pool_selftest.argtypes = [ctypes.c_int, ctypes.c_uint]
+    assert L.rp_pool_selftest(5000, 11) == 0

@@ -26,8 +26,10 @@
 #include <climits>
 #include <cstdio>
 #include <linux/futex.h>
+#include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -57,31 +59,37 @@ void note(Err &e, int rc) {
 class Pool {
     std::vector<std::thread> workers;
     const std::function<void(int)> *body = nullptr;
-    std::atomic<int> next{0}, gen{0}, running{0}, want{0}, done_flag{0};
-    int count = 0; std::atomic<bool> stop{false};
+    // ONE word tells a pool thread everything about a region: (generation << 12) | participants.  (Rounds 3-6 kept the participant count in a second
+    // atomic: a thread that did not take part in region G could read G's generation, lose the CPU, read the participant count of region G + 1, work in
+    // G + 1 - and then see G + 1's generation as new and take part in it a SECOND time: `running` reached zero one thread early and run() returned while
+    // a body was still executing.  Found by tools/soak_lockfree.py, which changes the thread count from run to run; one read of one word cannot tear.)
+    static constexpr int PART_BITS = 12, PART_MASK = (1 << PART_BITS) - 1;
+    std::atomic<int> word{0}, next{0}, running{0}, done_flag{0};
+    int count = 0, generation = 0; std::atomic<bool> stop{false};
     static long fut(std::atomic<int> *a, int op, int v) { return syscall(SYS_futex, reinterpret_cast<int *>(a), op, v, nullptr, nullptr, 0); }
     void work(int id) {
         int seen = 0;
         for (;;) {
-            for (int spins = 0;; spins++) {                                   // idle pool thread: spin briefly, then sleep on the generation word
-                const int g = gen.load(std::memory_order_acquire);
+            for (int spins = 0;; spins++) {                                   // idle pool thread: spin briefly, then sleep on the region word
+                const int w = word.load(std::memory_order_acquire);
                 if (stop.load()) return;
-                if (g != seen) { seen = g; if (id < want.load(std::memory_order_acquire)) break; else continue; }
-                if (spins < 200) __builtin_ia32_pause(); else fut(&gen, FUTEX_WAIT_PRIVATE, g);
+                if (w != seen) { seen = w; if (id < (w & PART_MASK)) break; else continue; }
+                if (spins < 200) __builtin_ia32_pause(); else fut(&word, FUTEX_WAIT_PRIVATE, w);
             }
             for (;;) { const int k = next.fetch_add(1); if (k >= count) break; (*body)(k); }
             if (running.fetch_sub(1, std::memory_order_acq_rel) == 1) { done_flag.store(1, std::memory_order_release); fut(&done_flag, FUTEX_WAKE_PRIVATE, 1); }
         }
     }
 public:
-    ~Pool() { stop = true; gen.fetch_add(1); fut(&gen, FUTEX_WAKE_PRIVATE, INT_MAX); for (auto &t : workers) t.join(); }
+    ~Pool() { stop = true; word.fetch_add(1 << PART_BITS); fut(&word, FUTEX_WAKE_PRIVATE, INT_MAX); for (auto &t : workers) t.join(); }
     void run(int n_items, int threads, const std::function<void(int)> &fn) {
         if (n_items < 2 || threads < 2) { for (int k = 0; k < n_items; k++) fn(k); return; }
-        const int nt = threads > n_items ? n_items : threads;
+        const int nt = std::min(threads > n_items ? n_items : threads, (int)PART_MASK);
         while ((int)workers.size() < nt) { const int id = (int)workers.size(); workers.emplace_back([this, id] { work(id); }); }
-        body = &fn; count = n_items; next.store(0); running.store(nt); done_flag.store(0); want.store(nt, std::memory_order_release);
-        gen.fetch_add(1, std::memory_order_acq_rel);
-        fut(&gen, FUTEX_WAKE_PRIVATE, INT_MAX);
+        body = &fn; count = n_items; next.store(0); running.store(nt); done_flag.store(0);
+        generation = (generation + 1) & 0x7FFFF;
+        word.store((generation << PART_BITS) | nt, std::memory_order_release);
+        fut(&word, FUTEX_WAKE_PRIVATE, INT_MAX);
         while (!done_flag.load(std::memory_order_acquire)) fut(&done_flag, FUTEX_WAIT_PRIVATE, 0);
     }
 };
@@ -208,6 +216,28 @@ extern "C" int rp_run2(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nl
     const uint32_t O = layers[nlayers - 1].O;
     for (int p = 0; p < nprimes; p++) memcpy(out + (size_t)p * O, cur[p].data(), (size_t)O * sizeof(cn_handle));
     return 0;
+}
+// Host-only self-test of the pool (no device call): `regions` parallel regions of pseudo-random width and item count.  Returns the number of
+// violations: an item executed twice or not at all, a body still running when its region has returned.
+extern "C" int rp_pool_selftest(int regions, unsigned seed) {
+    std::vector<std::atomic<int>> hits(1024);
+    std::atomic<int> alive{0};
+    int bad = 0;
+    uint64_t x = (uint64_t)seed * 0x9E3779B97F4A7C15ull + 1;
+    for (int r = 0; r < regions; r++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const int threads = (r & 1) ? 2 + (int)(x % 199) : 2 + (int)(x % 3), items = (r & 1) ? 2 + (int)((x >> 20) % 400) : 2 + (int)((x >> 20) % 4);
+        for (int i = 0; i < items; i++) hits[i].store(0);
+        parallel_process(items, threads, [&](int k) {                 // a body that lasts: a region that returns early is caught with a body alive
+            alive.fetch_add(1); hits[k].fetch_add(1);
+            for (volatile int spin = 0; spin < 2000; spin = spin + 1) {}
+            if ((k & 15) == 0) sched_yield();
+            alive.fetch_sub(1);
+        });
+        if (alive.load()) bad++;
+        for (int i = 0; i < items; i++) if (hits[i].load() != 1) bad++;
+    }
+    return bad;
 }
 extern "C" int rp_run(cn_ctx **ctx, int nprimes, const rp_layer *layers, int nlayers, const cn_handle *in, uint32_t n_in, cn_handle *out, int threads,
                       char *errmsg, size_t errlen) {
