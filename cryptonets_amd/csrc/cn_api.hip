@@ -33,13 +33,13 @@ size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 // drained (checked lazily) - the copy never reads memory that has gone out of scope, whatever the runtime does with pageable sources.
 // Host side of the small uploads: a ring of PINNED memory per context.  hipMemcpyAsync from pageable memory is staged by the runtime and
 // holds the calling thread for ~10 us a piece; a flush of queued LoLa calls uploads a few hundred small tables.  A block of the ring is
-// reused only after the stream has passed it: the ring synchronises once per lap.
+// reused only after the stream has passed it: the ring synchronises once per lap (CN_PIN_RING_MIB, cn_get_option "pin_laps").
 char *pin_block(cn_ctx *c, size_t bytes) {
-    const size_t cap = 8u << 20;
+    static const size_t cap = [] { const char *e = getenv("CN_PIN_RING_MIB"); const long m = e ? atol(e) : 0; return (size_t)(m >= 1 && m <= 1024 ? m : 32) << 20; }();    // 32 MiB: the unchanged CryptoNets caller uploads 0.4-0.75 MB of tables per prime and batch - a lap (one wait for the stream) every ~50 batches instead of every ~12 (8 MiB until round 6)
     bytes = (bytes + 63) & ~(size_t)63;
     if (bytes > cap / 2) return nullptr;
     if (!c->pin) { if (hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pin = nullptr; return nullptr; } c->pin_off = 0; }
-    if (c->pin_off + bytes > cap) { if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr; c->pin_off = 0; }
+    if (c->pin_off + bytes > cap) { c->pin_laps++; if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr; c->pin_off = 0; }
     char *p = c->pin + c->pin_off;
     c->pin_off += bytes;
     return p;
@@ -375,6 +375,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     if (!name || !value) return fail(CN_ERR_ARG, "null argument");
     if (!strcmp(name, "f64")) *value = ctx->use_f64;
     else if (!strcmp(name, "defer")) *value = ctx->defer.load(std::memory_order_relaxed);
+    else if (!strcmp(name, "pin_laps")) *value = (int)ctx->pin_laps;                      // laps of the pinned upload ring (each one waits for the stream)
     else if (!strcmp(name, "ready_handles")) *value = (int)ctx->ready->size();          // allocated single-ciphertext arrays waiting for a lock-free cn_ct_alloc
     else if (!strcmp(name, "ks_wide")) *value = ctx->ks_wide;
     else if (!strcmp(name, "ks_xi")) *value = (int)ctx->hc.ks_xi;

@@ -158,7 +158,7 @@ struct cn_ctx {
     bool ks_chain = true;     // SumAllSlots at N = 16384: every link of the rotate-and-add chain hands sigma_next(c1) to the next one (no permutation pass between links)
     int ks_wide = -1;         // -1 auto (small batches), 0 fused kernel, 1 two-launch with a workgroup per digit, 2 two-launch per source limb
     void *ks_part = nullptr; size_t ks_part_cap = 0;   // its partial products [ct][digit][2][k][N]
-    char *pin = nullptr, *pin_dev = nullptr; size_t pin_off = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
+    char *pin = nullptr, *pin_dev = nullptr; size_t pin_off = 0; uint32_t pin_laps = 0;           // ring of pinned host memory for the small table uploads (cn_api.hip: pin_block)
     char *stage = nullptr; size_t stage_cap = 0;       // staging arena of the deferred per-ciphertext rotations / plaintext products (gather, batched call, scatter)
     int ks_xcd = 0;           // cn_set_option("ks_xcd", v) / CN_KS_XCD=v: fused key switch, workgroup order: 0 (ciphertext, limb); 1 the k workgroups of a
     int gemm_order = 1;                          // scalar GEMM (VALU kernels): 1 = slice-major workgroup order (every input slice fetched once per XCD), 0 = group-major

@@ -181,6 +181,7 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                              "cgroup_periods": cg1.get("nr_periods", 0) - cg0.get("nr_periods", 0), "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
                              "cgroup_throttled_ms": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1)} if cg0 else {"cpu_s_per_wall_s": round((time.process_time() - cpu0) / dt, 2)}
                 LAST_LAUNCHES = (sum(g.stats()["kernel_launches"] for g in ctxs) - launches0) / steps       # how finely the queue was cut
+                LAST_HOST["pin_ring_laps"] = [g.get_option("pin_laps") for g in ctxs]                        # (cumulative per context: each lap of the pinned upload ring waits for the stream)
                 words = [np.stack([g.ct_download(int(h), 0, 1)[0] for h in out[p]]) for p, g in enumerate(ctxs)]
             for p, g in enumerate(ctxs):                 # Decrypt + Dispose of the result matrix
                 for h in out[p]:
