@@ -91,7 +91,8 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * an error is reported ONCE by the next call that synchronises with the context (cn_sync, downloads, cn_stats_get, any non-deferrable entry point:
  * "a call submitted without the lock (defer = 2) failed ..."), the calls around it are executed.  For callers that come from Defaults.ThreadCount =
  * Environment.ProcessorCount threads (HE Wrapper/Defaults.cs:11-15, Utils.cs:46-88): the unchanged CryptoNets layers run at the same rate from 4, 16 and
- * 256 threads.  cn_live_handles does not count the ready handles; "ready_handles" reads their number.
+ * 256 threads.  cn_live_handles does not count the ready handles; "ready_handles" reads their number; "pin_laps" the laps of the context's pinned
+ * upload ring (small tables of a flush; 32 MiB, CN_PIN_RING_MIB in the environment; a lap waits for the stream once).
  * "fold_zero" = 1 (default, round 6): a queued fresh encryption of zero (cn_encrypt with pt = 0 / cn_encrypt_zero_new) that only feeds ONE queued scalar
  * product and has been released by the caller (PoolLayer.ElementAt / ReleaseTemp, PoolLayer.cs:67-90) is not materialised: sum_t w_t Enc_t(0) is
  * added onto the scalar product's output by linearity - exact modular arithmetic on the same sampler draws (nonce, item), the SAME words as with
