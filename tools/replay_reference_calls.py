@@ -126,6 +126,7 @@ def replay_layers(chans, layers):
 
 
 LAST_LAUNCHES = None
+HOST_TIMES = []
 LAST_HOST = None            # host-side accounting of the last measure(): CPU seconds the process used per wall second, CFS bandwidth throttling of its cgroup
 
 
@@ -167,6 +168,8 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                 t0 = time.perf_counter()
             ts = time.perf_counter()
             out = rp.run(ins, threads, literal_taps=literal_taps, nonce0=1 + it * 100000, merged=merged, direct_free=bool(direct_free))
+            if it >= warmup and os.environ.get("REPLAY_HOST_TIMES"):       # when did the CALLERS finish batch `it` (no wait for the device)?  the last line of the list is the device's time
+                HOST_TIMES.append(round(1e3 * (time.perf_counter() - t0), 1))
             if per_step:
                 for g in ctxs:
                     g.sync()
@@ -175,6 +178,9 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
                 for g in ctxs:
                     g.sync()
                 dt = time.perf_counter() - t0
+                if os.environ.get("REPLAY_HOST_TIMES"):
+                    print("callers returned at (ms): %s; device done at %.1f" % (HOST_TIMES, 1e3 * dt), file=sys.stderr)
+                    del HOST_TIMES[:]
                 cg1 = _cgroup_cpu_stat()
                 global LAST_HOST
                 LAST_HOST = {"cpu_s_per_wall_s": round((time.process_time() - cpu0) / dt, 2),
