@@ -163,6 +163,11 @@ def measure(chans, layers, threads, steps, warmup=1, defer=True, literal_taps=Fa
             if it == warmup:
                 for g in ctxs:
                     g.sync()
+                if os.environ.get("REPLAY_OFFSET") and len(chans) > 1:      # experiment: ONE device-side offset between the primes at the start of the window, no ordering afterwards:
+                    for _ in range(int(os.environ["REPLAY_OFFSET"])):       # prime 0's stream gets `REPLAY_OFFSET` batched fronts of filler work (convolution + Multiply of 845), every other prime waits for it
+                        chans[0].front()
+                    for ch in chans[1:]:
+                        ch.g.wait_for(chans[0].g)
                 launches0 = sum(g.stats()["kernel_launches"] for g in ctxs)
                 cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
                 t0 = time.perf_counter()
