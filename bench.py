@@ -792,6 +792,18 @@ def main():
                 sync_all()
                 bwin.append(1e3 * (time.perf_counter() - tb) / reps)
             batched_ms = min(bwin)
+            # the batched program WITHOUT the half-batch stagger: the two prime chains issued one after the other run in lock step, which is what the queues of the unchanged caller do
+            # (profiles/r06_callers_vs_device.txt) - the second reference point of the unchanged figures
+            pwin = []
+            for _ in range(3):
+                sync_all()
+                tb = time.perf_counter()
+                for _ in range(reps):
+                    for ch in chans:
+                        ch.forward()
+                sync_all()
+                pwin.append(1e3 * (time.perf_counter() - tb) / reps)
+            plain_ms = min(pwin)
             # best of five (three for the secondary rows) short measurements each (a 100 ms window on a shared host: one scheduling hiccup is a third of it - the run-to-run
             # spread of single measurements is in profiles/r03_unchanged_caller_*.txt)
             lruns = [rp.measure(chans, layers, nthreads, reps, warmup=2, literal_taps=True) for _ in range(5)]
@@ -814,6 +826,7 @@ def main():
                 locked = {"error": str(ex)[:200]}
             unchanged = {"value": round(8192e3 / lms, 1), "unit": "images/s", "ms_per_step": round(lms, 2), "threads": nthreads,
                          "frac_of_batched": round(batched_ms / lms, 3), "verified_against_integer_model": lok, "verified_slots": 8192 * 10 * len(chans),
+                         "unstaggered_batched_ms": round(plain_ms, 2), "frac_of_unstaggered_batched": round(plain_ms / lms, 3),
                          "timing": "best of 5 windows of %d steps on BOTH sides of frac_of_batched (skipped_taps, at_visible_cpu_count: best of 3)" % reps,
                          "windows_ms": {"unchanged": [round(x, 2) for x in lwin], "batched": [round(x, 2) for x in bwin]},
                          "frac_of_batched_mean_over_mean": round((sum(bwin) / len(bwin)) / (sum(lwin) / len(lwin)), 3), "at_visible_cpu_count": visible,
