@@ -792,8 +792,8 @@ def main():
                 sync_all()
                 bwin.append(1e3 * (time.perf_counter() - tb) / reps)
             batched_ms = min(bwin)
-            # the batched program WITHOUT the half-batch stagger: the two prime chains issued one after the other run in lock step, which is what the queues of the unchanged caller do
-            # (profiles/r06_callers_vs_device.txt) - the second reference point of the unchanged figures
+            # the batched program WITHOUT the half-batch stagger of the primes: the two chains issued one after the other (cn_mul_relin pipelines each prime's 845 squarings in two
+            # halves over two streams by itself, "sq_halves": 12.6 -> 12.0 ms; the unchanged caller's queues run in lock step at ~13: profiles/r06_callers_vs_device.txt)
             pwin = []
             for _ in range(3):
                 sync_all()

@@ -39,7 +39,7 @@ char *pin_block(cn_ctx *c, size_t bytes) {
     bytes = (bytes + 63) & ~(size_t)63;
     if (bytes > cap / 2) return nullptr;
     if (!c->pin) { if (hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pin = nullptr; return nullptr; } c->pin_off = 0; }
-    if (c->pin_off + bytes > cap) { c->pin_laps++; if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr; c->pin_off = 0; }
+    if (c->pin_off + bytes > cap) { c->pin_laps++; if (hipStreamSynchronize(c->stream) != hipSuccess || (c->stream2 && hipStreamSynchronize(c->stream2) != hipSuccess)) return nullptr; c->pin_off = 0; }
     char *p = c->pin + c->pin_off;
     c->pin_off += bytes;
     return p;
@@ -265,6 +265,7 @@ int ctx_init(cn_ctx *c, uint32_t n, uint32_t k, int device, std::vector<uint64_t
     if (getenv("CN_SQ_LDS")) c->sq_lds = atoi(getenv("CN_SQ_LDS")) != 0;
     if (getenv("CN_SQ_PIPE")) c->sq_pipe = atoi(getenv("CN_SQ_PIPE"));
     if (getenv("CN_SQ_OVERLAP")) c->sq_overlap = atoi(getenv("CN_SQ_OVERLAP")) != 0;
+    if (getenv("CN_SQ_HALVES")) c->sq_halves = std::max(0, std::min(2, atoi(getenv("CN_SQ_HALVES"))));
     if (getenv("CN_DEFER_STAGGER")) c->defer_stagger = atoi(getenv("CN_DEFER_STAGGER")) != 0;
     if (getenv("CN_ENC_FUSED")) c->enc_fused = atoi(getenv("CN_ENC_FUSED"));
     if (getenv("CN_FOLD_ZERO")) c->fold_zero = atoi(getenv("CN_FOLD_ZERO")) != 0;
@@ -340,6 +341,7 @@ extern "C" int cn_set_option(cn_ctx *ctx, const char *name, int value) { API_BOD
     if (!strcmp(name, "sq_lds")) { ctx->sq_lds = value != 0; return 0; }
     if (!strcmp(name, "sq_pipe")) { ctx->sq_pipe = value; return 0; }
     if (!strcmp(name, "sq_overlap")) { ctx->sq_overlap = value != 0; return 0; }
+    if (!strcmp(name, "sq_halves")) { if (value < 0 || value > 2) return fail(CN_ERR_ARG, "sq_halves: 0, 1 or 2"); ctx->sq_halves = value; return 0; }
     if (!strcmp(name, "defer_stagger")) { ctx->defer_stagger = value != 0; return 0; }
     if (!strcmp(name, "enc_fused")) { ctx->enc_fused = value; return 0; }          // 0 three launches, 1 k_encrypt_fused, 2 k_encrypt_split
     if (!strcmp(name, "fold_zero")) { ctx->fold_zero = value != 0; return 0; }      // queued zero encryptions that only feed a queued scalar product: folded by linearity (default 1)
@@ -390,6 +392,7 @@ extern "C" int cn_get_option(cn_ctx *ctx, const char *name, int *value) { API_BO
     else if (!strcmp(name, "sq_lds")) *value = ctx->sq_lds;
     else if (!strcmp(name, "sq_pipe")) *value = ctx->sq_pipe;
     else if (!strcmp(name, "sq_overlap")) *value = ctx->sq_overlap;
+    else if (!strcmp(name, "sq_halves")) *value = ctx->sq_halves;
     else if (!strcmp(name, "defer_stagger")) *value = ctx->defer_stagger;
     else if (!strcmp(name, "enc_fused")) *value = ctx->enc_fused;
     else if (!strcmp(name, "fold_zero")) *value = ctx->fold_zero;

@@ -151,6 +151,28 @@ bool run_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *
 bool square_fused_ok(cn_ctx *c, uint32_t base_off, uint32_t Lm, bool &light);
 void run_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm, bool light);
 bool aux_stream_ready(cn_ctx *ctx);
+// "sq_halves": Multiply + Relinearize of a batch as two halves software-pipelined over the context's two streams - Multiply(first) | Relinearize(first) on the context's stream,
+// Multiply(second) behind Multiply(first) on the second stream (beside the first half's key switch: its HBM-bound base extension / floor and its transform kernels fill what the
+// FP64-bound key switch leaves), Relinearize(second) behind it; the context's stream continues behind both.  mul(first, count), ks(first, count) launch on ctx->stream.
+static const uint32_t SQ_HALVES_MIN = 512;
+template <class FM, class FK> static int pipelined_halves(cn_ctx *ctx, uint32_t c, FM mul, FK ks) {
+    const uint32_t c1 = ((c / 2) + 7) & ~7u, c2 = c - c1;
+    CHECK(mul(0u, c1));
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    std::swap(ctx->stream, ctx->stream2);
+    int rc = mul(c1, c2);
+    std::swap(ctx->stream, ctx->stream2);
+    CHECK(rc);
+    CHECK(ks(0u, c1));
+    std::swap(ctx->stream, ctx->stream2);
+    rc = ks(c1, c2);
+    if (!rc && hipEventRecord(ctx->ev_join, ctx->stream) != hipSuccess) rc = fail(CN_ERR_HIP, "hipEventRecord failed");
+    std::swap(ctx->stream, ctx->stream2);
+    CHECK(rc);
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return 0;
+}
 size_t mul_scratch_per_ct(cn_ctx *c, bool square);
 int do_multiply(cn_ctx *ctx, const uint64_t *a, uint32_t astride, const uint64_t *b, uint32_t bstride, uint64_t *out3, uint32_t cnt, const uint64_t *const *atab = nullptr, const uint64_t *const *btab = nullptr);
 int ensure_ks_part(cn_ctx *ctx, size_t need);

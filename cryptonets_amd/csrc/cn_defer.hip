@@ -322,10 +322,13 @@ int flush_mulrelin_group(cn_ctx *ctx, const std::vector<const DOp *> &all) {
             uint64_t *t3 = salloc<uint64_t>(ctx, (size_t)c * 3 * kn);
             if (!t3) return fail(CN_ERR_HIP, "internal: scratch exhausted in deferred multiply");
             const bool stagger = ctx->defer_stagger && c >= STAGGER_MIN_CTS && !ctx->capturing;
+            auto mul = [&](uint32_t f, uint32_t n_) { return do_multiply(ctx, nullptr, 1, nullptr, 1, t3 + (size_t)f * 3 * kn, n_, da + f, (sq ? da : db) + f); };
+            auto ksw = [&](uint32_t f, uint32_t n_) { uint64_t *t = t3 + (size_t)f * 3 * kn; return do_keyswitch(ctx, t + 2 * kn, 3 * kn, t, t + kn, 3 * kn, ctx->rlk, nullptr, n_, 0, nullptr, 0, dout + f); };
+            if (ctx->sq_halves >= 2 && !stagger && !ctx->sq_overlap && ctx->hc.logn <= 13 && c >= SQ_HALVES_MIN && !ctx->capturing && aux_stream_ready(ctx)) { CHECK(pipelined_halves(ctx, c, mul, ksw)); continue; }
             if (stagger) CHECK(stagger_front_begin(ctx));
-            CHECK(do_multiply(ctx, nullptr, 1, nullptr, 1, t3, c, da, sq ? da : db));
+            CHECK(mul(0, c));
             if (stagger) CHECK(stagger_front_end(ctx));
-            CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk, nullptr, c, 0, nullptr, 0, dout));
+            CHECK(ksw(0, c));
         }
     }
     return 0;

@@ -630,8 +630,11 @@ int mul_relin_body(cn_ctx *ctx, cn_handle a, uint32_t ai, uint32_t astride, cn_h
         uint32_t c = std::min(ch, count - s);
         CHECK(ensure_scratch(ctx, per * c + 8192));
         uint64_t *t3 = salloc<uint64_t>(ctx, (size_t)c * 3 * kn);
-        CHECK(do_multiply(ctx, pa + (size_t)s * astride * A->item_words, astride, pb + (size_t)s * bstride * B->item_words, bstride, t3, c));
-        CHECK(do_keyswitch(ctx, t3 + 2 * kn, 3 * kn, t3, t3 + kn, 3 * kn, ctx->rlk, O->d + (oi + s) * O->item_words, c, 0));
+        auto mul = [&](uint32_t f, uint32_t n_) { return do_multiply(ctx, pa + (size_t)(s + f) * astride * A->item_words, astride, pb + (size_t)(s + f) * bstride * B->item_words, bstride, t3 + (size_t)f * 3 * kn, n_); };
+        auto ksw = [&](uint32_t f, uint32_t n_) { uint64_t *t = t3 + (size_t)f * 3 * kn; return do_keyswitch(ctx, t + 2 * kn, 3 * kn, t, t + kn, 3 * kn, ctx->rlk, O->d + (oi + s + f) * O->item_words, n_, 0); };
+        if (ctx->sq_halves && !ctx->sq_overlap && ctx->hc.logn <= 13 && c >= SQ_HALVES_MIN && !ctx->capturing && aux_stream_ready(ctx)) { CHECK(pipelined_halves(ctx, c, mul, ksw)); continue; }
+        CHECK(mul(0, c));
+        CHECK(ksw(0, c));
     }
     ctx->st.Relinarization += count;
     return 0;

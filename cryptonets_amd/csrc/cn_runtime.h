@@ -185,6 +185,8 @@ struct cn_ctx {
     uint64_t uid = 0;         // creation order within the process (cn_ctx_create)
     bool defer_stagger = false; hipEvent_t ev_front = nullptr;   // deferred flush of a big Multiply + Relinearize group: its Multiply waits for the front of the context that flushed one last
                                                                 // on this device (cn_defer.hip: staggered plaintext-prime channels); three forms measured, none with a gain - OFF by default: cn_set_option("defer_stagger", 1) / CN_DEFER_STAGGER=1
+    int sq_halves = 1;        // Multiply + Relinearize of >= 512 ciphertexts (N <= 8192) as two halves software-pipelined over the context's two streams: the Multiply of the second half beside the key
+                              // switch of the first (pipelined_halves, cn_api_shared.h).  1 (default): the batched entry point cn_mul_relin; 2: also the queued per-ciphertext calls of a flush (measured slower there); 0: off
     bool sq_overlap = false;  // squaring of a batch: the q-side transform kernel on a second stream beside [k_behz_extend -> Bsk side] (cn_eval.hip: do_multiply); CN_SQ_OVERLAP / cn_set_option
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool stream2_failed = false;
     bool sq_fused = true;     // squarings: forward transforms + tensor + inverse transforms in one kernel; cn_set_option("sq_fused", 0) = separate launches

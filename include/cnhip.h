@@ -99,6 +99,10 @@ int cn_ctx_wait_for(cn_ctx *ctx, cn_ctx *other);
  * "fold_zero" = 0, a fifth of the transforms.  All or nothing per flush (every queued zero encryption must qualify).  "folded_zero_encryptions" reads the count.
  * "defer_stagger" = 0 (default; 1: the Multiply of a queued squaring group of >= 256 ciphertexts waits on the device for the Multiply of an older context of the same device -
  * measured without a gain, profiles/r06_stagger_ab.txt).
+ * "sq_halves" = 1 (default, round 6; 0 off; 2: also inside the flush of queued per-ciphertext calls - measured slower there): cn_mul_relin of >= 512 ciphertexts at
+ * N <= 8192 runs as two halves software-pipelined over two streams of the context - the Multiply of the second half beside the key switch of the first (its HBM-bound base
+ * extension / floor fill what the FP64-bound key switch leaves).  Same words; every later call on the context is ordered behind both halves.  A caller that issues its plaintext
+ * primes one after the other (or from parallel tasks) gets what bench.py's half-batch stagger of the primes gets (12.6 -> 12.0 ms per CryptoNets batch); a staggered caller nothing.
  * "sq_overlap" = 0 (default; 1: the q-side transform kernel of a batched squaring on a second stream beside the base extension - measured slower in
  * the two-context batch, profiles/r06_square_overlap.txt).
  * "gemm_order" = 1 (default): slice-major workgroup order of the VALU scalar GEMM (every input slice fetched once per XCD), 0 = group-major.

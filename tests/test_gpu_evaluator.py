@@ -224,6 +224,53 @@ def test_squaring_fused_kernel_is_the_separate_launches(name, rng):
         g.free(x)
 
 
+@pytest.mark.parametrize("name,cnt", [("tiny", 701), ("c3", 530)])
+def test_squaring_in_two_pipelined_halves_gives_the_same_words(name, cnt, rng):
+    """cn_set_option("sq_halves", 1): Multiply + Relinearize of >= 512 ciphertexts as two halves over the context's two streams (the second half's Multiply beside
+    the first half's key switch) - the words of the one-stream evaluation, for the batched call, at an offset, followed at once by a reader on the context's stream,
+    and for the deferred per-ciphertext calls (operand tables)"""
+    o, g = get_oracle(name, galois=False), get_gpu(name, galois=False)
+    from bench import uniform_ct_words
+    cts = uniform_ct_words(rng, o.q, o.n, cnt)
+    h, ref, out, out2 = up(g, cts), g.ct_alloc(cnt), g.ct_alloc(cnt), g.ct_alloc(cnt)
+    try:
+        g.set_option("sq_halves", 0)
+        g.mul_relin(h, 0, h, 0, ref, 0, cnt)
+        want = g.ct_download(ref, 0, cnt)
+        g.add(ref, 0, ref, 0, ref, 0, cnt)
+        want_sum = g.ct_download(ref, 0, cnt)
+        g.set_option("sq_halves", 1)
+        for rep in range(3):                                             # (the second stream is created at the first call)
+            g.mul_relin(h, 0, h, 0, out, 0, cnt)
+            g.add(out, 0, out, 0, out2, 0, cnt)                          # a reader right behind it on the context's stream: ordered behind BOTH halves
+            assert np.array_equal(g.ct_download(out2, 0, cnt), want_sum), rep
+            assert np.array_equal(g.ct_download(out, 0, cnt), want), rep
+        g.mul_relin(h, 3, h, 3, out, 0, cnt - 3)
+        assert np.array_equal(g.ct_download(out, 0, cnt - 3), want[3:])
+        for i in (0, cnt // 2 - 1, cnt // 2, cnt // 2 + 8, cnt - 1):
+            assert np.array_equal(want[i], o.relinearize(o.multiply(cts[i], cts[i]))), i
+        assert np.array_equal(g.ct_download(h, 0, cnt), cts)
+        hs = [g.ct_alloc(1) for _ in range(cnt)]
+        for i, x in enumerate(hs):
+            g.copy(h, i, x, 0, 1)
+        g.set_option("sq_halves", 2)                                     # ... and inside the flush of queued per-ciphertext calls
+        for mode in (1, 2):
+            g.set_option("defer", mode)
+            rs = [g.ct_alloc(1) for _ in range(cnt)]
+            for x, r in zip(hs, rs):
+                g.mul_relin(x, 0, x, 0, r, 0, 1)
+            g.set_option("defer", 0)
+            got = np.stack([g.ct_download(r, 0, 1)[0] for r in rs])
+            assert np.array_equal(got, want), mode
+            g.free_many(rs)
+        g.free_many(hs)
+    finally:
+        g.set_option("sq_halves", 1)
+        g.set_option("defer", 0)
+        for x in (h, ref, out, out2):
+            g.free(x)
+
+
 @pytest.mark.parametrize("name,cnt", [("tiny", 700), ("default4096", 300), ("c3", 230)])
 def test_pipelined_squaring_of_a_batch(name, cnt, rng):
     """k_square_pipe as the library picks it by itself (a batch of at least four blocks per resident workgroup): every workgroup squares several
