@@ -526,8 +526,9 @@ def main():
     ap.add_argument("--caller-threads", type=int, default=0, help="threads of the unchanged-caller replay; 0 = the processor count a runtime reports here "
                     "(cgroup CPU quota honoured) - the reference's Defaults.ThreadCount = Environment.ProcessorCount")
     ap.add_argument("--serialize", action="store_true", help="sync after every plaintext-prime channel (clean per-kernel profiles)")
-    ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "1")),
-                    help="1: the plaintext-prime channels run half a batch apart (key switch of one beside the HBM-bound layers of the other)")
+    ap.add_argument("--stagger", type=int, default=int(os.environ.get("BENCH_STAGGER", "0")),
+                    help="1: the plaintext-prime channels run half a batch apart (key switch of one beside the HBM-bound layers of the other; the default of rounds 3-6); "
+                         "0 (default): the plain loop, prime after prime - cn_mul_relin pipelines each prime's squarings in parts by itself")
     ap.add_argument("--workload", choices=("cryptonets", "lola", "cifar"), default="cryptonets",
                     help="cryptonets: BASELINE config 3, the headline metric (default); lola / cifar: the single-image networks of configs 4 / 5")
     ap.add_argument("--shard", choices=("images", "primes"), default="images", help="lola / cifar on N GPUs: independent images per rank, or the plaintext primes of one image")
@@ -606,18 +607,21 @@ def main():
         g.free(ph)
         chans.append(ch)
 
+    def step_staggered(split=1):
+        # The two plaintext-prime channels are independent kernel chains on two streams.  Staggered by half a batch (device-side ordering between the contexts,
+        # cn_ctx_wait_for; no host wait) the long FP64-bound key switch of one channel runs beside the HBM-bound layers of the other.  The default program of rounds 3-6 until
+        # cn_mul_relin pipelined a batch in parts by itself ("sq_halves"): since then the PLAIN loop below is as fast or faster (profiles/r06_mulrelin_parts.txt).
+        for i, ch in enumerate(chans):
+            ch.front() if split == 1 else ch.front2()             # (2: experiment - the split behind the whole squaring layer)
+            if not os.environ.get("BENCH_STAGGER_NOWAIT"):        # (A/B: the two halves without the device-side ordering)
+                chans[(i + 1) % len(chans)].g.wait_for(ch.g)      # the next channel('s next batch) starts where this one's key switch starts
+            ch.back() if split == 1 else ch.back2()
+
     def step():
         if args.stagger and not args.serialize and len(chans) > 1:
-            # The two plaintext-prime channels are independent kernel chains on two streams.  Issued one after the other they run in lock
-            # step - key switch beside key switch (both FP64-issue bound), scalar GEMM beside scalar GEMM (both HBM bound).  Staggered by
-            # half a batch (device-side ordering between the contexts, cn_ctx_wait_for; no host wait) the long FP64-bound kernel of one
-            # channel runs beside the HBM-bound layers of the other, which fit into the registers and issue slots it leaves free.
-            for i, ch in enumerate(chans):
-                ch.front()
-                if not os.environ.get("BENCH_STAGGER_NOWAIT"):        # (A/B: the two halves without the device-side ordering)
-                    chans[(i + 1) % len(chans)].g.wait_for(ch.g)      # the next channel('s next batch) starts where this one's key switch starts
-                ch.back()
-            return
+            return step_staggered(args.stagger)
+        # the reference's own sequence, prime after prime (EncryptedSealBfvVector.cs:225-236 runs them as parallel tasks): five batched calls per prime; cn_mul_relin
+        # pipelines the 845 squarings in three parts over two streams of its context, so a prime's key switches run beside its own and the other prime's Multiply steps
         for ch in chans:
             ch.forward()
             if args.serialize:
@@ -792,15 +796,14 @@ def main():
                 sync_all()
                 bwin.append(1e3 * (time.perf_counter() - tb) / reps)
             batched_ms = min(bwin)
-            # the batched program WITHOUT the half-batch stagger of the primes: the two chains issued one after the other (cn_mul_relin pipelines each prime's 845 squarings in two
-            # halves over two streams by itself, "sq_halves": 12.6 -> 12.0 ms; the unchanged caller's queues run in lock step at ~13: profiles/r06_callers_vs_device.txt)
+            # the other way to run the batched program: the two primes half a batch apart (cn_multiply + cn_relinearize, device-side ordering between the contexts) - the
+            # default of rounds 3-6; the plain loop of `value` has cn_mul_relin pipeline each prime's squarings in parts instead
             pwin = []
             for _ in range(3):
                 sync_all()
                 tb = time.perf_counter()
                 for _ in range(reps):
-                    for ch in chans:
-                        ch.forward()
+                    step_staggered(1) if not args.stagger else [ch.forward() for ch in chans]
                 sync_all()
                 pwin.append(1e3 * (time.perf_counter() - tb) / reps)
             plain_ms = min(pwin)
@@ -826,7 +829,7 @@ def main():
                 locked = {"error": str(ex)[:200]}
             unchanged = {"value": round(8192e3 / lms, 1), "unit": "images/s", "ms_per_step": round(lms, 2), "threads": nthreads,
                          "frac_of_batched": round(batched_ms / lms, 3), "verified_against_integer_model": lok, "verified_slots": 8192 * 10 * len(chans),
-                         "unstaggered_batched_ms": round(plain_ms, 2), "frac_of_unstaggered_batched": round(plain_ms / lms, 3),
+                         ("plain_loop_batched_ms" if args.stagger else "staggered_batched_ms"): round(plain_ms, 2), ("frac_of_plain_loop_batched" if args.stagger else "frac_of_staggered_batched"): round(plain_ms / lms, 3),
                          "timing": "best of 5 windows of %d steps on BOTH sides of frac_of_batched (skipped_taps, at_visible_cpu_count: best of 3)" % reps,
                          "windows_ms": {"unchanged": [round(x, 2) for x in lwin], "batched": [round(x, 2) for x in bwin]},
                          "frac_of_batched_mean_over_mean": round((sum(bwin) / len(bwin)) / (sum(lwin) / len(lwin)), 3), "at_visible_cpu_count": visible,
@@ -884,6 +887,8 @@ def main():
                                       "8192-image batch per GPU per step, N=8192, 5 RNS limbs, plaintext primes {549764251649, 549764284417}, "
                                       "dbc=10; synthetic MNIST-like images encrypted on the device, inputs and keys resident in HBM; batched program with the zero-weighted padded "
                                       "convolution taps elided (the reference's literal call sequence: literal_call_sequence); weights: " + args.weights,
+                          "program": ("the two plaintext primes half a batch apart (cn_multiply / cn_relinearize, device-side ordering between the contexts)" if args.stagger and not args.serialize else
+                                      "five batched calls per plaintext prime, prime after prime; cn_mul_relin pipelines the 845 squarings in parts over two streams of its context"),
                           "padded_taps": "elided",     # the batched program of `value` skips the 645 x 2 zero-weighted padded convolution taps per batch the reference encrypts and
                                                        # multiplies inside its timed window (PoolLayer.cs:67-80); `literal_call_sequence` / `unchanged_caller` = the reference's literal sequence
                           "batch_per_gpu": 8192, "parallelism": "batch-sharded x%d, RCCL key broadcast only" % world,

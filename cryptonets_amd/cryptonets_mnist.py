@@ -174,6 +174,18 @@ class CryptoNetsChannel:
         g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
         g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
 
+    # experiment (bench.py --stagger 2): the split behind the whole squaring layer - cn_mul_relin pipelines its 845 ciphertexts in parts by itself ("sq_halves")
+    def front2(self):
+        g, L = self.g, self.layers
+        g.gemm_apply(L[0]["plan"], self.h_in, self.h1, 0)
+        g.mul_relin(self.h1, 0, self.h1, 0, self.h2, 0, 845)
+
+    def back2(self):
+        g, L = self.g, self.layers
+        g.gemm_apply(L[1]["plan"], self.h2, self.h3, 0)
+        g.mul_relin(self.h3, 0, self.h3, 0, self.h4, 0, 100)
+        g.gemm_apply(L[2]["plan"], self.h4, self.h5, 0)
+
 
     # NOT the reference's call sequence (opt-in; `bench.py` reports it beside the headline, never as the headline): the squarings leave their
     # products UNRELINEARIZED (size 3) and the dense layer behind them runs on size-3 ciphertexts - Evaluator.MultiplyPlain / Add accept any

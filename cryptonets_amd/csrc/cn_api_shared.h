@@ -151,24 +151,39 @@ bool run_intt_tensor(cn_ctx *c, const uint64_t *A, const uint64_t *B, uint64_t *
 bool square_fused_ok(cn_ctx *c, uint32_t base_off, uint32_t Lm, bool &light);
 void run_square_fused(cn_ctx *c, const uint64_t *A, size_t astride, const uint64_t *const *atab, uint64_t *D, uint32_t cnt, uint32_t base_off, uint32_t Lm, bool light);
 bool aux_stream_ready(cn_ctx *ctx);
-// "sq_halves": Multiply + Relinearize of a batch as two halves software-pipelined over the context's two streams - Multiply(first) | Relinearize(first) on the context's stream,
-// Multiply(second) behind Multiply(first) on the second stream (beside the first half's key switch: its HBM-bound base extension / floor and its transform kernels fill what the
-// FP64-bound key switch leaves), Relinearize(second) behind it; the context's stream continues behind both.  mul(first, count), ks(first, count) launch on ctx->stream.
+// "sq_halves": Multiply + Relinearize of a batch software-pipelined in parts over the context's two streams (round 6): part i on stream i % 2, its Multiply behind the Multiply
+// of the part before it (event), its key switch behind its own Multiply (stream order) - [mul 0][ks 0 | mul 1][ks 1 | mul 2][ks 2]: the HBM-bound base extension / floor and
+// the transform kernels of a Multiply fill what the FP64-bound key switch of the part before leaves.  The context's stream continues behind the last part of either stream.
+// Three parts of 30 / 40 / 30 % measured best for the CryptoNets batch (profiles/r06_mulrelin_parts.txt: plain loop of the two primes 12.6 -> 12.0-12.2 ms, the half-batch
+// stagger of the primes 12.2-12.6; two parts 12.4-12.5, four 12.7, five 12.4); CN_SQ_PARTS / CN_SQ_SPLIT (cut points in per mille) for experiments.
+// mul(first, count), ks(first, count) launch on ctx->stream.
 static const uint32_t SQ_HALVES_MIN = 512;
 template <class FM, class FK> static int pipelined_halves(cn_ctx *ctx, uint32_t c, FM mul, FK ks) {
-    const uint32_t c1 = ((c / 2) + 7) & ~7u, c2 = c - c1;
-    CHECK(mul(0u, c1));
-    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    std::swap(ctx->stream, ctx->stream2);
-    int rc = mul(c1, c2);
-    std::swap(ctx->stream, ctx->stream2);
-    CHECK(rc);
-    CHECK(ks(0u, c1));
-    std::swap(ctx->stream, ctx->stream2);
-    rc = ks(c1, c2);
-    if (!rc && hipEventRecord(ctx->ev_join, ctx->stream) != hipSuccess) rc = fail(CN_ERR_HIP, "hipEventRecord failed");
-    std::swap(ctx->stream, ctx->stream2);
+    static const uint32_t parts_env = [] { const char *e = getenv("CN_SQ_PARTS"); const int v = e ? atoi(e) : 3; return (uint32_t)(v >= 2 && v <= 8 ? v : 3); }();
+    const uint32_t P = std::min<uint32_t>(parts_env, c / 128 ? c / 128 : 1);
+    if (P < 2) { CHECK(mul(0u, c)); return ks(0u, c); }
+    uint32_t first[9]; first[0] = 0;
+    for (uint32_t i = 1; i < P; i++) first[i] = (uint32_t)(((uint64_t)c * i / P + 7) & ~7ull);
+    first[P] = c;
+    static const std::vector<uint32_t> cuts = [] {                    // experiment: CN_SQ_SPLIT="250,625" = the cut points in per mille (P - 1 of them, increasing)
+        std::vector<uint32_t> v; const char *e = getenv("CN_SQ_SPLIT");
+        while (e && *e) { v.push_back((uint32_t)atoi(e)); e = strchr(e, ','); if (e) e++; }
+        return v; }();
+    if (cuts.empty() && P == 3) { first[1] = (uint32_t)(((uint64_t)c * 3 / 10 + 7) & ~7ull); first[2] = (uint32_t)(((uint64_t)c * 7 / 10 + 7) & ~7ull); }
+    if (cuts.size() + 1 == P) for (uint32_t i = 1; i < P; i++) first[i] = std::min<uint32_t>(c, (uint32_t)(((uint64_t)c * cuts[i - 1] / 1000 + 7) & ~7ull));
+    int rc = 0;
+    for (uint32_t i = 0; i < P && !rc; i++) {
+        const bool aux = (i & 1) != 0;
+        if (i) {                                                      // this part's Multiply behind the previous part's (recorded on the other stream)
+            if (hipStreamWaitEvent(aux ? ctx->stream2 : ctx->stream, ctx->ev_fork, 0) != hipSuccess) { rc = fail(CN_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        }
+        if (aux) std::swap(ctx->stream, ctx->stream2);
+        rc = mul(first[i], first[i + 1] - first[i]);
+        if (!rc && i + 1 < P && hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess) rc = fail(CN_ERR_HIP, "hipEventRecord failed");
+        if (!rc) rc = ks(first[i], first[i + 1] - first[i]);
+        if (!rc && aux && i + 2 >= P && hipEventRecord(ctx->ev_join, ctx->stream) != hipSuccess) rc = fail(CN_ERR_HIP, "hipEventRecord failed");      // the last part on the second stream
+        if (aux) std::swap(ctx->stream, ctx->stream2);
+    }
     CHECK(rc);
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return 0;
