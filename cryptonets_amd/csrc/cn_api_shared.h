@@ -157,7 +157,7 @@ bool aux_stream_ready(cn_ctx *ctx);
 // Three parts of 30 / 40 / 30 % measured best for the CryptoNets batch (profiles/r06_mulrelin_parts.txt: plain loop of the two primes 12.6 -> 12.0-12.2 ms, the half-batch
 // stagger of the primes 12.2-12.6; two parts 12.4-12.5, four 12.7, five 12.4); CN_SQ_PARTS / CN_SQ_SPLIT (cut points in per mille) for experiments.
 // mul(first, count), ks(first, count) launch on ctx->stream.
-static const uint32_t SQ_HALVES_MIN = 512;
+static const uint32_t SQ_HALVES_MIN = 512;       // (the 100-ciphertext layer of CryptoNets pipelined as well: 12.35 -> 13.4 ms per batch, visit AY)
 template <class FM, class FK> static int pipelined_halves(cn_ctx *ctx, uint32_t c, FM mul, FK ks) {
     static const uint32_t parts_env = [] { const char *e = getenv("CN_SQ_PARTS"); const int v = e ? atoi(e) : 3; return (uint32_t)(v >= 2 && v <= 8 ? v : 3); }();
     const uint32_t P = std::min<uint32_t>(parts_env, c / 128 ? c / 128 : 1);
